@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors that pin the oracle and the HIP path.
+
+Runs ONLY in the build container, where the upstream reference is mounted
+read-only at /root/reference.  It imports the reference's own `gbm/model.py`
+(`Attention`, `ResNet`) and `nnBlocks.py` (`BasicResBlock`,
+`CrossEntropyWithProbs`) on CPU through the two-line shim of SURVEY.md §8(c)
+(a stub `PyTorchHelpers` module; `.cuda()` made the identity), runs it on
+seeded synthetic bags and stores *tensors only* (inputs, the 65 state-dict
+entries, the 13 output-dict entries, stage activations, parameter gradients)
+as .npz files next to this script.  Nothing from the reference (source,
+bytecode, pickled modules) is stored.
+
+    python tests/golden/make_golden.py
+
+The fixtures are committed; the GPU box never runs this script.
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def load_reference():
+    sys.dont_write_bytecode = True
+    sys.path[:0] = [REF, os.path.join(REF, "gbm")]
+    sys.modules["PyTorchHelpers"] = types.ModuleType("PyTorchHelpers")
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    with contextlib.redirect_stdout(io.StringIO()):
+        import model  # noqa: the reference's gbm/model.py
+    return model
+
+
+def make_weights(model):
+    """Reference init under seed 1234, then seeded non-zero biases / BN affine /
+    weight_mask so that every term of the arithmetic is exercised."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        torch.manual_seed(1234)
+        net = model.Attention(3)
+    g = torch.Generator().manual_seed(4321)
+    sd = net.state_dict()
+    for k, v in sd.items():
+        if k.endswith(".bias") and "bn" not in k:
+            v.copy_(0.05 * torch.randn(v.shape, generator=g))
+    sd["context.bn.weight"].copy_(1.0 + 0.1 * torch.randn(80, generator=g))
+    sd["context.bn.bias"].copy_(0.1 * torch.randn(80, generator=g))
+    sd["weight_mask"].copy_(torch.tensor([0.25, -0.10, 0.05]))
+    net.load_state_dict(sd)
+    return net
+
+
+def synth_bag(n, h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, 3, h, w, generator=g).clamp_(-1.0, 1.0)
+
+
+def stage_hooks(net):
+    acts = {}
+    cnn = net.cnn.module
+    hs = []
+
+    def keep(name):
+        def hook(_m, _i, o):
+            acts[name] = o.detach().clone()
+        return hook
+    # conv1's output is modified in place by the LeakyReLU that follows, so hook the relu.
+    hs.append(cnn.relu.register_forward_hook(keep("stem")))
+    hs.append(cnn.maxpool.register_forward_hook(keep("pool")))
+    for i in (1, 2, 3, 4):
+        hs.append(getattr(cnn, f"layer{i}").register_forward_hook(keep(f"layer{i}")))
+    return acts, hs
+
+
+def run_case(model, net, name, x, y, *, train=False, seed=None, class_weights=None,
+             full_grads=False, stages=False, store_x=True):
+    if class_weights is not None:
+        # the loss module reads a plain attribute (nnBlocks.py:65)
+        net.loss.weight = class_weights
+    else:
+        net.loss.weight = None
+    net.train(train)
+    net.zero_grad(set_to_none=True)
+    rec = {}
+    extra_hooks = []
+    if train:
+        # gbm/model.py:193 draws randperm from the global RNG, then Dropout draws its mask.
+        torch.manual_seed(seed)
+        n0 = x.shape[0]
+        rec["indices"] = torch.randperm(n0)[: int(n0 * 0.2)].clone()
+        torch.manual_seed(seed)
+
+        def do_hook(_m, i, o):
+            rec["keep_mask"] = (o != 0).to(torch.uint8)
+        extra_hooks.append(net.context.do.register_forward_hook(do_hook))
+    acts, hs = stage_hooks(net) if stages else ({}, [])
+    out = net(x, y)
+    out["loss"].backward()
+    for h in hs + extra_hooks:
+        h.remove()
+
+    blob = {}
+    if store_x:
+        blob["x"] = x.numpy()
+    blob["y"] = y.numpy()
+    for k, v in out.items():
+        blob["out." + k] = v.detach().numpy()
+    for k, v in acts.items():
+        blob["act." + k] = v.numpy()
+    for k, v in rec.items():
+        blob["rec." + k] = v.numpy()
+    if class_weights is not None:
+        blob["class_weights"] = class_weights.numpy()
+    names, norms, sums = [], [], []
+    for k, p in net.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        names.append(k)
+        norms.append(float(g.double().norm()))
+        sums.append(float(g.double().sum()))
+        if full_grads:
+            blob["grad." + k] = g.numpy()
+    blob["gradnorm.names"] = np.array(names)
+    blob["gradnorm.l2"] = np.array(norms, dtype=np.float64)
+    blob["gradnorm.sum"] = np.array(sums, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **blob)
+    print(f"{name}: loss={out['loss'].item():.6f} y_pred={out['y_pred'].numpy().round(4)} "
+          f"|Fterm|max={out['Fterm'].abs().max().item():.4f}")
+
+
+def main():
+    model = load_reference()
+    net = make_weights(model)
+    np.savez_compressed(os.path.join(HERE, "weights.npz"),
+                        **{k: v.numpy() for k, v in net.state_dict().items()})
+    print("weights:", len(net.state_dict()), "tensors,",
+          sum(v.numel() for v in net.state_dict().values()), "params")
+
+    y1 = torch.tensor([1])
+    y2 = torch.tensor([2])
+    y0 = torch.tensor([0])
+    x8 = synth_bag(8, 64, 64, 20260104)
+    run_case(model, net, "eval_n8_64", x8, y1, full_grads=True, stages=True)
+    run_case(model, net, "eval_n8_64_cw", x8, y2,
+             class_weights=torch.tensor([0.5, 1.0, 2.0]))
+    run_case(model, net, "eval_n5_50x70", synth_bag(5, 50, 70, 20260105), y0, stages=True)
+    run_case(model, net, "train_n40_64", synth_bag(40, 64, 64, 20260106), y2,
+             train=True, seed=77, full_grads=True)
+    run_case(model, net, "eval_n2_256", synth_bag(2, 256, 256, 20260107), y1)
+    # BASELINE.json configs[0]: 1 bag x 64 tiles @256x256; input is regenerated from its seed.
+    run_case(model, net, "eval_n64_256_cfg1", synth_bag(64, 256, 256, 20260104), y1,
+             store_x=False)
+
+
+if __name__ == "__main__":
+    main()
