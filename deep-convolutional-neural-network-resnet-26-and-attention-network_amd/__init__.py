@@ -1,0 +1,10 @@
+"""MI355X-native ResNet-26 + attention-MIL hot path.
+
+Importable as `mil_amd` (repo-root shim `mil_amd.py`); the on-disk package directory keeps the
+project's hyphenated name."""
+from ._lib import LIB_PATH, MilLibraryError, build_library, lib  # noqa: F401
+from .encoder import BasicResBlock, ResNet  # noqa: F401
+from .model import Attention, ContextLayer, CrossEntropyWithProbs, TileParallel  # noqa: F401
+
+__all__ = ["Attention", "ResNet", "BasicResBlock", "ContextLayer", "CrossEntropyWithProbs", "TileParallel",
+           "build_library", "lib", "MilLibraryError", "LIB_PATH"]

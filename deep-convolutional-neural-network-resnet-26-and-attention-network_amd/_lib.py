@@ -1,0 +1,98 @@
+"""ctypes binding of libmil_hip.so (C ABI declared in include/mil_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails this module raises.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch  # noqa: F401  (must be imported first: the HIP runtime torch loaded is the one we bind to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmil_hip.so")
+
+MIL_DT_F32, MIL_DT_BF16 = 0, 1
+PACK_FWD, PACK_DGRAD, PACK_STEM = 0, 1, 2
+_ERR = {1: "invalid argument", 2: "unsupported shape / channel configuration", 3: "kernel launch failed"}
+
+
+class MilLibraryError(RuntimeError):
+    pass
+
+
+def build_library(verbose=False):
+    """Compile every HIP source for gfx950 into libmil_hip.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j", str(min(8, os.cpu_count() or 1))]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise MilLibraryError("building libmil_hip.so failed")
+    return LIB_PATH
+
+
+_c = ctypes
+_vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
+_SIGS = {
+    "mil_abi_version": ([], _i),
+    "mil_stem_s2d": ([_vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "mil_packed_weight_elems": ([_c.POINTER(_sz), _i, _i, _i, _i], _i),
+    "mil_pack_conv_weights": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
+    "mil_conv_igemm": ([_vp] * 6 + [_i] * 12 + [_f, _i, _vp], _i),
+    "mil_conv_wgrad_workspace": ([_c.POINTER(_sz)] + [_i] * 12, _i),
+    "mil_conv_wgrad": ([_vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 12 + [_vp], _i),
+    "mil_maxpool_fwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
+    "mil_maxpool_bwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp], _i),
+    "mil_avgpool_fc_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "mil_avgpool_fc_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
+    "mil_head_workspace_floats": ([_c.POINTER(_sz), _i, _i], _i),
+    "mil_head_grad_floats": ([], _i),
+    "mil_head_rec_floats": ([], _i),
+    "mil_head_fwd": ([_vp] * 13 + [_i, _i, _f, _f, _f, _f, _vp], _i),
+    "mil_head_bwd": ([_vp] * 12 + [_i, _i, _f, _f, _vp], _i),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises MilLibraryError (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MilLibraryError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C <package>/csrc`). This package has no CPU fallback.")
+        try:
+            handle = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise MilLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (args, ret) in _SIGS.items():
+            fn = getattr(handle, name, None)
+            if fn is None:
+                raise MilLibraryError(f"{LIB_PATH} does not export {name}")
+            fn.argtypes, fn.restype = args, ret
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise MilLibraryError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def dt_code(dtype):
+    if dtype == torch.float32:
+        return MIL_DT_F32
+    if dtype == torch.bfloat16:
+        return MIL_DT_BF16
+    raise ValueError(f"compute dtype must be torch.float32 or torch.bfloat16, got {dtype}")

@@ -1,0 +1,110 @@
+// Shared device helpers for the MI355X (gfx950) MIL hot path.  CDNA4 only: 64-lane waves,
+// v_mfma_f32_16x16x32_bf16 / v_mfma_f32_16x16x4_f32, ds_read_b64_tr_b16.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+#define MIL_OK 0
+#define MIL_ERR_ARG 1
+#define MIL_ERR_UNSUPPORTED 2
+#define MIL_ERR_LAUNCH 3
+
+#define MIL_DT_F32 0
+#define MIL_DT_BF16 1
+
+// Channel padding used by every NHWC activation tensor (multiple of 8 elements = one 16-B bf16 piece).
+__host__ __device__ constexpr int mil_cpad(int c) { return (c + 7) / 8 * 8; }
+// Output-channel tile count (16-wide MFMA columns) <-> padded channel count.
+__host__ __device__ constexpr int mil_nt_to_cp(int nt) { return nt == 2 ? 24 : nt == 3 ? 40 : nt == 4 ? 64 : 80; }
+
+struct F32 {
+    using elem = float;
+    static constexpr int ESZ = 4;
+    static constexpr int DT = MIL_DT_F32;
+};
+struct BF16 {
+    using elem = __bf16;
+    static constexpr int ESZ = 2;
+    static constexpr int DT = MIL_DT_BF16;
+};
+
+// One MFMA operand fragment = 8 consecutive-k elements per lane.
+template <typename T> struct Frag8;
+template <> struct Frag8<BF16> { bf16x8_t v; };
+template <> struct Frag8<F32> { f32x4_t lo, hi; };
+
+template <typename T>
+__device__ __forceinline__ Frag8<T> lds_frag(const char* p);
+template <>
+__device__ __forceinline__ Frag8<BF16> lds_frag<BF16>(const char* p) {
+    Frag8<BF16> f; f.v = *reinterpret_cast<const bf16x8_t*>(p); return f;
+}
+template <>
+__device__ __forceinline__ Frag8<F32> lds_frag<F32>(const char* p) {
+    Frag8<F32> f;
+    f.lo = *reinterpret_cast<const f32x4_t*>(p);
+    f.hi = *reinterpret_cast<const f32x4_t*>(p + 16);
+    return f;
+}
+
+// acc += A(16 x 32k) * B(32k x 16).  The bf16 form is one v_mfma_f32_16x16x32_bf16; the f32 form is
+// eight exact-f32 v_mfma_f32_16x16x4_f32 over the same 32 k (element j of lane-group g is k=(g,j) on
+// both operands, so any consistent k order is a valid contraction).
+__device__ __forceinline__ f32x4_t mma8(const Frag8<BF16>& a, const Frag8<BF16>& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4_t mma8(const Frag8<F32>& a, const Frag8<F32>& b, f32x4_t c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[j], b.lo[j], c, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[j], b.hi[j], c, 0, 0, 0);
+    return c;
+}
+
+// 8 consecutive channels of a tensor <-> 8 floats.
+template <typename T> __device__ __forceinline__ void load8(const typename T::elem* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<BF16>(const __bf16* p, float (&v)[8]) {
+    bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)t[j];
+}
+template <> __device__ __forceinline__ void load8<F32>(const float* p, float (&v)[8]) {
+    f32x4_t a = *reinterpret_cast<const f32x4_t*>(p);
+    f32x4_t b = *reinterpret_cast<const f32x4_t*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+}
+template <typename T> __device__ __forceinline__ void store8(typename T::elem* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<BF16>(__bf16* p, const float (&v)[8]) {
+    bf16x8_t t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = (__bf16)v[j];
+    *reinterpret_cast<bf16x8_t*>(p) = t;
+}
+template <> __device__ __forceinline__ void store8<F32>(float* p, const float (&v)[8]) {
+    f32x4_t a, b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = v[j]; b[j] = v[4 + j]; }
+    *reinterpret_cast<f32x4_t*>(p) = a;
+    *reinterpret_cast<f32x4_t*>(p + 4) = b;
+}
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+// derivative of LeakyReLU read off the saved OUTPUT (same sign as the pre-activation for slope>0;
+// torch uses grad = x > 0 ? 1 : slope, so 0 maps to slope).
+__device__ __forceinline__ float lrelu_grad(float out, float slope) { return out > 0.f ? 1.f : slope; }
+
+// LDS pixel pitch in bytes for a tile of [pixel][C] elements: an odd number of 16-B slots so that 16
+// consecutive pixels read by one ds_read_b128 lane group fall on distinct bank slots.
+__host__ __device__ constexpr int mil_pix_pitch(int cp, int esz) {
+    int n16 = cp * esz / 16;
+    return ((n16 & 1) ? n16 : n16 + 1) * 16;
+}
+
+#define MIL_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return MIL_ERR_LAUNCH; } while (0)

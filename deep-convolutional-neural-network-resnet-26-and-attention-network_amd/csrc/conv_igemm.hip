@@ -1,0 +1,219 @@
+// NHWC implicit-GEMM convolution on CDNA4 MFMA: forward conv and data-gradient (dgrad) of the
+// residual-block convolutions of the tile encoder (reference: nnBlocks.py:169-171 conv1/conv2,
+// gbm/model.py:24 stem, gbm/model.py:38-40 1x1 projection shortcut).
+//
+//   GEMM view:  M = output pixels (a TI x TH x TW tile per workgroup),  N = output channels
+//               (NT 16-wide MFMA column tiles),  K = taps x input channels, flattened in groups of 8
+//               channels so that one 16x16x32 MFMA consumes 4 (tap, channel-group) pairs.
+//   A operand:  the input halo tile, staged ONCE in LDS and re-read for every tap (no im2col in HBM).
+//   B operand:  weights pre-packed on device in MFMA B-fragment order (pack.hip), staged in LDS.
+//   Epilogue:   accumulators -> LDS (fp32) -> per-pixel 8-channel rows:
+//               v = acc + bias + residual;  v = lrelu(v);  v *= lrelu'(act);  16-B NHWC stores.
+//   dgrad:      the same kernel run over dz with transposed+flipped packed weights; stride-2 dgrad
+//               reads dz through the zero-insert loader (transposed convolution).
+#include "geom.cuh"
+
+template <typename T>
+struct ConvArgs {
+    const typename T::elem* x;
+    const typename T::elem* w;      // packed [nsteps][NT][64][8]
+    const float* bias;              // padded to NT*16, or null
+    const typename T::elem* res;    // residual / addend in output layout, or null
+    const typename T::elem* act;    // saved activation for the lrelu' mask, or null
+    typename T::elem* y;
+    ConvGeom g;
+    int nsteps, kc;                 // k-steps total / per weight chunk held in LDS
+    int lds_w_off;                  // byte offset of the weight chunk in LDS
+    int apply_lrelu;
+    float slope;
+};
+
+template <typename T, int CINP, int NT, int MTW>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ESZ = T::ESZ;
+    constexpr int PIXB = mil_pix_pitch(CINP, ESZ);
+    constexpr int CG = CINP / 8;
+    constexpr int FRAGB = 8 * ESZ;
+    constexpr int COUTP = mil_nt_to_cp(NT);
+    constexpr int NGRP = COUTP / 8;
+    constexpr int TILE_PX = 64 * MTW;
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, gq = lane >> 4;
+
+    const TileOrigin o = mil_tile_origin(g, blockIdx.x);
+    char* ldsA = smem;
+    char* ldsW = smem + a.lds_w_off;
+    mil_load_halo<T, CINP>(ldsA, a.x, g, o, tid, 256);
+
+    const int s_eff = g.zins ? 1 : g.stride;
+    int pixbase[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) pixbase[m] = mil_pix_base<PIXB>(g, (wave * MTW + m) * 16 + r, s_eff);
+
+    f32x4_t acc[MTW][NT];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int ntaps = g.ks * g.ks;
+    for (int s0 = 0; s0 < a.nsteps; s0 += a.kc) {
+        __syncthreads();
+        const int cs = min(a.kc, a.nsteps - s0);
+        {
+            const int nbytes = cs * NT * 64 * FRAGB;
+            const char* src = reinterpret_cast<const char*>(a.w) + (size_t)s0 * NT * 64 * FRAGB;
+            for (int i = tid * 16; i < nbytes; i += 256 * 16)
+                *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(src + i);
+        }
+        __syncthreads();
+        for (int sl = 0; sl < cs; ++sl) {
+            const int q = 4 * (s0 + sl) + gq;
+            int tap = q / CG;
+            int cg = q - tap * CG;
+            if (tap >= ntaps) { tap = 0; cg = 0; }      // K padding: weights there are zero
+            const int ky = tap / g.ks, kx = tap - ky * g.ks;
+            const int toff = (ky * g.hw + kx) * PIXB + cg * FRAGB;
+            Frag8<T> bf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bf[nt] = lds_frag<T>(ldsW + ((sl * NT + nt) * 64 + lane) * FRAGB);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const Frag8<T> af = lds_frag<T>(ldsA + pixbase[m] + toff);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(af, bf[nt], acc[m][nt]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // accumulators (col = lane&15, row = 4*(lane>>4)+i) -> LDS [tile pixel][NT*16] fp32
+    float* epi = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                epi[((wave * MTW + m) * 16 + gq * 4 + i) * (NT * 16) + nt * 16 + r] = acc[m][nt][i];
+    __syncthreads();
+
+    const int tw_mask = (1 << g.tw_log2) - 1, th_mask = (1 << g.th_log2) - 1;
+    for (int idx = tid; idx < TILE_PX * NGRP; idx += 256) {
+        const int tp = idx / NGRP, c8 = idx - tp * NGRP;
+        const int ox = o.ox0 + (tp & tw_mask);
+        const int oy = o.oy0 + ((tp >> g.tw_log2) & th_mask);
+        const int img = o.img0 + (tp >> (g.tw_log2 + g.th_log2));
+        if (img >= g.n_img || oy >= g.Ho || ox >= g.Wo) continue;
+        float v[8];
+        {
+            const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(epi + tp * (NT * 16) + c8 * 8);
+            const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(epi + tp * (NT * 16) + c8 * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+        }
+        if (a.bias) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += a.bias[c8 * 8 + j];
+        }
+        const size_t off = (((size_t)img * g.Ho + oy) * g.Wo + ox) * COUTP + c8 * 8;
+        if (a.res) {
+            float rv[8];
+            load8<T>(a.res + off, rv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += rv[j];
+        }
+        if (a.apply_lrelu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = lrelu(v[j], a.slope);
+        }
+        if (a.act) {
+            float av[8];
+            load8<T>(a.act + off, av);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= lrelu_grad(av[j], a.slope);
+        }
+        store8<T>(a.y + off, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T, int CINP, int NT, int MTW>
+static int launch_conv(const ConvArgs<T>& a0, hipStream_t stream) {
+    ConvArgs<T> a = a0;
+    constexpr int ESZ = T::ESZ;
+    constexpr int PIXB = mil_pix_pitch(CINP, ESZ);
+    constexpr int FRAGB = 8 * ESZ;
+    constexpr int TILE_PX = 64 * MTW;
+    mil_geom_tiles(a.g, MTW == 4 ? 8 : 6);
+    const int a_bytes = (((a.g.hh * a.g.hw) << a.g.ti_log2) * PIXB + 15) & ~15;
+    const int step_bytes = NT * 64 * FRAGB;
+    const int epi_bytes = TILE_PX * NT * 16 * 4;
+    const int budget = 160 * 1024 - a_bytes;
+    if (budget < step_bytes) return MIL_ERR_UNSUPPORTED;
+    int kc = a.nsteps;
+    if (kc * step_bytes > budget) kc = budget / step_bytes;
+    a.kc = kc;
+    a.lds_w_off = a_bytes;
+    int lds = a_bytes + kc * step_bytes;
+    if (lds < epi_bytes) lds = epi_bytes;
+    auto kern = conv_igemm_kernel<T, CINP, NT, MTW>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return MIL_ERR_LAUNCH;
+    }
+    const int grid = a.g.n_groups * a.g.tiles_y * a.g.tiles_x;
+    if (grid <= 0) return MIL_OK;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+template <typename T>
+static int dispatch_conv(const ConvArgs<T>& a, int cin_p, int cout_p, hipStream_t stream) {
+    const bool small_tile = (a.g.stride == 2 && !a.g.zins);     // stride-2 forward: 64-px tiles (halo is 4x)
+#define MIL_CONV_CASE(CI, NTV, MT) return launch_conv<T, CI, NTV, MT>(a, stream)
+    if (!small_tile) {
+        if (cin_p == 16 && cout_p == 24) MIL_CONV_CASE(16, 2, 4);
+        if (cin_p == 24 && cout_p == 24) MIL_CONV_CASE(24, 2, 4);
+        if (cin_p == 40 && cout_p == 40) MIL_CONV_CASE(40, 3, 4);
+        if (cin_p == 64 && cout_p == 64) MIL_CONV_CASE(64, 4, 4);
+        if (cin_p == 80 && cout_p == 80) MIL_CONV_CASE(80, 5, 4);
+        if (cin_p == 40 && cout_p == 24) MIL_CONV_CASE(40, 2, 4);   // dgrad of stage-entry convs
+        if (cin_p == 64 && cout_p == 40) MIL_CONV_CASE(64, 3, 4);
+        if (cin_p == 80 && cout_p == 64) MIL_CONV_CASE(80, 4, 4);
+    } else {
+        if (cin_p == 24 && cout_p == 40) MIL_CONV_CASE(24, 3, 1);
+        if (cin_p == 40 && cout_p == 64) MIL_CONV_CASE(40, 4, 1);
+        if (cin_p == 64 && cout_p == 80) MIL_CONV_CASE(64, 5, 1);
+    }
+#undef MIL_CONV_CASE
+    return MIL_ERR_UNSUPPORTED;
+}
+
+extern "C" int mil_conv_igemm(const void* x, const void* wpack, const float* bias_pad, const void* res,
+                              const void* act, void* y, int n_img, int H, int W, int cin_p, int Ho, int Wo,
+                              int cout_p, int ks, int stride, int pad, int zero_insert, int apply_lrelu,
+                              float slope, int dtype, void* stream) {
+    if (!x || !wpack || !y || n_img < 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return MIL_ERR_ARG;
+    if (!(ks == 1 || ks == 3 || ks == 4) || !(stride == 1 || stride == 2)) return MIL_ERR_ARG;
+    ConvGeom g{};
+    g.n_img = n_img; g.H = H; g.W = W; g.Ho = Ho; g.Wo = Wo; g.ks = ks; g.stride = stride; g.pad = pad;
+    g.zins = zero_insert ? 1 : 0;
+    const int nsteps = (ks * ks * (cin_p / 8) + 3) / 4;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIL_DT_BF16) {
+        ConvArgs<BF16> a{};
+        a.x = (const __bf16*)x; a.w = (const __bf16*)wpack; a.bias = bias_pad; a.res = (const __bf16*)res;
+        a.act = (const __bf16*)act; a.y = (__bf16*)y; a.g = g; a.nsteps = nsteps; a.apply_lrelu = apply_lrelu; a.slope = slope;
+        return dispatch_conv<BF16>(a, cin_p, cout_p, st);
+    } else if (dtype == MIL_DT_F32) {
+        ConvArgs<F32> a{};
+        a.x = (const float*)x; a.w = (const float*)wpack; a.bias = bias_pad; a.res = (const float*)res;
+        a.act = (const float*)act; a.y = (float*)y; a.g = g; a.nsteps = nsteps; a.apply_lrelu = apply_lrelu; a.slope = slope;
+        return dispatch_conv<F32>(a, cin_p, cout_p, st);
+    }
+    return MIL_ERR_ARG;
+}

@@ -1,0 +1,313 @@
+// Weight- and bias-gradient of the tile-encoder convolutions on CDNA4 MFMA (autograd of
+// nnBlocks.py:169-171, gbm/model.py:24, gbm/model.py:38-40 in the reference).
+//
+//   dW[(tap,ci)][co] = sum over output pixels p of  x[p (+) tap][ci] * dz[p][co]
+//   GEMM view:  M = taps x input channels (row groups of 8 channels, two per 16-row MFMA tile),
+//               N = output channels,  K = output pixels.
+//   Both operands are K(pixel)-major in NHWC memory but the MFMA wants 8 consecutive k per lane, so
+//   the bf16 path reads both LDS tiles with ds_read_b64_tr_b16 (hardware transpose); the exact-f32
+//   path uses v_mfma_f32_16x16x4_f32, whose one-element-per-lane operands need no transpose.
+//   Each workgroup walks a strided set of spatial tiles, keeps its partial dW in registers and writes
+//   ONE fp32 slab; a second kernel sums the slabs in fixed order (deterministic, no float atomics).
+//   db comes from an all-ones A fragment on wave 0 (column sums of dz on the same MFMA stream).
+#include "geom.cuh"
+
+template <typename T>
+struct WgradArgs {
+    const typename T::elem* x;
+    const typename T::elem* dz;
+    float* slab;            // [gridDim.x][(MT+1)*16][NT*16]
+    ConvGeom g;
+    int ntiles;
+    int tile_px;
+    int lds_z_off;
+};
+
+__device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
+    typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <typename T, int KS, int CINP, int NT, int MSPLIT>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ESZ = T::ESZ;
+    constexpr int PIXB = mil_pix_pitch(CINP, ESZ);
+    constexpr int COUTP = mil_nt_to_cp(NT);
+    constexpr int PIXZ = mil_pix_pitch(COUTP, ESZ);
+    constexpr int CG = CINP / 8;
+    constexpr int RG = KS * KS * CG;            // row groups of 8 input channels
+    constexpr int MT = (RG + 1) / 2;            // 16-row MFMA tiles over (tap, ci)
+    constexpr int MT_S = (MT + MSPLIT - 1) / MSPLIT;
+    constexpr int MW = (MT_S + 3) / 4;          // tiles per wave
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.y;
+    const bool bias_wave = (wave == 0 && split == 0);
+    char* ldsX = smem;
+    char* ldsZ = smem + a.lds_z_off;
+
+    // per-lane byte offset of this lane's (tap, channel) rows inside a halo pixel, per owned m-tile
+    int toff[MW];
+    bool mvalid[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+        const int ml = wave + 4 * i;
+        const int mt = split * MT_S + ml;
+        mvalid[i] = (ml < MT_S) && (mt < MT);
+        int rg, sub;
+        if constexpr (T::DT == MIL_DT_BF16) { const int p = lane & 3; rg = 2 * mt + (p >> 1); sub = (p & 1) * 8; }
+        else { const int row = lane & 15; rg = 2 * mt + (row >> 3); sub = (row & 7) * 4; }
+        if (rg >= RG) rg = 0;                    // rows past the filter: finite duplicates, never read back
+        const int tap = rg / CG, cg = rg - tap * CG;
+        const int ky = tap / KS, kx = tap - ky * KS;
+        toff[i] = (ky * g.hw + kx) * PIXB + cg * (8 * ESZ) + sub;
+    }
+
+    f32x4_t acc[MW][NT];
+    f32x4_t accb[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        accb[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MW; ++i) acc[i][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const TileOrigin o = mil_tile_origin(g, tile);
+        __syncthreads();
+        mil_load_halo<T, CINP>(ldsX, a.x, g, o, tid, 256);
+        mil_load_otile<T, COUTP>(ldsZ, a.dz, g, o, tid, 256, a.tile_px);
+        __syncthreads();
+        if constexpr (T::DT == MIL_DT_BF16) {
+            const int q4 = (lane & 15) >> 2, p = lane & 3, gq = lane >> 4;
+            bf16x8_t ones;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+            for (int k32 = 0; k32 < a.tile_px; k32 += 32) {
+                const int tp0 = k32 + 8 * gq + q4, tp1 = tp0 + 4;
+                const int pb0 = mil_pix_base<PIXB>(g, tp0, g.stride);
+                const int pb1 = mil_pix_base<PIXB>(g, tp1, g.stride);
+                const char* z0 = ldsZ + tp0 * PIXZ + p * 8;
+                const char* z1 = ldsZ + tp1 * PIXZ + p * 8;
+                bf16x8_t bf[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bf[nt] = tr_pair(z0 + nt * 32, z1 + nt * 32);
+#pragma unroll
+                for (int i = 0; i < MW; ++i) {
+                    if (mvalid[i]) {             // wave-uniform
+                        const bf16x8_t af = tr_pair(ldsX + pb0 + toff[i], ldsX + pb1 + toff[i]);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[nt], acc[i][nt], 0, 0, 0);
+                    }
+                }
+                if (bias_wave) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        accb[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bf[nt], accb[nt], 0, 0, 0);
+                }
+            }
+        } else {
+            const int gq = lane >> 4, col = lane & 15;
+            for (int k4 = 0; k4 < a.tile_px; k4 += 4) {
+                const int tp = k4 + gq;
+                const int pb = mil_pix_base<PIXB>(g, tp, g.stride);
+                float bf[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    bf[nt] = *reinterpret_cast<const float*>(ldsZ + tp * PIXZ + (nt * 16 + col) * 4);
+#pragma unroll
+                for (int i = 0; i < MW; ++i) {
+                    if (mvalid[i]) {
+                        const float af = *reinterpret_cast<const float*>(ldsX + pb + toff[i]);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[nt], acc[i][nt], 0, 0, 0);
+                    }
+                }
+                if (bias_wave) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        accb[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bf[nt], accb[nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // one slab per workgroup column; row = (tap*CINP + ci), col = co; bias sums live in tile MT
+    constexpr int SLAB_COLS = NT * 16;
+    constexpr size_t SLAB_ELEMS = (size_t)(MT + 1) * 16 * SLAB_COLS;
+    float* slab = a.slab + (size_t)blockIdx.x * SLAB_ELEMS;
+    const int gq = lane >> 4, col = lane & 15;
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+        if (!mvalid[i]) continue;
+        const int mt = split * MT_S + wave + 4 * i;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                slab[(size_t)(mt * 16 + gq * 4 + e) * SLAB_COLS + nt * 16 + col] = acc[i][nt][e];
+    }
+    if (bias_wave) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                slab[(size_t)(MT * 16 + gq * 4 + e) * SLAB_COLS + nt * 16 + col] = accb[nt][e];
+    }
+}
+
+// Sum the per-workgroup slabs in fixed order and scatter into the reference weight layout
+// [Cout][Cin][k][k] (fp32).  stem_mode maps the 4x4 space-to-depth taps back onto the 7x7 filter.
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, size_t slab_elems, int slab_cols,
+                                    float* __restrict__ dw, float* __restrict__ db, int cout, int cin, int ks,
+                                    int cinp, int stem_mode, int bias_row) {
+    const int kk = ks * ks;
+    const int total = cin * kk * cout;
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total) {
+        const int co = idx % cout;
+        const int rem = idx / cout;
+        const int ci = rem % cin;
+        const int tap = rem / cin;
+        const int ky = tap / ks, kx = tap - ky * ks;
+        int row;
+        if (stem_mode) {
+            const int ty = (ky + 1) >> 1, dy = (ky + 1) & 1, tx = (kx + 1) >> 1, dx = (kx + 1) & 1;
+            row = (ty * 4 + tx) * cinp + ci * 4 + dy * 2 + dx;
+        } else {
+            row = tap * cinp + ci;
+        }
+        const float* p = slab + (size_t)row * slab_cols + co;
+        float s = 0.f;
+        for (int i = 0; i < nslab; ++i) s += p[(size_t)i * slab_elems];
+        dw[((size_t)co * cin + ci) * kk + tap] = s;
+    } else if (db && idx < total + cout) {
+        const int co = idx - total;
+        const float* p = slab + (size_t)bias_row * slab_cols + co;
+        float s = 0.f;
+        for (int i = 0; i < nslab; ++i) s += p[(size_t)i * slab_elems];
+        db[co] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct WgradPlan { int grid_x; int msplit; size_t slab_elems; int slab_cols; int mt; int lds; int tile_px_log2; };
+
+template <typename T, int KS, int CINP, int NT, int MSPLIT>
+static int plan_wgrad(ConvGeom& g, WgradPlan& pl, int* lds_z_off) {
+    constexpr int ESZ = T::ESZ;
+    constexpr int PIXB = mil_pix_pitch(CINP, ESZ);
+    constexpr int PIXZ = mil_pix_pitch(mil_nt_to_cp(NT), ESZ);
+    constexpr int RG = KS * KS * (CINP / 8);
+    constexpr int MT = (RG + 1) / 2;
+    // 256-px tiles when the halo fits comfortably, else 64-px tiles (stride-2 layers, f32 wide layers)
+    for (int lg = 8; lg >= 6; lg -= 2) {
+        mil_geom_tiles(g, lg);
+        const int xb = ((((g.hh * g.hw) << g.ti_log2) * PIXB) + 15) & ~15;
+        const int zb = (1 << lg) * PIXZ;
+        if (xb + zb <= 150 * 1024 || lg == 6) {
+            if (xb + zb > 160 * 1024) return MIL_ERR_UNSUPPORTED;
+            pl.lds = xb + zb; *lds_z_off = xb; pl.tile_px_log2 = lg;
+            break;
+        }
+    }
+    pl.msplit = MSPLIT; pl.mt = MT; pl.slab_cols = NT * 16;
+    pl.slab_elems = (size_t)(MT + 1) * 16 * NT * 16;
+    const int ntiles = g.n_groups * g.tiles_y * g.tiles_x;
+    int gx = 512 / MSPLIT;
+    if (gx > ntiles) gx = ntiles;
+    if (gx < 1) gx = 1;
+    pl.grid_x = gx;
+    return MIL_OK;
+}
+
+template <typename T, int KS, int CINP, int NT, int MSPLIT>
+static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* ws, size_t ws_bytes, ConvGeom g,
+                     int cout, int cin, int stem_mode, bool query, size_t* need, hipStream_t stream) {
+    WgradPlan pl{};
+    int lds_z_off = 0;
+    int rc = plan_wgrad<T, KS, CINP, NT, MSPLIT>(g, pl, &lds_z_off);
+    if (rc != MIL_OK) return rc;
+    const size_t bytes = pl.slab_elems * pl.grid_x * sizeof(float);
+    if (query) { *need = bytes; return MIL_OK; }
+    if (ws_bytes < bytes || !ws) return MIL_ERR_ARG;
+    WgradArgs<T> a{};
+    a.x = (const typename T::elem*)x; a.dz = (const typename T::elem*)dz; a.slab = (float*)ws; a.g = g;
+    a.ntiles = g.n_groups * g.tiles_y * g.tiles_x; a.tile_px = 1 << pl.tile_px_log2; a.lds_z_off = lds_z_off;
+    auto kern = wgrad_kernel<T, KS, CINP, NT, MSPLIT>;
+    if (pl.lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds) != hipSuccess)
+            return MIL_ERR_LAUNCH;
+    }
+    if (MSPLIT > 1) {
+        // every (row tile) is written by exactly one split; nothing to clear
+    }
+    hipLaunchKernelGGL(kern, dim3(pl.grid_x, MSPLIT), dim3(256), pl.lds, stream, a);
+    MIL_CHECK_LAUNCH();
+    const int ks_master = stem_mode ? 7 : KS;
+    const int total = cin * ks_master * ks_master * cout + (db ? cout : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, (const float*)ws, pl.grid_x,
+                       pl.slab_elems, pl.slab_cols, dw, db, cout, cin, ks_master, CINP, stem_mode, pl.mt * 16);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+template <typename T>
+static int dispatch_wgrad(const void* x, const void* dz, float* dw, float* db, void* ws, size_t ws_bytes,
+                          const ConvGeom& g, int cout, int cin, int stem_mode, bool query, size_t* need,
+                          hipStream_t st) {
+    const int cinp = stem_mode ? 16 : mil_cpad(cin), coutp = mil_cpad(cout);
+#define MIL_WG(KSV, CI, NTV, MS) return run_wgrad<T, KSV, CI, NTV, MS>(x, dz, dw, db, ws, ws_bytes, g, cout, cin, stem_mode, query, need, st)
+    if (g.ks == 4 && cinp == 16 && coutp == 24) MIL_WG(4, 16, 2, 1);
+    if (g.ks == 3) {
+        if (cinp == 24 && coutp == 24) MIL_WG(3, 24, 2, 1);
+        if (cinp == 40 && coutp == 40) MIL_WG(3, 40, 3, 1);
+        if (cinp == 64 && coutp == 64) MIL_WG(3, 64, 4, 1);
+        if (cinp == 80 && coutp == 80) MIL_WG(3, 80, 5, 2);
+        if (cinp == 24 && coutp == 40) MIL_WG(3, 24, 3, 1);
+        if (cinp == 40 && coutp == 64) MIL_WG(3, 40, 4, 1);
+        if (cinp == 64 && coutp == 80) MIL_WG(3, 64, 5, 2);
+    }
+    if (g.ks == 1) {
+        if (cinp == 24 && coutp == 40) MIL_WG(1, 24, 3, 1);
+        if (cinp == 40 && coutp == 64) MIL_WG(1, 40, 4, 1);
+        if (cinp == 64 && coutp == 80) MIL_WG(1, 64, 5, 1);
+    }
+#undef MIL_WG
+    return MIL_ERR_UNSUPPORTED;
+}
+
+static int wgrad_entry(const void* x, const void* dz, float* dw, float* db, void* ws, size_t ws_bytes, int n_img,
+                       int H, int W, int cin, int Ho, int Wo, int cout, int ks, int stride, int pad, int stem_mode,
+                       int dtype, bool query, size_t* need, void* stream) {
+    if (n_img < 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return MIL_ERR_ARG;
+    ConvGeom g{};
+    g.n_img = n_img; g.H = H; g.W = W; g.Ho = Ho; g.Wo = Wo; g.ks = ks; g.stride = stride; g.pad = pad; g.zins = 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIL_DT_BF16) return dispatch_wgrad<BF16>(x, dz, dw, db, ws, ws_bytes, g, cout, cin, stem_mode, query, need, st);
+    if (dtype == MIL_DT_F32) return dispatch_wgrad<F32>(x, dz, dw, db, ws, ws_bytes, g, cout, cin, stem_mode, query, need, st);
+    return MIL_ERR_ARG;
+}
+
+extern "C" int mil_conv_wgrad_workspace(size_t* bytes, int n_img, int H, int W, int cin, int Ho, int Wo, int cout,
+                                        int ks, int stride, int pad, int stem_mode, int dtype) {
+    if (!bytes) return MIL_ERR_ARG;
+    return wgrad_entry(nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_img, H, W, cin, Ho, Wo, cout, ks, stride, pad,
+                       stem_mode, dtype, true, bytes, nullptr);
+}
+
+extern "C" int mil_conv_wgrad(const void* x, const void* dz, float* dw, float* db, void* workspace,
+                              size_t workspace_bytes, int n_img, int H, int W, int cin, int Ho, int Wo, int cout,
+                              int ks, int stride, int pad, int stem_mode, int dtype, void* stream) {
+    if (!x || !dz || !dw) return MIL_ERR_ARG;
+    size_t need = 0;
+    return wgrad_entry(x, dz, dw, db, workspace, workspace_bytes, n_img, H, W, cin, Ho, Wo, cout, ks, stride, pad,
+                       stem_mode, dtype, false, &need, stream);
+}

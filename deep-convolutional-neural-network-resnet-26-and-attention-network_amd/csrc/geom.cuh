@@ -1,0 +1,113 @@
+// Tile geometry + LDS tile loaders shared by the implicit-GEMM conv (fwd/dgrad) and wgrad kernels.
+#pragma once
+#include "common.cuh"
+
+// A workgroup owns TI images x TH rows x TW cols of OUTPUT pixels (power-of-two extents).
+struct ConvGeom {
+    int n_img;          // images in the launch
+    int H, W;           // spatial dims of the tensor the halo loader reads
+    int Ho, Wo;         // output-space dims (conv output; for wgrad: dims of dz)
+    int ks;             // filter extent (1, 3, or 4 for the space-to-depth stem)
+    int stride;         // 1 or 2 (forward stride; the zero-insert loader implies an effective stride of 1)
+    int pad;            // leading pad (1 for 3x3, 0 for 1x1, 2 for the 4x4 s2d stem)
+    int zins;           // 1: read the input as if zeros were inserted between its pixels (transposed stride-2)
+    int tw_log2, th_log2, ti_log2;
+    int tiles_x, tiles_y, n_groups;
+    int hh, hw;         // halo tile extent in input pixels
+};
+
+__host__ inline void mil_geom_tiles(ConvGeom& g, int tile_px_log2) {
+    // choose TW x TH x TI = 2^tile_px_log2 output pixels
+    int tw, th;
+    if (tile_px_log2 == 8) {          // 256 px
+        if (g.Wo > 8 || g.Ho > 8) { tw = 4; th = 4; }
+        else if (g.Wo > 4 || g.Ho > 4) { tw = 3; th = 3; }
+        else { tw = 2; th = 2; }
+    } else {                           // 64 px
+        if (g.Wo > 4 || g.Ho > 4) { tw = 3; th = 3; }
+        else { tw = 2; th = 2; }
+    }
+    g.tw_log2 = tw; g.th_log2 = th; g.ti_log2 = tile_px_log2 - tw - th;
+    g.tiles_x = (g.Wo + (1 << tw) - 1) >> tw;
+    g.tiles_y = (g.Ho + (1 << th) - 1) >> th;
+    g.n_groups = (g.n_img + (1 << g.ti_log2) - 1) >> g.ti_log2;
+    int s = g.zins ? 1 : g.stride;
+    g.hh = ((1 << th) - 1) * s + g.ks;
+    g.hw = ((1 << tw) - 1) * s + g.ks;
+}
+
+struct TileOrigin { int img0, oy0, ox0; };
+
+__device__ __forceinline__ TileOrigin mil_tile_origin(const ConvGeom& g, int tile) {
+    TileOrigin o;
+    int tx = tile % g.tiles_x; tile /= g.tiles_x;
+    int ty = tile % g.tiles_y; int grp = tile / g.tiles_y;
+    o.img0 = grp << g.ti_log2; o.oy0 = ty << g.th_log2; o.ox0 = tx << g.tw_log2;
+    return o;
+}
+
+// Input halo tile -> LDS, [ti][hy][hx] pixels of CINP channels at pitch PIXB; out-of-image pixels are
+// zero (the conv's zero padding).  One wave per halo row: a row's pixels are contiguous in NHWC memory.
+template <typename T, int CINP>
+__device__ __forceinline__ void mil_load_halo(char* lds, const typename T::elem* __restrict__ x,
+                                              const ConvGeom& g, const TileOrigin& o, int tid, int nthreads) {
+    constexpr int ESZ = T::ESZ;
+    constexpr int PIXB = mil_pix_pitch(CINP, ESZ);
+    constexpr int N16 = CINP * ESZ / 16;
+    const int wave = tid >> 6, lane = tid & 63, nwaves = nthreads >> 6;
+    const int s = g.zins ? 1 : g.stride;
+    const int iy0 = o.oy0 * s - g.pad, ix0 = o.ox0 * s - g.pad;
+    const int rows = g.hh << g.ti_log2;
+    const int ppr = g.hw * N16;
+    for (int row = wave; row < rows; row += nwaves) {
+        const int ti = row / g.hh, hy = row - ti * g.hh;
+        const int img = o.img0 + ti;
+        int iy = iy0 + hy;
+        bool row_ok = img < g.n_img && iy >= 0;
+        if (g.zins) { row_ok = row_ok && !(iy & 1); iy >>= 1; }
+        row_ok = row_ok && iy < g.H;
+        const char* src_row = reinterpret_cast<const char*>(x) + ((size_t)img * g.H + iy) * g.W * (CINP * ESZ);
+        char* dst_row = lds + (size_t)row * g.hw * PIXB;
+        for (int piece = lane; piece < ppr; piece += 64) {
+            const int hx = piece / N16, j = piece - hx * N16;
+            int ix = ix0 + hx;
+            bool ok = row_ok && ix >= 0;
+            if (g.zins) { ok = ok && !(ix & 1); ix >>= 1; }
+            ok = ok && ix < g.W;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (ok) v = *reinterpret_cast<const uint4*>(src_row + (size_t)ix * (CINP * ESZ) + j * 16);
+            *reinterpret_cast<uint4*>(dst_row + hx * PIXB + j * 16) = v;
+        }
+    }
+}
+
+// Output-space tile (no halo) -> LDS, [tile pixel][CP] at pitch PIXZ; pixels outside the image are zero.
+template <typename T, int CP>
+__device__ __forceinline__ void mil_load_otile(char* lds, const typename T::elem* __restrict__ z,
+                                               const ConvGeom& g, const TileOrigin& o, int tid, int nthreads,
+                                               int tile_px) {
+    constexpr int ESZ = T::ESZ;
+    constexpr int PIXZ = mil_pix_pitch(CP, ESZ);
+    constexpr int N16 = CP * ESZ / 16;
+    const int tw_mask = (1 << g.tw_log2) - 1, th_mask = (1 << g.th_log2) - 1;
+    for (int idx = tid; idx < tile_px * N16; idx += nthreads) {
+        const int tp = idx / N16, j = idx - tp * N16;
+        const int ox = o.ox0 + (tp & tw_mask);
+        const int oy = o.oy0 + ((tp >> g.tw_log2) & th_mask);
+        const int img = o.img0 + (tp >> (g.tw_log2 + g.th_log2));
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (img < g.n_img && oy < g.Ho && ox < g.Wo)
+            v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(z) +
+                    (((size_t)img * g.Ho + oy) * g.Wo + ox) * (CP * ESZ) + j * 16);
+        *reinterpret_cast<uint4*>(lds + tp * PIXZ + j * 16) = v;
+    }
+}
+
+// Byte offset of tile pixel tp's (top-left tap) position inside the halo tile.
+template <int PIXB>
+__device__ __forceinline__ int mil_pix_base(const ConvGeom& g, int tp, int s_eff) {
+    const int tx = tp & ((1 << g.tw_log2) - 1);
+    const int ty = (tp >> g.tw_log2) & ((1 << g.th_log2) - 1);
+    const int ti = tp >> (g.tw_log2 + g.th_log2);
+    return ((ti * g.hh + ty * s_eff) * g.hw + tx * s_eff) * PIXB;
+}

@@ -1,0 +1,470 @@
+// Attention-MIL head, forward + backward, fp32, segmented over the bags of a batch.
+// Reference arithmetic: gbm/model.py:198-246 (`Attention.forward` after the backbone),
+// gbm/model.py:108-111 (`ContextLayer`), nnBlocks.py:71-85,121-134 (label-smoothed soft-target CE).
+//
+//   per bag b with instances n in [off[b], off[b+1]):
+//     Hz  = gamma*(H-mean_n)/sqrt(var_n+eps)+beta          (batch statistics over the bag's instances)
+//     Hm  = lrelu(H) * keep/(1-p)                          (keep == null  <=>  eval)
+//     A   = W2 tanh(W1 Hz + b1) + b2 ;  Am = sig(-10w)*softplus(A) + sig(10w) ;  A1 = Am / sum_n|Am|
+//     B   = Wc lrelu(Wl Hm + bl) + bc ;  M = A1^T B ;  loss = sum_y t_y cw_y (lse(M) - M_y)
+//
+// All reductions over instances are per bag (never across bags), in fixed order (deterministic).
+#include "common.cuh"
+
+#define HL 80
+#define HD 40
+#define HK 3
+
+struct HeadWeights {
+    const float *bn_w, *bn_b, *a_w1, *a_b1, *a_w2, *a_b2, *b_w1, *b_b1, *b_wc, *b_bc, *wmask;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    // 256-thread block reduction, result broadcast to every thread
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// K1: per-bag column statistics.  stats[b] = { mu[80], rstd[80] }, kld[b] = 0.5*mean(H^2)
+__global__ __launch_bounds__(256) void head_colstats_kernel(const float* __restrict__ H, const int* __restrict__ off,
+                                                            float* __restrict__ stats, float* __restrict__ kld, float eps) {
+    __shared__ float part[3][HL];
+    __shared__ float mu_s[HL];
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n0 = off[b], n1 = off[b + 1], N = n1 - n0;
+    const int i = tid % HL, p = tid / HL;
+    float s = 0.f, sq = 0.f;
+    if (p < 3) for (int n = n0 + p; n < n1; n += 3) { const float v = H[(size_t)n * HL + i]; s += v; sq += v * v; }
+    if (p < 3) part[p][i] = s;
+    const float sq_tot = block_sum(p < 3 ? sq : 0.f, red);
+    __syncthreads();
+    if (tid < HL) mu_s[tid] = (part[0][tid] + part[1][tid] + part[2][tid]) / (float)N;
+    __syncthreads();
+    float v2 = 0.f;
+    if (p < 3) { const float m = mu_s[i]; for (int n = n0 + p; n < n1; n += 3) { const float d = H[(size_t)n * HL + i] - m; v2 += d * d; } }
+    __syncthreads();
+    if (p < 3) part[p][i] = v2;
+    __syncthreads();
+    if (tid < HL) {
+        const float var = (part[0][tid] + part[1][tid] + part[2][tid]) / (float)N;
+        stats[(size_t)b * 2 * HL + tid] = mu_s[tid];
+        stats[(size_t)b * 2 * HL + HL + tid] = 1.f / sqrtf(var + eps);
+    }
+    if (tid == 0) kld[b] = 0.5f * sq_tot / ((float)N * HL);
+}
+
+// K2: per-instance forward of both MLPs.  Saves t=tanh(u) [n,40], v (buffer pre-activation) [n,40],
+// A_raw [n,3], B [n].
+__global__ __launch_bounds__(128) void head_inst_fwd_kernel(const float* __restrict__ H, const int* __restrict__ inst_bag,
+                                                            const float* __restrict__ stats, const uint8_t* __restrict__ keep,
+                                                            HeadWeights w, float* __restrict__ t_out, float* __restrict__ v_out,
+                                                            float* __restrict__ araw, float* __restrict__ bterm, int ntot,
+                                                            float slope, float keep_scale) {
+    __shared__ float w1[HD * HL], wl[HD * HL];
+    __shared__ float b1[HD], bl[HD], w2[HK * HD], wc[HD], gam[HL], bet[HL];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < HD * HL; i += 128) { w1[i] = w.a_w1[i]; wl[i] = w.b_w1[i]; }
+    for (int i = tid; i < HK * HD; i += 128) w2[i] = w.a_w2[i];
+    if (tid < HD) { b1[tid] = w.a_b1[tid]; bl[tid] = w.b_b1[tid]; wc[tid] = w.b_wc[tid]; }
+    if (tid < HL) { gam[tid] = w.bn_w[tid]; bet[tid] = w.bn_b[tid]; }
+    __syncthreads();
+    const int n = blockIdx.x * 128 + tid;
+    if (n >= ntot) return;
+    const int b = inst_bag[n];
+    const float* st = stats + (size_t)b * 2 * HL;
+    float h[HL], z[HL];
+#pragma unroll
+    for (int i = 0; i < HL; i += 4) {
+        const f32x4_t q = *reinterpret_cast<const f32x4_t*>(H + (size_t)n * HL + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[i + j] = q[j];
+    }
+#pragma unroll
+    for (int i = 0; i < HL; ++i) z[i] = gam[i] * ((h[i] - st[i]) * st[HL + i]) + bet[i];
+    float a[HK];
+#pragma unroll
+    for (int k = 0; k < HK; ++k) a[k] = w.a_b2[k];
+    for (int j = 0; j < HD; ++j) {
+        float u = b1[j];
+#pragma unroll
+        for (int i = 0; i < HL; ++i) u += w1[j * HL + i] * z[i];
+        const float t = tanhf(u);
+        t_out[(size_t)n * HD + j] = t;
+#pragma unroll
+        for (int k = 0; k < HK; ++k) a[k] += w2[k * HD + j] * t;
+    }
+#pragma unroll
+    for (int k = 0; k < HK; ++k) araw[(size_t)n * HK + k] = a[k];
+    // buffer branch: Hm = dropout(lrelu(H))
+#pragma unroll
+    for (int i = 0; i < HL; ++i) {
+        float m = lrelu(h[i], slope);
+        if (keep) m = keep[(size_t)n * HL + i] ? m * keep_scale : 0.f;
+        z[i] = m;
+    }
+    float bsum = w.b_bc[0];
+    for (int j = 0; j < HD; ++j) {
+        float v = bl[j];
+#pragma unroll
+        for (int i = 0; i < HL; ++i) v += wl[j * HL + i] * z[i];
+        v_out[(size_t)n * HD + j] = v;
+        bsum += wc[j] * lrelu(v, slope);
+    }
+    bterm[n] = bsum;
+}
+
+// Per-bag scalar record written by K3 and read back by the host wrapper / backward kernels.
+//   [0..2] Mterm  [3..5] y_pred  [6] loss  [7] error  [8] Aterm_mu  [9] Aterm_var  [10..12] D (L1 norms)
+//   [13..15] dloss/dM (for unit upstream grad)  [16] y_hat (as float)  [17] l2 (bag 0 only)
+#define HREC 24
+
+__global__ __launch_bounds__(256) void head_bag_fwd_kernel(const float* __restrict__ araw, const float* __restrict__ bterm,
+                                                           const int* __restrict__ off, const int64_t* __restrict__ label,
+                                                           const float* __restrict__ cw, HeadWeights w, float smoothing,
+                                                           float* __restrict__ a1, float* __restrict__ wrois,
+                                                           float* __restrict__ rec) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n0 = off[b], n1 = off[b + 1], N = n1 - n0;
+    float s0[HK], s1[HK];
+#pragma unroll
+    for (int k = 0; k < HK; ++k) { s0[k] = sigmoidf_(-10.f * w.wmask[k]); s1[k] = sigmoidf_(10.f * w.wmask[k]); }
+    float S[HK] = {0.f, 0.f, 0.f}, sa[HK] = {0.f, 0.f, 0.f}, cr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int n = n0 + tid; n < n1; n += 256) {
+        float a[HK];
+#pragma unroll
+        for (int k = 0; k < HK; ++k) { a[k] = araw[(size_t)n * HK + k]; S[k] += fabsf(s0[k] * softplusf_(a[k]) + s1[k]); sa[k] += a[k]; }
+        cr[0] += a[0] * a[0]; cr[1] += a[0] * a[1]; cr[2] += a[0] * a[2];
+        cr[3] += a[1] * a[1]; cr[4] += a[1] * a[2]; cr[5] += a[2] * a[2];
+    }
+#pragma unroll
+    for (int k = 0; k < HK; ++k) { S[k] = block_sum(S[k], red); sa[k] = block_sum(sa[k], red); }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cr[k] = block_sum(cr[k], red);
+    float D[HK], M[HK] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < HK; ++k) D[k] = fmaxf(S[k], 1e-12f);
+    for (int n = n0 + tid; n < n1; n += 256) {
+        const float bv = bterm[n];
+#pragma unroll
+        for (int k = 0; k < HK; ++k) {
+            const float v = (s0[k] * softplusf_(araw[(size_t)n * HK + k]) + s1[k]) / D[k];
+            a1[(size_t)n * HK + k] = v;
+            wrois[(size_t)3 * n0 + (size_t)k * N + (n - n0)] = v * bv;
+            M[k] += v * bv;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < HK; ++k) M[k] = block_sum(M[k], red);
+    float l2 = 0.f;
+    if (b == 0) {
+        float q1 = 0.f, q2 = 0.f;
+        for (int i = tid; i < HD * HL; i += 256) { const float v = w.b_w1[i]; q1 += v * v; }
+        if (tid < HD) { const float v = w.b_wc[tid]; q2 = v * v; }
+        q1 = block_sum(q1, red); q2 = block_sum(q2, red);
+        l2 = 0.5f * (sqrtf(q1) + sqrtf(q2));
+    }
+    if (tid == 0) {
+        float* r = rec + (size_t)b * HREC;
+        const float mx = fmaxf(M[0], fmaxf(M[1], M[2]));
+        float e[HK], se = 0.f;
+#pragma unroll
+        for (int k = 0; k < HK; ++k) { e[k] = expf(M[k] - mx); se += e[k]; }
+        const float lse = mx + logf(se);
+        int yh = 0; float best = e[0];
+#pragma unroll
+        for (int k = 1; k < HK; ++k) if (e[k] > best) { best = e[k]; yh = k; }
+        const int y = (int)label[b];
+        float loss = 0.f, tw = 0.f, tk[HK];
+#pragma unroll
+        for (int k = 0; k < HK; ++k) {
+            const float t = (k == y) ? 1.f - smoothing : smoothing / (HK - 1);
+            tk[k] = t * (cw ? cw[k] : 1.f);
+            tw += tk[k];
+            loss += tk[k] * (lse - M[k]);
+        }
+        const float nrm[HK] = {fmaxf(sqrtf(cr[0]), 1e-12f), fmaxf(sqrtf(cr[3]), 1e-12f), fmaxf(sqrtf(cr[5]), 1e-12f)};
+        const float avar = 2.f * (cr[1] / (nrm[0] * nrm[1]) + cr[2] / (nrm[0] * nrm[2]) + cr[4] / (nrm[1] * nrm[2])) / 9.f;
+        float amu = 0.f;
+#pragma unroll
+        for (int k = 0; k < HK; ++k) { const float m = sa[k] / (float)N; amu += m * m; }
+#pragma unroll
+        for (int k = 0; k < HK; ++k) {
+            r[k] = M[k]; r[3 + k] = e[k] / se; r[10 + k] = D[k];
+            r[13 + k] = tw * (e[k] / se) - tk[k];
+        }
+        r[6] = loss; r[7] = (yh == y) ? 0.f : 1.f; r[8] = 0.5f * amu; r[9] = avar; r[16] = (float)yh;
+        if (b == 0) r[17] = l2;
+    }
+}
+
+// K4: per-instance backward.  Writes dA_raw-derived quantities for the weight-gradient pass and the
+// buffer-branch part of dH; the BN-branch part is finished by K6.
+__global__ __launch_bounds__(128) void head_inst_bwd_kernel(const float* __restrict__ H, const int* __restrict__ inst_bag,
+                                                            const uint8_t* __restrict__ keep, HeadWeights w,
+                                                            const float* __restrict__ t_in, const float* __restrict__ v_in,
+                                                            const float* __restrict__ araw, const float* __restrict__ bterm,
+                                                            const float* __restrict__ rec, const float* __restrict__ gloss,
+                                                            float* __restrict__ du_out, float* __restrict__ dv_out,
+                                                            float* __restrict__ da_out, float* __restrict__ dwm_out,
+                                                            float* __restrict__ db_out, float* __restrict__ dhz_out,
+                                                            float* __restrict__ dH, int ntot, float slope, float keep_scale) {
+    __shared__ float w1[HD * HL], wl[HD * HL];
+    __shared__ float w2[HK * HD], wc[HD];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < HD * HL; i += 128) { w1[i] = w.a_w1[i]; wl[i] = w.b_w1[i]; }
+    for (int i = tid; i < HK * HD; i += 128) w2[i] = w.a_w2[i];
+    if (tid < HD) wc[tid] = w.b_wc[tid];
+    __syncthreads();
+    const int n = blockIdx.x * 128 + tid;
+    if (n >= ntot) return;
+    const int b = inst_bag[n];
+    const float* r = rec + (size_t)b * HREC;
+    const float g = gloss[b];
+    const float bv = bterm[n];
+    float da[HK], dB = 0.f;
+#pragma unroll
+    for (int k = 0; k < HK; ++k) {
+        const float wk = w.wmask[k];
+        const float s0 = sigmoidf_(-10.f * wk), s1 = sigmoidf_(10.f * wk);
+        const float a = araw[(size_t)n * HK + k];
+        const float sp = softplusf_(a);
+        const float dM = g * r[13 + k];
+        const float D = r[10 + k];
+        const float a1 = (s0 * sp + s1) / D;
+        dB += dM * a1;
+        const float dam = dM * (bv - r[k]) / D;                 // d loss / d A_mask[n,k]
+        dwm_out[(size_t)n * HK + k] = dam * (sp * (-10.f * s0 * (1.f - s0)) + 10.f * s1 * (1.f - s1));
+        da[k] = dam * s0 * (a > 20.f ? 1.f : sigmoidf_(a));     // softplus'
+        da_out[(size_t)n * HK + k] = da[k];
+    }
+    db_out[n] = dB;
+    float du[HD], dv[HD];
+#pragma unroll
+    for (int j = 0; j < HD; ++j) {
+        const float t = t_in[(size_t)n * HD + j];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < HK; ++k) s += da[k] * w2[k * HD + j];
+        du[j] = s * (1.f - t * t);
+        du_out[(size_t)n * HD + j] = du[j];
+        const float v = v_in[(size_t)n * HD + j];
+        dv[j] = dB * wc[j] * lrelu_grad(v, slope);
+        dv_out[(size_t)n * HD + j] = dv[j];
+    }
+    for (int i = 0; i < HL; ++i) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < HD; ++j) { s1 += du[j] * w1[j * HL + i]; s2 += dv[j] * wl[j * HL + i]; }
+        dhz_out[(size_t)n * HL + i] = s1;
+        const float h = H[(size_t)n * HL + i];
+        float m = s2 * lrelu_grad(h, slope);
+        if (keep) m = keep[(size_t)n * HL + i] ? m * keep_scale : 0.f;
+        dH[(size_t)n * HL + i] = m;
+    }
+}
+
+// K5: parameter gradients, one thread per parameter element, summing over every instance of the
+// batch in index order.  Layout of `grads`: the 11 head tensors back to back (see mil_hip.h).
+#define G_BNW 0
+#define G_BNB (G_BNW + HL)
+#define G_AW1 (G_BNB + HL)
+#define G_AB1 (G_AW1 + HD * HL)
+#define G_AW2 (G_AB1 + HD)
+#define G_AB2 (G_AW2 + HK * HD)
+#define G_BW1 (G_AB2 + HK)
+#define G_BB1 (G_BW1 + HD * HL)
+#define G_BWC (G_BB1 + HD)
+#define G_BBC (G_BWC + HD)
+#define G_WM (G_BBC + 1)
+#define G_TOTAL (G_WM + HK)
+
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ H, const int* __restrict__ inst_bag,
+                                                         const float* __restrict__ stats, const uint8_t* __restrict__ keep,
+                                                         HeadWeights w, const float* __restrict__ t_in, const float* __restrict__ v_in,
+                                                         const float* __restrict__ du, const float* __restrict__ dv,
+                                                         const float* __restrict__ da, const float* __restrict__ dwm,
+                                                         const float* __restrict__ db, const float* __restrict__ dhz,
+                                                         float* __restrict__ grads, int ntot, float slope, float keep_scale) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= G_TOTAL) return;
+    float s = 0.f;
+    if (e < G_AW1) {                      // bn weight / bias
+        const int i = e % HL; const bool is_w = e < G_BNB;
+        for (int n = 0; n < ntot; ++n) {
+            const float* st = stats + (size_t)inst_bag[n] * 2 * HL;
+            const float d = dhz[(size_t)n * HL + i];
+            s += is_w ? d * ((H[(size_t)n * HL + i] - st[i]) * st[HL + i]) : d;
+        }
+    } else if (e < G_AB1) {               // attention.lin1.weight [40,80]
+        const int j = (e - G_AW1) / HL, i = (e - G_AW1) % HL;
+        const float gm = w.bn_w[i], bt = w.bn_b[i];
+        for (int n = 0; n < ntot; ++n) {
+            const float* st = stats + (size_t)inst_bag[n] * 2 * HL;
+            const float z = gm * ((H[(size_t)n * HL + i] - st[i]) * st[HL + i]) + bt;
+            s += du[(size_t)n * HD + j] * z;
+        }
+    } else if (e < G_AW2) {
+        const int j = e - G_AB1;
+        for (int n = 0; n < ntot; ++n) s += du[(size_t)n * HD + j];
+    } else if (e < G_AB2) {               // attention.lin2.weight [3,40]
+        const int k = (e - G_AW2) / HD, j = (e - G_AW2) % HD;
+        for (int n = 0; n < ntot; ++n) s += da[(size_t)n * HK + k] * t_in[(size_t)n * HD + j];
+    } else if (e < G_BW1) {
+        const int k = e - G_AB2;
+        for (int n = 0; n < ntot; ++n) s += da[(size_t)n * HK + k];
+    } else if (e < G_BB1) {               // buffer.lin1.weight [40,80]
+        const int j = (e - G_BW1) / HL, i = (e - G_BW1) % HL;
+        for (int n = 0; n < ntot; ++n) {
+            float m = lrelu(H[(size_t)n * HL + i], slope);
+            if (keep) m = keep[(size_t)n * HL + i] ? m * keep_scale : 0.f;
+            s += dv[(size_t)n * HD + j] * m;
+        }
+    } else if (e < G_BWC) {
+        const int j = e - G_BB1;
+        for (int n = 0; n < ntot; ++n) s += dv[(size_t)n * HD + j];
+    } else if (e < G_BBC) {               // buffer.classifier.weight [1,40]
+        const int j = e - G_BWC;
+        for (int n = 0; n < ntot; ++n) s += db[n] * lrelu(v_in[(size_t)n * HD + j], slope);
+    } else if (e < G_WM) {
+        for (int n = 0; n < ntot; ++n) s += db[n];
+    } else {
+        const int k = e - G_WM;
+        for (int n = 0; n < ntot; ++n) s += dwm[(size_t)n * HK + k];
+    }
+    grads[e] = s;
+}
+
+// l2 = 0.5*(||Wl||_F + ||Wc||_F) contributes gl2 * 0.5 * W/||W|| to the two buffer weights.
+__global__ __launch_bounds__(256) void head_l2_grad_kernel(HeadWeights w, const float* __restrict__ gl2, float* __restrict__ grads) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    float q1 = 0.f, q2 = 0.f;
+    for (int i = tid; i < HD * HL; i += 256) { const float v = w.b_w1[i]; q1 += v * v; }
+    if (tid < HD) { const float v = w.b_wc[tid]; q2 = v * v; }
+    q1 = block_sum(q1, red); q2 = block_sum(q2, red);
+    const float g = gl2[0] * 0.5f;
+    const float n1 = sqrtf(q1), n2 = sqrtf(q2);
+    for (int i = tid; i < HD * HL; i += 256) grads[G_BW1 + i] += (n1 > 0.f) ? g * w.b_w1[i] / n1 : 0.f;
+    if (tid < HD) grads[G_BWC + tid] += (n2 > 0.f) ? g * w.b_wc[tid] / n2 : 0.f;
+}
+
+// K6: finish dH with the batch-norm branch:  dH += rstd/N * (N*dx - sum(dx) - xhat*sum(dx*xhat)), dx = dHz*gamma
+__global__ __launch_bounds__(256) void head_bn_bwd_kernel(const float* __restrict__ H, const int* __restrict__ off,
+                                                          const float* __restrict__ stats, HeadWeights w,
+                                                          const float* __restrict__ dhz, float* __restrict__ dH) {
+    __shared__ float p1[3][HL], p2[3][HL];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n0 = off[b], n1 = off[b + 1], N = n1 - n0;
+    const int i = tid % HL, p = tid / HL;
+    const float* st = stats + (size_t)b * 2 * HL;
+    float s1 = 0.f, s2 = 0.f;
+    if (p < 3) {
+        const float gm = w.bn_w[i], mu = st[i], rs = st[HL + i];
+        for (int n = n0 + p; n < n1; n += 3) {
+            const float dx = dhz[(size_t)n * HL + i] * gm;
+            s1 += dx; s2 += dx * ((H[(size_t)n * HL + i] - mu) * rs);
+        }
+        p1[p][i] = s1; p2[p][i] = s2;
+    }
+    __syncthreads();
+    if (p < 3) {
+        const float gm = w.bn_w[i], mu = st[i], rs = st[HL + i];
+        const float t1 = p1[0][i] + p1[1][i] + p1[2][i], t2 = p2[0][i] + p2[1][i] + p2[2][i];
+        const float invn = 1.f / (float)N;
+        for (int n = n0 + p; n < n1; n += 3) {
+            const float xh = (H[(size_t)n * HL + i] - mu) * rs;
+            const float dx = dhz[(size_t)n * HL + i] * gm;
+            dH[(size_t)n * HL + i] += rs * (dx - invn * t1 - invn * xh * t2);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static HeadWeights make_weights(const float* const* p) {
+    HeadWeights w;
+    w.bn_w = p[0]; w.bn_b = p[1]; w.a_w1 = p[2]; w.a_b1 = p[3]; w.a_w2 = p[4]; w.a_b2 = p[5];
+    w.b_w1 = p[6]; w.b_b1 = p[7]; w.b_wc = p[8]; w.b_bc = p[9]; w.wmask = p[10];
+    return w;
+}
+
+extern "C" int mil_head_workspace_floats(size_t* floats, int ntot, int nbags) {
+    if (!floats || ntot < 0 || nbags < 0) return MIL_ERR_ARG;
+    // stats[nbags*160] t[n*40] v[n*40] araw[n*3] b[n] | du[n*40] dv[n*40] da[n*3] dwm[n*3] db[n] dhz[n*80]
+    *floats = (size_t)nbags * 2 * HL + (size_t)ntot * (HD + HD + HK + 1 + HD + HD + HK + HK + 1 + HL);
+    return MIL_OK;
+}
+
+struct HeadWs { float *stats, *t, *v, *araw, *b, *du, *dv, *da, *dwm, *db, *dhz; };
+static HeadWs carve(float* ws, int ntot, int nbags) {
+    HeadWs h; float* p = ws;
+    h.stats = p; p += (size_t)nbags * 2 * HL;
+    h.t = p; p += (size_t)ntot * HD; h.v = p; p += (size_t)ntot * HD; h.araw = p; p += (size_t)ntot * HK; h.b = p; p += ntot;
+    h.du = p; p += (size_t)ntot * HD; h.dv = p; p += (size_t)ntot * HD; h.da = p; p += (size_t)ntot * HK;
+    h.dwm = p; p += (size_t)ntot * HK; h.db = p; p += ntot; h.dhz = p;
+    return h;
+}
+
+// weights: array of 11 device pointers in the order
+//   context.bn.weight, context.bn.bias, attention.lin1.weight, attention.lin1.bias, attention.lin2.weight,
+//   attention.lin2.bias, buffer.lin1.weight, buffer.lin1.bias, buffer.classifier.weight,
+//   buffer.classifier.bias, weight_mask
+extern "C" int mil_head_fwd(const float* H, const int* bag_offsets, const int* inst_bag, const int64_t* labels,
+                            const uint8_t* keep_mask, const float* class_weights, const float* const* weights,
+                            float* workspace, float* a1, float* wrois, float* bterm, float* kld, float* rec, int ntot,
+                            int nbags, float slope, float drop_p, float smoothing, float bn_eps, void* stream) {
+    if (!H || !bag_offsets || !inst_bag || !labels || !weights || !workspace || !a1 || !wrois || !bterm || !kld || !rec)
+        return MIL_ERR_ARG;
+    if (ntot <= 0 || nbags <= 0) return MIL_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const HeadWeights w = make_weights(weights);
+    HeadWs ws = carve(workspace, ntot, nbags);
+    const float ks = 1.f / (1.f - drop_p);
+    hipLaunchKernelGGL(head_colstats_kernel, dim3(nbags), dim3(256), 0, st, H, bag_offsets, ws.stats, kld, bn_eps);
+    MIL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(head_inst_fwd_kernel, dim3((ntot + 127) / 128), dim3(128), 0, st, H, inst_bag, ws.stats, keep_mask, w,
+                       ws.t, ws.v, ws.araw, bterm, ntot, slope, ks);
+    MIL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(head_bag_fwd_kernel, dim3(nbags), dim3(256), 0, st, ws.araw, bterm, bag_offsets, labels, class_weights, w,
+                       smoothing, a1, wrois, rec);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+// grads: G_TOTAL (=6807) floats, the 11 head tensors' gradients back to back in the `weights` order.
+extern "C" int mil_head_bwd(const float* H, const int* bag_offsets, const int* inst_bag, const uint8_t* keep_mask,
+                            const float* const* weights, float* workspace, const float* bterm, const float* rec,
+                            const float* grad_loss, const float* grad_l2, float* dH, float* grads, int ntot, int nbags,
+                            float slope, float drop_p, void* stream) {
+    if (!H || !bag_offsets || !inst_bag || !weights || !workspace || !bterm || !rec || !grad_loss || !dH || !grads)
+        return MIL_ERR_ARG;
+    if (ntot <= 0 || nbags <= 0) return MIL_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const HeadWeights w = make_weights(weights);
+    HeadWs ws = carve(workspace, ntot, nbags);
+    const float ks = 1.f / (1.f - drop_p);
+    hipLaunchKernelGGL(head_inst_bwd_kernel, dim3((ntot + 127) / 128), dim3(128), 0, st, H, inst_bag, keep_mask, w, ws.t, ws.v,
+                       ws.araw, bterm, rec, grad_loss, ws.du, ws.dv, ws.da, ws.dwm, ws.db, ws.dhz, dH, ntot, slope, ks);
+    MIL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3((G_TOTAL + 255) / 256), dim3(256), 0, st, H, inst_bag, ws.stats, keep_mask, w, ws.t,
+                       ws.v, ws.du, ws.dv, ws.da, ws.dwm, ws.db, ws.dhz, grads, ntot, slope, ks);
+    MIL_CHECK_LAUNCH();
+    if (grad_l2) {
+        hipLaunchKernelGGL(head_l2_grad_kernel, dim3(1), dim3(256), 0, st, w, grad_l2, grads);
+        MIL_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(head_bn_bwd_kernel, dim3(nbags), dim3(256), 0, st, H, bag_offsets, ws.stats, w, ws.dhz, dH);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_head_grad_floats(void) { return G_TOTAL; }
+extern "C" int mil_head_rec_floats(void) { return HREC; }

@@ -1,0 +1,333 @@
+// Bandwidth-bound helpers around the MFMA kernels: input space-to-depth packing, weight packing into
+// MFMA fragment order, max-pool (fwd + bwd fused with the stem's LeakyReLU mask), global average pool
+// + bias-free linear (fwd + bwd).  Reference ops: gbm/model.py:24-26 (stem conv/LeakyReLU/MaxPool2d),
+// gbm/model.py:31-32,58-60 (AdaptiveAvgPool2d + fc).
+#include "common.cuh"
+
+// ---------------------------------------------------------------------------------------------
+// fp32 NCHW [n,3,H,W]  ->  NHWC space-to-depth [n, ceil(H/2), ceil(W/2), 16]; channel = c*4 + dy*2 + dx
+// (12 real channels, 4 zero).  Turns the 7x7 stride-2 stem into a 4x4 stride-1 conv on 16-B pieces.
+template <typename T>
+__global__ void stem_s2d_kernel(const float* __restrict__ x, typename T::elem* __restrict__ out, int n, int H, int W,
+                                int H2, int W2) {
+    const size_t total = (size_t)n * H2 * W2;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int x2 = (int)(idx % W2);
+        const size_t r = idx / W2;
+        const int y2 = (int)(r % H2);
+        const int img = (int)(r / H2);
+        float v0[8], v1[8];
+#pragma unroll
+        for (int ch = 0; ch < 16; ++ch) {
+            float val = 0.f;
+            if (ch < 12) {
+                const int c = ch >> 2, dy = (ch >> 1) & 1, dx = ch & 1;
+                const int iy = 2 * y2 + dy, ix = 2 * x2 + dx;
+                if (iy < H && ix < W) val = x[(((size_t)img * 3 + c) * H + iy) * W + ix];
+            }
+            if (ch < 8) v0[ch] = val; else v1[ch - 8] = val;
+        }
+        store8<T>(out + idx * 16, v0);
+        store8<T>(out + idx * 16 + 8, v1);
+    }
+}
+
+extern "C" int mil_stem_s2d(const float* x_nchw, void* out, int n, int H, int W, int dtype, void* stream) {
+    if (!x_nchw || !out || n < 0 || H <= 0 || W <= 0) return MIL_ERR_ARG;
+    const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+    const size_t total = (size_t)n * H2 * W2;
+    if (total == 0) return MIL_OK;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 65536) grid = 65536;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIL_DT_BF16) hipLaunchKernelGGL(stem_s2d_kernel<BF16>, dim3(grid), dim3(256), 0, st, x_nchw, (__bf16*)out, n, H, W, H2, W2);
+    else if (dtype == MIL_DT_F32) hipLaunchKernelGGL(stem_s2d_kernel<F32>, dim3(grid), dim3(256), 0, st, x_nchw, (float*)out, n, H, W, H2, W2);
+    else return MIL_ERR_ARG;
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 master weights [Cout][Cin][k][k] -> MFMA B-fragment order [kstep][ntile][lane][8].
+//   k-group q = 4*kstep + (lane>>4) = tap*CG + cg; element j is input channel cg*8+j; column = lane&15.
+//   mode 0 (forward):  B[(tap,ci)][co] = W[co][ci][ky][kx]
+//   mode 1 (dgrad):    B[(tap,co)][ci] = W[co][ci][k-1-ky][k-1-kx]   (transposed + flipped)
+//   mode 2 (stem):     7x7 stride-2 filter re-indexed as a 4x4 filter over the 12 space-to-depth channels
+#define MIL_PACK_FWD 0
+#define MIL_PACK_DGRAD 1
+#define MIL_PACK_STEM 2
+
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                    typename T::elem* __restrict__ out, float* __restrict__ bias_pad, int cout, int cin,
+                                    int ks, int mode, int CG, int NT, int nsteps) {
+    const int total = nsteps * NT * 64 * 8;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < NT * 16 && bias_pad) {
+        const int n_out = (mode == MIL_PACK_DGRAD) ? cin : cout;
+        bias_pad[idx] = (bias && idx < n_out) ? bias[idx] : 0.f;
+    }
+    if (idx >= total) return;
+    const int j = idx & 7, lane = (idx >> 3) & 63;
+    const int t = idx >> 9;
+    const int nt = t % NT, s = t / NT;
+    const int q = 4 * s + (lane >> 4);
+    const int tap = q / CG, cg = q - tap * CG;
+    const int kin = cg * 8 + j, nout = nt * 16 + (lane & 15);
+    float val = 0.f;
+    if (mode == MIL_PACK_FWD) {
+        if (tap < ks * ks && kin < cin && nout < cout) val = w[((size_t)nout * cin + kin) * ks * ks + tap];
+    } else if (mode == MIL_PACK_DGRAD) {
+        if (tap < ks * ks && kin < cout && nout < cin) val = w[((size_t)kin * cin + nout) * ks * ks + (ks * ks - 1 - tap)];
+    } else {
+        if (tap < 16 && kin < 12 && nout < cout) {
+            const int c = kin >> 2, dy = (kin >> 1) & 1, dx = kin & 1;
+            const int ky = 2 * (tap >> 2) + dy - 1, kx = 2 * (tap & 3) + dx - 1;
+            if (ky >= 0 && ky < 7 && kx >= 0 && kx < 7) val = w[(((size_t)nout * 3 + c) * 7 + ky) * 7 + kx];
+        }
+    }
+    out[idx] = (typename T::elem)val;
+}
+
+static void pack_dims(int cout, int cin, int ks, int mode, int* CG, int* NT, int* nsteps) {
+    int cin_exec, cout_exec, ks_exec;
+    if (mode == MIL_PACK_STEM) { cin_exec = 16; cout_exec = mil_cpad(cout); ks_exec = 4; }
+    else if (mode == MIL_PACK_DGRAD) { cin_exec = mil_cpad(cout); cout_exec = mil_cpad(cin); ks_exec = ks; }
+    else { cin_exec = mil_cpad(cin); cout_exec = mil_cpad(cout); ks_exec = ks; }
+    *CG = cin_exec / 8;
+    *NT = (cout_exec + 15) / 16;
+    *nsteps = (ks_exec * ks_exec * (*CG) + 3) / 4;
+}
+
+extern "C" int mil_packed_weight_elems(size_t* elems, int cout, int cin, int ks, int mode) {
+    if (!elems || cout <= 0 || cin <= 0) return MIL_ERR_ARG;
+    int CG, NT, nsteps;
+    pack_dims(cout, cin, ks, mode, &CG, &NT, &nsteps);
+    *elems = (size_t)nsteps * NT * 64 * 8;
+    return MIL_OK;
+}
+
+extern "C" int mil_pack_conv_weights(const float* w, const float* bias, void* wpack, float* bias_pad, int cout, int cin,
+                                     int ks, int mode, int dtype, void* stream) {
+    if (!w || !wpack || cout <= 0 || cin <= 0 || mode < 0 || mode > 2) return MIL_ERR_ARG;
+    int CG, NT, nsteps;
+    pack_dims(cout, cin, ks, mode, &CG, &NT, &nsteps);
+    const int total = nsteps * NT * 64 * 8;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIL_DT_BF16)
+        hipLaunchKernelGGL(pack_weights_kernel<BF16>, dim3((total + 255) / 256), dim3(256), 0, st, w, bias, (__bf16*)wpack, bias_pad, cout, cin, ks, mode, CG, NT, nsteps);
+    else if (dtype == MIL_DT_F32)
+        hipLaunchKernelGGL(pack_weights_kernel<F32>, dim3((total + 255) / 256), dim3(256), 0, st, w, bias, (float*)wpack, bias_pad, cout, cin, ks, mode, CG, NT, nsteps);
+    else return MIL_ERR_ARG;
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool2d(kernel 3, stride 2, pad 1), NHWC; -inf padding; first maximum in (ky,kx) scan order wins
+// (torch semantics).  Records the winning tap (0..8) per output element for the backward pass.
+template <typename T>
+__global__ void maxpool_fwd_kernel(const typename T::elem* __restrict__ x, typename T::elem* __restrict__ y,
+                                   uint8_t* __restrict__ widx, int n, int H, int W, int Ho, int Wo, int CP) {
+    const int ng = CP / 8;
+    const size_t total = (size_t)n * Ho * Wo * ng;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(idx % ng);
+        size_t r = idx / ng;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int img = (int)(r / Ho);
+        float best[8];
+        uint8_t bi[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy - 1 + ky;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox - 1 + kx;
+                if (ix < 0 || ix >= W) continue;
+                float v[8];
+                load8<T>(x + (((size_t)img * H + iy) * W + ix) * CP + c8 * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (v[j] > best[j]) { best[j] = v[j]; bi[j] = (uint8_t)(ky * 3 + kx); }
+            }
+        }
+        const size_t o = (((size_t)img * Ho + oy) * Wo + ox) * CP + c8 * 8;
+        store8<T>(y + o, best);
+        uint2 packed;
+        packed.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | ((uint32_t)bi[3] << 24);
+        packed.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | ((uint32_t)bi[7] << 24);
+        *reinterpret_cast<uint2*>(widx + o) = packed;
+    }
+}
+
+// gx[y,x,c] = lrelu'(act[y,x,c]) * sum over the (<=4) pooling windows that contain (y,x) and whose
+// recorded winner is (y,x) of gy[window].  Gather form: no atomics, deterministic.
+template <typename T>
+__global__ void maxpool_bwd_kernel(const typename T::elem* __restrict__ gy, const uint8_t* __restrict__ widx,
+                                   const typename T::elem* __restrict__ act, typename T::elem* __restrict__ gx, int n,
+                                   int H, int W, int Ho, int Wo, int CP, float slope) {
+    const int ng = CP / 8;
+    const size_t total = (size_t)n * H * W * ng;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(idx % ng);
+        size_t r = idx / ng;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const int img = (int)(r / H);
+        float g[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = 0.f;
+        const int oy_lo = y >> 1, oy_hi = (y + 1) >> 1;      // windows with 2*oy-1 <= y <= 2*oy+1
+        const int ox_lo = x >> 1, ox_hi = (x + 1) >> 1;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            if (oy >= Ho) continue;
+            const int ky = y - (2 * oy - 1);
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                if (ox >= Wo) continue;
+                const int kx = x - (2 * ox - 1);
+                const uint32_t me = (uint32_t)(ky * 3 + kx);
+                const size_t o = (((size_t)img * Ho + oy) * Wo + ox) * CP + c8 * 8;
+                const uint2 packed = *reinterpret_cast<const uint2*>(widx + o);
+                float gv[8];
+                load8<T>(gy + o, gv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t w = ((j < 4 ? packed.x : packed.y) >> (8 * (j & 3))) & 0xffu;
+                    if (w == me) g[j] += gv[j];
+                }
+            }
+        }
+        const size_t o = (((size_t)img * H + y) * W + x) * CP + c8 * 8;
+        if (act) {
+            float av[8];
+            load8<T>(act + o, av);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] *= lrelu_grad(av[j], slope);
+        }
+        store8<T>(gx + o, g);
+    }
+}
+
+static int grid_for(size_t total) {
+    size_t g = (total + 255) / 256;
+    return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+
+extern "C" int mil_maxpool_fwd(const void* x, void* y, uint8_t* widx, int n, int H, int W, int cp, int dtype, void* stream) {
+    if (!x || !y || !widx || cp % 8) return MIL_ERR_ARG;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const size_t total = (size_t)n * Ho * Wo * (cp / 8);
+    if (!total) return MIL_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIL_DT_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, st, (const __bf16*)x, (__bf16*)y, widx, n, H, W, Ho, Wo, cp);
+    else if (dtype == MIL_DT_F32) hipLaunchKernelGGL(maxpool_fwd_kernel<F32>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, (float*)y, widx, n, H, W, Ho, Wo, cp);
+    else return MIL_ERR_ARG;
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_maxpool_bwd(const void* gy, const uint8_t* widx, const void* act, void* gx, int n, int H, int W,
+                               int cp, float slope, int dtype, void* stream) {
+    if (!gy || !widx || !gx || cp % 8) return MIL_ERR_ARG;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const size_t total = (size_t)n * H * W * (cp / 8);
+    if (!total) return MIL_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIL_DT_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, st, (const __bf16*)gy, widx, (const __bf16*)act, (__bf16*)gx, n, H, W, Ho, Wo, cp, slope);
+    else if (dtype == MIL_DT_F32) hipLaunchKernelGGL(maxpool_bwd_kernel<F32>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)gy, widx, (const float*)act, (float*)gx, n, H, W, Ho, Wo, cp, slope);
+    else return MIL_ERR_ARG;
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Global average pool over h*w + bias-free linear: feats[t][o] = sum_i mean_p(x[t][p][i]) * Wfc[o][i].
+// One 128-thread workgroup per tile; pooled means are kept (fp32) for the backward pass.
+template <typename T>
+__global__ __launch_bounds__(128) void avgpool_fc_fwd_kernel(const typename T::elem* __restrict__ x,
+                                                             const float* __restrict__ wfc, float* __restrict__ pooled,
+                                                             float* __restrict__ feats, int hw, int CP, int C, int NF) {
+    __shared__ float sp[128];
+    const int t = blockIdx.x, c = threadIdx.x;
+    float s = 0.f;
+    if (c < C) {
+        const typename T::elem* p = x + (size_t)t * hw * CP + c;
+        for (int i = 0; i < hw; ++i) s += (float)p[(size_t)i * CP];
+        s /= (float)hw;
+        pooled[(size_t)t * C + c] = s;
+    }
+    sp[c] = s;
+    __syncthreads();
+    if (c < NF) {
+        float acc = 0.f;
+        for (int i = 0; i < C; ++i) acc += sp[i] * wfc[(size_t)c * C + i];
+        feats[(size_t)t * NF + c] = acc;
+    }
+}
+
+// dz[t][p][c] = lrelu'(act[t][p][c]) * (sum_o dfeats[t][o] * Wfc[o][c]) / hw      (padded channels -> 0)
+template <typename T>
+__global__ __launch_bounds__(128) void avgpool_fc_bwd_kernel(const float* __restrict__ dfeats, const float* __restrict__ wfc,
+                                                             const typename T::elem* __restrict__ act,
+                                                             typename T::elem* __restrict__ dz, int hw, int CP, int C, int NF,
+                                                             float slope) {
+    __shared__ float sd[128];
+    const int t = blockIdx.x, c = threadIdx.x;
+    sd[c] = (c < NF) ? dfeats[(size_t)t * NF + c] : 0.f;
+    __syncthreads();
+    if (c >= CP) return;
+    float g = 0.f;
+    if (c < C) {
+        for (int o = 0; o < NF; ++o) g += sd[o] * wfc[(size_t)o * C + c];
+        g /= (float)hw;
+    }
+    for (int i = 0; i < hw; ++i) {
+        const size_t off = ((size_t)t * hw + i) * CP + c;
+        float v = g;
+        if (act) v *= lrelu_grad((float)act[off], slope);
+        dz[off] = (typename T::elem)v;
+    }
+}
+
+// dWfc[o][i] = sum_t dfeats[t][o] * pooled[t][i]   (fixed summation order)
+__global__ void fc_wgrad_kernel(const float* __restrict__ dfeats, const float* __restrict__ pooled, float* __restrict__ dw,
+                                int n, int C, int NF) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= NF * C) return;
+    const int o = idx / C, i = idx - o * C;
+    float s = 0.f;
+    for (int t = 0; t < n; ++t) s += dfeats[(size_t)t * NF + o] * pooled[(size_t)t * C + i];
+    dw[idx] = s;
+}
+
+extern "C" int mil_avgpool_fc_fwd(const void* x, const float* wfc, float* pooled, float* feats, int n, int hw, int cp,
+                                  int c, int nf, int dtype, void* stream) {
+    if (!x || !wfc || !pooled || !feats || c > 128 || nf > 128 || cp > 128 || hw <= 0) return MIL_ERR_ARG;
+    if (n == 0) return MIL_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIL_DT_BF16) hipLaunchKernelGGL(avgpool_fc_fwd_kernel<BF16>, dim3(n), dim3(128), 0, st, (const __bf16*)x, wfc, pooled, feats, hw, cp, c, nf);
+    else if (dtype == MIL_DT_F32) hipLaunchKernelGGL(avgpool_fc_fwd_kernel<F32>, dim3(n), dim3(128), 0, st, (const float*)x, wfc, pooled, feats, hw, cp, c, nf);
+    else return MIL_ERR_ARG;
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_avgpool_fc_bwd(const float* dfeats, const float* wfc, const float* pooled, const void* act, void* dz,
+                                  float* dwfc, int n, int hw, int cp, int c, int nf, float slope, int dtype, void* stream) {
+    if (!dfeats || !wfc || !pooled || !dz || !dwfc || c > 128 || nf > 128 || cp > 128 || hw <= 0) return MIL_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (n > 0) {
+        if (dtype == MIL_DT_BF16) hipLaunchKernelGGL(avgpool_fc_bwd_kernel<BF16>, dim3(n), dim3(128), 0, st, dfeats, wfc, (const __bf16*)act, (__bf16*)dz, hw, cp, c, nf, slope);
+        else if (dtype == MIL_DT_F32) hipLaunchKernelGGL(avgpool_fc_bwd_kernel<F32>, dim3(n), dim3(128), 0, st, dfeats, wfc, (const float*)act, (float*)dz, hw, cp, c, nf, slope);
+        else return MIL_ERR_ARG;
+        MIL_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(fc_wgrad_kernel, dim3((nf * c + 255) / 256), dim3(256), 0, st, dfeats, pooled, dwfc, n, c, nf);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}

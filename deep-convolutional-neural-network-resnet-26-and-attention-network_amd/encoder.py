@@ -1,0 +1,193 @@
+"""ResNet-26 tile encoder on the HIP kernels: forward and hand-written backward.
+
+Mirrors the reference's `ResNet` (gbm/model.py:14-61) built from `BasicResBlock`
+(nnBlocks.py:157-189) with layers [3,3,3,3] and widths 20/40/60/80 — same module tree, same
+state-dict keys — but `forward` never calls a torch conv: it sequences the C-ABI kernels of
+include/mil_hip.h (NHWC, channel-padded, fp32 or bf16 operands) and a custom autograd Function
+provides the backward (dgrad / wgrad / pooling backward) from saved NHWC activations.
+"""
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import ops
+
+STAGE_WIDTHS = (20, 40, 60, 80)        # gbm/model.py:27-30
+STEM_WIDTH = 20                        # gbm/model.py:20
+
+
+class BasicResBlock(nn.Module):
+    """Parameter container with the reference block's layout (nnBlocks.py:157-173): conv1 (3x3,
+    stride s, bias), conv2 (3x3, bias), optional `downsample` = Sequential(1x1 stride-s conv, no bias).
+    The arithmetic of nnBlocks.py:175-189 is executed by the fused HIP kernels in `encoder_forward`."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64):
+        super().__init__()
+        if groups != 1 or base_width != 64:
+            raise ValueError("BasicBlock only supports groups=1 and base_width=64")
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=True)
+        self.relu = nn.LeakyReLU(ops.LEAK)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=1, padding=1, bias=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        raise RuntimeError("BasicResBlock is executed by the fused HIP encoder (ResNet.forward); "
+                           "it has no stand-alone torch path")
+
+
+class ResNet(nn.Module):
+    """Tile encoder [T,3,H,W] fp32 -> [T,num_classes] fp32 (gbm/model.py:14-61)."""
+
+    def __init__(self, block=BasicResBlock, layers=(3, 3, 3, 3), num_classes=80, zero_init_residual=False,
+                 groups=1, width_per_group=64, compute_dtype=torch.bfloat16):
+        super().__init__()
+        if block is not BasicResBlock or groups != 1 or width_per_group != 64:
+            raise ValueError("the HIP encoder implements BasicResBlock with groups=1, base_width=64")
+        self.inplanes = STEM_WIDTH
+        self.conv1 = nn.Conv2d(3, STEM_WIDTH, kernel_size=7, stride=2, padding=3)
+        self.relu = nn.LeakyReLU(ops.LEAK, inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        for i, (width, depth) in enumerate(zip(STAGE_WIDTHS, layers)):
+            setattr(self, f"layer{i + 1}", self._make_layer(width, depth, stride=1 if i == 0 else 2))
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(STAGE_WIDTHS[-1], num_classes, bias=False)
+        self.compute_dtype = compute_dtype
+        self._pack_cache = {}
+
+    def _make_layer(self, planes, blocks, stride=1):
+        shortcut = None
+        if stride != 1 or self.inplanes != planes:
+            shortcut = nn.Sequential(nn.Conv2d(self.inplanes, planes, kernel_size=1, stride=stride, bias=False))
+        seq = [BasicResBlock(self.inplanes, planes, stride, shortcut)]
+        self.inplanes = planes
+        seq += [BasicResBlock(planes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*seq)
+
+    # ---- execution ---------------------------------------------------------------------------
+    def blocks(self):
+        for i in range(4):
+            for blk in getattr(self, f"layer{i + 1}"):
+                yield blk
+
+    def encoder_params(self):
+        """Flat, ordered parameter list handed to the autograd Function."""
+        ps = [self.conv1.weight, self.conv1.bias]
+        for blk in self.blocks():
+            ps += [blk.conv1.weight, blk.conv1.bias, blk.conv2.weight, blk.conv2.bias]
+            if blk.downsample is not None:
+                ps.append(blk.downsample[0].weight)
+        ps.append(self.fc.weight)
+        return ps
+
+    def _packed(self, key, weight, bias, mode, dtype):
+        """Packed MFMA-fragment copy of a conv weight, rebuilt only when the parameter changed."""
+        tag = (weight._version, weight.data_ptr(), None if bias is None else bias._version, dtype)
+        hit = self._pack_cache.get((key, mode))
+        if hit is None or hit[0] != tag:
+            hit = (tag, ops.pack_weights(weight, bias, mode, dtype))
+            self._pack_cache[(key, mode)] = hit
+        return hit[1]
+
+    def forward(self, x):
+        return _EncoderFn.apply(self, x, *self.encoder_params())
+
+
+def encoder_forward(net, x, dtype):
+    """Runs the kernels; returns (feats [T,80] fp32, saved-state dict for the backward)."""
+    xs = ops.stem_s2d(x, dtype)
+    wp, bp = net._packed("stem", net.conv1.weight, net.conv1.bias, L.PACK_STEM, dtype)
+    stem = ops.conv(xs, wp, bp, ops.cpad(STEM_WIDTH), ks=4, stride=1, pad=2, lrelu=True)
+    pool, widx = ops.maxpool_fwd(stem)
+    saved = {"xs": xs, "stem": stem, "widx": widx, "blocks": []}
+    t = pool
+    for bi, blk in enumerate(net.blocks()):
+        cout = blk.conv1.out_channels
+        s = blk.stride
+        w1, b1 = net._packed(f"b{bi}.c1", blk.conv1.weight, blk.conv1.bias, L.PACK_FWD, dtype)
+        w2, b2 = net._packed(f"b{bi}.c2", blk.conv2.weight, blk.conv2.bias, L.PACK_FWD, dtype)
+        o1 = ops.conv(t, w1, b1, ops.cpad(cout), ks=3, stride=s, pad=1, lrelu=True)
+        if blk.downsample is not None:
+            wd, _ = net._packed(f"b{bi}.ds", blk.downsample[0].weight, None, L.PACK_FWD, dtype)
+            short = ops.conv(t, wd, None, ops.cpad(cout), ks=1, stride=s, pad=0)
+        else:
+            short = t
+        out = ops.conv(o1, w2, b2, ops.cpad(cout), ks=3, stride=1, pad=1, res=short, lrelu=True)
+        saved["blocks"].append((t, o1, out))
+        t = out
+    pooled, feats = ops.avgpool_fc_fwd(t, net.fc.weight.detach(), STAGE_WIDTHS[-1])
+    saved["pooled"] = pooled
+    return feats, saved
+
+
+def encoder_backward(net, saved, dfeats, dtype):
+    """Gradients of every encoder parameter, in `encoder_params()` order (the input is detached in
+    the reference, gbm/model.py:194-196, so no data-gradient is produced for the tiles)."""
+    blocks = list(net.blocks())
+    grads = {}
+    last_out = saved["blocks"][-1][2]
+    dz, dwfc = ops.avgpool_fc_bwd(dfeats.contiguous(), net.fc.weight.detach(), saved["pooled"], last_out,
+                                  STAGE_WIDTHS[-1])
+    ws = None
+
+    def wgrad(xin, dzz, cin, cout, **kw):
+        nonlocal ws
+        n, h, w, _ = xin.shape
+        _, ho, wo, _ = dzz.shape
+        need = ops.wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, kw["ks"], kw["stride"], kw["pad"],
+                                         kw.get("stem", False), xin.dtype)
+        if ws is None or ws.numel() * 4 < need:
+            ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=xin.device)
+        return ops.conv_wgrad(xin, dzz, cin, cout, workspace=ws, **kw)
+
+    for bi in range(len(blocks) - 1, -1, -1):
+        blk = blocks[bi]
+        xin, o1, _out = saved["blocks"][bi]
+        cin, cout, s = blk.conv1.in_channels, blk.conv1.out_channels, blk.stride
+        grads[f"b{bi}.c2"] = wgrad(o1, dz, cout, cout, ks=3, stride=1, pad=1)
+        w2d, _ = net._packed(f"b{bi}.c2", blk.conv2.weight, None, L.PACK_DGRAD, dtype)
+        dz1 = ops.conv(dz, w2d, None, ops.cpad(cout), ks=3, stride=1, pad=1, act=o1)
+        grads[f"b{bi}.c1"] = wgrad(xin, dz1, cin, cout, ks=3, stride=s, pad=1)
+        if blk.downsample is not None:
+            grads[f"b{bi}.ds"] = wgrad(xin, dz, cin, cout, ks=1, stride=s, pad=0, want_bias=False)
+            wdd, _ = net._packed(f"b{bi}.ds", blk.downsample[0].weight, None, L.PACK_DGRAD, dtype)
+            if s == 2:
+                addend = ops.conv(dz, wdd, None, ops.cpad(cin), ks=1, stride=1, pad=0, zero_insert=True,
+                                  out_hw=xin.shape[1:3])
+            else:
+                addend = ops.conv(dz, wdd, None, ops.cpad(cin), ks=1, stride=1, pad=0)
+        else:
+            addend = dz
+        w1d, _ = net._packed(f"b{bi}.c1", blk.conv1.weight, None, L.PACK_DGRAD, dtype)
+        mask = xin if bi > 0 else None          # block 0 reads the max-pool output (no activation in between)
+        if s == 2:
+            dz = ops.conv(dz1, w1d, None, ops.cpad(cin), ks=3, stride=1, pad=1, zero_insert=True,
+                          out_hw=xin.shape[1:3], res=addend, act=mask)
+        else:
+            dz = ops.conv(dz1, w1d, None, ops.cpad(cin), ks=3, stride=1, pad=1, res=addend, act=mask)
+    dstem = ops.maxpool_bwd(dz, saved["widx"], saved["stem"])
+    grads["stem"] = wgrad(saved["xs"], dstem, 3, STEM_WIDTH, ks=4, stride=1, pad=2, stem=True)
+
+    flat = [grads["stem"][0], grads["stem"][1]]
+    for bi, blk in enumerate(blocks):
+        flat += [grads[f"b{bi}.c1"][0], grads[f"b{bi}.c1"][1], grads[f"b{bi}.c2"][0], grads[f"b{bi}.c2"][1]]
+        if blk.downsample is not None:
+            flat.append(grads[f"b{bi}.ds"][0])
+    flat.append(dwfc)
+    return flat
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        dtype = net.compute_dtype
+        feats, saved = encoder_forward(net, x.detach(), dtype)
+        ctx.net, ctx.saved, ctx.dtype = net, saved, dtype
+        return feats
+
+    @staticmethod
+    def backward(ctx, dfeats):
+        grads = encoder_backward(ctx.net, ctx.saved, dfeats, ctx.dtype)
+        ctx.saved = None
+        return (None, None, *grads)

@@ -1,0 +1,106 @@
+"""Attention-MIL head on the HIP kernels (mil_head_fwd / mil_head_bwd of include/mil_hip.h) as a
+torch.autograd.Function.  Reference arithmetic: gbm/model.py:198-246; segmented over bags so that a
+batch of bags is one launch sequence while every reduction over instances stays inside its bag."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+DROP_P = 0.25       # gbm/model.py:107
+SMOOTHING = 0.25    # gbm/model.py:128
+BN_EPS = 1e-5       # BatchNorm1d default, gbm/model.py:105
+N_FEATS = 80
+
+
+class BagLayout:
+    """Device-side description of how the rows of H split into bags."""
+
+    def __init__(self, sizes, device):
+        sizes = [int(s) for s in sizes]
+        if len(sizes) == 0 or min(sizes) < 2:
+            # torch's batch-statistics BatchNorm1d refuses a single instance (gbm/model.py:105)
+            raise ValueError("Expected more than 1 value per channel when training, got input size "
+                             f"torch.Size([{min(sizes) if sizes else 0}, {N_FEATS}])")
+        self.sizes = sizes
+        self.nbags = len(sizes)
+        self.ntot = sum(sizes)
+        offs = [0]
+        for s in sizes:
+            offs.append(offs[-1] + s)
+        self.offsets_host = offs
+        self.offsets = torch.tensor(offs, dtype=torch.int32, device=device)
+        self.inst_bag = torch.repeat_interleave(torch.arange(self.nbags, dtype=torch.int32, device=device),
+                                                torch.tensor(sizes, device=device))
+
+
+def _weight_array(ws):
+    arr = (ctypes.c_void_p * 11)()
+    for i, w in enumerate(ws):
+        if w.dtype != torch.float32 or not w.is_cuda:
+            raise ValueError("head parameters must be CUDA fp32")
+        arr[i] = w.data_ptr()
+    return arr
+
+
+class _HeadFn(torch.autograd.Function):
+    """(H, 11 head parameters) -> (loss [nbags], l2 []) with grad; a1/wrois/bterm/kld/rec without."""
+
+    @staticmethod
+    def forward(ctx, H, layout, labels, keep_mask, class_weights, *weights):
+        lib = L.lib()
+        H = H.contiguous()
+        ws = [w.detach().contiguous() for w in weights]
+        dev = H.device
+        ntot, nbags = layout.ntot, layout.nbags
+        if tuple(H.shape) != (ntot, N_FEATS) or H.dtype != torch.float32:
+            raise ValueError(f"H must be fp32 [{ntot},{N_FEATS}], got {tuple(H.shape)} {H.dtype}")
+        if keep_mask is not None and (tuple(keep_mask.shape) != (ntot, N_FEATS) or keep_mask.dtype != torch.uint8):
+            raise ValueError("keep_mask must be uint8 [N,80]")
+        need = ctypes.c_size_t(0)
+        L.check(lib.mil_head_workspace_floats(ctypes.byref(need), ntot, nbags), "mil_head_workspace_floats")
+        work = torch.empty(need.value, dtype=torch.float32, device=dev)
+        a1 = torch.empty((ntot, 3), dtype=torch.float32, device=dev)
+        wrois = torch.empty(3 * ntot, dtype=torch.float32, device=dev)
+        bterm = torch.empty(ntot, dtype=torch.float32, device=dev)
+        kld = torch.empty(nbags, dtype=torch.float32, device=dev)
+        rec = torch.zeros((nbags, lib.mil_head_rec_floats()), dtype=torch.float32, device=dev)
+        arr = _weight_array(ws)
+        L.check(lib.mil_head_fwd(H.data_ptr(), layout.offsets.data_ptr(), layout.inst_bag.data_ptr(), labels.data_ptr(),
+                                 L.ptr(keep_mask), L.ptr(class_weights), arr, work.data_ptr(), a1.data_ptr(),
+                                 wrois.data_ptr(), bterm.data_ptr(), kld.data_ptr(), rec.data_ptr(), ntot, nbags,
+                                 ops.LEAK, DROP_P, SMOOTHING, BN_EPS, L.stream_ptr()), "mil_head_fwd")
+        ctx.layout, ctx.keep_mask, ctx.ws, ctx.work = layout, keep_mask, ws, work
+        ctx.save_for_backward(H, bterm, rec)
+        loss = rec[:, 6].clone()
+        l2 = rec[0, 17].clone()
+        ctx.mark_non_differentiable(a1, wrois, bterm, kld, rec)
+        return loss, l2, a1, wrois, bterm, kld, rec
+
+    @staticmethod
+    def backward(ctx, g_loss, g_l2, *_unused):
+        lib = L.lib()
+        H, bterm, rec = ctx.saved_tensors
+        layout = ctx.layout
+        dev = H.device
+        if g_loss is None:
+            g_loss = torch.zeros(layout.nbags, dtype=torch.float32, device=dev)
+        g_loss = g_loss.contiguous().float()
+        g_l2 = None if g_l2 is None else g_l2.reshape(1).contiguous().float()
+        dH = torch.empty_like(H)
+        grads = torch.empty(lib.mil_head_grad_floats(), dtype=torch.float32, device=dev)
+        arr = _weight_array(ctx.ws)
+        L.check(lib.mil_head_bwd(H.data_ptr(), layout.offsets.data_ptr(), layout.inst_bag.data_ptr(), L.ptr(ctx.keep_mask),
+                                 arr, ctx.work.data_ptr(), bterm.data_ptr(), rec.data_ptr(), g_loss.data_ptr(),
+                                 L.ptr(g_l2), dH.data_ptr(), grads.data_ptr(), layout.ntot, layout.nbags, ops.LEAK,
+                                 DROP_P, L.stream_ptr()), "mil_head_bwd")
+        out, o = [], 0
+        for w in ctx.ws:
+            out.append(grads[o:o + w.numel()].view(w.shape))
+            o += w.numel()
+        return (dH, None, None, None, None, *out)
+
+
+def head_apply(H, layout, labels, keep_mask, class_weights, weights):
+    return _HeadFn.apply(H, layout, labels, keep_mask, class_weights, *weights)

@@ -1,0 +1,142 @@
+"""Thin tensor-level wrappers over the C ABI (include/mil_hip.h).  Each wrapper checks shapes on the
+host (a wrong extent in a hand-written kernel is a GPU fault, not an exception), allocates outputs with
+torch (plumbing) and enqueues the HIP kernel on torch's current stream."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+LEAK = 0.1   # LeakyReLU slope of the reference (nnBlocks.py:170, gbm/model.py:25)
+
+
+def cpad(c):
+    return (c + 7) // 8 * 8
+
+
+def _need(t, shape, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda or not t.is_contiguous():
+        raise ValueError(f"{name} must be a contiguous CUDA tensor")
+    if tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+        raise ValueError(f"{name}: expected {tuple(shape)} {dtype}, got {tuple(t.shape)} {t.dtype}")
+
+
+def stem_s2d(x, dtype):
+    """[n,3,H,W] fp32 NCHW -> [n,ceil(H/2),ceil(W/2),16] NHWC space-to-depth of `dtype`."""
+    if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or not x.is_cuda:
+        raise ValueError(f"expected a CUDA fp32 [N,3,H,W] tile stack, got {tuple(x.shape)} {x.dtype} on {x.device}")
+    x = x.contiguous()
+    n, _, h, w = x.shape
+    out = torch.empty((n, (h + 1) // 2, (w + 1) // 2, 16), dtype=dtype, device=x.device)
+    L.check(L.lib().mil_stem_s2d(x.data_ptr(), out.data_ptr(), n, h, w, L.dt_code(dtype), L.stream_ptr()), "mil_stem_s2d")
+    return out
+
+
+def pack_weights(w, bias, mode, dtype):
+    """fp32 [Cout,Cin,k,k] -> (packed MFMA-fragment weights, zero-padded fp32 bias)."""
+    w = w.detach()
+    if w.dtype != torch.float32 or not w.is_cuda or w.dim() != 4:
+        raise ValueError("weights must be CUDA fp32 [Cout,Cin,k,k]")
+    w = w.contiguous()
+    cout, cin, ks, _ = w.shape
+    elems = ctypes.c_size_t(0)
+    L.check(L.lib().mil_packed_weight_elems(ctypes.byref(elems), cout, cin, ks, mode), "mil_packed_weight_elems")
+    packed = torch.empty(elems.value, dtype=dtype, device=w.device)
+    n_out = cin if mode == L.PACK_DGRAD else cout
+    nt = (cpad(n_out) + 15) // 16
+    bias_pad = torch.empty(nt * 16, dtype=torch.float32, device=w.device)
+    b = None if bias is None else bias.detach().contiguous()
+    L.check(L.lib().mil_pack_conv_weights(w.data_ptr(), L.ptr(b), packed.data_ptr(), bias_pad.data_ptr(), cout, cin, ks,
+                                          mode, L.dt_code(dtype), L.stream_ptr()), "mil_pack_conv_weights")
+    return packed, bias_pad
+
+
+def conv(x, wpack, bias_pad, cout_p, *, ks, stride, pad, out_hw=None, res=None, act=None, lrelu=False,
+         zero_insert=False, slope=LEAK):
+    """y = mask(lrelu?(conv(x)+bias+res)) — see mil_conv_igemm in include/mil_hip.h."""
+    n, h, w, cin_p = x.shape
+    if zero_insert:
+        if out_hw is None:
+            raise ValueError("zero_insert needs the full-resolution output size")
+        ho, wo = out_hw
+    else:
+        ho = (h + 2 * pad - ks) // stride + 1 if ks != 4 else h
+        wo = (w + 2 * pad - ks) // stride + 1 if ks != 4 else w
+    y = torch.empty((n, ho, wo, cout_p), dtype=x.dtype, device=x.device)
+    _need(x, x.shape, x.dtype, "x")
+    _need(res, y.shape, x.dtype, "res")
+    _need(act, y.shape, x.dtype, "act")
+    L.check(L.lib().mil_conv_igemm(x.data_ptr(), wpack.data_ptr(), L.ptr(bias_pad), L.ptr(res), L.ptr(act), y.data_ptr(),
+                                   n, h, w, cin_p, ho, wo, cout_p, ks, 1 if zero_insert else stride, pad,
+                                   1 if zero_insert else 0, 1 if lrelu else 0, slope, L.dt_code(x.dtype), L.stream_ptr()),
+            "mil_conv_igemm")
+    return y
+
+
+def wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, ks, stride, pad, stem, dtype):
+    need = ctypes.c_size_t(0)
+    L.check(L.lib().mil_conv_wgrad_workspace(ctypes.byref(need), n, h, w, cin, ho, wo, cout, ks, stride, pad,
+                                             1 if stem else 0, L.dt_code(dtype)), "mil_conv_wgrad_workspace")
+    return need.value
+
+
+def conv_wgrad(x, dz, cin, cout, *, ks, stride, pad, stem=False, want_bias=True, workspace=None):
+    """(dW [cout,cin,k,k] fp32, db [cout] fp32 or None) — see mil_conv_wgrad."""
+    n, h, w, cin_p = x.shape
+    _, ho, wo, cout_p = dz.shape
+    _need(dz, (n, ho, wo, cpad(cout)), x.dtype, "dz")
+    _need(x, (n, h, w, 16 if stem else cpad(cin)), x.dtype, "x")
+    need = wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, ks, stride, pad, stem, x.dtype)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+    kk = 7 if stem else ks
+    dw = torch.empty((cout, cin, kk, kk), dtype=torch.float32, device=x.device)
+    db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
+    L.check(L.lib().mil_conv_wgrad(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), L.ptr(db), workspace.data_ptr(),
+                                   workspace.numel() * workspace.element_size(), n, h, w, cin, ho, wo, cout, ks, stride,
+                                   pad, 1 if stem else 0, L.dt_code(x.dtype), L.stream_ptr()), "mil_conv_wgrad")
+    return dw, db
+
+
+def maxpool_fwd(x):
+    n, h, w, cp = x.shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = torch.empty((n, ho, wo, cp), dtype=x.dtype, device=x.device)
+    widx = torch.empty((n, ho, wo, cp), dtype=torch.uint8, device=x.device)
+    L.check(L.lib().mil_maxpool_fwd(x.data_ptr(), y.data_ptr(), widx.data_ptr(), n, h, w, cp, L.dt_code(x.dtype),
+                                    L.stream_ptr()), "mil_maxpool_fwd")
+    return y, widx
+
+
+def maxpool_bwd(gy, widx, act, slope=LEAK):
+    n, h, w, cp = act.shape
+    _need(gy, widx.shape, act.dtype, "gy")
+    gx = torch.empty_like(act)
+    L.check(L.lib().mil_maxpool_bwd(gy.data_ptr(), widx.data_ptr(), act.data_ptr(), gx.data_ptr(), n, h, w, cp, slope,
+                                    L.dt_code(act.dtype), L.stream_ptr()), "mil_maxpool_bwd")
+    return gx
+
+
+def avgpool_fc_fwd(x, wfc, c):
+    n, h, w, cp = x.shape
+    nf = wfc.shape[0]
+    _need(wfc, (nf, c), torch.float32, "fc.weight")
+    pooled = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    feats = torch.empty((n, nf), dtype=torch.float32, device=x.device)
+    L.check(L.lib().mil_avgpool_fc_fwd(x.data_ptr(), wfc.data_ptr(), pooled.data_ptr(), feats.data_ptr(), n, h * w, cp, c,
+                                       nf, L.dt_code(x.dtype), L.stream_ptr()), "mil_avgpool_fc_fwd")
+    return pooled, feats
+
+
+def avgpool_fc_bwd(dfeats, wfc, pooled, act, c, slope=LEAK):
+    n, h, w, cp = act.shape
+    nf = wfc.shape[0]
+    _need(dfeats, (n, nf), torch.float32, "dfeats")
+    dz = torch.empty_like(act)
+    dwfc = torch.empty((nf, c), dtype=torch.float32, device=act.device)
+    L.check(L.lib().mil_avgpool_fc_bwd(dfeats.data_ptr(), wfc.data_ptr(), pooled.data_ptr(), act.data_ptr(), dz.data_ptr(),
+                                       dwfc.data_ptr(), n, h * w, cp, c, nf, slope, L.dt_code(act.dtype), L.stream_ptr()),
+            "mil_avgpool_fc_bwd")
+    return dz, dwfc

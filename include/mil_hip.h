@@ -1,0 +1,131 @@
+/* mil_hip.h — C ABI of libmil_hip.so, the MI355X (gfx950) kernels under the ResNet-26 +
+ * attention-MIL hot path.
+ *
+ * The reference (frankenz/Deep-convolutional-neural-network-ResNet-26-and-Attention-network) is
+ * pure Python on stock PyTorch and has no FFI of its own; the "plugin interface" of this path is
+ * the `nn.Module` surface of `Attention` (gbm/model.py:114-264).  This header is what a binding
+ * for that path binds instead of the cuDNN/ATen library ops the reference dispatches to.  Each
+ * entry point names the reference op(s) it replaces (file:line relative to the upstream repo).
+ *
+ * Conventions
+ *   - plain C: raw device pointers, ints, floats; `stream` is a hipStream_t passed as void*.
+ *   - every function returns MIL_OK (0) or an error code; nothing allocates, nothing synchronises,
+ *     no global state: work is enqueued on `stream`, buffers are caller-owned.
+ *   - activations are NHWC with channels padded to a multiple of 8 (20->24, 40, 60->64, 80; padded
+ *     channels hold zeros); `dtype` selects the activation/weight-operand type:
+ *         MIL_DT_F32  (0): exact-fp32 MFMA (v_mfma_f32_16x16x4_f32)  — the parity gate
+ *         MIL_DT_BF16 (1): bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16) — the fast path
+ *   - master weights, biases, all gradients of parameters, and the whole MIL head are fp32.
+ */
+#ifndef MIL_HIP_H
+#define MIL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIL_OK 0
+#define MIL_ERR_ARG 1
+#define MIL_ERR_UNSUPPORTED 2
+#define MIL_ERR_LAUNCH 3
+
+#define MIL_DT_F32 0
+#define MIL_DT_BF16 1
+
+#define MIL_PACK_FWD 0   /* B[(tap,ci)][co] = W[co][ci][ky][kx]                     */
+#define MIL_PACK_DGRAD 1 /* B[(tap,co)][ci] = W[co][ci][k-1-ky][k-1-kx]             */
+#define MIL_PACK_STEM 2  /* 7x7/s2 filter as a 4x4/s1 filter over space-to-depth x  */
+
+/* ABI version of this header (bumped on any signature change). */
+int mil_abi_version(void);
+
+/* ---- input packing ------------------------------------------------------------------------
+ * fp32 NCHW tiles [n,3,H,W] (what `Attention.forward` receives, gbm/model.py:189-196) ->
+ * NHWC space-to-depth [n, ceil(H/2), ceil(W/2), 16] of `dtype` (channel = c*4+dy*2+dx, 12 real).
+ * Lets the 7x7 stride-2 stem conv (gbm/model.py:24) run as a 4x4 stride-1 implicit GEMM. */
+int mil_stem_s2d(const float* x_nchw, void* out, int n, int H, int W, int dtype, void* stream);
+
+/* ---- weight packing -----------------------------------------------------------------------
+ * fp32 master weights in the reference state-dict layout [Cout][Cin][k][k] ->
+ * MFMA B-fragment order [kstep][ntile][64 lanes][8].  `bias_pad` (optional) receives the bias
+ * zero-padded to ntile*16 floats.  Element count of the packed buffer: mil_packed_weight_elems. */
+int mil_packed_weight_elems(size_t* elems, int cout, int cin, int ks, int mode);
+int mil_pack_conv_weights(const float* w, const float* bias, void* wpack, float* bias_pad, int cout, int cin,
+                          int ks, int mode, int dtype, void* stream);
+
+/* ---- convolution forward / data-gradient ---------------------------------------------------
+ * Replaces nn.Conv2d forward (+bias) fused with LeakyReLU(0.1) and the residual add of
+ * BasicResBlock.forward (nnBlocks.py:175-189), the stem conv+LeakyReLU (gbm/model.py:51-52), the
+ * 1x1 stride-2 projection (gbm/model.py:38-40), and — run over dz with MIL_PACK_DGRAD weights — the
+ * autograd data-gradient of those convs fused with the LeakyReLU backward mask.
+ *     y = mask( lrelu?( conv(x) + bias? + res? ) ),   mask(v) = v * (act > 0 ? 1 : slope) if act
+ *   x   [n,H,W,cin_p]; y/res/act [n,Ho,Wo,cout_p]; ks in {1,3,4}; stride in {1,2}; pad = leading pad.
+ *   zero_insert=1 reads x as if zeros sat between its pixels (transposed stride-2 conv: dgrad of a
+ *   stride-2 conv); H,W are then the dims of the small tensor and Ho,Wo the full-resolution dims. */
+int mil_conv_igemm(const void* x, const void* wpack, const float* bias_pad, const void* res, const void* act,
+                   void* y, int n_img, int H, int W, int cin_p, int Ho, int Wo, int cout_p, int ks, int stride,
+                   int pad, int zero_insert, int apply_lrelu, float slope, int dtype, void* stream);
+
+/* ---- convolution weight / bias gradient ----------------------------------------------------
+ * Replaces the autograd weight- and bias-gradient of the same convs.  dw is written (not
+ * accumulated) in the reference layout [cout][cin][k][k] fp32 (k = 7 when stem_mode), db [cout]
+ * (may be null).  x [n,H,W,cpad(cin)] (or the 16-channel s2d tensor when stem_mode), dz
+ * [n,Ho,Wo,cpad(cout)].  Split-K over workgroups with a fixed-order second pass: bitwise
+ * reproducible.  `workspace` must hold mil_conv_wgrad_workspace() bytes. */
+int mil_conv_wgrad_workspace(size_t* bytes, int n_img, int H, int W, int cin, int Ho, int Wo, int cout, int ks,
+                             int stride, int pad, int stem_mode, int dtype);
+int mil_conv_wgrad(const void* x, const void* dz, float* dw, float* db, void* workspace, size_t workspace_bytes,
+                   int n_img, int H, int W, int cin, int Ho, int Wo, int cout, int ks, int stride, int pad,
+                   int stem_mode, int dtype, void* stream);
+
+/* ---- pooling -------------------------------------------------------------------------------
+ * MaxPool2d(3, stride 2, pad 1) (gbm/model.py:26,53): y [n,Ho,Wo,cp], Ho=(H-1)/2+1; `widx` records
+ * the winning tap per output element (uint8, same shape as y).  The backward gathers gy through
+ * widx and multiplies by the LeakyReLU mask of `act` (the stem output) when act != null. */
+int mil_maxpool_fwd(const void* x, void* y, uint8_t* widx, int n, int H, int W, int cp, int dtype, void* stream);
+int mil_maxpool_bwd(const void* gy, const uint8_t* widx, const void* act, void* gx, int n, int H, int W, int cp,
+                    float slope, int dtype, void* stream);
+
+/* AdaptiveAvgPool2d((1,1)) + flatten + Linear(80,L,bias=False) (gbm/model.py:31-32,58-60).
+ * x [n,hw,cp] -> pooled [n,c] fp32 (kept for backward), feats [n,nf] fp32 = pooled @ wfc^T.
+ * Backward: dz [n,hw,cp] = lrelu'(act) * (dfeats @ wfc)/hw, dwfc [nf,c] = dfeats^T @ pooled. */
+int mil_avgpool_fc_fwd(const void* x, const float* wfc, float* pooled, float* feats, int n, int hw, int cp, int c,
+                       int nf, int dtype, void* stream);
+int mil_avgpool_fc_bwd(const float* dfeats, const float* wfc, const float* pooled, const void* act, void* dz,
+                       float* dwfc, int n, int hw, int cp, int c, int nf, float slope, int dtype, void* stream);
+
+/* ---- attention-MIL head --------------------------------------------------------------------
+ * Replaces everything after the backbone in Attention.forward (gbm/model.py:198-246): ContextLayer
+ * (batch-statistics BatchNorm1d + LeakyReLU + Dropout, :108-111), attention MLP + softplus/mask/L1
+ * normalisation (:209-214), diagnostics (:201,216-219), buffer MLP (:223), pooling (:227-229),
+ * softmax / argmax / label-smoothed weighted CE (:233-242, nnBlocks.py:71-85,121-134), l2 (:246).
+ * Segmented over `nbags` bags: instances of bag b are rows [bag_offsets[b], bag_offsets[b+1]) of
+ * H [ntot,80]; inst_bag[n] is the bag of row n.  keep_mask [ntot,80] uint8 (1 = kept) enables
+ * Dropout(drop_p) as in training; null = eval.  class_weights [3] or null.
+ * `weights` = 11 device pointers: context.bn.weight, context.bn.bias, attention.lin1.weight,
+ * attention.lin1.bias, attention.lin2.weight, attention.lin2.bias, buffer.lin1.weight,
+ * buffer.lin1.bias, buffer.classifier.weight, buffer.classifier.bias, weight_mask.
+ * Outputs: a1 [ntot,3] (Aterm^T), wrois (bag b's [3,N_b] block at 3*bag_offsets[b]), bterm [ntot],
+ * kld [nbags], rec [nbags, mil_head_rec_floats()] =
+ *   {Mterm[3], y_pred[3], loss, error, Aterm_mu, Aterm_var, D[3], dloss/dM[3], y_hat, l2(bag 0)}.
+ * Backward: dH [ntot,80] and `grads` (mil_head_grad_floats() floats: the 11 tensors' gradients back
+ * to back, summed over bags), given grad_loss [nbags] and optional grad_l2 [1]. */
+int mil_head_workspace_floats(size_t* floats, int ntot, int nbags);
+int mil_head_grad_floats(void);
+int mil_head_rec_floats(void);
+int mil_head_fwd(const float* H, const int* bag_offsets, const int* inst_bag, const int64_t* labels,
+                 const uint8_t* keep_mask, const float* class_weights, const float* const* weights,
+                 float* workspace, float* a1, float* wrois, float* bterm, float* kld, float* rec, int ntot,
+                 int nbags, float slope, float drop_p, float smoothing, float bn_eps, void* stream);
+int mil_head_bwd(const float* H, const int* bag_offsets, const int* inst_bag, const uint8_t* keep_mask,
+                 const float* const* weights, float* workspace, const float* bterm, const float* rec,
+                 const float* grad_loss, const float* grad_l2, float* dH, float* grads, int ntot, int nbags,
+                 float slope, float drop_p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIL_HIP_H */

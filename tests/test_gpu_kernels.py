@@ -1,0 +1,174 @@
+"""-m gpu: every HIP kernel, called through the C ABI wrappers, against the same op in fp32 torch on
+the CPU (the oracle's building blocks).  fp32 kernels: tight tolerance.  bf16 kernels: inputs are
+pre-rounded to bf16 so the comparison isolates the kernel (fp32 accumulation; only the output rounding
+to bf16, 2^-8 relative, remains)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import cpad, from_nhwc, rel_err, round_to, to_nhwc
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 8e-3}
+LEAK = 0.1
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import mil_amd  # noqa: F401
+    from mil_amd import ops as o
+    assert torch.cuda.is_available()
+    return o
+
+
+def _lib():
+    from mil_amd import _lib as L
+    return L
+
+
+CONV_CASES = [
+    # cin, cout, ks, stride, n, H, W
+    (20, 20, 3, 1, 3, 16, 16),
+    (20, 20, 3, 1, 2, 19, 23),      # ragged tiles
+    (20, 40, 3, 2, 2, 16, 16),
+    (20, 40, 3, 2, 3, 19, 13),
+    (20, 40, 1, 2, 2, 16, 16),
+    (40, 40, 3, 1, 5, 8, 8),        # 8x8 maps: 4 images per tile
+    (40, 60, 3, 2, 2, 10, 10),
+    (40, 60, 1, 2, 3, 9, 7),
+    (60, 60, 3, 1, 2, 16, 16),
+    (60, 60, 3, 1, 17, 4, 4),       # 4x4 maps: 16 images per tile
+    (60, 80, 3, 2, 3, 16, 16),
+    (60, 80, 1, 2, 2, 8, 8),
+    (80, 80, 3, 1, 2, 8, 8),
+    (80, 80, 3, 1, 1, 18, 18),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_epilogues(ops, dtype, case):
+    L = _lib()
+    cin, cout, ks, stride, n, h, w = case
+    g = torch.Generator().manual_seed(hash(case) % 10000)
+    pad = 1 if ks == 3 else 0
+    x = round_to(torch.randn(n, cin, h, w, generator=g), dtype)
+    wt = round_to(torch.randn(cout, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5, dtype)
+    b = torch.randn(cout, generator=g) * 0.1
+    ref_lin = F.conv2d(x, wt, b, stride=stride, padding=pad)
+    res = round_to(torch.randn(ref_lin.shape, generator=g), dtype)
+    xg = to_nhwc(x, dtype)
+    wp, bp = ops.pack_weights(wt.cuda(), b.cuda(), L.PACK_FWD, dtype)
+    # conv + bias + lrelu
+    y = ops.conv(xg, wp, bp, cpad(cout), ks=ks, stride=stride, pad=pad, lrelu=True)
+    assert rel_err(from_nhwc(y, cout), F.leaky_relu(ref_lin, LEAK)) < TOL[dtype]
+    assert float(y[..., cout:].float().abs().max() if cpad(cout) > cout else 0.0) == 0.0   # padded channels stay 0
+    # conv + bias + residual + lrelu
+    y = ops.conv(xg, wp, bp, cpad(cout), ks=ks, stride=stride, pad=pad, res=to_nhwc(res, dtype), lrelu=True)
+    assert rel_err(from_nhwc(y, cout), F.leaky_relu(ref_lin + res, LEAK)) < TOL[dtype]
+    # plain conv, no bias (projection shortcut)
+    wp0, _ = ops.pack_weights(wt.cuda(), None, L.PACK_FWD, dtype)
+    y = ops.conv(xg, wp0, None, cpad(cout), ks=ks, stride=stride, pad=pad)
+    assert rel_err(from_nhwc(y, cout), F.conv2d(x, wt, None, stride=stride, padding=pad)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_dgrad_and_wgrad(ops, dtype, case):
+    L = _lib()
+    cin, cout, ks, stride, n, h, w = case
+    g = torch.Generator().manual_seed(1 + hash(case) % 10000)
+    pad = 1 if ks == 3 else 0
+    x = round_to(torch.randn(n, cin, h, w, generator=g), dtype).requires_grad_(True)
+    wt = round_to(torch.randn(cout, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5, dtype).requires_grad_(True)
+    b = torch.zeros(cout, requires_grad=True)
+    y = F.conv2d(x, wt, b, stride=stride, padding=pad)
+    dz = round_to(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dz)
+    addend = round_to(torch.randn(x.shape, generator=g), dtype)
+    act = round_to(torch.randn(x.shape, generator=g), dtype)
+    want = (x.grad + addend) * torch.where(act > 0, 1.0, LEAK)
+
+    dzg = to_nhwc(dz, dtype)
+    wd, _ = ops.pack_weights(wt.detach().cuda(), None, L.PACK_DGRAD, dtype)
+    if stride == 2:
+        dx = ops.conv(dzg, wd, None, cpad(cin), ks=ks, stride=1, pad=pad, zero_insert=True, out_hw=(h, w),
+                      res=to_nhwc(addend, dtype), act=to_nhwc(act, dtype))
+    else:
+        dx = ops.conv(dzg, wd, None, cpad(cin), ks=ks, stride=1, pad=pad, res=to_nhwc(addend, dtype),
+                      act=to_nhwc(act, dtype))
+    assert rel_err(from_nhwc(dx, cin), want) < TOL[dtype]
+
+    dw, db = ops.conv_wgrad(to_nhwc(x.detach(), dtype), dzg, cin, cout, ks=ks, stride=stride, pad=pad)
+    assert dw.shape == wt.shape
+    assert rel_err(dw.cpu(), wt.grad) < 3e-5      # operands are exact in both dtypes; accumulation is fp32
+    assert rel_err(db.cpu(), b.grad) < 3e-5
+    # bitwise reproducible (fixed-order slab reduction, no float atomics)
+    dw2, db2 = ops.conv_wgrad(to_nhwc(x.detach(), dtype), dzg, cin, cout, ks=ks, stride=stride, pad=pad)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 32, 32), (3, 50, 70), (1, 37, 41), (2, 64, 64)])
+def test_stem_conv_and_wgrad(ops, dtype, shape):
+    L = _lib()
+    n, h, w = shape
+    g = torch.Generator().manual_seed(7 + h)
+    x = round_to(torch.randn(n, 3, h, w, generator=g).clamp_(-1, 1), dtype)
+    wt = round_to(torch.randn(20, 3, 7, 7, generator=g) / 147 ** 0.5, dtype).requires_grad_(True)
+    b = (torch.randn(20, generator=g) * 0.1).requires_grad_(True)
+    lin = F.conv2d(x, wt, b, stride=2, padding=3)
+    ref = F.leaky_relu(lin, LEAK)
+    xs = ops.stem_s2d(x.cuda(), dtype)
+    assert xs.shape == (n, (h + 1) // 2, (w + 1) // 2, 16)
+    wp, bp = ops.pack_weights(wt.detach().cuda(), b.detach().cuda(), L.PACK_STEM, dtype)
+    y = ops.conv(xs, wp, bp, 24, ks=4, stride=1, pad=2, lrelu=True)
+    assert y.shape[1:3] == ref.shape[2:]
+    assert rel_err(from_nhwc(y, 20), ref) < TOL[dtype]
+    dz = round_to(torch.randn(lin.shape, generator=g), dtype)
+    lin.backward(dz)
+    dw, db = ops.conv_wgrad(xs, to_nhwc(dz, dtype), 3, 20, ks=4, stride=1, pad=2, stem=True)
+    assert dw.shape == (20, 3, 7, 7)
+    assert rel_err(dw.cpu(), wt.grad) < 3e-5
+    assert rel_err(db.cpu(), b.grad) < 3e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 20, 16, 16), (3, 20, 25, 35), (1, 20, 7, 9)])
+def test_maxpool(ops, dtype, shape):
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(11)
+    # quantise so that ties inside a window do occur (first-maximum rule must match torch)
+    x = (torch.randn(n, c, h, w, generator=g) * 2).round() / 2
+    x = round_to(x, dtype).requires_grad_(True)
+    ref = F.max_pool2d(x, 3, 2, 1)
+    gy = round_to(torch.randn(ref.shape, generator=g), dtype)
+    ref.backward(gy)
+    xg = to_nhwc(x.detach(), dtype)
+    y, widx = ops.maxpool_fwd(xg)
+    assert torch.equal(from_nhwc(y, c), ref.detach())
+    gx = ops.maxpool_bwd(to_nhwc(gy, dtype), widx, xg)
+    want = x.grad * torch.where(x.detach() > 0, 1.0, LEAK)
+    assert rel_err(from_nhwc(gx, c), want) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(5, 8, 8), (3, 4, 5), (2, 16, 16)])
+def test_avgpool_fc(ops, dtype, shape):
+    n, h, w = shape
+    g = torch.Generator().manual_seed(13)
+    x = round_to(torch.randn(n, 80, h, w, generator=g), dtype)
+    wfc = (torch.randn(80, 80, generator=g) / 9).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    feats_ref = xr.mean(dim=(2, 3)) @ wfc.t()
+    df = torch.randn(n, 80, generator=g)
+    feats_ref.backward(df)
+    xg = to_nhwc(x, dtype)
+    pooled, feats = ops.avgpool_fc_fwd(xg, wfc.detach().cuda(), 80)
+    assert rel_err(feats.cpu(), feats_ref.detach()) < 2e-5
+    dz, dwfc = ops.avgpool_fc_bwd(df.cuda(), wfc.detach().cuda(), pooled, xg, 80)
+    want = xr.grad * torch.where(x > 0, 1.0, LEAK)
+    assert rel_err(from_nhwc(dz, 80), want) < TOL[dtype]
+    assert rel_err(dwfc.cpu(), wfc.grad) < 2e-5
