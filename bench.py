@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: tiles/sec, forward+backward, ResNet-26 + attention-MIL on synthetic 256x256x3
+bags (BASELINE.json metric, configs[1]: 8 bags x 256 tiles per GPU, bf16 operands / fp32 accumulate).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = zero the flat gradient bucket, one encoder pass over every tile of this rank's bags (full-bag
+path: all tiles through the backbone, gradients enabled), the segmented MIL head, the full backward and —
+for N>1 — one RCCL all-reduce (sum) of the flat gradient bucket.  Weak scaling: every rank owns 8 bags.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+GFLOP_PER_TILE_FWD_BWD_256 = 1.6298    # fwd + dgrad + wgrad of every conv, no stem dgrad
+MFMA_PEAK_BF16_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA
+MFMA_PEAK_F32_TFLOPS = 157.3
+HBM_PEAK_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bags", type=int, default=8, help="bags per GPU per step")
+    ap.add_argument("--tiles", type=int, default=256, help="tiles per bag")
+    ap.add_argument("--size", type=int, default=256, help="tile edge in pixels")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(size, weights_npz):
+    """The oracle (CPU restatement of the reference, pinned by golden vectors) timed on this box's host
+    cores on a bounded sample of the same workload: 1 bag x 64 tiles, forward+backward, full-bag path."""
+    from oracle import mil_oracle as orc
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    cores = max(1, min(cores, 64))
+    torch.set_num_threads(cores)
+    sd = orc.load_state(weights_npz, requires_grad=True)
+    gen = torch.Generator().manual_seed(20260104)
+    n = 64
+    x = torch.randn(n, 3, size, size, generator=gen).clamp_(-1.0, 1.0)
+    y = torch.tensor([1])
+    times = []
+    for it in range(6):
+        for p in sd.values():
+            p.grad = None
+        t0 = time.perf_counter()
+        out = orc.attention_forward(sd, x, y)
+        out["loss"].backward()
+        dt = time.perf_counter() - t0
+        if it >= 1:
+            times.append(dt)
+        if sum(times) > 25.0:
+            break
+    med = float(np.median(times))
+    return {"value": n / med, "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/mil_oracle.py (fp32 torch CPU, {cores} threads): 1 bag x {n} tiles @{size}x{size}, "
+                      f"fwd+bwd, median of {len(times)} after 1 warm-up"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    elif args.gpus != 1:
+        raise SystemExit("--gpus N>1 must be launched through torch.distributed.run (one process per GPU)")
+    else:
+        torch.cuda.set_device(0)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    import mil_amd
+    from mil_amd import ops
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    w = np.load(os.path.join(ROOT, "tests", "golden", "weights.npz"))
+    net = mil_amd.Attention(3, compute_dtype=dtype, device=dev).eval()     # eval = full-bag path (all tiles encoded)
+    net.load_state_dict({k: torch.tensor(w[k]) for k in w.keys()})
+    flat = mil_amd.FlatParams(net)
+    flat.broadcast_params()
+
+    # synthetic bags, generated on the device and resident before the timed region
+    n_tiles = args.bags * args.tiles
+    gen = torch.Generator(device=dev).manual_seed(20260104 + rank)
+    x_all = torch.empty((n_tiles, 3, args.size, args.size), dtype=torch.float32, device=dev)
+    for b in range(args.bags):          # bag by bag: bounded temporary memory
+        x_all[b * args.tiles:(b + 1) * args.tiles] = torch.randn(
+            (args.tiles, 3, args.size, args.size), generator=gen, device=dev).clamp_(-1.0, 1.0)
+    sizes = [args.tiles] * args.bags
+    labels = torch.tensor([(rank * args.bags + b) % 3 for b in range(args.bags)], device=dev)
+
+    def step():
+        flat.zero_grad()
+        outs = net.forward_bags((x_all, sizes), labels)
+        torch.stack([o["loss"] for o in outs]).sum().backward()
+        flat.allreduce_grads()
+        return outs
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    # dominant kernel: the 3x3 stride-1 conv at 20(24)->20(24) channels on the 64x64 maps (layer1 forward
+    # convs and their data-gradients run the same instantiation, conv_igemm_kernel<BF16,24,2,4>)
+    dom = ("conv", 24, 24, 3, 1, False)
+    timer = None
+    if not args.no_kernel_timer:
+        timer = ops.KernelTimer(lambda label: label[:6] == dom)
+        ops.TIMER = timer
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outs = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    loss_val = float(torch.stack([o["loss"] for o in outs]).mean())
+    if not np.isfinite(loss_val):
+        raise SystemExit("non-finite loss in benchmark step")
+
+    if rank == 0:
+        total_tiles = n_tiles * world * args.steps
+        value = total_tiles / elapsed
+        scale = (args.size / 256.0) ** 2
+        achieved_model_tflops = value * GFLOP_PER_TILE_FWD_BWD_256 * scale / 1e3
+        peak = MFMA_PEAK_BF16_TFLOPS if args.dtype == "bf16" else MFMA_PEAK_F32_TFLOPS
+        roofline = None
+        if timer is not None:
+            spans = timer.durations_ms()
+            if spans:
+                label = spans[0][0]
+                n_img, ho, wo = label[6], label[7], label[8]
+                avg_ms = float(np.mean([d for _, d in spans]))
+                flops = 2.0 * 9 * 20 * 20 * n_img * ho * wo            # algorithmic: 20 real channels in and out
+                esz = 2 if args.dtype == "bf16" else 4
+                alg_bytes = n_img * ho * wo * (20 + 20) * esz           # read x once, write y once
+                ach = flops / (avg_ms * 1e-3) / 1e12
+                roofline = {
+                    "bound": "mfma", "kernel": f"conv_igemm_kernel<{args.dtype.upper()},24,2,4> (3x3 s1, 20->20 ch, "
+                                               f"{ho}x{wo} maps, {n_img} tiles/launch; fwd conv and dgrad launches)",
+                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                    "launches_timed": len(spans), "avg_launch_ms": avg_ms,
+                    "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
+                    "algorithmic_hbm_gbps": alg_bytes / (avg_ms * 1e-3) / 1e9,
+                    "hbm_capped_attainable_tflops": min(peak, flops / alg_bytes * HBM_PEAK_GBPS / 1e3),
+                    "whole_step_model_tflops": achieved_model_tflops,
+                    "whole_step_frac_of_mfma_peak": achieved_model_tflops / peak,
+                }
+        line = {
+            "metric": "tiles/sec fwd+bwd, 256x256x3 bags, ResNet-26+attn",
+            "value": value, "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.bags} bags x {args.tiles} tiles @{args.size}x{args.size}x3 per GPU, "
+                                   "ResNet-26 (20/40/60/80) + attention-MIL head, fwd+bwd full-bag path "
+                                   "(BASELINE.json configs[1])",
+                       "global_bags": args.bags * world, "tiles_per_bag": args.tiles, "tile": args.size,
+                       "parallelism": f"bag-parallel dp{world}, one RCCL all-reduce of the flat 2.56 MB gradient bucket"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.size, w)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

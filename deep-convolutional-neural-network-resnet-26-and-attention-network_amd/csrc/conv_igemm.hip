@@ -171,24 +171,31 @@ static int launch_conv(const ConvArgs<T>& a0, hipStream_t stream) {
     return MIL_OK;
 }
 
+// 256-px tiles (4 MFMA row tiles per wave) when the halo + a weight chunk fit in LDS, else 64-px tiles.
+template <typename T, int CINP, int NT>
+static int launch_conv_auto(const ConvArgs<T>& a, bool small_tile, hipStream_t stream) {
+    if (!small_tile) {
+        const int rc = launch_conv<T, CINP, NT, 4>(a, stream);
+        if (rc != MIL_ERR_UNSUPPORTED) return rc;
+    }
+    return launch_conv<T, CINP, NT, 1>(a, stream);
+}
+
 template <typename T>
 static int dispatch_conv(const ConvArgs<T>& a, int cin_p, int cout_p, hipStream_t stream) {
-    const bool small_tile = (a.g.stride == 2 && !a.g.zins);     // stride-2 forward: 64-px tiles (halo is 4x)
-#define MIL_CONV_CASE(CI, NTV, MT) return launch_conv<T, CI, NTV, MT>(a, stream)
-    if (!small_tile) {
-        if (cin_p == 16 && cout_p == 24) MIL_CONV_CASE(16, 2, 4);
-        if (cin_p == 24 && cout_p == 24) MIL_CONV_CASE(24, 2, 4);
-        if (cin_p == 40 && cout_p == 40) MIL_CONV_CASE(40, 3, 4);
-        if (cin_p == 64 && cout_p == 64) MIL_CONV_CASE(64, 4, 4);
-        if (cin_p == 80 && cout_p == 80) MIL_CONV_CASE(80, 5, 4);
-        if (cin_p == 40 && cout_p == 24) MIL_CONV_CASE(40, 2, 4);   // dgrad of stage-entry convs
-        if (cin_p == 64 && cout_p == 40) MIL_CONV_CASE(64, 3, 4);
-        if (cin_p == 80 && cout_p == 64) MIL_CONV_CASE(80, 4, 4);
-    } else {
-        if (cin_p == 24 && cout_p == 40) MIL_CONV_CASE(24, 3, 1);
-        if (cin_p == 40 && cout_p == 64) MIL_CONV_CASE(40, 4, 1);
-        if (cin_p == 64 && cout_p == 80) MIL_CONV_CASE(64, 5, 1);
-    }
+    const bool small_tile = (a.g.stride == 2 && !a.g.zins);     // stride-2 forward: the halo is 4x the tile
+#define MIL_CONV_CASE(CI, NTV) return launch_conv_auto<T, CI, NTV>(a, small_tile, stream)
+    if (cin_p == 16 && cout_p == 24) MIL_CONV_CASE(16, 2);
+    if (cin_p == 24 && cout_p == 24) MIL_CONV_CASE(24, 2);
+    if (cin_p == 40 && cout_p == 40) MIL_CONV_CASE(40, 3);
+    if (cin_p == 64 && cout_p == 64) MIL_CONV_CASE(64, 4);
+    if (cin_p == 80 && cout_p == 80) MIL_CONV_CASE(80, 5);
+    if (cin_p == 40 && cout_p == 24) MIL_CONV_CASE(40, 2);   // dgrad of stage-entry convs
+    if (cin_p == 64 && cout_p == 40) MIL_CONV_CASE(64, 3);
+    if (cin_p == 80 && cout_p == 64) MIL_CONV_CASE(80, 4);
+    if (cin_p == 24 && cout_p == 40) MIL_CONV_CASE(24, 3);   // stage-entry convs / projections
+    if (cin_p == 40 && cout_p == 64) MIL_CONV_CASE(40, 4);
+    if (cin_p == 64 && cout_p == 80) MIL_CONV_CASE(64, 5);
 #undef MIL_CONV_CASE
     return MIL_ERR_UNSUPPORTED;
 }

@@ -1,0 +1,76 @@
+"""Bag-parallel data parallelism: one process per GPU, bags sharded across ranks, ONE all-reduce of a
+flat fp32 gradient bucket per optimizer step over RCCL/xGMI.
+
+Replaces the reference's single-process `nn.DataParallel(ResNet, device_ids=[0,1,2,3])`
+(gbm/model.py:132-135), which scatters the tiles of one bag, re-broadcasts all weights every forward
+and gathers features to GPU 0.  Here weights stay resident on every rank, every per-bag reduction
+(BatchNorm statistics, L1 normalisation, pooling) stays on the rank that owns the bag, and the only
+exchange is the 640,967-float gradient sum (2.56 MB) — the reference sums gradients over bags before
+an optimizer step (gbm/classify_combined.py:446-454), so the collective is a SUM, not a mean.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bags(n_bags, rank, world):
+    """Indices of the bags rank `rank` owns: g, g+G, g+2G, ...."""
+    return list(range(rank, n_bags, world))
+
+
+class FlatParams:
+    """Re-points every parameter (and its .grad) of `module` into one contiguous fp32 buffer each, so the
+    gradient exchange is a single collective and an optimizer can sweep one array."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("module has no trainable parameters")
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                self.flat[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat[off:off + n].view(p.shape)
+                p.grad = self.flat_grad[off:off + n].view(p.shape)
+                off += n
+        self.numel = total
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        off = 0
+        for p in self.params:       # re-attach in case something replaced .grad (e.g. set_to_none)
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad[off:off + n].data_ptr():
+                p.grad = self.flat_grad[off:off + n].view(p.shape)
+            off += n
+
+    def allreduce_grads(self, group=None):
+        """Sum the flat gradient bucket over ranks (no-op for a single process)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
+        return self.flat_grad
+
+    def broadcast_params(self, src=0, group=None):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.broadcast(self.flat, src=src, group=group)
+
+
+def gather_features(feats, group=None):
+    """Tile-parallel inference of ONE large bag (BASELINE config 5): every rank encodes its slice of the
+    tiles, then all ranks gather H [N/G,80] and run the (tiny) head redundantly."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return feats
+    world = dist.get_world_size(group)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=feats.device) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([feats.shape[0]], dtype=torch.int64, device=feats.device), group=group)
+    sizes = [int(s) for s in sizes]
+    mx = max(sizes)
+    padded = torch.zeros((mx, feats.shape[1]), dtype=feats.dtype, device=feats.device)
+    padded[:feats.shape[0]] = feats
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)

@@ -129,12 +129,25 @@ class Attention(nn.Module):
 
     # ---- a batch of bags: one encoder pass over all tiles, segmented head --------------------------
     def forward_bags(self, bags, labels):
-        """bags: list of [N_b,3,H,W] fp32 tensors (same H,W); labels: [len(bags)].  Returns one output
-        dict per bag (keys/shapes/grad flags of gbm/model.py:249-264); each `loss` back-propagates."""
+        """bags: list of [N_b,3,H,W] fp32 tensors (same H,W), or (x_all [sum N_b,3,H,W], [N_b...]) when the
+        tiles already sit back to back in one tensor; labels: [n_bags].  Returns one output dict per bag
+        (keys/shapes/grad flags of gbm/model.py:249-264); each `loss` back-propagates."""
         dev = self.weight_mask.device
         if dev.type != "cuda":
             raise RuntimeError("Attention runs on an AMD GPU only (module parameters are not on a CUDA/HIP device)")
+        if isinstance(bags, tuple):
+            x_cat, cat_sizes = bags
+            if x_cat.shape[0] != sum(cat_sizes):
+                raise ValueError("bag sizes do not add up to the number of tiles")
+            if self.training:      # per-bag subsampling needs the bags separately
+                bags = list(torch.split(x_cat, list(cat_sizes), dim=0))
+            else:
+                bags = None
         tiles, sizes, keep = [], [], None
+        if bags is None:
+            if x_cat.dim() != 4 or x_cat.shape[1] != 3:
+                raise ValueError(f"expected [N,3,H,W], got {tuple(x_cat.shape)}")
+            tiles, sizes, bags = [x_cat.detach().to(dev, torch.float32)], list(cat_sizes), []
         for b, x in enumerate(bags):
             x = x.detach()
             if x.dim() != 4 or x.shape[1] != 3:

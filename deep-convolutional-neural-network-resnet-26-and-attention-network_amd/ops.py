@@ -10,6 +10,31 @@ from . import _lib as L
 LEAK = 0.1   # LeakyReLU slope of the reference (nnBlocks.py:170, gbm/model.py:25)
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).
+    `want(label)` selects which launches are bracketed; everything else runs untouched."""
+
+    def __init__(self, want):
+        self.want = want
+        self.spans = []
+
+    def bracket(self, label):
+        if not self.want(label):
+            return None
+        start = torch.cuda.Event(enable_timing=True)
+        end = torch.cuda.Event(enable_timing=True)
+        start.record()
+        self.spans.append((label, start, end))
+        return end
+
+    def durations_ms(self):
+        torch.cuda.synchronize()
+        return [(label, s.elapsed_time(e)) for label, s, e in self.spans]
+
+
+TIMER = None   # set to a KernelTimer by bench.py
+
+
 def cpad(c):
     return (c + 7) // 8 * 8
 
@@ -68,10 +93,13 @@ def conv(x, wpack, bias_pad, cout_p, *, ks, stride, pad, out_hw=None, res=None, 
     _need(x, x.shape, x.dtype, "x")
     _need(res, y.shape, x.dtype, "res")
     _need(act, y.shape, x.dtype, "act")
+    end = TIMER.bracket(("conv", cin_p, cout_p, ks, stride, bool(zero_insert), n, ho, wo)) if TIMER else None
     L.check(L.lib().mil_conv_igemm(x.data_ptr(), wpack.data_ptr(), L.ptr(bias_pad), L.ptr(res), L.ptr(act), y.data_ptr(),
                                    n, h, w, cin_p, ho, wo, cout_p, ks, 1 if zero_insert else stride, pad,
                                    1 if zero_insert else 0, 1 if lrelu else 0, slope, L.dt_code(x.dtype), L.stream_ptr()),
             "mil_conv_igemm")
+    if end is not None:
+        end.record()
     return y
 
 

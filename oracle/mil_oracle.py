@@ -55,28 +55,64 @@ def state_dict_spec():
     return spec
 
 
-def residual_block(sd, prefix, x, stride):
-    """nnBlocks.py:175-189."""
-    o = F.leaky_relu(F.conv2d(x, sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"],
-                              stride=stride, padding=1), LEAK)
-    o = F.conv2d(o, sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], stride=1, padding=1)
+class _RoundFwd(torch.autograd.Function):
+    """y = bf16(x) in the forward pass, identity gradient (a tensor STORED in bf16)."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundBwd(torch.autograd.Function):
+    """identity in the forward pass, g = bf16(g) in the backward pass (a GRADIENT stored in bf16)."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+def _ident(t):
+    return t
+
+
+def residual_block(sd, prefix, x, stride, rf=_ident, rb=_ident):
+    """nnBlocks.py:175-189.  rf/rb are identity for the fp32 reference arithmetic; the bf16-storage
+    emulation passes rounding functions at the points where the HIP path stores bf16 tensors."""
+    o = F.leaky_relu(rb(F.conv2d(x, rf(sd[prefix + "conv1.weight"]), sd[prefix + "conv1.bias"],
+                                 stride=stride, padding=1)), LEAK)
+    o = rf(o)
+    o = F.conv2d(o, rf(sd[prefix + "conv2.weight"]), sd[prefix + "conv2.bias"], stride=1, padding=1)
     key = prefix + "downsample.0.weight"
-    shortcut = F.conv2d(x, sd[key], None, stride=stride) if key in sd else x
-    return F.leaky_relu(o + shortcut, LEAK)
+    shortcut = rf(F.conv2d(rb(x), rf(sd[key]), None, stride=stride)) if key in sd else x
+    return rf(F.leaky_relu(rb(o + shortcut), LEAK))
 
 
-def backbone(sd, x, acts=None, prefix="cnn.module."):
-    """gbm/model.py:50-61.  x: [T,3,H,W] fp32 -> [T,80]."""
-    t = F.leaky_relu(F.conv2d(x, sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"],
-                              stride=2, padding=3), LEAK)
+def backbone(sd, x, acts=None, prefix="cnn.module.", emulate_bf16=False):
+    """gbm/model.py:50-61.  x: [T,3,H,W] fp32 -> [T,80].
+
+    emulate_bf16=True is NOT reference arithmetic: it is the same fp32 computation with every tensor the
+    HIP bf16 path keeps in HBM (activations, their gradients, MFMA weight operands) rounded to bf16 at
+    the point where that path stores it, so that the bf16 kernels can be checked tightly instead of
+    only against a loose bf16-vs-fp32 bound."""
+    rf = _RoundFwd.apply if emulate_bf16 else _ident
+    rb = _RoundBwd.apply if emulate_bf16 else _ident
+    t = F.leaky_relu(rb(F.conv2d(rf(x), rf(sd[prefix + "conv1.weight"]), sd[prefix + "conv1.bias"],
+                                 stride=2, padding=3)), LEAK)
+    t = rf(t)
     if acts is not None:
         acts["stem"] = t
-    t = F.max_pool2d(t, kernel_size=3, stride=2, padding=1)
+    t = rb(F.max_pool2d(t, kernel_size=3, stride=2, padding=1))
     if acts is not None:
         acts["pool"] = t
     for li, _planes, stride in STAGES:
         for b in range(BLOCKS_PER_STAGE):
-            t = residual_block(sd, f"{prefix}layer{li}.{b}.", t, stride if b == 0 else 1)
+            t = residual_block(sd, f"{prefix}layer{li}.{b}.", t, stride if b == 0 else 1, rf, rb)
         if acts is not None:
             acts[f"layer{li}"] = t
     t = t.mean(dim=(2, 3))
@@ -139,7 +175,7 @@ def mil_head(sd, feats, label, *, keep_mask=None, class_weights=None):
 
 
 def attention_forward(sd, full_input, label, *, training=False, indices=None, keep_mask=None,
-                      class_weights=None, acts=None):
+                      class_weights=None, acts=None, emulate_bf16=False):
     """gbm/model.py:189-264.  In training mode the caller supplies what the reference draws
     from the global RNG: `indices` (the randperm subsample, :193) and `keep_mask` (Dropout)."""
     x = full_input.detach()
@@ -151,7 +187,7 @@ def attention_forward(sd, full_input, label, *, training=False, indices=None, ke
             keep_mask = (torch.rand(x.shape[0], 80) >= DROP_P)
     else:
         keep_mask = None
-    feats = backbone(sd, x, acts)
+    feats = backbone(sd, x, acts, emulate_bf16=emulate_bf16)
     return mil_head(sd, feats, label, keep_mask=keep_mask, class_weights=class_weights)
 
 
