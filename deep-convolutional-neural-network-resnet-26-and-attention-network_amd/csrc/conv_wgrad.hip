@@ -164,36 +164,46 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs<T> a) {
 }
 
 // Sum the per-workgroup slabs in fixed order and scatter into the reference weight layout
-// [Cout][Cin][k][k] (fp32).  stem_mode maps the 4x4 space-to-depth taps back onto the 7x7 filter.
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, size_t slab_elems, int slab_cols,
-                                    float* __restrict__ dw, float* __restrict__ db, int cout, int cin, int ks,
-                                    int cinp, int stem_mode, int bias_row) {
-    const int kk = ks * ks;
-    const int total = cin * kk * cout;
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < total) {
-        const int co = idx % cout;
-        const int rem = idx / cout;
-        const int ci = rem % cin;
-        const int tap = rem / cin;
-        const int ky = tap / ks, kx = tap - ky * ks;
-        int row;
-        if (stem_mode) {
-            const int ty = (ky + 1) >> 1, dy = (ky + 1) & 1, tx = (kx + 1) >> 1, dx = (kx + 1) & 1;
-            row = (ty * 4 + tx) * cinp + ci * 4 + dy * 2 + dx;
-        } else {
-            row = tap * cinp + ci;
-        }
-        const float* p = slab + (size_t)row * slab_cols + co;
-        float s = 0.f;
-        for (int i = 0; i < nslab; ++i) s += p[(size_t)i * slab_elems];
-        dw[((size_t)co * cin + ci) * kk + tap] = s;
-    } else if (db && idx < total + cout) {
-        const int co = idx - total;
-        const float* p = slab + (size_t)bias_row * slab_cols + co;
-        float s = 0.f;
-        for (int i = 0; i < nslab; ++i) s += p[(size_t)i * slab_elems];
-        db[co] = s;
+// [Cout][Cin][k][k] (fp32).  A 256-thread block owns 32 consecutive slab elements (coalesced 128-B reads);
+// its 8 thread groups each sum every 8th slab, then group 0 adds the 8 partials in order: the summation
+// tree is fixed, so results are bitwise reproducible.  stem_mode maps the 4x4 space-to-depth taps back
+// onto the 7x7 filter.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, size_t slab_elems,
+                                                           int slab_cols, int n_rows, float* __restrict__ dw,
+                                                           float* __restrict__ db, int cout, int cin, int ks, int cinp,
+                                                           int stem_mode, int bias_row) {
+    __shared__ float part[8][32];
+    const int c = threadIdx.x & 31, gq = threadIdx.x >> 5;
+    // rows [0, n_rows) are weight rows, row n_rows stands for the bias row
+    const int e = blockIdx.x * 32 + c;
+    const int total = (n_rows + 1) * slab_cols;
+    float s = 0.f;
+    size_t src = 0;
+    bool live = e < total;
+    if (live) {
+        const int row = e / slab_cols, col = e - row * slab_cols;
+        src = (size_t)(row == n_rows ? bias_row : row) * slab_cols + col;
+        for (int i = gq; i < nslab; i += 8) s += slab[(size_t)i * slab_elems + src];
+    }
+    part[gq][c] = s;
+    __syncthreads();
+    if (gq != 0 || !live) return;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += part[k][c];
+    const int row = e / slab_cols, co = e - row * slab_cols;
+    if (co >= cout) return;
+    if (row == n_rows) { if (db) db[co] = v; return; }
+    const int tap = row / cinp, ch = row - tap * cinp;
+    if (stem_mode) {
+        if (ch >= 12) return;
+        const int ci = ch >> 2, dy = (ch >> 1) & 1, dx = ch & 1;
+        const int ky = 2 * (tap >> 2) + dy - 1, kx = 2 * (tap & 3) + dx - 1;
+        if (ky < 0 || ky >= 7 || kx < 0 || kx >= 7) return;
+        dw[(((size_t)co * 3 + ci) * 7 + ky) * 7 + kx] = v;
+    } else {
+        if (ch >= cin) return;
+        dw[((size_t)co * cin + ch) * (ks * ks) + tap] = v;
     }
 }
 
@@ -251,10 +261,10 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     }
     hipLaunchKernelGGL(kern, dim3(pl.grid_x, MSPLIT), dim3(256), pl.lds, stream, a);
     MIL_CHECK_LAUNCH();
-    const int ks_master = stem_mode ? 7 : KS;
-    const int total = cin * ks_master * ks_master * cout + (db ? cout : 0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, (const float*)ws, pl.grid_x,
-                       pl.slab_elems, pl.slab_cols, dw, db, cout, cin, ks_master, CINP, stem_mode, pl.mt * 16);
+    const int n_rows = KS * KS * CINP;
+    const int total = (n_rows + 1) * pl.slab_cols;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, stream, (const float*)ws, pl.grid_x,
+                       pl.slab_elems, pl.slab_cols, n_rows, dw, db, cout, cin, KS, CINP, stem_mode, pl.mt * 16);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

@@ -294,12 +294,14 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
                                                          const float* __restrict__ da, const float* __restrict__ dwm,
                                                          const float* __restrict__ db, const float* __restrict__ dhz,
                                                          float* __restrict__ grads, int ntot, float slope, float keep_scale) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per parameter element: lanes stride the instances, then a fixed shuffle tree
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (e >= G_TOTAL) return;
     float s = 0.f;
     if (e < G_AW1) {                      // bn weight / bias
         const int i = e % HL; const bool is_w = e < G_BNB;
-        for (int n = 0; n < ntot; ++n) {
+        for (int n = lane; n < ntot; n += 64) {
             const float* st = stats + (size_t)inst_bag[n] * 2 * HL;
             const float d = dhz[(size_t)n * HL + i];
             s += is_w ? d * ((H[(size_t)n * HL + i] - st[i]) * st[HL + i]) : d;
@@ -307,40 +309,41 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
     } else if (e < G_AB1) {               // attention.lin1.weight [40,80]
         const int j = (e - G_AW1) / HL, i = (e - G_AW1) % HL;
         const float gm = w.bn_w[i], bt = w.bn_b[i];
-        for (int n = 0; n < ntot; ++n) {
+        for (int n = lane; n < ntot; n += 64) {
             const float* st = stats + (size_t)inst_bag[n] * 2 * HL;
             const float z = gm * ((H[(size_t)n * HL + i] - st[i]) * st[HL + i]) + bt;
             s += du[(size_t)n * HD + j] * z;
         }
     } else if (e < G_AW2) {
         const int j = e - G_AB1;
-        for (int n = 0; n < ntot; ++n) s += du[(size_t)n * HD + j];
+        for (int n = lane; n < ntot; n += 64) s += du[(size_t)n * HD + j];
     } else if (e < G_AB2) {               // attention.lin2.weight [3,40]
         const int k = (e - G_AW2) / HD, j = (e - G_AW2) % HD;
-        for (int n = 0; n < ntot; ++n) s += da[(size_t)n * HK + k] * t_in[(size_t)n * HD + j];
+        for (int n = lane; n < ntot; n += 64) s += da[(size_t)n * HK + k] * t_in[(size_t)n * HD + j];
     } else if (e < G_BW1) {
         const int k = e - G_AB2;
-        for (int n = 0; n < ntot; ++n) s += da[(size_t)n * HK + k];
+        for (int n = lane; n < ntot; n += 64) s += da[(size_t)n * HK + k];
     } else if (e < G_BB1) {               // buffer.lin1.weight [40,80]
         const int j = (e - G_BW1) / HL, i = (e - G_BW1) % HL;
-        for (int n = 0; n < ntot; ++n) {
+        for (int n = lane; n < ntot; n += 64) {
             float m = lrelu(H[(size_t)n * HL + i], slope);
             if (keep) m = keep[(size_t)n * HL + i] ? m * keep_scale : 0.f;
             s += dv[(size_t)n * HD + j] * m;
         }
     } else if (e < G_BWC) {
         const int j = e - G_BB1;
-        for (int n = 0; n < ntot; ++n) s += dv[(size_t)n * HD + j];
+        for (int n = lane; n < ntot; n += 64) s += dv[(size_t)n * HD + j];
     } else if (e < G_BBC) {               // buffer.classifier.weight [1,40]
         const int j = e - G_BWC;
-        for (int n = 0; n < ntot; ++n) s += db[n] * lrelu(v_in[(size_t)n * HD + j], slope);
+        for (int n = lane; n < ntot; n += 64) s += db[n] * lrelu(v_in[(size_t)n * HD + j], slope);
     } else if (e < G_WM) {
-        for (int n = 0; n < ntot; ++n) s += db[n];
+        for (int n = lane; n < ntot; n += 64) s += db[n];
     } else {
         const int k = e - G_WM;
-        for (int n = 0; n < ntot; ++n) s += dwm[(size_t)n * HK + k];
+        for (int n = lane; n < ntot; n += 64) s += dwm[(size_t)n * HK + k];
     }
-    grads[e] = s;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) grads[e] = s;
 }
 
 // l2 = 0.5*(||Wl||_F + ||Wc||_F) contributes gl2 * 0.5 * W/||W|| to the two buffer weights.
@@ -454,7 +457,7 @@ extern "C" int mil_head_bwd(const float* H, const int* bag_offsets, const int* i
     hipLaunchKernelGGL(head_inst_bwd_kernel, dim3((ntot + 127) / 128), dim3(128), 0, st, H, inst_bag, keep_mask, w, ws.t, ws.v,
                        ws.araw, bterm, rec, grad_loss, ws.du, ws.dv, ws.da, ws.dwm, ws.db, ws.dhz, dH, ntot, slope, ks);
     MIL_CHECK_LAUNCH();
-    hipLaunchKernelGGL(head_wgrad_kernel, dim3((G_TOTAL + 255) / 256), dim3(256), 0, st, H, inst_bag, ws.stats, keep_mask, w, ws.t,
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3((G_TOTAL + 3) / 4), dim3(256), 0, st, H, inst_bag, ws.stats, keep_mask, w, ws.t,
                        ws.v, ws.du, ws.dv, ws.da, ws.dwm, ws.db, ws.dhz, grads, ntot, slope, ks);
     MIL_CHECK_LAUNCH();
     if (grad_l2) {

@@ -294,15 +294,18 @@ __global__ __launch_bounds__(128) void avgpool_fc_bwd_kernel(const float* __rest
     }
 }
 
-// dWfc[o][i] = sum_t dfeats[t][o] * pooled[t][i]   (fixed summation order)
-__global__ void fc_wgrad_kernel(const float* __restrict__ dfeats, const float* __restrict__ pooled, float* __restrict__ dw,
-                                int n, int C, int NF) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// dWfc[o][i] = sum_t dfeats[t][o] * pooled[t][i].  One wave per output element: lanes stride the tiles,
+// then a fixed shuffle tree (deterministic).
+__global__ __launch_bounds__(256) void fc_wgrad_kernel(const float* __restrict__ dfeats, const float* __restrict__ pooled,
+                                                       float* __restrict__ dw, int n, int C, int NF) {
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (idx >= NF * C) return;
     const int o = idx / C, i = idx - o * C;
     float s = 0.f;
-    for (int t = 0; t < n; ++t) s += dfeats[(size_t)t * NF + o] * pooled[(size_t)t * C + i];
-    dw[idx] = s;
+    for (int t = lane; t < n; t += 64) s += dfeats[(size_t)t * NF + o] * pooled[(size_t)t * C + i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) dw[idx] = s;
 }
 
 extern "C" int mil_avgpool_fc_fwd(const void* x, const float* wfc, float* pooled, float* feats, int n, int hw, int cp,
@@ -327,7 +330,7 @@ extern "C" int mil_avgpool_fc_bwd(const float* dfeats, const float* wfc, const f
         else return MIL_ERR_ARG;
         MIL_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(fc_wgrad_kernel, dim3((nf * c + 255) / 256), dim3(256), 0, st, dfeats, pooled, dwfc, n, c, nf);
+    hipLaunchKernelGGL(fc_wgrad_kernel, dim3((nf * c + 3) / 4), dim3(256), 0, st, dfeats, pooled, dwfc, n, c, nf);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
