@@ -140,6 +140,235 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs<T> a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Persistent, software-pipelined form for the narrow (HBM-bound) layers (bf16 path).
+//   * each workgroup stages the packed filter in LDS ONCE and walks a strided list of 256-px tiles;
+//   * while tile i's MFMA loop runs, the loads of tile i+1's halo and of tile i's epilogue operands
+//     (residual, activation mask) are already in flight into registers (issue-early / write-late);
+//   * the MFMA operands are swapped (A = filter fragment, B = pixel fragment) so the accumulator holds
+//     D[channel][pixel]: every lane owns 4 consecutive channels of one pixel and the whole epilogue
+//     (bias, residual, LeakyReLU, mask, bf16 store) runs from registers with 8-byte accesses — no LDS
+//     round trip and one barrier fewer per tile;
+//   * everything that does not depend on the tile (piece -> halo coordinate, k-step -> tap offset,
+//     lane -> output pixel) is computed once per workgroup: the per-tile instruction stream is loads,
+//     MFMAs and the element-wise epilogue, which is what keeps the kernel on the HBM roof rather than
+//     on the vector-issue roof.
+template <int CINP, int NT, int KS>
+__global__ __launch_bounds__(256) void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using T = BF16;
+    constexpr int PIXB = mil_pix_pitch(CINP, 2);
+    constexpr int CG = CINP / 8;
+    constexpr int N16 = CINP / 8;
+    constexpr int COUTP = mil_nt_to_cp(NT);
+    constexpr int MTW = 4;
+    constexpr int NPX = mil_halo_np(CINP, 2);
+    constexpr int KSTEPS = (KS * KS * CG + 3) / 4;
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, gq = lane >> 4;
+    char* ldsA = smem;
+    char* ldsW = smem + a.lds_w_off;
+
+    {
+        const int nbytes = a.nsteps * NT * 64 * 16;
+        const char* src = reinterpret_cast<const char*>(a.w);
+        for (int i = tid * 16; i < nbytes; i += 256 * 16)
+            *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(src + i);
+    }
+    const int s_eff = g.zins ? 1 : g.stride;
+    const int TW = 1 << g.tw_log2, TH = 1 << g.th_log2;
+
+    // ---- tile-invariant tables -------------------------------------------------------------------
+    // halo pieces owned by this thread: source offset relative to the tile origin, LDS offset, (ti,hy,hx)
+    int h_src[NPX], h_lds[NPX], h_pos[NPX];
+    {
+        const int ppr = g.hw * N16;
+        const int total = (g.hh << g.ti_log2) * ppr;
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            const int idx = tid + 256 * i;
+            h_pos[i] = -1;
+            h_src[i] = 0; h_lds[i] = 0;
+            if (idx < total) {
+                const int row = idx / ppr, piece = idx - row * ppr;
+                const int ti = row / g.hh, hy = row - ti * g.hh;
+                const int hx = piece / N16, j = piece - hx * N16;
+                h_pos[i] = (ti << 20) | (hy << 10) | hx;
+                h_lds[i] = (row * g.hw + hx) * PIXB + j * 16;
+                if (g.zins) h_src[i] = j * 16;              // coordinates are halved per tile (parity-dependent)
+                else h_src[i] = ((ti * g.H + hy) * g.W + hx) * (CINP * 2) + j * 16;
+            }
+        }
+    }
+    // k-step -> byte offset of this lane's (tap, channel-group) inside a halo pixel
+    int toff[KSTEPS];
+#pragma unroll
+    for (int sl = 0; sl < KSTEPS; ++sl) {
+        const int q = 4 * sl + gq;
+        int tap = q / CG, cg = q - tap * CG;
+        if (tap >= KS * KS) { tap = 0; cg = 0; }
+        const int ky = tap / KS, kx = tap - ky * KS;
+        toff[sl] = (ky * g.hw + kx) * PIXB + cg * 16;
+    }
+    // lane -> the 4 output pixels it owns (one per MFMA row tile): halo base, output offset, (ti,ty,tx)
+    int pixbase[MTW], o_rel[MTW], o_pos[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        const int tp = (wave * MTW + m) * 16 + r;
+        const int tx = tp & (TW - 1), ty = (tp >> g.tw_log2) & (TH - 1), ti = tp >> (g.tw_log2 + g.th_log2);
+        pixbase[m] = ((ti * g.hh + ty * s_eff) * g.hw + tx * s_eff) * PIXB;
+        o_rel[m] = ((ti * g.Ho + ty) * g.Wo + tx) * (COUTP * 2) + gq * 8;
+        o_pos[m] = (ti << 20) | (ty << 10) | tx;
+    }
+    // channels 4*gq..4*gq+3 of column tile nt exist?
+    bool ch_ok[NT];
+    float bias_r[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        ch_ok[nt] = (nt * 16 + gq * 4) < COUTP;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias_r[nt][i] = a.bias ? a.bias[nt * 16 + gq * 4 + i] : 0.f;
+    }
+
+    auto fetch_halo = [&](uint4 (&rx)[NPX], int tile) {
+        const TileOrigin o = mil_tile_origin(g, tile);
+        const int iy0 = o.oy0 * s_eff - g.pad, ix0 = o.ox0 * s_eff - g.pad;
+        const int ilim = g.n_img - o.img0;
+        const char* base = reinterpret_cast<const char*>(a.x);
+        if (!g.zins) base += (((size_t)o.img0 * g.H + iy0) * (size_t)g.W + ix0) * (CINP * 2);   // may point before x: only valid lanes dereference
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (h_pos[i] >= 0) {
+                const int ti = h_pos[i] >> 20;
+                int iy = iy0 + ((h_pos[i] >> 10) & 1023), ix = ix0 + (h_pos[i] & 1023);
+                if (!g.zins) {
+                    if (ti < ilim && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+                        v = *reinterpret_cast<const uint4*>(base + h_src[i]);
+                } else {
+                    if (ti < ilim && iy >= 0 && ix >= 0 && !((iy | ix) & 1) && (iy >> 1) < g.H && (ix >> 1) < g.W)
+                        v = *reinterpret_cast<const uint4*>(base + (((size_t)(o.img0 + ti) * g.H + (iy >> 1)) * g.W + (ix >> 1)) * (CINP * 2) + h_src[i]);
+                }
+            }
+            rx[i] = v;
+        }
+    };
+
+    uint4 rx[NPX];
+    if ((int)blockIdx.x < ntiles) fetch_halo(rx, blockIdx.x);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const TileOrigin o = mil_tile_origin(g, tile);
+        __syncthreads();                       // every wave has finished reading ldsA for the previous tile
+#pragma unroll
+        for (int i = 0; i < NPX; ++i)
+            if (h_pos[i] >= 0) *reinterpret_cast<uint4*>(ldsA + h_lds[i]) = rx[i];
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch_halo(rx, tile + gridDim.x);
+
+        // this tile's epilogue operands, 8 bytes (4 channels) per lane per (row tile, column tile)
+        const size_t obase = (((size_t)o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (COUTP * 2);
+        const int ylim = g.Ho - o.oy0, xlim = g.Wo - o.ox0, ilim = g.n_img - o.img0;
+        bool pix_ok[MTW];
+        uint2 rres[MTW][NT], ract[MTW][NT];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            pix_ok[m] = (o_pos[m] >> 20) < ilim && ((o_pos[m] >> 10) & 1023) < ylim && (o_pos[m] & 1023) < xlim;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                rres[m][nt] = make_uint2(0u, 0u);
+                ract[m][nt] = make_uint2(0u, 0u);
+                if (pix_ok[m] && ch_ok[nt]) {
+                    const size_t off = obase + o_rel[m] + nt * 32;
+                    if (a.res) rres[m][nt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.res) + off);
+                    if (a.act) ract[m][nt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.act) + off);
+                }
+            }
+        }
+
+        f32x4_t acc[MTW][NT];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sl = 0; sl < KSTEPS; ++sl) {
+            Frag8<T> wf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<T>(ldsW + ((sl * NT + nt) * 64 + lane) * 16);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const Frag8<T> xf = lds_frag<T>(ldsA + pixbase[m] + toff[sl]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wf[nt], xf, acc[m][nt]);   // D[channel][pixel]
+            }
+        }
+
+        // register epilogue: lane owns channels nt*16 + 4*gq + {0..3} of pixel (row tile m, column r)
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (!(pix_ok[m] && ch_ok[nt])) continue;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = acc[m][nt][i] + bias_r[nt][i];
+                if (a.res) {
+                    const bf16x4_t t = __builtin_bit_cast(bf16x4_t, rres[m][nt]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += (float)t[i];
+                }
+                if (a.apply_lrelu) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], v[i] * a.slope);      // 0 < slope < 1
+                }
+                if (a.act) {
+                    const bf16x4_t t = __builtin_bit_cast(bf16x4_t, ract[m][nt]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] *= ((float)t[i] > 0.f ? 1.f : a.slope);
+                }
+                bf16x4_t ov;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ov[i] = (__bf16)v[i];
+                *reinterpret_cast<bf16x4_t*>(reinterpret_cast<char*>(a.y) + obase + o_rel[m] + nt * 32) = ov;
+            }
+        }
+    }
+}
+
+template <int CINP, int NT, int KS>
+static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool* taken) {
+    ConvArgs<BF16> a = a0;
+    constexpr int PIXB = mil_pix_pitch(CINP, 2);
+    constexpr int FRAGB = 16;
+    *taken = false;
+    mil_geom_tiles(a.g, 8);
+    const int halo_px = (a.g.hh * a.g.hw) << a.g.ti_log2;
+    if (halo_px > 400) return MIL_OK;
+    const int a_bytes = (halo_px * PIXB + 15) & ~15;
+    const int w_bytes = a.nsteps * NT * 64 * FRAGB;
+    const int lds = a_bytes + w_bytes;
+    if (lds > 160 * 1024) return MIL_OK;
+    if (a.g.hh >= 1024 || a.g.hw >= 1024 || a.slope <= 0.f || a.slope >= 1.f) return MIL_OK;
+    const int ntiles = a.g.n_groups * a.g.tiles_y * a.g.tiles_x;
+    if (ntiles < 512) return MIL_OK;             // not enough tiles to amortise a persistent launch
+    a.kc = a.nsteps;
+    a.lds_w_off = a_bytes;
+    auto kern = conv_igemm_pf_kernel<CINP, NT, KS>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return MIL_ERR_LAUNCH;
+    }
+    const int per_cu = (160 * 1024) / lds;
+    int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a, ntiles);
+    MIL_CHECK_LAUNCH();
+    *taken = true;
+    return MIL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 template <typename T, int CINP, int NT, int MTW>
 static int launch_conv(const ConvArgs<T>& a0, hipStream_t stream) {
     ConvArgs<T> a = a0;
@@ -171,9 +400,29 @@ static int launch_conv(const ConvArgs<T>& a0, hipStream_t stream) {
     return MIL_OK;
 }
 
+template <int CINP, int NT>
+static int launch_conv_pf(const ConvArgs<BF16>& a, hipStream_t stream, bool* taken) {
+    *taken = false;
+    if constexpr (CINP == 16 && NT == 2) { if (a.g.ks == 4) return launch_conv_pf_ks<16, 2, 4>(a, stream, taken); }
+    if constexpr (CINP == 24 && NT == 2) { if (a.g.ks == 3) return launch_conv_pf_ks<24, 2, 3>(a, stream, taken); }
+    if constexpr (CINP == 40 && NT == 3) { if (a.g.ks == 3) return launch_conv_pf_ks<40, 3, 3>(a, stream, taken); }
+    if constexpr (CINP == 40 && NT == 2) {
+        if (a.g.ks == 3) return launch_conv_pf_ks<40, 2, 3>(a, stream, taken);
+        if (a.g.ks == 1) return launch_conv_pf_ks<40, 2, 1>(a, stream, taken);
+    }
+    return MIL_OK;
+}
+
 // 256-px tiles (4 MFMA row tiles per wave) when the halo + a weight chunk fit in LDS, else 64-px tiles.
 template <typename T, int CINP, int NT>
 static int launch_conv_auto(const ConvArgs<T>& a, bool small_tile, hipStream_t stream) {
+    if constexpr (T::DT == MIL_DT_BF16 && CINP <= 40) {
+        if (!small_tile) {
+            bool taken = false;
+            const int rc = launch_conv_pf<CINP, NT>(a, stream, &taken);
+            if (rc != MIL_OK || taken) return rc;
+        }
+    }
     if (!small_tile) {
         const int rc = launch_conv<T, CINP, NT, 4>(a, stream);
         if (rc != MIL_ERR_UNSUPPORTED) return rc;

@@ -32,7 +32,7 @@ __device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <typename T, int KS, int CINP, int NT, int MSPLIT>
+template <typename T, int KS, int CINP, int NT, int MSPLIT, bool PF>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ESZ = T::ESZ;
@@ -77,11 +77,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs<T> a) {
         for (int i = 0; i < MW; ++i) acc[i][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
 
+    // PF: software pipeline — the next tile's global loads are issued (into registers) before this tile's
+    // MFMA loop and written to LDS after the loop's barrier, so HBM latency hides under compute.
+    constexpr int NPX = PF ? mil_halo_np(CINP, ESZ) : 1;
+    constexpr int NPZ = PF ? COUTP * ESZ / 16 : 1;
+    uint4 rx[NPX], rz[NPZ];
+    if constexpr (PF) {
+        if ((int)blockIdx.x < a.ntiles) {
+            const TileOrigin o0 = mil_tile_origin(g, blockIdx.x);
+            mil_halo_fetch<T, CINP, NPX>(rx, a.x, g, o0, tid);
+            mil_otile_fetch<T, COUTP, NPZ>(rz, a.dz, g, o0, tid, a.tile_px);
+        }
+    }
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const TileOrigin o = mil_tile_origin(g, tile);
         __syncthreads();
-        mil_load_halo<T, CINP>(ldsX, a.x, g, o, tid, 256);
-        mil_load_otile<T, COUTP>(ldsZ, a.dz, g, o, tid, 256, a.tile_px);
+        if constexpr (PF) {
+            mil_halo_commit<T, CINP, NPX>(rx, ldsX, g, tid);
+            mil_otile_commit<T, COUTP, NPZ>(rz, ldsZ, tid, a.tile_px);
+            const int nxt = tile + gridDim.x;
+            if (nxt < a.ntiles) {
+                const TileOrigin on = mil_tile_origin(g, nxt);
+                mil_halo_fetch<T, CINP, NPX>(rx, a.x, g, on, tid);
+                mil_otile_fetch<T, COUTP, NPZ>(rz, a.dz, g, on, tid, a.tile_px);
+            }
+        } else {
+            const TileOrigin o = mil_tile_origin(g, tile);
+            mil_load_halo<T, CINP>(ldsX, a.x, g, o, tid, 256);
+            mil_load_otile<T, COUTP>(ldsZ, a.dz, g, o, tid, 256, a.tile_px);
+        }
         __syncthreads();
         if constexpr (T::DT == MIL_DT_BF16) {
             const int q4 = (lane & 15) >> 2, p = lane & 3, gq = lane >> 4;
@@ -251,13 +274,13 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     WgradArgs<T> a{};
     a.x = (const typename T::elem*)x; a.dz = (const typename T::elem*)dz; a.slab = (float*)ws; a.g = g;
     a.ntiles = g.n_groups * g.tiles_y * g.tiles_x; a.tile_px = 1 << pl.tile_px_log2; a.lds_z_off = lds_z_off;
-    auto kern = wgrad_kernel<T, KS, CINP, NT, MSPLIT>;
+    // register-prefetch pipeline for the bf16 path when the halo is small enough for its register budget
+    constexpr bool PF_OK = (T::DT == MIL_DT_BF16) && CINP <= 40;      // wider layers: accumulators own the registers
+    const bool pf = PF_OK && (((g.hh * g.hw) << g.ti_log2) <= 400) && a.tile_px == 256;
+    auto kern = pf ? wgrad_kernel<T, KS, CINP, NT, MSPLIT, PF_OK> : wgrad_kernel<T, KS, CINP, NT, MSPLIT, false>;
     if (pl.lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds) != hipSuccess)
             return MIL_ERR_LAUNCH;
-    }
-    if (MSPLIT > 1) {
-        // every (row tile) is written by exactly one split; nothing to clear
     }
     hipLaunchKernelGGL(kern, dim3(pl.grid_x, MSPLIT), dim3(256), pl.lds, stream, a);
     MIL_CHECK_LAUNCH();

@@ -111,3 +111,92 @@ __device__ __forceinline__ int mil_pix_base(const ConvGeom& g, int tp, int s_eff
     const int ti = tp >> (g.tw_log2 + g.th_log2);
     return ((ti * g.hh + ty * s_eff) * g.hw + tx * s_eff) * PIXB;
 }
+
+// ---- split (issue-early / write-late) forms of the two loaders: global -> registers now, registers -> LDS
+// after the next barrier, so a persistent workgroup keeps the NEXT tile's loads in flight while it computes.
+// Flat piece index = tid + 256*i; NP is a compile-time bound on pieces per thread (guarded by the real count).
+template <typename T, int CINP, int NP>
+__device__ __forceinline__ void mil_halo_fetch(uint4 (&r)[NP], const typename T::elem* __restrict__ x, const ConvGeom& g,
+                                               const TileOrigin& o, int tid) {
+    constexpr int ESZ = T::ESZ;
+    constexpr int N16 = CINP * ESZ / 16;
+    const int s = g.zins ? 1 : g.stride;
+    const int iy0 = o.oy0 * s - g.pad, ix0 = o.ox0 * s - g.pad;
+    const int ppr = g.hw * N16;
+    const int total = (g.hh << g.ti_log2) * ppr;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int idx = tid + 256 * i;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (idx < total) {
+            const int row = idx / ppr, piece = idx - row * ppr;
+            const int ti = row / g.hh, hy = row - ti * g.hh;
+            const int hx = piece / N16, j = piece - hx * N16;
+            const int img = o.img0 + ti;
+            int iy = iy0 + hy, ix = ix0 + hx;
+            bool ok = img < g.n_img && iy >= 0 && ix >= 0;
+            if (g.zins) { ok = ok && !((iy | ix) & 1); iy >>= 1; ix >>= 1; }
+            ok = ok && iy < g.H && ix < g.W;
+            if (ok) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) +
+                            (((size_t)img * g.H + iy) * g.W + ix) * (CINP * ESZ) + j * 16);
+        }
+        r[i] = v;
+    }
+}
+
+template <typename T, int CINP, int NP>
+__device__ __forceinline__ void mil_halo_commit(const uint4 (&r)[NP], char* lds, const ConvGeom& g, int tid) {
+    constexpr int ESZ = T::ESZ;
+    constexpr int PIXB = mil_pix_pitch(CINP, ESZ);
+    constexpr int N16 = CINP * ESZ / 16;
+    const int total = (g.hh * g.hw << g.ti_log2) * N16;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < total) {
+            const int px = idx / N16, j = idx - px * N16;
+            *reinterpret_cast<uint4*>(lds + px * PIXB + j * 16) = r[i];
+        }
+    }
+}
+
+template <typename T, int CP, int NP>
+__device__ __forceinline__ void mil_otile_fetch(uint4 (&r)[NP], const typename T::elem* __restrict__ z, const ConvGeom& g,
+                                                const TileOrigin& o, int tid, int tile_px) {
+    constexpr int ESZ = T::ESZ;
+    constexpr int N16 = CP * ESZ / 16;
+    const int tw_mask = (1 << g.tw_log2) - 1, th_mask = (1 << g.th_log2) - 1;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int idx = tid + 256 * i;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (idx < tile_px * N16) {
+            const int tp = idx / N16, j = idx - tp * N16;
+            const int ox = o.ox0 + (tp & tw_mask);
+            const int oy = o.oy0 + ((tp >> g.tw_log2) & th_mask);
+            const int img = o.img0 + (tp >> (g.tw_log2 + g.th_log2));
+            if (img < g.n_img && oy < g.Ho && ox < g.Wo)
+                v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(z) +
+                        (((size_t)img * g.Ho + oy) * g.Wo + ox) * (CP * ESZ) + j * 16);
+        }
+        r[i] = v;
+    }
+}
+
+template <typename T, int CP, int NP>
+__device__ __forceinline__ void mil_otile_commit(const uint4 (&r)[NP], char* lds, int tid, int tile_px) {
+    constexpr int ESZ = T::ESZ;
+    constexpr int PIXZ = mil_pix_pitch(CP, ESZ);
+    constexpr int N16 = CP * ESZ / 16;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < tile_px * N16) {
+            const int tp = idx / N16, j = idx - tp * N16;
+            *reinterpret_cast<uint4*>(lds + tp * PIXZ + j * 16) = r[i];
+        }
+    }
+}
+
+// pieces-per-thread bound for a halo of at most 400 pixels (18x18, 19x19 and 4 x 10x10 tiles)
+__host__ __device__ constexpr int mil_halo_np(int cinp, int esz) { return (400 * (cinp * esz / 16) + 255) / 256; }
