@@ -352,6 +352,7 @@ static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool*
     if (a.g.hh >= 1024 || a.g.hw >= 1024 || a.slope <= 0.f || a.slope >= 1.f) return MIL_OK;
     const int ntiles = a.g.n_groups * a.g.tiles_y * a.g.tiles_x;
     if (ntiles < 512) return MIL_OK;             // not enough tiles to amortise a persistent launch
+
     a.kc = a.nsteps;
     a.lds_w_off = a_bytes;
     auto kern = conv_igemm_pf_kernel<CINP, NT, KS>;
@@ -410,13 +411,18 @@ static int launch_conv_pf(const ConvArgs<BF16>& a, hipStream_t stream, bool* tak
         if (a.g.ks == 3) return launch_conv_pf_ks<40, 2, 3>(a, stream, taken);
         if (a.g.ks == 1) return launch_conv_pf_ks<40, 2, 1>(a, stream, taken);
     }
+    if constexpr (CINP == 64 && NT == 4) { if (a.g.ks == 3) return launch_conv_pf_ks<64, 4, 3>(a, stream, taken); }
+    if constexpr (CINP == 64 && NT == 3) {
+        if (a.g.ks == 3) return launch_conv_pf_ks<64, 3, 3>(a, stream, taken);
+        if (a.g.ks == 1) return launch_conv_pf_ks<64, 3, 1>(a, stream, taken);
+    }
     return MIL_OK;
 }
 
 // 256-px tiles (4 MFMA row tiles per wave) when the halo + a weight chunk fit in LDS, else 64-px tiles.
 template <typename T, int CINP, int NT>
 static int launch_conv_auto(const ConvArgs<T>& a, bool small_tile, hipStream_t stream) {
-    if constexpr (T::DT == MIL_DT_BF16 && CINP <= 40) {
+    if constexpr (T::DT == MIL_DT_BF16 && CINP <= 64) {
         if (!small_tile) {
             bool taken = false;
             const int rc = launch_conv_pf<CINP, NT>(a, stream, &taken);

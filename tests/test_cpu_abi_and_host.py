@@ -1,0 +1,92 @@
+"""CPU (-m "not gpu"): the C-ABI library loads and exports every symbol include/mil_hip.h declares (no
+compute calls without a GPU), host-side logic (module surface, state-dict layout, error behaviour,
+shape/argument checks that must fire before a kernel is launched)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "mil_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mil_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import mil_amd
+    assert os.path.exists(mil_amd.LIB_PATH), "libmil_hip.so missing: run __graft_entry__.build()"
+    handle = ctypes.CDLL(mil_amd.LIB_PATH)
+    declared = _header_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in include/mil_hip.h but not exported"
+    from mil_amd import _lib
+    assert sorted(_lib.EXPORTS) == declared           # the ctypes binding covers exactly the header
+    assert mil_amd.lib().mil_abi_version() == 1
+    assert mil_amd.lib().mil_head_grad_floats() == 6807   # 11 head tensors
+
+
+def test_host_side_queries_need_no_gpu():
+    import mil_amd
+    lib = mil_amd.lib()
+    n = ctypes.c_size_t(0)
+    assert lib.mil_packed_weight_elems(ctypes.byref(n), 20, 20, 3, 0) == 0
+    assert n.value == 7 * 2 * 64 * 8                   # 27 channel groups -> 7 k-steps, 2 column tiles
+    assert lib.mil_packed_weight_elems(ctypes.byref(n), 20, 3, 7, 2) == 0
+    assert n.value == 8 * 2 * 64 * 8                   # stem as 4x4 over 16 s2d channels
+    assert lib.mil_conv_wgrad_workspace(ctypes.byref(n), 8, 64, 64, 20, 64, 64, 20, 3, 1, 1, 0, 1) == 0
+    assert n.value > 0
+    assert lib.mil_conv_wgrad_workspace(ctypes.byref(n), 8, 64, 64, 33, 64, 64, 20, 3, 1, 1, 0, 1) == 2   # unsupported width
+    assert lib.mil_head_workspace_floats(ctypes.byref(n), 100, 3) == 0 and n.value > 0
+    # argument errors are status codes, never crashes
+    assert lib.mil_conv_igemm(None, None, None, None, None, None, 1, 8, 8, 24, 8, 8, 24, 3, 1, 1, 0, 0, 0.1, 1, None) == 1
+
+
+def test_module_surface_matches_reference(golden_dir):
+    import mil_amd
+    w = np.load(os.path.join(golden_dir, "weights.npz"))
+    net = mil_amd.Attention(3, device="cpu")
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(w.keys())                       # 65 keys, reference order
+    assert all(tuple(sd[k].shape) == w[k].shape for k in sd)
+    assert sum(p.numel() for p in net.parameters()) == 640967
+    missing, unexpected = net.load_state_dict({k: torch.tensor(w[k]) for k in w.keys()}, strict=False)
+    assert not missing and not unexpected
+    # attributes the reference driver touches
+    assert isinstance(net.weight_mask, torch.nn.Parameter) and net.weight_mask.shape == (3,)
+    assert hasattr(net.cnn, "module") and hasattr(net, "context") and hasattr(net, "attention") and hasattr(net, "buffer")
+    assert "off_diag" not in sd and tuple(net.off_diag.shape) == (3, 3)
+    assert net.train().training and not net.eval().training
+    assert "ResNet" in str(net) and len(list(net.named_parameters())) == 65
+    # transfer-style filtering on key names works as in the reference driver (conv-only keys)
+    assert len([k for k in sd if "cnn" in k and "conv" in k]) == 50
+
+
+def test_no_cpu_fallback():
+    import mil_amd
+    net = mil_amd.Attention(3, device="cpu")
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(4, 3, 32, 32), torch.tensor([0]))
+    with pytest.raises(RuntimeError):
+        net.cnn.module.layer1[0](torch.zeros(1, 20, 8, 8))
+    with pytest.raises(ValueError):
+        mil_amd.Attention(5, device="cpu")
+
+
+def test_bag_layout_and_sharding():
+    from mil_amd.dist import shard_bags
+    from mil_amd.head import BagLayout
+    lay = BagLayout([3, 5, 2], torch.device("cpu"))
+    assert lay.offsets.tolist() == [0, 3, 8, 10] and lay.inst_bag.tolist() == [0] * 3 + [1] * 5 + [2] * 2
+    with pytest.raises(ValueError):
+        BagLayout([4, 1], torch.device("cpu"))           # single-instance bag: batch-norm refuses it
+    with pytest.raises(ValueError):
+        BagLayout([], torch.device("cpu"))
+    assert shard_bags(10, 1, 4) == [1, 5, 9]
+    assert sorted(sum((shard_bags(10, r, 4) for r in range(4)), [])) == list(range(10))
