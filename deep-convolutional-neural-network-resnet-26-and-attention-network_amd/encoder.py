@@ -54,7 +54,9 @@ class ResNet(nn.Module):
         self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
         self.fc = nn.Linear(STAGE_WIDTHS[-1], num_classes, bias=False)
         self.compute_dtype = compute_dtype
+        self.overlap_wgrad = True
         self._pack_cache = {}
+        self._side = None
 
     def _make_layer(self, planes, blocks, stride=1):
         shortcut = None
@@ -80,6 +82,11 @@ class ResNet(nn.Module):
                 ps.append(blk.downsample[0].weight)
         ps.append(self.fc.weight)
         return ps
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        return self._side
 
     def _packed(self, key, weight, bias, mode, dtype):
         """Packed MFMA-fragment copy of a conv weight, rebuilt only when the parameter changed."""
@@ -130,6 +137,11 @@ def encoder_backward(net, saved, dfeats, dtype):
     dz, dwfc = ops.avgpool_fc_bwd(dfeats.contiguous(), net.fc.weight.detach(), saved["pooled"], last_out,
                                   STAGE_WIDTHS[-1])
     ws = None
+    # Weight gradients only consume (x, dz) and nothing downstream waits for them, so they run on a side
+    # stream beside the sequential dgrad chain (the small late-layer launches do not fill 256 CUs alone).
+    main = torch.cuda.current_stream()
+    side = net._side_stream()
+    use_side = net.overlap_wgrad
 
     def wgrad(xin, dzz, cin, cout, **kw):
         nonlocal ws
@@ -137,9 +149,18 @@ def encoder_backward(net, saved, dfeats, dtype):
         _, ho, wo, _ = dzz.shape
         need = ops.wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, kw["ks"], kw["stride"], kw["pad"],
                                          kw.get("stem", False), xin.dtype)
-        if ws is None or ws.numel() * 4 < need:
-            ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=xin.device)
-        return ops.conv_wgrad(xin, dzz, cin, cout, workspace=ws, **kw)
+        if not use_side:
+            if ws is None or ws.numel() * 4 < need:
+                ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=xin.device)
+            return ops.conv_wgrad(xin, dzz, cin, cout, workspace=ws, **kw)
+        side.wait_stream(main)                       # dz was produced on the main stream
+        with torch.cuda.stream(side):
+            if ws is None or ws.numel() * 4 < need:  # launches on `side` are serialised: one slab buffer suffices
+                ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=xin.device)
+            out = ops.conv_wgrad(xin, dzz, cin, cout, workspace=ws, **kw)
+        xin.record_stream(side)
+        dzz.record_stream(side)
+        return out
 
     for bi in range(len(blocks) - 1, -1, -1):
         blk = blocks[bi]
@@ -169,6 +190,8 @@ def encoder_backward(net, saved, dfeats, dtype):
     dstem = ops.maxpool_bwd(dz, saved["widx"], saved["stem"])
     grads["stem"] = wgrad(saved["xs"], dstem, 3, STEM_WIDTH, ks=4, stride=1, pad=2, stem=True)
 
+    if use_side:
+        main.wait_stream(side)
     flat = [grads["stem"][0], grads["stem"][1]]
     for bi, blk in enumerate(blocks):
         flat += [grads[f"b{bi}.c1"][0], grads[f"b{bi}.c1"][1], grads[f"b{bi}.c2"][0], grads[f"b{bi}.c2"][1]]
