@@ -41,6 +41,8 @@ _SIGS = {
     "mil_conv_igemm": ([_vp] * 6 + [_i] * 12 + [_f, _i, _vp], _i),
     "mil_conv_wgrad_workspace": ([_c.POINTER(_sz)] + [_i] * 12, _i),
     "mil_conv_wgrad": ([_vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 12 + [_vp], _i),
+    "mil_conv_bwd_fused_workspace": ([_c.POINTER(_sz)] + [_i] * 8, _i),
+    "mil_conv_bwd_fused": ([_vp] * 8 + [_sz] + [_i] * 8 + [_f, _i, _vp], _i),
     "mil_maxpool_fwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "mil_maxpool_bwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp], _i),
     "mil_avgpool_fc_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),

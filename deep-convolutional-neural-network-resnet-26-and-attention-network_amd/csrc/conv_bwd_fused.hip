@@ -1,0 +1,362 @@
+// Fused backward of one 3x3 stride-1 convolution of a residual block (bf16 path, narrow layers):
+// ONE pass over dz and x produces both gradients that the reference's autograd computes for
+// nnBlocks.py:169-171 —
+//     dx = ( conv^T(dz, W) + addend ) * lrelu'(x)            (data gradient, fused mask/residual-grad)
+//     dW[co][ci][ky][kx] = sum_p x[p+(ky,kx)-1][ci] * dz[p][co],   db[co] = sum_p dz[p][co]
+// instead of a dgrad kernel (reads dz, x-as-mask) plus a wgrad kernel (reads x and dz again).
+//
+// Structure = the persistent prefetch-pipelined conv kernel (conv_igemm.hip) run over dz with the
+// transposed+flipped packed filter, plus a second MFMA loop on the SAME LDS tiles:
+//   dW'[(tap',co)][ci] = sum_q dz[q (+) tap'][co] * x[q][ci]        (q = the tile's 256 centre pixels)
+// i.e. the weight gradient written with the halo on dz instead of on x (tap' is the flipped tap), so the
+// dz halo tile already staged for the data gradient is its A operand and the x centre tile (needed
+// anyway for the mask) is its B operand, both read with ds_read_b64_tr_b16.  Per-workgroup partial sums
+// stay in registers across tiles and leave as one fp32 slab; a fixed-order reduction finishes them.
+#include "pf_common.cuh"
+
+struct BwdFusedArgs {
+    const __bf16* dz;       // [n,H,W,CZ]
+    const __bf16* w;        // dgrad-packed filter [ksteps][NTX][64][8]
+    const __bf16* x;        // [n,H,W,CX]  conv input (mask source + wgrad operand)
+    const __bf16* addend;   // [n,H,W,CX] or null
+    __bf16* dx;             // [n,H,W,CX]
+    float* slab;            // [gridDim.x][(MT+1)*16][NTX*16]
+    ConvGeom g;
+    int ntiles;
+    int lds_w_off, lds_x_off;
+    int apply_mask;
+    float slope;
+    unsigned z_bytes, x_bytes;      // byte sizes of dz and of x/addend/dx (buffer descriptors)
+};
+
+template <int CZ, int NTX, int KS>
+__global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(BwdFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PIXB = mil_pix_pitch(CZ, 2);            // dz halo pixel pitch
+    constexpr int CG = CZ / 8;
+    constexpr int CX = mil_nt_to_cp(NTX);
+    constexpr int PIXX = mil_pix_pitch(CX, 2);            // x centre tile pixel pitch
+    constexpr int MTW = 4;
+    constexpr int NPX = mil_halo_np(CZ, 2);
+    constexpr int KSTEPS = (KS * KS * CG + 3) / 4;
+    constexpr int RG = KS * KS * CG;                       // wgrad row groups (tap', 8 dz channels)
+    constexpr int MT = (RG + 1) / 2;
+    constexpr int MW = (MT + 3) / 4;
+    constexpr int CTAP = (KS * KS) / 2;                    // centre tap
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave id through readfirstlane: provably wave-uniform, so branches on it are scalar branches (an MFMA or a
+    // ds_read_b64_tr_b16 inside an EXEC-masked region would still execute / need all lanes)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, gq = lane >> 4;
+    char* ldsA = smem;
+    char* ldsW = smem + a.lds_w_off;
+    char* ldsX = smem + a.lds_x_off;
+
+    {
+        const int nbytes = KSTEPS * NTX * 64 * 16;
+        const char* src = reinterpret_cast<const char*>(a.w);
+        for (int i = tid * 16; i < nbytes; i += 256 * 16)
+            *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(src + i);
+    }
+    const int TW = 1 << g.tw_log2, TH = 1 << g.th_log2;
+
+    const __amdgpu_buffer_rsrc_t rs_z = mil_rsrc(a.dz, a.z_bytes);
+    const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rs_add = mil_rsrc(a.addend, a.addend ? a.x_bytes : 0);
+    const __amdgpu_buffer_rsrc_t rs_dx = mil_rsrc(a.dx, a.x_bytes);
+
+    // ---- tile-invariant tables (see conv_igemm_pf_kernel) -------------------------------------------
+    HaloTables<NPX> ht;
+    mil_build_halo_tables<CZ, NPX>(ht, g, tid);
+    int toff[KSTEPS];
+#pragma unroll
+    for (int sl = 0; sl < KSTEPS; ++sl) {
+        const int q = 4 * sl + gq;
+        int tap = q / CG, cg = q - tap * CG;
+        if (tap >= KS * KS) { tap = 0; cg = 0; }
+        const int ky = tap / KS, kx = tap - ky * KS;
+        toff[sl] = (ky * g.hw + kx) * PIXB + cg * 16;
+    }
+    int pixbase[MTW], o_rel[MTW], o_pos[MTW], x_lds[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+        const int tp = (wave * MTW + m) * 16 + r;
+        const int tx = tp & (TW - 1), ty = (tp >> g.tw_log2) & (TH - 1), ti = tp >> (g.tw_log2 + g.th_log2);
+        pixbase[m] = ((ti * g.hh + ty) * g.hw + tx) * PIXB;
+        o_rel[m] = ((ti * g.Ho + ty) * g.Wo + tx) * (CX * 2) + gq * 8;
+        o_pos[m] = (ti << 20) | (ty << 10) | tx;
+        x_lds[m] = tp * PIXX + gq * 8;
+    }
+    constexpr bool LAST_PARTIAL = (CX % 16) != 0;
+    const bool last_ok = !LAST_PARTIAL || gq < 2;
+
+    // wgrad: this wave's row tiles mt = wave + 4*i; per-lane tr-read offset inside a dz halo pixel
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3;
+    int wtoff[MW];
+    bool mvalid[MW];
+    int bias_i = -1;                                       // which owned row tile holds centre-tap rows
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+        const int mt = wave + 4 * i;
+        mvalid[i] = mt < MT;
+        int rg = 2 * mt + (p4 >> 1);
+        if (rg >= RG) rg = 0;
+        const int tap = rg / CG, cg = rg - tap * CG;
+        const int ky = tap / KS, kx = tap - ky * KS;
+        wtoff[i] = (ky * g.hw + kx) * PIXB + cg * 16 + (p4 & 1) * 8;
+        const int rg_lo = 2 * mt, rg_hi = 2 * mt + 1;
+        if (mvalid[i] && rg_hi >= CTAP * CG && rg_lo < (CTAP + 1) * CG) bias_i = i;
+    }
+    f32x4_t wacc[MW][NTX];
+    f32x4_t bacc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int nt = 0; nt < NTX; ++nt) wacc[i][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+    TileWalker cur, nxt;
+    cur.init(g, blockIdx.x, gridDim.x);
+    nxt = cur; nxt.advance();
+    u32x4_t rx[NPX];
+    if ((int)blockIdx.x < a.ntiles) mil_fetch_halo<CZ, NPX>(rx, rs_z, ht, g, cur.origin(g));
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const TileOrigin o = cur.origin(g);
+        __syncthreads();                       // previous tile: all reads of ldsA / ldsX are done
+        mil_commit_halo<NPX>(rx, ldsA, ht);
+
+        // this tile's x (mask + wgrad operand) and addend, 8 bytes per lane per (row tile, column tile)
+        const int obase = ((o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (CX * 2);
+        const int ylim = g.Ho - o.oy0, xlim = g.Wo - o.ox0, ilim = g.n_img - o.img0;
+        unsigned ooff[MTW];
+        u32x2_t rxc[MTW][NTX], radd[MTW][NTX];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            const bool ok = (o_pos[m] >> 20) < ilim && ((o_pos[m] >> 10) & 1023) < ylim && (o_pos[m] & 1023) < xlim;
+            ooff[m] = ok ? (unsigned)(obase + o_rel[m]) : MIL_OOB;
+#pragma unroll
+            for (int nt = 0; nt < NTX; ++nt) {
+                const unsigned off = (LAST_PARTIAL && nt == NTX - 1 && !last_ok) ? MIL_OOB : ooff[m] + nt * 32;
+                rxc[m][nt] = __builtin_amdgcn_raw_buffer_load_b64(rs_x, off, 0, 0);
+                if (a.addend) radd[m][nt] = __builtin_amdgcn_raw_buffer_load_b64(rs_add, off, 0, 0);
+            }
+        }
+        __syncthreads();                       // dz halo visible
+        if (tile + (int)gridDim.x < a.ntiles) mil_fetch_halo<CZ, NPX>(rx, rs_z, ht, g, nxt.origin(g));
+        cur = nxt; nxt.advance();
+
+        // ---- data gradient: D[cx][pixel] -----------------------------------------------------------
+        f32x4_t acc[MTW][NTX];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NTX; ++nt) acc[m][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sl = 0; sl < KSTEPS; ++sl) {
+            Frag8<BF16> wf[NTX];
+#pragma unroll
+            for (int nt = 0; nt < NTX; ++nt) wf[nt] = lds_frag<BF16>(ldsW + ((sl * NTX + nt) * 64 + lane) * 16);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const Frag8<BF16> zf = lds_frag<BF16>(ldsA + pixbase[m] + toff[sl]);
+#pragma unroll
+                for (int nt = 0; nt < NTX; ++nt) acc[m][nt] = mma8(wf[nt], zf, acc[m][nt]);
+            }
+        }
+
+        // x centre tile -> LDS [pixel][CX] (zeros outside the image: no contribution to dW)
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NTX; ++nt)
+                if (!(LAST_PARTIAL && nt == NTX - 1) || last_ok)
+                    *reinterpret_cast<u32x2_t*>(ldsX + x_lds[m] + nt * 32) = rxc[m][nt];
+
+        // ---- data-gradient epilogue from registers ---------------------------------------------------
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+#pragma unroll
+            for (int nt = 0; nt < NTX; ++nt) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = acc[m][nt][i];
+                if (a.addend) {
+                    const bf16x4_t t = __builtin_bit_cast(bf16x4_t, radd[m][nt]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += (float)t[i];
+                }
+                if (a.apply_mask) {
+                    const bf16x4_t t = __builtin_bit_cast(bf16x4_t, rxc[m][nt]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] *= ((float)t[i] > 0.f ? 1.f : a.slope);
+                }
+                bf16x4_t ov;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ov[i] = (__bf16)v[i];
+                const unsigned off = (LAST_PARTIAL && nt == NTX - 1 && !last_ok) ? MIL_OOB : ooff[m] + nt * 32;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, ov), rs_dx, off, 0, 0);
+            }
+        }
+        __syncthreads();                       // x centre tile visible
+
+        // ---- weight gradient: rows (tap', dz channel), cols x channel, K = the tile's 256 pixels -------
+        for (int k32 = 0; k32 < 256; k32 += 32) {
+            const int tp0 = k32 + 8 * gq + q4, tp1 = tp0 + 4;
+            const int pb0 = mil_pix_base<PIXB>(g, tp0, 1);
+            const int pb1 = mil_pix_base<PIXB>(g, tp1, 1);
+            const char* x0 = ldsX + tp0 * PIXX + p4 * 8;
+            const char* x1 = ldsX + tp1 * PIXX + p4 * 8;
+            bf16x8_t xf[NTX];
+#pragma unroll
+            for (int nt = 0; nt < NTX; ++nt) xf[nt] = mil_tr_pair(x0 + nt * 32, x1 + nt * 32);
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+                if (mvalid[i]) {
+                    const bf16x8_t zf = mil_tr_pair(ldsA + pb0 + wtoff[i], ldsA + pb1 + wtoff[i]);
+#pragma unroll
+                    for (int nt = 0; nt < NTX; ++nt)
+                        wacc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf, xf[nt], wacc[i][nt], 0, 0, 0);
+                    if (i == bias_i) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf, ones, bacc, 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- partial sums -> slab: rows tap'*CZ + co, cols ci; bias sums in the extra row tile ---------------
+    constexpr int SLAB_COLS = NTX * 16;
+    constexpr size_t SLAB_ELEMS = (size_t)(MT + 1) * 16 * SLAB_COLS;
+    float* slab = a.slab + (size_t)blockIdx.x * SLAB_ELEMS;
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+        if (!mvalid[i]) continue;
+        const int mt = wave + 4 * i;
+#pragma unroll
+        for (int nt = 0; nt < NTX; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                slab[(size_t)(mt * 16 + gq * 4 + e) * SLAB_COLS + nt * 16 + r] = wacc[i][nt][e];
+        if (i == bias_i && r == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = mt * 16 + gq * 4 + e;          // = tap'*CZ + co
+                const int co = row - CTAP * CZ;
+                if (co >= 0 && co < CZ) slab[(size_t)MT * 16 * SLAB_COLS + co] = bacc[e];
+            }
+        }
+    }
+}
+
+// Fixed-order slab reduction for the fused kernel's layout: row = tap'*CZ + co (tap' = flipped tap),
+// col = ci  ->  dW[co][ci][k*k-1-tap'];  db from the extra row tile.
+__global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const float* __restrict__ slab, int nslab, size_t slab_elems,
+                                                             int slab_cols, int n_rows, float* __restrict__ dw,
+                                                             float* __restrict__ db, int cout, int cin, int ks, int czp,
+                                                             int bias_off) {
+    __shared__ float part[8][32];
+    const int c = threadIdx.x & 31, gq = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + c;
+    const int total = n_rows * slab_cols + czp;           // weight elements, then czp bias sums
+    float s = 0.f;
+    const bool live = e < total;
+    if (live) {
+        const size_t src = e < n_rows * slab_cols ? (size_t)e : (size_t)bias_off + (e - n_rows * slab_cols);
+        for (int i = gq; i < nslab; i += 8) s += slab[(size_t)i * slab_elems + src];
+    }
+    part[gq][c] = s;
+    __syncthreads();
+    if (gq != 0 || !live) return;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += part[k][c];
+    if (e >= n_rows * slab_cols) {
+        const int co = e - n_rows * slab_cols;
+        if (co < cout && db) db[co] = v;
+        return;
+    }
+    const int row = e / slab_cols, ci = e - row * slab_cols;
+    const int tapf = row / czp, co = row - tapf * czp;
+    if (ci >= cin || co >= cout) return;
+    dw[((size_t)co * cin + ci) * (ks * ks) + (ks * ks - 1 - tapf)] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int CZ, int NTX, int KS>
+static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t ws_bytes, int cout, int cin, bool query,
+                         size_t* need, hipStream_t stream) {
+    constexpr int PIXB = mil_pix_pitch(CZ, 2);
+    constexpr int CX = mil_nt_to_cp(NTX);
+    constexpr int PIXX = mil_pix_pitch(CX, 2);
+    constexpr int KSTEPS = (KS * KS * (CZ / 8) + 3) / 4;
+    constexpr int RG = KS * KS * (CZ / 8);
+    constexpr int MT = (RG + 1) / 2;
+    mil_geom_tiles(a.g, 8);
+    const int halo_px = (a.g.hh * a.g.hw) << a.g.ti_log2;
+    if (halo_px > 400 || a.g.hh >= 1024 || a.g.hw >= 1024) return MIL_ERR_UNSUPPORTED;
+    if ((size_t)a.g.n_img * a.g.H * a.g.W * (CZ > CX ? CZ : CX) * 2 >= ((size_t)1 << 31)) return MIL_ERR_UNSUPPORTED;   // buffer descriptors: < 2 GiB
+    const int a_bytes = (halo_px * PIXB + 15) & ~15;
+    const int w_bytes = KSTEPS * NTX * 64 * 16;
+    const int x_bytes = 256 * PIXX;
+    const int lds = a_bytes + w_bytes + x_bytes;
+    if (lds > 160 * 1024) return MIL_ERR_UNSUPPORTED;
+    const int ntiles = a.g.n_groups * a.g.tiles_y * a.g.tiles_x;
+    const int per_cu = (160 * 1024) / lds;
+    int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu));
+    if (grid > ntiles) grid = ntiles;
+    const size_t slab_elems = (size_t)(MT + 1) * 16 * NTX * 16;
+    const size_t bytes = slab_elems * grid * sizeof(float);
+    if (query) { *need = bytes; return MIL_OK; }
+    if (!ws || ws_bytes < bytes) return MIL_ERR_ARG;
+    a.slab = (float*)ws; a.ntiles = ntiles; a.lds_w_off = a_bytes; a.lds_x_off = a_bytes + w_bytes;
+    a.z_bytes = (unsigned)((size_t)a.g.n_img * a.g.H * a.g.W * CZ * 2);
+    a.x_bytes = (unsigned)((size_t)a.g.n_img * a.g.H * a.g.W * CX * 2);
+    auto kern = conv_bwd_fused_kernel<CZ, NTX, KS>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return MIL_ERR_LAUNCH;
+    }
+    if (grid <= 0) return MIL_OK;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    MIL_CHECK_LAUNCH();
+    const int n_rows = KS * KS * CZ;
+    const int total = n_rows * NTX * 16 + CZ;
+    hipLaunchKernelGGL(wgrad_reduce_t_kernel, dim3((total + 31) / 32), dim3(256), 0, stream, (const float*)ws, grid, slab_elems,
+                       NTX * 16, n_rows, dw, db, cout, cin, KS, CZ, MT * 16 * NTX * 16);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+static int bwd_fused_entry(const void* dz, const void* wpack, const void* x, const void* addend, void* dx, float* dw,
+                           float* db, void* ws, size_t ws_bytes, int n_img, int H, int W, int cout, int cin, int ks,
+                           int pad, int apply_mask, float slope, int dtype, bool query, size_t* need, void* stream) {
+    if (dtype != MIL_DT_BF16 || ks != 3 || pad != 1) return MIL_ERR_UNSUPPORTED;
+    if (n_img <= 0 || H <= 0 || W <= 0) return MIL_ERR_ARG;
+    if (slope <= 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
+    BwdFusedArgs a{};
+    a.dz = (const __bf16*)dz; a.w = (const __bf16*)wpack; a.x = (const __bf16*)x; a.addend = (const __bf16*)addend;
+    a.dx = (__bf16*)dx; a.apply_mask = apply_mask; a.slope = slope;
+    a.g.n_img = n_img; a.g.H = H; a.g.W = W; a.g.Ho = H; a.g.Wo = W; a.g.ks = ks; a.g.stride = 1; a.g.pad = pad; a.g.zins = 0;
+    const int czp = mil_cpad(cout), cxp = mil_cpad(cin);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (czp == 24 && cxp == 24) return run_bwd_fused<24, 2, 3>(a, dw, db, ws, ws_bytes, cout, cin, query, need, st);
+    return MIL_ERR_UNSUPPORTED;
+}
+
+extern "C" int mil_conv_bwd_fused_workspace(size_t* bytes, int n_img, int H, int W, int cout, int cin, int ks, int pad,
+                                            int dtype) {
+    if (!bytes) return MIL_ERR_ARG;
+    return bwd_fused_entry(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_img, H, W, cout, cin,
+                           ks, pad, 0, 0.1f, dtype, true, bytes, nullptr);
+}
+
+extern "C" int mil_conv_bwd_fused(const void* dz, const void* wpack_dgrad, const void* x, const void* addend, void* dx,
+                                  float* dw, float* db, void* workspace, size_t workspace_bytes, int n_img, int H, int W,
+                                  int cout, int cin, int ks, int pad, int apply_mask, float slope, int dtype, void* stream) {
+    if (!dz || !wpack_dgrad || !x || !dx || !dw) return MIL_ERR_ARG;
+    size_t need = 0;
+    return bwd_fused_entry(dz, wpack_dgrad, x, addend, dx, dw, db, workspace, workspace_bytes, n_img, H, W, cout, cin, ks,
+                           pad, apply_mask, slope, dtype, false, &need, stream);
+}

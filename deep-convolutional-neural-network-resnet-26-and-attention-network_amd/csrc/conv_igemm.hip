@@ -12,6 +12,7 @@
 //   dgrad:      the same kernel run over dz with transposed+flipped packed weights; stride-2 dgrad
 //               reads dz through the zero-insert loader (transposed convolution).
 #include "geom.cuh"
+#include "pf_common.cuh"
 
 template <typename T>
 struct ConvArgs {
@@ -39,7 +40,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs<T> a) {
     constexpr int NGRP = COUTP / 8;
     constexpr int TILE_PX = 64 * MTW;
     const ConvGeom& g = a.g;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave id through readfirstlane: provably wave-uniform, so branches on it are scalar branches (an MFMA or a
+    // ds_read_b64_tr_b16 inside an EXEC-masked region would still execute / need all lanes)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, gq = lane >> 4;
 
     const TileOrigin o = mil_tile_origin(g, blockIdx.x);
@@ -146,61 +150,48 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs<T> a) {
 //     (residual, activation mask) are already in flight into registers (issue-early / write-late);
 //   * the MFMA operands are swapped (A = filter fragment, B = pixel fragment) so the accumulator holds
 //     D[channel][pixel]: every lane owns 4 consecutive channels of one pixel and the whole epilogue
-//     (bias, residual, LeakyReLU, mask, bf16 store) runs from registers with 8-byte accesses — no LDS
-//     round trip and one barrier fewer per tile;
+//     (residual, LeakyReLU, mask, bf16 store) runs from registers with 8-byte accesses — no LDS round
+//     trip; the accumulators start from the bias instead of zero;
 //   * everything that does not depend on the tile (piece -> halo coordinate, k-step -> tap offset,
-//     lane -> output pixel) is computed once per workgroup: the per-tile instruction stream is loads,
-//     MFMAs and the element-wise epilogue, which is what keeps the kernel on the HBM roof rather than
-//     on the vector-issue roof.
+//     lane -> output pixel) is computed once per workgroup, the tile walk runs on the scalar unit, and
+//     memory goes through buffer descriptors with out-of-range offsets as the predicate (pf_common.cuh):
+//     the per-tile instruction stream is loads, MFMAs and the element-wise epilogue, which is what keeps
+//     the kernel on the HBM roof rather than on the vector-issue roof.
 template <int CINP, int NT, int KS>
-__global__ __launch_bounds__(256) void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles) {
+__global__ __launch_bounds__(256, (CINP <= 40 ? 2 : 1)) void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles,
+                                                                                  unsigned x_bytes, unsigned y_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using T = BF16;
     constexpr int PIXB = mil_pix_pitch(CINP, 2);
     constexpr int CG = CINP / 8;
-    constexpr int N16 = CINP / 8;
     constexpr int COUTP = mil_nt_to_cp(NT);
     constexpr int MTW = 4;
     constexpr int NPX = mil_halo_np(CINP, 2);
     constexpr int KSTEPS = (KS * KS * CG + 3) / 4;
+    constexpr bool LAST_PARTIAL = (COUTP % 16) != 0;        // the last column tile holds only 8 channels
     const ConvGeom& g = a.g;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, gq = lane >> 4;
     char* ldsA = smem;
     char* ldsW = smem + a.lds_w_off;
 
     {
-        const int nbytes = a.nsteps * NT * 64 * 16;
+        const int nbytes = KSTEPS * NT * 64 * 16;
         const char* src = reinterpret_cast<const char*>(a.w);
         for (int i = tid * 16; i < nbytes; i += 256 * 16)
             *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(src + i);
     }
+    const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, x_bytes);
+    const __amdgpu_buffer_rsrc_t rs_res = mil_rsrc(a.res, a.res ? y_bytes : 0);
+    const __amdgpu_buffer_rsrc_t rs_act = mil_rsrc(a.act, a.act ? y_bytes : 0);
+    const __amdgpu_buffer_rsrc_t rs_y = mil_rsrc(a.y, y_bytes);
     const int s_eff = g.zins ? 1 : g.stride;
     const int TW = 1 << g.tw_log2, TH = 1 << g.th_log2;
 
-    // ---- tile-invariant tables -------------------------------------------------------------------
-    // halo pieces owned by this thread: source offset relative to the tile origin, LDS offset, (ti,hy,hx)
-    int h_src[NPX], h_lds[NPX], h_pos[NPX];
-    {
-        const int ppr = g.hw * N16;
-        const int total = (g.hh << g.ti_log2) * ppr;
-#pragma unroll
-        for (int i = 0; i < NPX; ++i) {
-            const int idx = tid + 256 * i;
-            h_pos[i] = -1;
-            h_src[i] = 0; h_lds[i] = 0;
-            if (idx < total) {
-                const int row = idx / ppr, piece = idx - row * ppr;
-                const int ti = row / g.hh, hy = row - ti * g.hh;
-                const int hx = piece / N16, j = piece - hx * N16;
-                h_pos[i] = (ti << 20) | (hy << 10) | hx;
-                h_lds[i] = (row * g.hw + hx) * PIXB + j * 16;
-                if (g.zins) h_src[i] = j * 16;              // coordinates are halved per tile (parity-dependent)
-                else h_src[i] = ((ti * g.H + hy) * g.W + hx) * (CINP * 2) + j * 16;
-            }
-        }
-    }
-    // k-step -> byte offset of this lane's (tap, channel-group) inside a halo pixel
+    // ---- tile-invariant tables ---------------------------------------------------------------------
+    HaloTables<NPX> ht;
+    mil_build_halo_tables<CINP, NPX>(ht, g, tid);
     int toff[KSTEPS];
 #pragma unroll
     for (int sl = 0; sl < KSTEPS; ++sl) {
@@ -210,7 +201,6 @@ __global__ __launch_bounds__(256) void conv_igemm_pf_kernel(ConvArgs<BF16> a, in
         const int ky = tap / KS, kx = tap - ky * KS;
         toff[sl] = (ky * g.hw + kx) * PIXB + cg * 16;
     }
-    // lane -> the 4 output pixels it owns (one per MFMA row tile): halo base, output offset, (ti,ty,tx)
     int pixbase[MTW], o_rel[MTW], o_pos[MTW];
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
@@ -220,69 +210,41 @@ __global__ __launch_bounds__(256) void conv_igemm_pf_kernel(ConvArgs<BF16> a, in
         o_rel[m] = ((ti * g.Ho + ty) * g.Wo + tx) * (COUTP * 2) + gq * 8;
         o_pos[m] = (ti << 20) | (ty << 10) | tx;
     }
-    // channels 4*gq..4*gq+3 of column tile nt exist?
-    bool ch_ok[NT];
-    float bias_r[NT][4];
+    const bool last_ok = !LAST_PARTIAL || gq < 2;           // channels of the last column tile this lane owns exist
+    f32x4_t bias_r[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        ch_ok[nt] = (nt * 16 + gq * 4) < COUTP;
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) bias_r[nt][i] = a.bias ? a.bias[nt * 16 + gq * 4 + i] : 0.f;
-    }
 
-    auto fetch_halo = [&](uint4 (&rx)[NPX], int tile) {
-        const TileOrigin o = mil_tile_origin(g, tile);
-        const int iy0 = o.oy0 * s_eff - g.pad, ix0 = o.ox0 * s_eff - g.pad;
-        const int ilim = g.n_img - o.img0;
-        const char* base = reinterpret_cast<const char*>(a.x);
-        if (!g.zins) base += (((size_t)o.img0 * g.H + iy0) * (size_t)g.W + ix0) * (CINP * 2);   // may point before x: only valid lanes dereference
-#pragma unroll
-        for (int i = 0; i < NPX; ++i) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (h_pos[i] >= 0) {
-                const int ti = h_pos[i] >> 20;
-                int iy = iy0 + ((h_pos[i] >> 10) & 1023), ix = ix0 + (h_pos[i] & 1023);
-                if (!g.zins) {
-                    if (ti < ilim && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-                        v = *reinterpret_cast<const uint4*>(base + h_src[i]);
-                } else {
-                    if (ti < ilim && iy >= 0 && ix >= 0 && !((iy | ix) & 1) && (iy >> 1) < g.H && (ix >> 1) < g.W)
-                        v = *reinterpret_cast<const uint4*>(base + (((size_t)(o.img0 + ti) * g.H + (iy >> 1)) * g.W + (ix >> 1)) * (CINP * 2) + h_src[i]);
-                }
-            }
-            rx[i] = v;
-        }
-    };
-
-    uint4 rx[NPX];
-    if ((int)blockIdx.x < ntiles) fetch_halo(rx, blockIdx.x);
+    TileWalker cur, nxt;
+    cur.init(g, blockIdx.x, gridDim.x);
+    nxt = cur; nxt.advance();
+    u32x4_t rx[NPX];
+    if ((int)blockIdx.x < ntiles) mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, cur.origin(g));
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const TileOrigin o = mil_tile_origin(g, tile);
+        const TileOrigin o = cur.origin(g);
         __syncthreads();                       // every wave has finished reading ldsA for the previous tile
-#pragma unroll
-        for (int i = 0; i < NPX; ++i)
-            if (h_pos[i] >= 0) *reinterpret_cast<uint4*>(ldsA + h_lds[i]) = rx[i];
+        mil_commit_halo<NPX>(rx, ldsA, ht);
         __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) fetch_halo(rx, tile + gridDim.x);
+        if (tile + (int)gridDim.x < ntiles) mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, nxt.origin(g));
+        cur = nxt; nxt.advance();
 
         // this tile's epilogue operands, 8 bytes (4 channels) per lane per (row tile, column tile)
-        const size_t obase = (((size_t)o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (COUTP * 2);
+        const int obase = ((o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (COUTP * 2);
         const int ylim = g.Ho - o.oy0, xlim = g.Wo - o.ox0, ilim = g.n_img - o.img0;
-        bool pix_ok[MTW];
-        uint2 rres[MTW][NT], ract[MTW][NT];
+        unsigned ooff[MTW];
+        u32x2_t rres[MTW][NT], ract[MTW][NT];
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
-            pix_ok[m] = (o_pos[m] >> 20) < ilim && ((o_pos[m] >> 10) & 1023) < ylim && (o_pos[m] & 1023) < xlim;
+            const bool ok = (o_pos[m] >> 20) < ilim && ((o_pos[m] >> 10) & 1023) < ylim && (o_pos[m] & 1023) < xlim;
+            ooff[m] = ok ? (unsigned)(obase + o_rel[m]) : MIL_OOB;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                rres[m][nt] = make_uint2(0u, 0u);
-                ract[m][nt] = make_uint2(0u, 0u);
-                if (pix_ok[m] && ch_ok[nt]) {
-                    const size_t off = obase + o_rel[m] + nt * 32;
-                    if (a.res) rres[m][nt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.res) + off);
-                    if (a.act) ract[m][nt] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.act) + off);
-                }
+                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[m] + nt * 32;
+                if (a.res) rres[m][nt] = __builtin_amdgcn_raw_buffer_load_b64(rs_res, off, 0, 0);
+                if (a.act) ract[m][nt] = __builtin_amdgcn_raw_buffer_load_b64(rs_act, off, 0, 0);
             }
         }
 
@@ -290,7 +252,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pf_kernel(ConvArgs<BF16> a, in
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = bias_r[nt];
 #pragma unroll
         for (int sl = 0; sl < KSTEPS; ++sl) {
             Frag8<T> wf[NT];
@@ -309,10 +271,9 @@ __global__ __launch_bounds__(256) void conv_igemm_pf_kernel(ConvArgs<BF16> a, in
         for (int m = 0; m < MTW; ++m) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                if (!(pix_ok[m] && ch_ok[nt])) continue;
                 float v[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = acc[m][nt][i] + bias_r[nt][i];
+                for (int i = 0; i < 4; ++i) v[i] = acc[m][nt][i];
                 if (a.res) {
                     const bf16x4_t t = __builtin_bit_cast(bf16x4_t, rres[m][nt]);
 #pragma unroll
@@ -330,46 +291,13 @@ __global__ __launch_bounds__(256) void conv_igemm_pf_kernel(ConvArgs<BF16> a, in
                 bf16x4_t ov;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ov[i] = (__bf16)v[i];
-                *reinterpret_cast<bf16x4_t*>(reinterpret_cast<char*>(a.y) + obase + o_rel[m] + nt * 32) = ov;
+                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[m] + nt * 32;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, ov), rs_y, off, 0, 0);
             }
         }
     }
 }
 
-template <int CINP, int NT, int KS>
-static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool* taken) {
-    ConvArgs<BF16> a = a0;
-    constexpr int PIXB = mil_pix_pitch(CINP, 2);
-    constexpr int FRAGB = 16;
-    *taken = false;
-    mil_geom_tiles(a.g, 8);
-    const int halo_px = (a.g.hh * a.g.hw) << a.g.ti_log2;
-    if (halo_px > 400) return MIL_OK;
-    const int a_bytes = (halo_px * PIXB + 15) & ~15;
-    const int w_bytes = a.nsteps * NT * 64 * FRAGB;
-    const int lds = a_bytes + w_bytes;
-    if (lds > 160 * 1024) return MIL_OK;
-    if (a.g.hh >= 1024 || a.g.hw >= 1024 || a.slope <= 0.f || a.slope >= 1.f) return MIL_OK;
-    const int ntiles = a.g.n_groups * a.g.tiles_y * a.g.tiles_x;
-    if (ntiles < 512) return MIL_OK;             // not enough tiles to amortise a persistent launch
-
-    a.kc = a.nsteps;
-    a.lds_w_off = a_bytes;
-    auto kern = conv_igemm_pf_kernel<CINP, NT, KS>;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return MIL_ERR_LAUNCH;
-    }
-    const int per_cu = (160 * 1024) / lds;
-    int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
-    if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a, ntiles);
-    MIL_CHECK_LAUNCH();
-    *taken = true;
-    return MIL_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
 template <typename T, int CINP, int NT, int MTW>
 static int launch_conv(const ConvArgs<T>& a0, hipStream_t stream) {
     ConvArgs<T> a = a0;
@@ -398,6 +326,54 @@ static int launch_conv(const ConvArgs<T>& a0, hipStream_t stream) {
     if (grid <= 0) return MIL_OK;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
     MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+
+template <int CINP, int NT, int KS>
+static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool* taken) {
+    ConvArgs<BF16> a = a0;
+    constexpr int PIXB = mil_pix_pitch(CINP, 2);
+    constexpr int COUTP = mil_nt_to_cp(NT);
+    *taken = false;
+    mil_geom_tiles(a.g, 8);
+    const int halo_px = (a.g.hh * a.g.hw) << a.g.ti_log2;
+    if (halo_px > 400) return MIL_OK;
+    const int a_bytes = (halo_px * PIXB + 15) & ~15;
+    const int w_bytes = a.nsteps * NT * 64 * 16;
+    const int lds = a_bytes + w_bytes;
+    if (lds > 160 * 1024) return MIL_OK;
+    if (a.g.hh >= 1024 || a.g.hw >= 1024 || a.slope <= 0.f || a.slope >= 1.f) return MIL_OK;
+    if ((a.g.n_groups * a.g.tiles_y * a.g.tiles_x) < 512) return MIL_OK;    // too few tiles for a persistent launch
+    a.kc = a.nsteps;
+    a.lds_w_off = a_bytes;
+    auto kern = conv_igemm_pf_kernel<CINP, NT, KS>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return MIL_ERR_LAUNCH;
+    }
+    const int per_cu = (160 * 1024) / lds;
+    // buffer descriptors address < 2 GiB: split the launch by images when a tensor is larger
+    const size_t x_img = (size_t)a.g.H * a.g.W * CINP * 2, y_img = (size_t)a.g.Ho * a.g.Wo * COUTP * 2;
+    int chunk = mil_imgs_under_2g(x_img > y_img ? x_img : y_img);
+    if (chunk >= 16) chunk &= ~15;                       // keep image groups (<= 16 images per tile) intact
+    const int n_total = a0.g.n_img;
+    for (int i0 = 0; i0 < n_total; i0 += chunk) {
+        const int n = (n_total - i0 < chunk) ? n_total - i0 : chunk;
+        ConvArgs<BF16> c = a;
+        c.g.n_img = n;
+        c.g.n_groups = (n + (1 << c.g.ti_log2) - 1) >> c.g.ti_log2;
+        c.x = a.x + (size_t)i0 * (x_img / 2);
+        c.y = a.y + (size_t)i0 * (y_img / 2);
+        if (a.res) c.res = a.res + (size_t)i0 * (y_img / 2);
+        if (a.act) c.act = a.act + (size_t)i0 * (y_img / 2);
+        const int ntiles = c.g.n_groups * c.g.tiles_y * c.g.tiles_x;
+        int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+        if (grid > ntiles) grid = ntiles;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, c, ntiles, (unsigned)(x_img * n), (unsigned)(y_img * n));
+        MIL_CHECK_LAUNCH();
+    }
+    *taken = true;
     return MIL_OK;
 }
 

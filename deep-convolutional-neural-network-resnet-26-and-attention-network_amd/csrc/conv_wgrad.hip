@@ -45,7 +45,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs<T> a) {
     constexpr int MT_S = (MT + MSPLIT - 1) / MSPLIT;
     constexpr int MW = (MT_S + 3) / 4;          // tiles per wave
     const ConvGeom& g = a.g;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave id through readfirstlane: provably wave-uniform, so branches on it are scalar branches (an MFMA or a
+    // ds_read_b64_tr_b16 inside an EXEC-masked region would still execute / need all lanes)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int split = blockIdx.y;
     const bool bias_wave = (wave == 0 && split == 0);
     char* ldsX = smem;

@@ -1,0 +1,119 @@
+// Shared pieces of the persistent, prefetch-pipelined bf16 kernels (conv_igemm_pf_kernel,
+// conv_bwd_fused_kernel): buffer-resource addressing, tile walking on the scalar unit, and the
+// tile-invariant halo tables.
+//
+// Global memory goes through raw buffer loads/stores (SGPR descriptor + 32-bit per-lane byte offset):
+// no 64-bit per-lane address arithmetic, and predication costs ONE v_cndmask — an invalid lane gets the
+// offset MIL_OOB (>= num_records), for which the hardware returns zeros on a load and drops a store, so no
+// EXEC-mask save/restore sequences surround the memory instructions.  Tensors handed to these kernels must
+// be < 2 GiB (the launchers split larger launches by image).
+#pragma once
+#include "geom.cuh"
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+#define MIL_OOB 0x80000000u
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mil_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// Walks tile ids t0, t0+G, t0+2G, ... as (image group, tile row, tile col) with carries instead of
+// divisions; every member is wave-uniform (lives in SGPRs).
+struct TileWalker {
+    int tx, ty, grp;
+    int dtx, dty, dgrp;
+    int tiles_x, tiles_y;
+    __device__ __forceinline__ void init(const ConvGeom& g, int t0, int stride) {
+        tiles_x = g.tiles_x; tiles_y = g.tiles_y;
+        tx = t0 % tiles_x; int q = t0 / tiles_x; ty = q % tiles_y; grp = q / tiles_y;
+        dtx = stride % tiles_x; q = stride / tiles_x; dty = q % tiles_y; dgrp = q / tiles_y;
+    }
+    __device__ __forceinline__ void advance() {
+        tx += dtx; ty += dty; grp += dgrp;
+        if (tx >= tiles_x) { tx -= tiles_x; ty += 1; }
+        if (ty >= tiles_y) { ty -= tiles_y; grp += 1; }
+    }
+    __device__ __forceinline__ TileOrigin origin(const ConvGeom& g) const {
+        TileOrigin o; o.img0 = grp << g.ti_log2; o.oy0 = ty << g.th_log2; o.ox0 = tx << g.tw_log2; return o;
+    }
+};
+
+// Halo pieces (16 B) owned by a thread: flat piece id = tid + 256*i.
+//   pos = (ti<<20)|(hy<<10)|hx, or -1 when the slot is unused;  lds = byte offset in the LDS halo tile;
+//   rel = byte offset of the piece relative to the halo origin pixel of image img0 (plain loader only)
+template <int NP>
+struct HaloTables { int pos[NP], lds[NP], rel[NP]; };
+
+template <int CP, int NP>
+__device__ __forceinline__ void mil_build_halo_tables(HaloTables<NP>& t, const ConvGeom& g, int tid) {
+    constexpr int N16 = CP / 8;
+    constexpr int PIXB = mil_pix_pitch(CP, 2);
+    const int ppr = g.hw * N16;
+    const int total = (g.hh << g.ti_log2) * ppr;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int idx = tid + 256 * i;
+        t.pos[i] = -1; t.lds[i] = 0; t.rel[i] = 0;
+        if (idx < total) {
+            const int row = idx / ppr, piece = idx - row * ppr;
+            const int ti = row / g.hh, hy = row - ti * g.hh;
+            const int hx = piece / N16, j = piece - hx * N16;
+            t.pos[i] = (ti << 20) | (hy << 10) | hx;
+            t.lds[i] = (row * g.hw + hx) * PIXB + j * 16;
+            t.rel[i] = g.zins ? j * 16 : ((ti * g.H + hy) * g.W + hx) * (CP * 2) + j * 16;
+        }
+    }
+}
+
+// Issue the loads of one halo tile into registers (zero for padding / outside the image).
+template <int CP, int NP>
+__device__ __forceinline__ void mil_fetch_halo(u32x4_t (&rx)[NP], __amdgpu_buffer_rsrc_t src, const HaloTables<NP>& t,
+                                               const ConvGeom& g, const TileOrigin& o) {
+    const int s = g.zins ? 1 : g.stride;
+    const int iy0 = o.oy0 * s - g.pad, ix0 = o.ox0 * s - g.pad;
+    const int ilim = g.n_img - o.img0;
+    if (!g.zins) {
+        const int base = ((o.img0 * g.H + iy0) * g.W + ix0) * (CP * 2);      // may be negative; valid lanes are not
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int p = t.pos[i];
+            const int iy = iy0 + ((p >> 10) & 1023), ix = ix0 + (p & 1023);
+            const bool ok = p >= 0 && (p >> 20) < ilim && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(src, ok ? (unsigned)(base + t.rel[i]) : MIL_OOB, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int p = t.pos[i];
+            const int iy = iy0 + ((p >> 10) & 1023), ix = ix0 + (p & 1023);
+            const bool ok = p >= 0 && (p >> 20) < ilim && iy >= 0 && ix >= 0 && !((iy | ix) & 1) && (iy >> 1) < g.H && (ix >> 1) < g.W;
+            const int off = (((o.img0 + (p >> 20)) * g.H + (iy >> 1)) * g.W + (ix >> 1)) * (CP * 2) + t.rel[i];
+            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(src, ok ? (unsigned)off : MIL_OOB, 0, 0);
+        }
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void mil_commit_halo(const u32x4_t (&rx)[NP], char* lds, const HaloTables<NP>& t) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+        if (t.pos[i] >= 0) *reinterpret_cast<u32x4_t*>(lds + t.lds[i]) = rx[i];
+}
+
+__device__ __forceinline__ bf16x8_t mil_tr_pair(const char* p0, const char* p1) {
+    typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// How many images of `bytes_per_img` bytes fit under the 2 GiB buffer limit.
+__host__ inline int mil_imgs_under_2g(size_t bytes_per_img) {
+    const size_t lim = ((size_t)1 << 31) - 4096;
+    size_t n = bytes_per_img ? lim / bytes_per_img : 1;
+    return (int)(n < 1 ? 1 : (n > (1u << 30) ? (1u << 30) : n));
+}

@@ -55,6 +55,7 @@ class ResNet(nn.Module):
         self.fc = nn.Linear(STAGE_WIDTHS[-1], num_classes, bias=False)
         self.compute_dtype = compute_dtype
         self.overlap_wgrad = True
+        self.fuse_backward = True
         self._pack_cache = {}
         self._side = None
 
@@ -162,13 +163,36 @@ def encoder_backward(net, saved, dfeats, dtype):
         dzz.record_stream(side)
         return out
 
+    fws = None
+
+    def fused_bwd(dzz, wd, xin, cin, cout, addend, mask):
+        nonlocal fws
+        n, h, w, _ = dzz.shape
+        need = ops.bwd_fused_workspace_bytes(n, h, w, cout, cin, 3, 1, dzz.dtype)
+        if need is None:
+            return None
+        if fws is None or fws.numel() * 4 < need:
+            fws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dzz.device)
+        return ops.conv_bwd_fused(dzz, wd, xin, cin, cout, addend=addend, mask=mask, workspace=fws)
+
     for bi in range(len(blocks) - 1, -1, -1):
         blk = blocks[bi]
         xin, o1, _out = saved["blocks"][bi]
         cin, cout, s = blk.conv1.in_channels, blk.conv1.out_channels, blk.stride
-        grads[f"b{bi}.c2"] = wgrad(o1, dz, cout, cout, ks=3, stride=1, pad=1)
         w2d, _ = net._packed(f"b{bi}.c2", blk.conv2.weight, None, L.PACK_DGRAD, dtype)
-        dz1 = ops.conv(dz, w2d, None, ops.cpad(cout), ks=3, stride=1, pad=1, act=o1)
+        fused = fused_bwd(dz, w2d, o1, cout, cout, None, True) if net.fuse_backward else None
+        if fused is not None:                       # one pass: dz1 and dW2/db2
+            dz1, grads[f"b{bi}.c2"] = fused[0], (fused[1], fused[2])
+        else:
+            grads[f"b{bi}.c2"] = wgrad(o1, dz, cout, cout, ks=3, stride=1, pad=1)
+            dz1 = ops.conv(dz, w2d, None, ops.cpad(cout), ks=3, stride=1, pad=1, act=o1)
+        w1d, _ = net._packed(f"b{bi}.c1", blk.conv1.weight, None, L.PACK_DGRAD, dtype)
+        mask = xin if bi > 0 else None          # block 0 reads the max-pool output (no activation in between)
+        if s == 1 and blk.downsample is None and net.fuse_backward:
+            fused = fused_bwd(dz1, w1d, xin, cin, cout, dz, mask is not None)
+            if fused is not None:                   # one pass: previous block's dz and dW1/db1
+                dz, grads[f"b{bi}.c1"] = fused[0], (fused[1], fused[2])
+                continue
         grads[f"b{bi}.c1"] = wgrad(xin, dz1, cin, cout, ks=3, stride=s, pad=1)
         if blk.downsample is not None:
             grads[f"b{bi}.ds"] = wgrad(xin, dz, cin, cout, ks=1, stride=s, pad=0, want_bias=False)
@@ -180,8 +204,6 @@ def encoder_backward(net, saved, dfeats, dtype):
                 addend = ops.conv(dz, wdd, None, ops.cpad(cin), ks=1, stride=1, pad=0)
         else:
             addend = dz
-        w1d, _ = net._packed(f"b{bi}.c1", blk.conv1.weight, None, L.PACK_DGRAD, dtype)
-        mask = xin if bi > 0 else None          # block 0 reads the max-pool output (no activation in between)
         if s == 2:
             dz = ops.conv(dz1, w1d, None, ops.cpad(cin), ks=3, stride=1, pad=1, zero_insert=True,
                           out_hw=xin.shape[1:3], res=addend, act=mask)

@@ -128,6 +128,40 @@ def conv_wgrad(x, dz, cin, cout, *, ks, stride, pad, stem=False, want_bias=True,
     return dw, db
 
 
+def bwd_fused_workspace_bytes(n, h, w, cout, cin, ks, pad, dtype):
+    """Slab bytes the fused backward needs, or None when this shape has no fused kernel."""
+    need = ctypes.c_size_t(0)
+    rc = L.lib().mil_conv_bwd_fused_workspace(ctypes.byref(need), n, h, w, cout, cin, ks, pad, L.dt_code(dtype))
+    if rc == 2:
+        return None
+    L.check(rc, "mil_conv_bwd_fused_workspace")
+    return need.value
+
+
+def conv_bwd_fused(dz, wpack_dgrad, x, cin, cout, *, addend=None, mask=True, ks=3, pad=1, workspace=None, slope=LEAK):
+    """(dx, dW, db) of a 3x3 stride-1 conv in one pass, or None if unsupported — see mil_conv_bwd_fused."""
+    n, h, w, _ = dz.shape
+    need = bwd_fused_workspace_bytes(n, h, w, cout, cin, ks, pad, dz.dtype)
+    if need is None:
+        return None
+    _need(dz, (n, h, w, cpad(cout)), dz.dtype, "dz")
+    _need(x, (n, h, w, cpad(cin)), dz.dtype, "x")
+    _need(addend, (n, h, w, cpad(cin)), dz.dtype, "addend")
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=dz.device)
+    dx = torch.empty_like(x)
+    dw = torch.empty((cout, cin, ks, ks), dtype=torch.float32, device=dz.device)
+    db = torch.empty(cout, dtype=torch.float32, device=dz.device)
+    end = TIMER.bracket(("bwd_fused", cpad(cout), cpad(cin), ks, 1, False, n, h, w)) if TIMER else None
+    L.check(L.lib().mil_conv_bwd_fused(dz.data_ptr(), wpack_dgrad.data_ptr(), x.data_ptr(), L.ptr(addend), dx.data_ptr(),
+                                       dw.data_ptr(), db.data_ptr(), workspace.data_ptr(),
+                                       workspace.numel() * workspace.element_size(), n, h, w, cout, cin, ks, pad,
+                                       1 if mask else 0, slope, L.dt_code(dz.dtype), L.stream_ptr()), "mil_conv_bwd_fused")
+    if end is not None:
+        end.record()
+    return dx, dw, db
+
+
 def maxpool_fwd(x):
     n, h, w, cp = x.shape
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1

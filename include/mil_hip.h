@@ -81,6 +81,17 @@ int mil_conv_wgrad(const void* x, const void* dz, float* dw, float* db, void* wo
                    int n_img, int H, int W, int cin, int Ho, int Wo, int cout, int ks, int stride, int pad,
                    int stem_mode, int dtype, void* stream);
 
+/* ---- fused backward of a 3x3 stride-1 conv (bf16 path, narrow layers) --------------------------
+ * One pass over dz and x yields BOTH autograd results of nn.Conv2d (nnBlocks.py:169-171):
+ *     dx = (conv^T(dz, W) + addend?) * (apply_mask ? lrelu'(x) : 1)      and      dW, db
+ * (replaces one mil_conv_igemm dgrad launch + one mil_conv_wgrad launch and their second read of x and
+ * dz).  dz [n,H,W,cpad(cout)], x/addend/dx [n,H,W,cpad(cin)], wpack_dgrad = MIL_PACK_DGRAD weights.
+ * Returns MIL_ERR_UNSUPPORTED for shapes without a fused kernel (caller then uses the two calls). */
+int mil_conv_bwd_fused_workspace(size_t* bytes, int n_img, int H, int W, int cout, int cin, int ks, int pad, int dtype);
+int mil_conv_bwd_fused(const void* dz, const void* wpack_dgrad, const void* x, const void* addend, void* dx, float* dw,
+                       float* db, void* workspace, size_t workspace_bytes, int n_img, int H, int W, int cout, int cin,
+                       int ks, int pad, int apply_mask, float slope, int dtype, void* stream);
+
 /* ---- pooling -------------------------------------------------------------------------------
  * MaxPool2d(3, stride 2, pad 1) (gbm/model.py:26,53): y [n,Ho,Wo,cp], Ho=(H-1)/2+1; `widx` records
  * the winning tap per output element (uint8, same shape as y).  The backward gathers gy through
