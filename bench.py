@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="run weight-gradient launches on the main stream")
     return ap.parse_args()
 
 
@@ -103,6 +104,8 @@ def main():
     w = np.load(os.path.join(ROOT, "tests", "golden", "weights.npz"))
     net = mil_amd.Attention(3, compute_dtype=dtype, device=dev).eval()     # eval = full-bag path (all tiles encoded)
     net.load_state_dict({k: torch.tensor(w[k]) for k in w.keys()})
+    if args.no_overlap:
+        net.cnn.module.overlap_wgrad = False
     flat = mil_amd.FlatParams(net)
     flat.broadcast_params()
 

@@ -10,7 +10,7 @@
 //   Each workgroup walks a strided set of spatial tiles, keeps its partial dW in registers and writes
 //   ONE fp32 slab; a second kernel sums the slabs in fixed order (deterministic, no float atomics).
 //   db comes from an all-ones A fragment on wave 0 (column sums of dz on the same MFMA stream).
-#include "geom.cuh"
+#include "pf_common.cuh"
 
 template <typename T>
 struct WgradArgs {
@@ -21,6 +21,7 @@ struct WgradArgs {
     int ntiles;
     int tile_px;
     int lds_z_off;
+    unsigned x_bytes, z_bytes;   // buffer-descriptor sizes (prefetch-pipelined path)
 };
 
 __device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
@@ -81,28 +82,37 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs<T> a) {
     }
 
     // PF: software pipeline — the next tile's global loads are issued (into registers) before this tile's
-    // MFMA loop and written to LDS after the loop's barrier, so HBM latency hides under compute.
+    // MFMA loop and written to LDS after the loop's barrier, so HBM latency hides under compute.  Addressing
+    // through buffer descriptors + tile-invariant tables (pf_common.cuh) keeps the per-tile VALU work small.
     constexpr int NPX = PF ? mil_halo_np(CINP, ESZ) : 1;
     constexpr int NPZ = PF ? COUTP * ESZ / 16 : 1;
-    uint4 rx[NPX], rz[NPZ];
+    u32x4_t rx[NPX], rz[NPZ];
+    HaloTables<NPX> ht;
+    OtileTables<NPZ> zt;
+    TileWalker cur, nxt;
+    __amdgpu_buffer_rsrc_t rs_x, rs_z;
     if constexpr (PF) {
+        rs_x = mil_rsrc(a.x, a.x_bytes);
+        rs_z = mil_rsrc(a.dz, a.z_bytes);
+        mil_build_halo_tables<CINP, NPX>(ht, g, tid);
+        mil_build_otile_tables<COUTP, NPZ>(zt, g, tid, a.tile_px);
+        cur.init(g, blockIdx.x, gridDim.x);
+        nxt = cur; nxt.advance();
         if ((int)blockIdx.x < a.ntiles) {
-            const TileOrigin o0 = mil_tile_origin(g, blockIdx.x);
-            mil_halo_fetch<T, CINP, NPX>(rx, a.x, g, o0, tid);
-            mil_otile_fetch<T, COUTP, NPZ>(rz, a.dz, g, o0, tid, a.tile_px);
+            mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, cur.origin(g));
+            mil_fetch_otile<COUTP, NPZ>(rz, rs_z, zt, g, cur.origin(g));
         }
     }
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         __syncthreads();
         if constexpr (PF) {
-            mil_halo_commit<T, CINP, NPX>(rx, ldsX, g, tid);
-            mil_otile_commit<T, COUTP, NPZ>(rz, ldsZ, tid, a.tile_px);
-            const int nxt = tile + gridDim.x;
-            if (nxt < a.ntiles) {
-                const TileOrigin on = mil_tile_origin(g, nxt);
-                mil_halo_fetch<T, CINP, NPX>(rx, a.x, g, on, tid);
-                mil_otile_fetch<T, COUTP, NPZ>(rz, a.dz, g, on, tid, a.tile_px);
+            mil_commit_halo<NPX>(rx, ldsX, ht);
+            mil_commit_otile<NPZ>(rz, ldsZ, zt);
+            if (tile + (int)gridDim.x < a.ntiles) {
+                mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, nxt.origin(g));
+                mil_fetch_otile<COUTP, NPZ>(rz, rs_z, zt, g, nxt.origin(g));
             }
+            cur = nxt; nxt.advance();
         } else {
             const TileOrigin o = mil_tile_origin(g, tile);
             mil_load_halo<T, CINP>(ldsX, a.x, g, o, tid, 256);
@@ -244,11 +254,13 @@ static int plan_wgrad(ConvGeom& g, WgradPlan& pl, int* lds_z_off) {
     constexpr int RG = KS * KS * (CINP / 8);
     constexpr int MT = (RG + 1) / 2;
     // 256-px tiles when the halo fits comfortably, else 64-px tiles (stride-2 layers, f32 wide layers)
+    constexpr bool PF_OK = (T::DT == MIL_DT_BF16) && CINP <= 40;
     for (int lg = 8; lg >= 6; lg -= 2) {
         mil_geom_tiles(g, lg);
         const int xb = ((((g.hh * g.hw) << g.ti_log2) * PIXB) + 15) & ~15;
         const int zb = (1 << lg) * PIXZ;
-        if (xb + zb <= 150 * 1024 || lg == 6) {
+        const bool halo_fits_regs = ((g.hh * g.hw) << g.ti_log2) <= 400;
+        if ((xb + zb <= 150 * 1024 && (halo_fits_regs || !PF_OK)) || lg == 6) {
             if (xb + zb > 160 * 1024) return MIL_ERR_UNSUPPORTED;
             pl.lds = xb + zb; *lds_z_off = xb; pl.tile_px_log2 = lg;
             break;
@@ -279,7 +291,11 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     a.ntiles = g.n_groups * g.tiles_y * g.tiles_x; a.tile_px = 1 << pl.tile_px_log2; a.lds_z_off = lds_z_off;
     // register-prefetch pipeline for the bf16 path when the halo is small enough for its register budget
     constexpr bool PF_OK = (T::DT == MIL_DT_BF16) && CINP <= 40;      // wider layers: accumulators own the registers
-    const bool pf = PF_OK && (((g.hh * g.hw) << g.ti_log2) <= 400) && a.tile_px == 256;
+    const size_t xb_total = (size_t)g.n_img * g.H * g.W * CINP * T::ESZ;
+    const size_t zb_total = (size_t)g.n_img * g.Ho * g.Wo * mil_nt_to_cp(NT) * T::ESZ;
+    const bool pf = PF_OK && (((g.hh * g.hw) << g.ti_log2) <= 400) && g.hh < 1024 && g.hw < 1024 &&
+                    xb_total < ((size_t)1 << 31) && zb_total < ((size_t)1 << 31);
+    a.x_bytes = (unsigned)xb_total; a.z_bytes = (unsigned)zb_total;
     auto kern = pf ? wgrad_kernel<T, KS, CINP, NT, MSPLIT, PF_OK> : wgrad_kernel<T, KS, CINP, NT, MSPLIT, false>;
     if (pl.lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds) != hipSuccess)

@@ -102,6 +102,49 @@ __device__ __forceinline__ void mil_commit_halo(const u32x4_t (&rx)[NP], char* l
         if (t.pos[i] >= 0) *reinterpret_cast<u32x4_t*>(lds + t.lds[i]) = rx[i];
 }
 
+// Output-space tile (no halo) pieces owned by a thread: flat piece id = tid + 256*i -> (tile pixel, 16-B piece).
+template <int NP>
+struct OtileTables { int pos[NP], lds[NP], rel[NP]; };
+
+template <int CP, int NP>
+__device__ __forceinline__ void mil_build_otile_tables(OtileTables<NP>& t, const ConvGeom& g, int tid, int tile_px) {
+    constexpr int N16 = CP / 8;
+    constexpr int PIXZ = mil_pix_pitch(CP, 2);
+    const int tw_mask = (1 << g.tw_log2) - 1, th_mask = (1 << g.th_log2) - 1;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int idx = tid + 256 * i;
+        t.pos[i] = -1; t.lds[i] = 0; t.rel[i] = 0;
+        if (idx < tile_px * N16) {
+            const int tp = idx / N16, j = idx - tp * N16;
+            const int tx = tp & tw_mask, ty = (tp >> g.tw_log2) & th_mask, ti = tp >> (g.tw_log2 + g.th_log2);
+            t.pos[i] = (ti << 20) | (ty << 10) | tx;
+            t.lds[i] = tp * PIXZ + j * 16;
+            t.rel[i] = ((ti * g.Ho + ty) * g.Wo + tx) * (CP * 2) + j * 16;
+        }
+    }
+}
+
+template <int CP, int NP>
+__device__ __forceinline__ void mil_fetch_otile(u32x4_t (&rz)[NP], __amdgpu_buffer_rsrc_t src, const OtileTables<NP>& t,
+                                                const ConvGeom& g, const TileOrigin& o) {
+    const int base = ((o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (CP * 2);
+    const int ylim = g.Ho - o.oy0, xlim = g.Wo - o.ox0, ilim = g.n_img - o.img0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int p = t.pos[i];
+        const bool ok = p >= 0 && (p >> 20) < ilim && ((p >> 10) & 1023) < ylim && (p & 1023) < xlim;
+        rz[i] = __builtin_amdgcn_raw_buffer_load_b128(src, ok ? (unsigned)(base + t.rel[i]) : MIL_OOB, 0, 0);
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void mil_commit_otile(const u32x4_t (&rz)[NP], char* lds, const OtileTables<NP>& t) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+        if (t.pos[i] >= 0) *reinterpret_cast<u32x4_t*>(lds + t.lds[i]) = rz[i];
+}
+
 __device__ __forceinline__ bf16x8_t mil_tr_pair(const char* p0, const char* p1) {
     typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
     s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));

@@ -55,6 +55,7 @@ class ResNet(nn.Module):
         self.fc = nn.Linear(STAGE_WIDTHS[-1], num_classes, bias=False)
         self.compute_dtype = compute_dtype
         self.overlap_wgrad = True
+        self.n_side_streams = 1
         self.fuse_backward = True
         self._pack_cache = {}
         self._side = None
@@ -84,9 +85,9 @@ class ResNet(nn.Module):
         ps.append(self.fc.weight)
         return ps
 
-    def _side_stream(self):
+    def _side_streams(self):
         if self._side is None:
-            self._side = torch.cuda.Stream()
+            self._side = [torch.cuda.Stream() for _ in range(self.n_side_streams)]
         return self._side
 
     def _packed(self, key, weight, bias, mode, dtype):
@@ -137,28 +138,32 @@ def encoder_backward(net, saved, dfeats, dtype):
     last_out = saved["blocks"][-1][2]
     dz, dwfc = ops.avgpool_fc_bwd(dfeats.contiguous(), net.fc.weight.detach(), saved["pooled"], last_out,
                                   STAGE_WIDTHS[-1])
-    ws = None
-    # Weight gradients only consume (x, dz) and nothing downstream waits for them, so they run on a side
-    # stream beside the sequential dgrad chain (the small late-layer launches do not fill 256 CUs alone).
+    # Weight gradients only consume (x, dz) and nothing downstream waits for them, so they run on side
+    # streams (round-robin, one slab workspace each) beside the sequential dgrad chain: the small late-layer
+    # and stride-2 launches do not fill 256 CUs alone.
     main = torch.cuda.current_stream()
-    side = net._side_stream()
+    sides = net._side_streams()
     use_side = net.overlap_wgrad
+    ws = [None] * (len(sides) + 1)
+    rr = [0]
 
     def wgrad(xin, dzz, cin, cout, **kw):
-        nonlocal ws
         n, h, w, _ = xin.shape
         _, ho, wo, _ = dzz.shape
         need = ops.wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, kw["ks"], kw["stride"], kw["pad"],
                                          kw.get("stem", False), xin.dtype)
         if not use_side:
-            if ws is None or ws.numel() * 4 < need:
-                ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=xin.device)
-            return ops.conv_wgrad(xin, dzz, cin, cout, workspace=ws, **kw)
+            if ws[-1] is None or ws[-1].numel() * 4 < need:
+                ws[-1] = torch.empty((need + 3) // 4, dtype=torch.float32, device=xin.device)
+            return ops.conv_wgrad(xin, dzz, cin, cout, workspace=ws[-1], **kw)
+        k = rr[0] % len(sides)
+        rr[0] += 1
+        side = sides[k]
         side.wait_stream(main)                       # dz was produced on the main stream
         with torch.cuda.stream(side):
-            if ws is None or ws.numel() * 4 < need:  # launches on `side` are serialised: one slab buffer suffices
-                ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=xin.device)
-            out = ops.conv_wgrad(xin, dzz, cin, cout, workspace=ws, **kw)
+            if ws[k] is None or ws[k].numel() * 4 < need:   # launches on one stream are serialised: one buffer each
+                ws[k] = torch.empty((need + 3) // 4, dtype=torch.float32, device=xin.device)
+            out = ops.conv_wgrad(xin, dzz, cin, cout, workspace=ws[k], **kw)
         xin.record_stream(side)
         dzz.record_stream(side)
         return out
@@ -213,7 +218,8 @@ def encoder_backward(net, saved, dfeats, dtype):
     grads["stem"] = wgrad(saved["xs"], dstem, 3, STEM_WIDTH, ks=4, stride=1, pad=2, stem=True)
 
     if use_side:
-        main.wait_stream(side)
+        for side in sides:
+            main.wait_stream(side)
     flat = [grads["stem"][0], grads["stem"][1]]
     for bi, blk in enumerate(blocks):
         flat += [grads[f"b{bi}.c1"][0], grads[f"b{bi}.c1"][1], grads[f"b{bi}.c2"][0], grads[f"b{bi}.c2"][1]]
