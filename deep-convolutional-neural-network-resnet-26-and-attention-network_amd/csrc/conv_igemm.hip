@@ -220,22 +220,10 @@ __global__ __launch_bounds__(256, (CINP <= 40 ? 2 : 1)) void conv_igemm_pf_kerne
     TileWalker cur, nxt;
     cur.init(g, blockIdx.x, gridDim.x);
     nxt = cur; nxt.advance();
-    u32x4_t rx[NPX];
-    if ((int)blockIdx.x < ntiles) mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, cur.origin(g));
-
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const TileOrigin o = cur.origin(g);
-        __syncthreads();                       // every wave has finished reading ldsA for the previous tile
-        mil_commit_halo<NPX>(rx, ldsA, ht);
-        __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, nxt.origin(g));
-        cur = nxt; nxt.advance();
-
-        // this tile's epilogue operands, 8 bytes (4 channels) per lane per (row tile, column tile)
+    // epilogue operand offsets + loads of one tile (8 bytes = 4 channels per lane per (row tile, column tile))
+    auto fetch_epi = [&](const TileOrigin& o, unsigned (&ooff)[MTW], u32x2_t (&rres)[MTW][NT], u32x2_t (&ract)[MTW][NT]) {
         const int obase = ((o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (COUTP * 2);
         const int ylim = g.Ho - o.oy0, xlim = g.Wo - o.ox0, ilim = g.n_img - o.img0;
-        unsigned ooff[MTW];
-        u32x2_t rres[MTW][NT], ract[MTW][NT];
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
             const bool ok = (o_pos[m] >> 20) < ilim && ((o_pos[m] >> 10) & 1023) < ylim && (o_pos[m] & 1023) < xlim;
@@ -247,6 +235,41 @@ __global__ __launch_bounds__(256, (CINP <= 40 ? 2 : 1)) void conv_igemm_pf_kerne
                 if (a.act) ract[m][nt] = __builtin_amdgcn_raw_buffer_load_b64(rs_act, off, 0, 0);
             }
         }
+    };
+
+    // EPI_AHEAD: request the epilogue operands a whole tile ahead (costs one more register set; the 40/64-channel
+    // instantiations have no room for it and request them at the start of their own tile instead)
+    constexpr bool EPI_AHEAD = CINP <= 24;
+    u32x4_t rx[NPX];
+    unsigned ooff_n[EPI_AHEAD ? MTW : 1];
+    u32x2_t rres_n[EPI_AHEAD ? MTW : 1][NT], ract_n[EPI_AHEAD ? MTW : 1][NT];
+    if ((int)blockIdx.x < ntiles) {
+        mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, cur.origin(g));
+        if constexpr (EPI_AHEAD) fetch_epi(cur.origin(g), ooff_n, rres_n, ract_n);
+    }
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                       // every wave has finished reading ldsA for the previous tile
+        mil_commit_halo<NPX>(rx, ldsA, ht);
+        // this tile's epilogue operands were requested one tile ago; take them over before re-issuing
+        unsigned ooff[MTW];
+        u32x2_t rres[MTW][NT], ract[MTW][NT];
+        if constexpr (EPI_AHEAD) {
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                ooff[m] = ooff_n[m];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { rres[m][nt] = rres_n[m][nt]; ract[m][nt] = ract_n[m][nt]; }
+            }
+        }
+        __syncthreads();
+        // issue-early: the NEXT tile's halo (and epilogue operands) stay in flight under this tile's MFMA loop
+        if constexpr (!EPI_AHEAD) fetch_epi(cur.origin(g), ooff, rres, ract);
+        if (tile + (int)gridDim.x < ntiles) {
+            mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, nxt.origin(g));
+            if constexpr (EPI_AHEAD) fetch_epi(nxt.origin(g), ooff_n, rres_n, ract_n);
+        }
+        cur = nxt; nxt.advance();
 
         f32x4_t acc[MTW][NT];
 #pragma unroll
