@@ -157,16 +157,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs<T> a) {
 //     memory goes through buffer descriptors with out-of-range offsets as the predicate (pf_common.cuh):
 //     the per-tile instruction stream is loads, MFMAs and the element-wise epilogue, which is what keeps
 //     the kernel on the HBM roof rather than on the vector-issue roof.
-template <int CINP, int NT, int KS>
-__global__ __launch_bounds__(256, (CINP <= 40 ? 2 : 1)) void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles,
+template <int CINP, int NT, int KS, int MTW>
+__global__ __launch_bounds__(256, (MTW == 2 ? 4 : (CINP <= 40 ? 2 : 1))) void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles,
                                                                                   unsigned x_bytes, unsigned y_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using T = BF16;
     constexpr int PIXB = mil_pix_pitch(CINP, 2);
     constexpr int CG = CINP / 8;
     constexpr int COUTP = mil_nt_to_cp(NT);
-    constexpr int MTW = 4;
-    constexpr int NPX = mil_halo_np(CINP, 2);
+    constexpr int NPX = mil_halo_np_mtw(CINP, 2, MTW);
     constexpr int KSTEPS = (KS * KS * CG + 3) / 4;
     constexpr bool LAST_PARTIAL = (COUTP % 16) != 0;        // the last column tile holds only 8 channels
     const ConvGeom& g = a.g;
@@ -201,16 +200,27 @@ __global__ __launch_bounds__(256, (CINP <= 40 ? 2 : 1)) void conv_igemm_pf_kerne
         const int ky = tap / KS, kx = tap - ky * KS;
         toff[sl] = (ky * g.hw + kx) * PIXB + cg * 16;
     }
-    int pixbase[MTW], o_rel[MTW], o_pos[MTW];
+    int pixbase[MTW];
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
         const int tp = (wave * MTW + m) * 16 + r;
         const int tx = tp & (TW - 1), ty = (tp >> g.tw_log2) & (TH - 1), ti = tp >> (g.tw_log2 + g.th_log2);
         pixbase[m] = ((ti * g.hh + ty * s_eff) * g.hw + tx * s_eff) * PIXB;
-        o_rel[m] = ((ti * g.Ho + ty) * g.Wo + tx) * (COUTP * 2) + gq * 8;
-        o_pos[m] = (ti << 20) | (ty << 10) | tx;
     }
-    const bool last_ok = !LAST_PARTIAL || gq < 2;           // channels of the last column tile this lane owns exist
+    // Epilogue layout.  After the MFMA loop a lane holds 4 consecutive channels of pixel (m, r) for each row
+    // tile m.  One v_permlane16_swap per accumulator register between row tiles 2p and 2p+1 turns that into
+    // 8 consecutive channels of ONE pixel per lane — pixel (2p + (gq&1), r), channels 16*nt + 8*(gq>>1) ... —
+    // so residual / mask loads and the output store are 16-byte accesses (half the VMEM instructions).
+    constexpr int NPAIR = MTW / 2;
+    int o_rel[NPAIR], o_pos[NPAIR];
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {
+        const int tp = (wave * MTW + 2 * p + (gq & 1)) * 16 + r;
+        const int tx = tp & (TW - 1), ty = (tp >> g.tw_log2) & (TH - 1), ti = tp >> (g.tw_log2 + g.th_log2);
+        o_rel[p] = ((ti * g.Ho + ty) * g.Wo + tx) * (COUTP * 2) + (gq >> 1) * 16;
+        o_pos[p] = (ti << 20) | (ty << 10) | tx;
+    }
+    const bool last_ok = !LAST_PARTIAL || (gq >> 1) == 0;   // channels of the last column tile this lane owns exist
     f32x4_t bias_r[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -220,56 +230,66 @@ __global__ __launch_bounds__(256, (CINP <= 40 ? 2 : 1)) void conv_igemm_pf_kerne
     TileWalker cur, nxt;
     cur.init(g, blockIdx.x, gridDim.x);
     nxt = cur; nxt.advance();
-    // epilogue operand offsets + loads of one tile (8 bytes = 4 channels per lane per (row tile, column tile))
-    auto fetch_epi = [&](const TileOrigin& o, unsigned (&ooff)[MTW], u32x2_t (&rres)[MTW][NT], u32x2_t (&ract)[MTW][NT]) {
+    // epilogue operand offsets + loads of one tile (16 bytes = 8 channels per lane per (row-tile pair, column tile))
+    auto fetch_epi = [&](const TileOrigin& o, unsigned (&ooff)[NPAIR], u32x4_t (&rres)[NPAIR][NT], u32x4_t (&ract)[NPAIR][NT]) {
         const int obase = ((o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (COUTP * 2);
         const int ylim = g.Ho - o.oy0, xlim = g.Wo - o.ox0, ilim = g.n_img - o.img0;
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) {
-            const bool ok = (o_pos[m] >> 20) < ilim && ((o_pos[m] >> 10) & 1023) < ylim && (o_pos[m] & 1023) < xlim;
-            ooff[m] = ok ? (unsigned)(obase + o_rel[m]) : MIL_OOB;
+        for (int p = 0; p < NPAIR; ++p) {
+            const bool ok = (o_pos[p] >> 20) < ilim && ((o_pos[p] >> 10) & 1023) < ylim && (o_pos[p] & 1023) < xlim;
+            ooff[p] = ok ? (unsigned)(obase + o_rel[p]) : MIL_OOB;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[m] + nt * 32;
-                if (a.res) rres[m][nt] = __builtin_amdgcn_raw_buffer_load_b64(rs_res, off, 0, 0);
-                if (a.act) ract[m][nt] = __builtin_amdgcn_raw_buffer_load_b64(rs_act, off, 0, 0);
+                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 32;
+                if (a.res) rres[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0);
+                if (a.act) ract[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, off, 0, 0);
             }
         }
     };
 
     // EPI_AHEAD: request the epilogue operands a whole tile ahead (costs one more register set; the 40/64-channel
-    // instantiations have no room for it and request them at the start of their own tile instead)
+    // instantiations have no room for it and request them at the start of their own tile instead).
+    // DEPTH: how many tiles ahead the halo loads run.  A load round trip under load is ~2 us whether it hits
+    // L2 or HBM, about one tile time, so the narrowest layers keep TWO tiles of halo loads in flight (two
+    // register sets, tile loop unrolled by two).
     constexpr bool EPI_AHEAD = CINP <= 24;
-    u32x4_t rx[NPX];
-    unsigned ooff_n[EPI_AHEAD ? MTW : 1];
-    u32x2_t rres_n[EPI_AHEAD ? MTW : 1][NT], ract_n[EPI_AHEAD ? MTW : 1][NT];
+    constexpr int DEPTH = 1;     // measured: a second tile in flight (DEPTH 2, CINP <= 24) is 8% slower — the limit is VMEM issue, not latency
+    const int G = gridDim.x;
+    TileWalker nx2 = nxt;
+    nx2.advance();
+    u32x4_t rxA[NPX], rxB[DEPTH == 2 ? NPX : 1];
+    unsigned ooff_n[EPI_AHEAD ? NPAIR : 1];
+    u32x4_t rres_n[EPI_AHEAD ? NPAIR : 1][NT], ract_n[EPI_AHEAD ? NPAIR : 1][NT];
     if ((int)blockIdx.x < ntiles) {
-        mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, cur.origin(g));
+        mil_fetch_halo<CINP, NPX>(rxA, rs_x, ht, g, cur.origin(g));
         if constexpr (EPI_AHEAD) fetch_epi(cur.origin(g), ooff_n, rres_n, ract_n);
     }
+    if constexpr (DEPTH == 2) {
+        if ((int)blockIdx.x + G < ntiles) mil_fetch_halo<CINP, NPX>(rxB, rs_x, ht, g, nxt.origin(g));
+    }
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    auto do_tile = [&](u32x4_t (&rx)[NPX], int tile) {
         __syncthreads();                       // every wave has finished reading ldsA for the previous tile
         mil_commit_halo<NPX>(rx, ldsA, ht);
         // this tile's epilogue operands were requested one tile ago; take them over before re-issuing
-        unsigned ooff[MTW];
-        u32x2_t rres[MTW][NT], ract[MTW][NT];
+        unsigned ooff[NPAIR];
+        u32x4_t rres[NPAIR][NT], ract[NPAIR][NT];
         if constexpr (EPI_AHEAD) {
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) {
-                ooff[m] = ooff_n[m];
+            for (int p = 0; p < NPAIR; ++p) {
+                ooff[p] = ooff_n[p];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) { rres[m][nt] = rres_n[m][nt]; ract[m][nt] = ract_n[m][nt]; }
+                for (int nt = 0; nt < NT; ++nt) { rres[p][nt] = rres_n[p][nt]; ract[p][nt] = ract_n[p][nt]; }
             }
         }
         __syncthreads();
-        // issue-early: the NEXT tile's halo (and epilogue operands) stay in flight under this tile's MFMA loop
+        // issue-early: refill the register set just written to LDS with the halo of the tile DEPTH ahead
         if constexpr (!EPI_AHEAD) fetch_epi(cur.origin(g), ooff, rres, ract);
-        if (tile + (int)gridDim.x < ntiles) {
-            mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, nxt.origin(g));
-            if constexpr (EPI_AHEAD) fetch_epi(nxt.origin(g), ooff_n, rres_n, ract_n);
+        if (tile + DEPTH * G < ntiles) mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, (DEPTH == 2 ? nx2 : nxt).origin(g));
+        if constexpr (EPI_AHEAD) {
+            if (tile + G < ntiles) fetch_epi(nxt.origin(g), ooff_n, rres_n, ract_n);
         }
-        cur = nxt; nxt.advance();
+        cur = nxt; nxt = nx2; nx2.advance();
 
         f32x4_t acc[MTW][NT];
 #pragma unroll
@@ -289,34 +309,49 @@ __global__ __launch_bounds__(256, (CINP <= 40 ? 2 : 1)) void conv_igemm_pf_kerne
             }
         }
 
-        // register epilogue: lane owns channels nt*16 + 4*gq + {0..3} of pixel (row tile m, column r)
+        // register epilogue on 8 channels per lane (see "Epilogue layout" above)
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) {
+        for (int p = 0; p < NPAIR; ++p) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                float v[4];
+                float v[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = acc[m][nt][i];
+                for (int i = 0; i < 4; ++i) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, acc[2 * p][nt][i]),
+                                                                     __builtin_bit_cast(unsigned, acc[2 * p + 1][nt][i]), false, false);
+                    v[i] = __builtin_bit_cast(float, sw[0]);
+                    v[4 + i] = __builtin_bit_cast(float, sw[1]);
+                }
                 if (a.res) {
-                    const bf16x4_t t = __builtin_bit_cast(bf16x4_t, rres[m][nt]);
+                    const bf16x8_t t = __builtin_bit_cast(bf16x8_t, rres[p][nt]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += (float)t[i];
+                    for (int i = 0; i < 8; ++i) v[i] += (float)t[i];
                 }
                 if (a.apply_lrelu) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], v[i] * a.slope);      // 0 < slope < 1
+                    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], v[i] * a.slope);      // 0 < slope < 1
                 }
                 if (a.act) {
-                    const bf16x4_t t = __builtin_bit_cast(bf16x4_t, ract[m][nt]);
+                    const bf16x8_t t = __builtin_bit_cast(bf16x8_t, ract[p][nt]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] *= ((float)t[i] > 0.f ? 1.f : a.slope);
+                    for (int i = 0; i < 8; ++i) v[i] *= ((float)t[i] > 0.f ? 1.f : a.slope);
                 }
-                bf16x4_t ov;
+                bf16x8_t ov;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ov[i] = (__bf16)v[i];
-                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[m] + nt * 32;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, ov), rs_y, off, 0, 0);
+                for (int i = 0; i < 8; ++i) ov[i] = (__bf16)v[i];
+                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 32;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), rs_y, off, 0, 0);
             }
+        }
+    };
+
+    for (int tile = blockIdx.x; tile < ntiles;) {
+        do_tile(rxA, tile);
+        tile += G;
+        if constexpr (DEPTH == 2) {
+            if (tile >= ntiles) break;
+            do_tile(rxB, tile);
+            tile += G;
         }
     }
 }
@@ -353,15 +388,21 @@ static int launch_conv(const ConvArgs<T>& a0, hipStream_t stream) {
 }
 
 
-template <int CINP, int NT, int KS>
+#ifndef MIL_PF_WG_PER_CU
+#define MIL_PF_WG_PER_CU 4
+#endif
+#ifndef MIL_PF_MTW_24
+#define MIL_PF_MTW_24 4
+#endif
+template <int CINP, int NT, int KS, int MTW = 4>
 static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool* taken) {
     ConvArgs<BF16> a = a0;
     constexpr int PIXB = mil_pix_pitch(CINP, 2);
     constexpr int COUTP = mil_nt_to_cp(NT);
     *taken = false;
-    mil_geom_tiles(a.g, 8);
+    mil_geom_tiles(a.g, MTW == 4 ? 8 : 7);
     const int halo_px = (a.g.hh * a.g.hw) << a.g.ti_log2;
-    if (halo_px > 400) return MIL_OK;
+    if (halo_px > mil_halo_px_max(MTW)) return MIL_OK;
     const int a_bytes = (halo_px * PIXB + 15) & ~15;
     const int w_bytes = a.nsteps * NT * 64 * 16;
     const int lds = a_bytes + w_bytes;
@@ -370,7 +411,7 @@ static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool*
     if ((a.g.n_groups * a.g.tiles_y * a.g.tiles_x) < 512) return MIL_OK;    // too few tiles for a persistent launch
     a.kc = a.nsteps;
     a.lds_w_off = a_bytes;
-    auto kern = conv_igemm_pf_kernel<CINP, NT, KS>;
+    auto kern = conv_igemm_pf_kernel<CINP, NT, KS, MTW>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return MIL_ERR_LAUNCH;
@@ -391,7 +432,7 @@ static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool*
         if (a.res) c.res = a.res + (size_t)i0 * (y_img / 2);
         if (a.act) c.act = a.act + (size_t)i0 * (y_img / 2);
         const int ntiles = c.g.n_groups * c.g.tiles_y * c.g.tiles_x;
-        int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+        int grid = 256 * (per_cu < 1 ? 1 : (per_cu > MIL_PF_WG_PER_CU ? MIL_PF_WG_PER_CU : per_cu));
         if (grid > ntiles) grid = ntiles;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, c, ntiles, (unsigned)(x_img * n), (unsigned)(y_img * n));
         MIL_CHECK_LAUNCH();
@@ -404,7 +445,7 @@ template <int CINP, int NT>
 static int launch_conv_pf(const ConvArgs<BF16>& a, hipStream_t stream, bool* taken) {
     *taken = false;
     if constexpr (CINP == 16 && NT == 2) { if (a.g.ks == 4) return launch_conv_pf_ks<16, 2, 4>(a, stream, taken); }
-    if constexpr (CINP == 24 && NT == 2) { if (a.g.ks == 3) return launch_conv_pf_ks<24, 2, 3>(a, stream, taken); }
+    if constexpr (CINP == 24 && NT == 2) { if (a.g.ks == 3) return launch_conv_pf_ks<24, 2, 3, MIL_PF_MTW_24>(a, stream, taken); }
     if constexpr (CINP == 40 && NT == 3) { if (a.g.ks == 3) return launch_conv_pf_ks<40, 3, 3>(a, stream, taken); }
     if constexpr (CINP == 40 && NT == 2) {
         if (a.g.ks == 3) return launch_conv_pf_ks<40, 2, 3>(a, stream, taken);

@@ -23,6 +23,10 @@ __host__ inline void mil_geom_tiles(ConvGeom& g, int tile_px_log2) {
         if (g.Wo > 8 || g.Ho > 8) { tw = 4; th = 4; }
         else if (g.Wo > 4 || g.Ho > 4) { tw = 3; th = 3; }
         else { tw = 2; th = 2; }
+    } else if (tile_px_log2 == 7) {   // 128 px
+        if (g.Wo > 8 || g.Ho > 8) { tw = 4; th = 3; }
+        else if (g.Wo > 4 || g.Ho > 4) { tw = 3; th = 3; }
+        else { tw = 2; th = 2; }
     } else {                           // 64 px
         if (g.Wo > 4 || g.Ho > 4) { tw = 3; th = 3; }
         else { tw = 2; th = 2; }
@@ -200,3 +204,6 @@ __device__ __forceinline__ void mil_otile_commit(const uint4 (&r)[NP], char* lds
 
 // pieces-per-thread bound for a halo of at most 400 pixels (18x18, 19x19 and 4 x 10x10 tiles)
 __host__ __device__ constexpr int mil_halo_np(int cinp, int esz) { return (400 * (cinp * esz / 16) + 255) / 256; }
+// same for 128-px tiles: 10x18, 2 x 10x10 and 8 x 6x6 halos (<= 288 pixels)
+__host__ __device__ constexpr int mil_halo_px_max(int mtw) { return mtw == 4 ? 400 : 288; }
+__host__ __device__ constexpr int mil_halo_np_mtw(int cinp, int esz, int mtw) { return (mil_halo_px_max(mtw) * (cinp * esz / 16) + 255) / 256; }
