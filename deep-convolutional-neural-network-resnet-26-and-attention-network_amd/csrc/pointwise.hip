@@ -125,7 +125,10 @@ extern "C" int mil_pack_conv_weights(const float* w, const float* bias, void* wp
 
 // ---------------------------------------------------------------------------------------------
 // MaxPool2d(kernel 3, stride 2, pad 1), NHWC; -inf padding; first maximum in (ky,kx) scan order wins
-// (torch semantics).  Records the winning tap (0..8) per output element for the backward pass.
+// (torch semantics).  Records per output element, for the backward pass, the winning tap (bits 0-3) and
+// whether the winning value is <= 0 (bit 4): the input is a LeakyReLU output, so that bit is the lrelu'
+// mask of the only input element that receives this window's gradient and the backward pass never has to
+// re-read the (4x larger) input tensor.
 template <typename T>
 __global__ void maxpool_fwd_kernel(const typename T::elem* __restrict__ x, typename T::elem* __restrict__ y,
                                    uint8_t* __restrict__ widx, int n, int H, int W, int Ho, int Wo, int CP) {
@@ -158,6 +161,8 @@ __global__ void maxpool_fwd_kernel(const typename T::elem* __restrict__ x, typen
         }
         const size_t o = (((size_t)img * Ho + oy) * Wo + ox) * CP + c8 * 8;
         store8<T>(y + o, best);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bi[j] |= (best[j] > 0.f) ? 0 : 16;
         uint2 packed;
         packed.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | ((uint32_t)bi[3] << 24);
         packed.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | ((uint32_t)bi[7] << 24);
@@ -165,51 +170,74 @@ __global__ void maxpool_fwd_kernel(const typename T::elem* __restrict__ x, typen
     }
 }
 
-// gx[y,x,c] = lrelu'(act[y,x,c]) * sum over the (<=4) pooling windows that contain (y,x) and whose
-// recorded winner is (y,x) of gy[window].  Gather form: no atomics, deterministic.
+// gx[y,x,c] = lrelu'(x[y,x,c]) * sum over the (<=4) pooling windows that contain (y,x) and whose recorded
+// winner is (y,x) of gy[window].  Gather form: no atomics, deterministic.  One thread owns the 2x2 block of
+// input pixels (2by..2by+1, 2bx..2bx+1) for 8 channels: those four pixels are covered by exactly the four
+// windows (by..by+1, bx..bx+1) — the even/even pixel by one of them, the mixed ones by two, the odd/odd one
+// by all four — so the four winner records and gradients are loaded once and 9 tap tests replace 16.
+// With use_mask the lrelu' factor comes from bit 4 of the winner record.
 template <typename T>
 __global__ void maxpool_bwd_kernel(const typename T::elem* __restrict__ gy, const uint8_t* __restrict__ widx,
-                                   const typename T::elem* __restrict__ act, typename T::elem* __restrict__ gx, int n,
-                                   int H, int W, int Ho, int Wo, int CP, float slope) {
+                                   typename T::elem* __restrict__ gx, int n, int H, int W, int Ho, int Wo, int CP,
+                                   float slope, int use_mask) {
     const int ng = CP / 8;
-    const size_t total = (size_t)n * H * W * ng;
+    const int Hb = (H + 1) / 2, Wb = (W + 1) / 2;
+    const size_t total = (size_t)n * Hb * Wb * ng;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int c8 = (int)(idx % ng);
         size_t r = idx / ng;
-        const int x = (int)(r % W); r /= W;
-        const int y = (int)(r % H);
-        const int img = (int)(r / H);
-        float g[8];
+        const int bx = (int)(r % Wb); r /= Wb;
+        const int by = (int)(r % Hb);
+        const int img = (int)(r / Hb);
+        float g[2][2][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] = 0.f;
-        const int oy_lo = y >> 1, oy_hi = (y + 1) >> 1;      // windows with 2*oy-1 <= y <= 2*oy+1
-        const int ox_lo = x >> 1, ox_hi = (x + 1) >> 1;
-        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[a][b][j] = 0.f;
+#pragma unroll
+        for (int wy = 0; wy < 2; ++wy) {
+            const int oy = by + wy;
             if (oy >= Ho) continue;
-            const int ky = y - (2 * oy - 1);
-            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+#pragma unroll
+            for (int wx = 0; wx < 2; ++wx) {
+                const int ox = bx + wx;
                 if (ox >= Wo) continue;
-                const int kx = x - (2 * ox - 1);
-                const uint32_t me = (uint32_t)(ky * 3 + kx);
                 const size_t o = (((size_t)img * Ho + oy) * Wo + ox) * CP + c8 * 8;
                 const uint2 packed = *reinterpret_cast<const uint2*>(widx + o);
                 float gv[8];
                 load8<T>(gy + o, gv);
+                // window (oy,ox) covers rows 2oy-1..2oy+1: block row dy (pixel 2by+dy) is its tap row ky below
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t w = ((j < 4 ? packed.x : packed.y) >> (8 * (j & 3))) & 0xffu;
-                    if (w == me) g[j] += gv[j];
+                for (int dy = 0; dy < 2; ++dy) {
+                    const int ky = 2 * by + dy - (2 * oy - 1);          // wy=0: 1,2   wy=1: -1,0
+                    if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int kx = 2 * bx + dx - (2 * ox - 1);
+                        if (kx < 0 || kx > 2) continue;
+                        const uint32_t me = (uint32_t)(ky * 3 + kx);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const uint32_t w = ((j < 4 ? packed.x : packed.y) >> (8 * (j & 3))) & 0xffu;
+                            if ((w & 15u) == me) g[dy][dx][j] += (use_mask && (w & 16u)) ? gv[j] * slope : gv[j];
+                        }
+                    }
                 }
             }
         }
-        const size_t o = (((size_t)img * H + y) * W + x) * CP + c8 * 8;
-        if (act) {
-            float av[8];
-            load8<T>(act + o, av);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g[j] *= lrelu_grad(av[j], slope);
+        for (int dy = 0; dy < 2; ++dy) {
+            const int y = 2 * by + dy;
+            if (y >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int x = 2 * bx + dx;
+                if (x >= W) continue;
+                store8<T>(gx + (((size_t)img * H + y) * W + x) * CP + c8 * 8, g[dy][dx]);
+            }
         }
-        store8<T>(gx + o, g);
     }
 }
 
@@ -231,15 +259,15 @@ extern "C" int mil_maxpool_fwd(const void* x, void* y, uint8_t* widx, int n, int
     return MIL_OK;
 }
 
-extern "C" int mil_maxpool_bwd(const void* gy, const uint8_t* widx, const void* act, void* gx, int n, int H, int W,
-                               int cp, float slope, int dtype, void* stream) {
+extern "C" int mil_maxpool_bwd(const void* gy, const uint8_t* widx, void* gx, int n, int H, int W, int cp,
+                               int apply_lrelu_mask, float slope, int dtype, void* stream) {
     if (!gy || !widx || !gx || cp % 8) return MIL_ERR_ARG;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const size_t total = (size_t)n * H * W * (cp / 8);
+    const size_t total = (size_t)n * ((H + 1) / 2) * ((W + 1) / 2) * (cp / 8);
     if (!total) return MIL_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MIL_DT_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, st, (const __bf16*)gy, widx, (const __bf16*)act, (__bf16*)gx, n, H, W, Ho, Wo, cp, slope);
-    else if (dtype == MIL_DT_F32) hipLaunchKernelGGL(maxpool_bwd_kernel<F32>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)gy, widx, (const float*)act, (float*)gx, n, H, W, Ho, Wo, cp, slope);
+    if (dtype == MIL_DT_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, st, (const __bf16*)gy, widx, (__bf16*)gx, n, H, W, Ho, Wo, cp, slope, apply_lrelu_mask);
+    else if (dtype == MIL_DT_F32) hipLaunchKernelGGL(maxpool_bwd_kernel<F32>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)gy, widx, (float*)gx, n, H, W, Ho, Wo, cp, slope, apply_lrelu_mask);
     else return MIL_ERR_ARG;
     MIL_CHECK_LAUNCH();
     return MIL_OK;

@@ -109,7 +109,7 @@ def encoder_forward(net, x, dtype):
     wp, bp = net._packed("stem", net.conv1.weight, net.conv1.bias, L.PACK_STEM, dtype)
     stem = ops.conv(xs, wp, bp, ops.cpad(STEM_WIDTH), ks=4, stride=1, pad=2, lrelu=True)
     pool, widx = ops.maxpool_fwd(stem)
-    saved = {"xs": xs, "stem": stem, "widx": widx, "blocks": []}
+    saved = {"xs": xs, "stem_hw": tuple(stem.shape[1:3]), "widx": widx, "blocks": []}      # the stem output itself is not kept
     t = pool
     for bi, blk in enumerate(net.blocks()):
         cout = blk.conv1.out_channels
@@ -214,7 +214,7 @@ def encoder_backward(net, saved, dfeats, dtype):
                           out_hw=xin.shape[1:3], res=addend, act=mask)
         else:
             dz = ops.conv(dz1, w1d, None, ops.cpad(cin), ks=3, stride=1, pad=1, res=addend, act=mask)
-    dstem = ops.maxpool_bwd(dz, saved["widx"], saved["stem"])
+    dstem = ops.maxpool_bwd(dz, saved["widx"], saved["stem_hw"])
     grads["stem"] = wgrad(saved["xs"], dstem, 3, STEM_WIDTH, ks=4, stride=1, pad=2, stem=True)
 
     if use_side:

@@ -172,12 +172,17 @@ def maxpool_fwd(x):
     return y, widx
 
 
-def maxpool_bwd(gy, widx, act, slope=LEAK):
-    n, h, w, cp = act.shape
-    _need(gy, widx.shape, act.dtype, "gy")
-    gx = torch.empty_like(act)
-    L.check(L.lib().mil_maxpool_bwd(gy.data_ptr(), widx.data_ptr(), act.data_ptr(), gx.data_ptr(), n, h, w, cp, slope,
-                                    L.dt_code(act.dtype), L.stream_ptr()), "mil_maxpool_bwd")
+def maxpool_bwd(gy, widx, in_hw, lrelu_mask=True, slope=LEAK):
+    """Gradient of the pooled tensor scattered back to the [n,H,W,cp] pool input; with lrelu_mask the LeakyReLU
+    backward of that input is applied too (from the sign bit recorded in widx)."""
+    n, ho, wo, cp = widx.shape
+    h, w = in_hw
+    if ((h - 1) // 2 + 1, (w - 1) // 2 + 1) != (ho, wo):
+        raise ValueError(f"pool input {h}x{w} does not produce {ho}x{wo}")
+    _need(gy, widx.shape, gy.dtype, "gy")
+    gx = torch.empty((n, h, w, cp), dtype=gy.dtype, device=gy.device)
+    L.check(L.lib().mil_maxpool_bwd(gy.data_ptr(), widx.data_ptr(), gx.data_ptr(), n, h, w, cp, 1 if lrelu_mask else 0,
+                                    slope, L.dt_code(gy.dtype), L.stream_ptr()), "mil_maxpool_bwd")
     return gx
 
 

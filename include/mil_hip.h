@@ -93,12 +93,14 @@ int mil_conv_bwd_fused(const void* dz, const void* wpack_dgrad, const void* x, c
                        int ks, int pad, int apply_mask, float slope, int dtype, void* stream);
 
 /* ---- pooling -------------------------------------------------------------------------------
- * MaxPool2d(3, stride 2, pad 1) (gbm/model.py:26,53): y [n,Ho,Wo,cp], Ho=(H-1)/2+1; `widx` records
- * the winning tap per output element (uint8, same shape as y).  The backward gathers gy through
- * widx and multiplies by the LeakyReLU mask of `act` (the stem output) when act != null. */
+ * MaxPool2d(3, stride 2, pad 1) (gbm/model.py:26,53): y [n,Ho,Wo,cp], Ho=(H-1)/2+1; `widx` records per
+ * output element (uint8, same shape as y) the winning tap (bits 0-3) and whether the winner is <= 0
+ * (bit 4).  The backward gathers gy through widx into gx [n,H,W,cp]; with apply_lrelu_mask it also
+ * applies the LeakyReLU backward of the stem activation (gbm/model.py:25,52) from bit 4, so the stem
+ * output itself is never re-read. */
 int mil_maxpool_fwd(const void* x, void* y, uint8_t* widx, int n, int H, int W, int cp, int dtype, void* stream);
-int mil_maxpool_bwd(const void* gy, const uint8_t* widx, const void* act, void* gx, int n, int H, int W, int cp,
-                    float slope, int dtype, void* stream);
+int mil_maxpool_bwd(const void* gy, const uint8_t* widx, void* gx, int n, int H, int W, int cp,
+                    int apply_lrelu_mask, float slope, int dtype, void* stream);
 
 /* AdaptiveAvgPool2d((1,1)) + flatten + Linear(80,L,bias=False) (gbm/model.py:31-32,58-60).
  * x [n,hw,cp] -> pooled [n,c] fp32 (kept for backward), feats [n,nf] fp32 = pooled @ wfc^T.

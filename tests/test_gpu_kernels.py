@@ -149,7 +149,9 @@ def test_maxpool(ops, dtype, shape):
     xg = to_nhwc(x.detach(), dtype)
     y, widx = ops.maxpool_fwd(xg)
     assert torch.equal(from_nhwc(y, c), ref.detach())
-    gx = ops.maxpool_bwd(to_nhwc(gy, dtype), widx, xg)
+    gx = ops.maxpool_bwd(to_nhwc(gy, dtype), widx, (h, w))
+    gx_nomask = ops.maxpool_bwd(to_nhwc(gy, dtype), widx, (h, w), lrelu_mask=False)
+    assert rel_err(from_nhwc(gx_nomask, c), x.grad) < TOL[dtype]
     want = x.grad * torch.where(x.detach() > 0, 1.0, LEAK)
     assert rel_err(from_nhwc(gx, c), want) < TOL[dtype]
 

@@ -105,8 +105,6 @@ def test_fp32_stage_activations(golden_dir, name):
     enc = net.cnn.module
     with torch.no_grad():
         feats, saved = encoder.encoder_forward(enc, torch.tensor(g["x"]).cuda(), torch.float32)
-    stem = saved["stem"][..., :20].permute(0, 3, 1, 2).cpu().numpy()
-    assert _rel(stem, g["act.stem"]) < 1e-5
     for li, bi in ((1, 2), (2, 5), (3, 8), (4, 11)):
         c = (20, 40, 60, 80)[li - 1]
         act = saved["blocks"][bi][2][..., :c].permute(0, 3, 1, 2).cpu().numpy()
