@@ -6,9 +6,9 @@ bags (BASELINE.json metric, configs[1]: 8 bags x 256 tiles per GPU, bf16 operand
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One step = zero the flat gradient bucket, one encoder pass over every tile of this rank's bags (full-bag
-path: all tiles through the backbone, gradients enabled), the segmented MIL head, the full backward and —
-for N>1 — one RCCL all-reduce (sum) of the flat gradient bucket.  Weak scaling: every rank owns 8 bags.
+One step = zero the flat gradient bucket, re-pack the filters (they changed), one encoder pass over every tile of
+this rank's bags (full-bag path: all tiles through the backbone, gradients enabled), the segmented MIL head, the
+full backward, — for N>1 — one RCCL all-reduce (sum) of the flat gradient bucket, and one fused Adam step.  Weak scaling: every rank owns 8 bags.
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
 import argparse
@@ -108,6 +108,7 @@ def main():
         net.cnn.module.overlap_wgrad = False
     flat = mil_amd.FlatParams(net)
     flat.broadcast_params()
+    opt = mil_amd.FlatAdam(flat, lr=2e-4)               # reference optimizer: Adam(lr=2e-4), gbm/classify_combined.py:519
 
     # synthetic bags, generated on the device and resident before the timed region
     n_tiles = args.bags * args.tiles
@@ -124,6 +125,7 @@ def main():
         outs = net.forward_bags((x_all, sizes), labels)
         torch.stack([o["loss"] for o in outs]).sum().backward()
         flat.allreduce_grads()
+        opt.step()                      # weights change every step: the next forward re-packs all filters
         return outs
 
     def fence():

@@ -4,8 +4,8 @@ Importable as `mil_amd` (repo-root shim `mil_amd.py`); the on-disk package direc
 project's hyphenated name."""
 from ._lib import LIB_PATH, MilLibraryError, build_library, lib  # noqa: F401
 from .encoder import BasicResBlock, ResNet  # noqa: F401
-from .dist import FlatParams, gather_features, shard_bags  # noqa: F401
+from .dist import FlatAdam, FlatParams, gather_features, shard_bags  # noqa: F401
 from .model import Attention, ContextLayer, CrossEntropyWithProbs, TileParallel  # noqa: F401
 
 __all__ = ["Attention", "ResNet", "BasicResBlock", "ContextLayer", "CrossEntropyWithProbs", "TileParallel",
-           "FlatParams", "shard_bags", "gather_features", "build_library", "lib", "MilLibraryError", "LIB_PATH"]
+           "FlatParams", "FlatAdam", "shard_bags", "gather_features", "build_library", "lib", "MilLibraryError", "LIB_PATH"]

@@ -47,6 +47,10 @@ _SIGS = {
     "mil_maxpool_bwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
     "mil_avgpool_fc_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mil_avgpool_fc_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
+    "mil_adam_step": ([_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp], _i),
+    "mil_pack_job_bytes": ([], _i),
+    "mil_pack_job_fill": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i], _i),
+    "mil_pack_all": ([_vp, _i, _vp], _i),
     "mil_head_workspace_floats": ([_c.POINTER(_sz), _i, _i], _i),
     "mil_head_grad_floats": ([], _i),
     "mil_head_rec_floats": ([], _i),

@@ -74,3 +74,32 @@ def gather_features(feats, group=None):
     parts = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(parts, padded, group=group)
     return torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
+
+
+class FlatAdam:
+    """torch.optim.Adam semantics (the reference's optimizer, gbm/classify_combined.py:519) as ONE HIP launch over
+    the flat parameter / gradient buckets of a FlatParams (mil_adam_step in include/mil_hip.h)."""
+
+    def __init__(self, flat, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.flat, self.lr, self.betas, self.eps, self.weight_decay = flat, lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(flat.flat)
+        self.exp_avg_sq = torch.zeros_like(flat.flat)
+        self.t = 0
+
+    def step(self, grad_scale=1.0):
+        from . import _lib as L
+        from .encoder import WEIGHT_EPOCH
+        if not self.flat.flat.is_cuda:
+            raise RuntimeError("FlatAdam runs on the GPU only")
+        self.t += 1
+        L.check(L.lib().mil_adam_step(self.flat.flat.data_ptr(), self.flat.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                      self.exp_avg_sq.data_ptr(), self.flat.numel, self.lr, self.betas[0], self.betas[1],
+                                      self.eps, self.weight_decay, self.t, grad_scale, L.stream_ptr()), "mil_adam_step")
+        WEIGHT_EPOCH[0] += 1          # packed filter copies are stale now
+
+    def state_dict(self):
+        return {"t": self.t, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr}
+
+    def load_state_dict(self, sd):
+        self.t = int(sd["t"]); self.lr = float(sd.get("lr", self.lr))
+        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])

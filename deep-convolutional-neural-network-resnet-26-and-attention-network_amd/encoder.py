@@ -13,6 +13,7 @@ from . import _lib as L
 from . import ops
 
 STAGE_WIDTHS = (20, 40, 60, 80)        # gbm/model.py:27-30
+WEIGHT_EPOCH = [0]                     # bumped by optimizers that update weights through raw kernels (FlatAdam)
 STEM_WIDTH = 20                        # gbm/model.py:20
 
 
@@ -57,7 +58,8 @@ class ResNet(nn.Module):
         self.overlap_wgrad = True
         self.n_side_streams = 1
         self.fuse_backward = True
-        self._pack_cache = {}
+        self._pack_table = None
+        self._pack_version = None
         self._side = None
 
     def _make_layer(self, planes, blocks, stride=1):
@@ -90,14 +92,54 @@ class ResNet(nn.Module):
             self._side = [torch.cuda.Stream() for _ in range(self.n_side_streams)]
         return self._side
 
+    # ---- packed (MFMA fragment order) copies of every filter, refreshed by ONE launch -------------------
+    def _pack_specs(self):
+        """(key, weight, bias, mode) for every packed filter the forward and backward passes use."""
+        specs = [("stem", self.conv1.weight, self.conv1.bias, L.PACK_STEM)]
+        for bi, blk in enumerate(self.blocks()):
+            for name, conv in (("c1", blk.conv1), ("c2", blk.conv2)):
+                specs.append((f"b{bi}.{name}", conv.weight, conv.bias, L.PACK_FWD))
+                specs.append((f"b{bi}.{name}", conv.weight, None, L.PACK_DGRAD))
+            if blk.downsample is not None:
+                specs.append((f"b{bi}.ds", blk.downsample[0].weight, None, L.PACK_FWD))
+                specs.append((f"b{bi}.ds", blk.downsample[0].weight, None, L.PACK_DGRAD))
+        return specs
+
+    def refresh_packed(self, dtype):
+        """Make the packed filters current: rebuild the job table if storage moved, re-run the single pack launch
+        if any weight changed (parameter version counters, or WEIGHT_EPOCH bumped by FlatAdam.step)."""
+        import ctypes
+        lib = L.lib()
+        specs = self._pack_specs()
+        ptr_tag = (dtype,) + tuple(w.data_ptr() for _k, w, _b, _m in specs) + tuple(0 if b is None else b.data_ptr() for _k, _w, b, _m in specs)
+        if self._pack_table is None or self._pack_table[0] != ptr_tag:
+            dev = self.conv1.weight.device
+            rec = lib.mil_pack_job_bytes()
+            host = (ctypes.c_char * (rec * len(specs)))()
+            store = {}
+            for i, (key, w, b, mode) in enumerate(specs):
+                if w.dtype != torch.float32 or not w.is_cuda or not w.is_contiguous():
+                    raise ValueError("conv weights must be contiguous CUDA fp32 tensors")
+                cout, cin, ks, _ = w.shape
+                elems = ctypes.c_size_t(0)
+                L.check(lib.mil_packed_weight_elems(ctypes.byref(elems), cout, cin, ks, mode), "mil_packed_weight_elems")
+                packed = torch.empty(elems.value, dtype=dtype, device=dev)
+                n_out = cin if mode == L.PACK_DGRAD else cout
+                bias_pad = torch.empty((ops.cpad(n_out) + 15) // 16 * 16, dtype=torch.float32, device=dev)
+                L.check(lib.mil_pack_job_fill(ctypes.byref(host, i * rec), w.data_ptr(), L.ptr(b), packed.data_ptr(),
+                                              bias_pad.data_ptr(), cout, cin, ks, mode, L.dt_code(dtype)), "mil_pack_job_fill")
+                store[(key, mode)] = (packed, bias_pad)
+            table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev)
+            self._pack_table = (ptr_tag, table, store, len(specs))
+            self._pack_version = None
+        ver = (WEIGHT_EPOCH[0],) + tuple(w._version for _k, w, _b, _m in specs) + tuple(0 if b is None else b._version for _k, _w, b, _m in specs)
+        if self._pack_version != ver:
+            _tag, table, _store, njobs = self._pack_table
+            L.check(lib.mil_pack_all(table.data_ptr(), njobs, L.stream_ptr()), "mil_pack_all")
+            self._pack_version = ver
+
     def _packed(self, key, weight, bias, mode, dtype):
-        """Packed MFMA-fragment copy of a conv weight, rebuilt only when the parameter changed."""
-        tag = (weight._version, weight.data_ptr(), None if bias is None else bias._version, dtype)
-        hit = self._pack_cache.get((key, mode))
-        if hit is None or hit[0] != tag:
-            hit = (tag, ops.pack_weights(weight, bias, mode, dtype))
-            self._pack_cache[(key, mode)] = hit
-        return hit[1]
+        return self._pack_table[2][(key, mode)]
 
     def forward(self, x):
         return _EncoderFn.apply(self, x, *self.encoder_params())
@@ -105,6 +147,7 @@ class ResNet(nn.Module):
 
 def encoder_forward(net, x, dtype):
     """Runs the kernels; returns (feats [T,80] fp32, saved-state dict for the backward)."""
+    net.refresh_packed(dtype)
     xs = ops.stem_s2d(x, dtype)
     wp, bp = net._packed("stem", net.conv1.weight, net.conv1.bias, L.PACK_STEM, dtype)
     stem = ops.conv(xs, wp, bp, ops.cpad(STEM_WIDTH), ks=4, stride=1, pad=2, lrelu=True)

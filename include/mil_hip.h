@@ -138,6 +138,20 @@ int mil_head_bwd(const float* H, const int* bag_offsets, const int* inst_bag, co
                  const float* grad_loss, const float* grad_l2, float* dH, float* grads, int ntot, int nbags,
                  float slope, float drop_p, void* stream);
 
+/* ---- training-step closure ---------------------------------------------------
+ * mil_adam_step: torch.optim.Adam (gbm/classify_combined.py:519, stepped at :450-454) over the flat fp32
+ * parameter / gradient buckets in ONE launch; `step` is the 1-based step count (bias correction),
+ * `grad_scale` multiplies the gradient first (1/accumulated-bags, or 1).
+ * mil_pack_all: re-pack every conv filter into MFMA fragment order in ONE launch from a device-resident
+ * table of mil_pack_job_bytes()-sized records filled on the host by mil_pack_job_fill (same index maps as
+ * mil_pack_conv_weights). */
+int mil_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+int mil_pack_job_bytes(void);
+int mil_pack_job_fill(void* job_host, const float* w, const float* bias, void* out, float* bias_pad, int cout, int cin,
+                      int ks, int mode, int dtype);
+int mil_pack_all(const void* jobs_device, int njobs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -227,3 +227,33 @@ def test_errors_are_exceptions(golden_dir):
         net(torch.zeros(1, 3, 32, 32).cuda(), torch.tensor([0]))          # single-instance bag (BatchNorm)
     with pytest.raises(ValueError):
         net(torch.zeros(4, 1, 32, 32).cuda(), torch.tensor([0]))          # wrong channel count
+
+
+def test_flat_adam_matches_torch_adam(golden_dir):
+    """mil_adam_step (one launch over the flat buckets) == torch.optim.Adam for several steps, and the packed
+    filters follow the updated weights (outputs change, stay finite, and equal a freshly built model's)."""
+    import mil_amd
+    g = np.load(os.path.join(golden_dir, "eval_n8_64.npz"))
+    x, y = torch.tensor(g["x"]).cuda(), torch.tensor(g["y"]).cuda()
+    net = _model(golden_dir, torch.float32).eval()
+    flat = mil_amd.FlatParams(net)
+    opt = mil_amd.FlatAdam(flat, lr=1e-3)
+    ref_params = [p.detach().clone().cpu().requires_grad_(True) for p in net.parameters()]
+    ref_opt = torch.optim.Adam(ref_params, lr=1e-3)
+    losses = []
+    for _ in range(3):
+        flat.zero_grad()
+        out = net(x, y)
+        out["loss"].backward()
+        losses.append(float(out["loss"].detach()))
+        for rp, p in zip(ref_params, net.parameters()):
+            rp.grad = p.grad.detach().cpu().clone()
+        opt.step()
+        ref_opt.step()
+        for rp, p in zip(ref_params, net.parameters()):
+            assert torch.allclose(p.detach().cpu(), rp.detach(), rtol=1e-5, atol=1e-7)
+    assert losses[2] < losses[0]                       # three Adam steps on one bag reduce its loss
+    fresh = _model(golden_dir, torch.float32).eval()
+    fresh.load_state_dict(net.state_dict())
+    a, b = net(x, y), fresh(x, y)
+    assert torch.allclose(a["Mterm"], b["Mterm"], rtol=1e-6, atol=1e-7)
