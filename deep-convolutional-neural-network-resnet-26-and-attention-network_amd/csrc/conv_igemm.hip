@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs<T> a) {
 //     the per-tile instruction stream is loads, MFMAs and the element-wise epilogue, which is what keeps
 //     the kernel on the HBM roof rather than on the vector-issue roof.
 template <int CINP, int NT, int KS, int MTW>
-__global__ __launch_bounds__(256, (MTW == 2 ? 4 : (CINP <= 40 ? 2 : 1))) void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles,
+__global__ __launch_bounds__(256, ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 40 ? 2 : 1))) void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles,
                                                                                   unsigned x_bytes, unsigned y_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using T = BF16;
@@ -456,13 +456,19 @@ static int launch_conv_pf(const ConvArgs<BF16>& a, hipStream_t stream, bool* tak
         if (a.g.ks == 3) return launch_conv_pf_ks<64, 3, 3>(a, stream, taken);
         if (a.g.ks == 1) return launch_conv_pf_ks<64, 3, 1>(a, stream, taken);
     }
+    // 80-channel layers: the whole filter (115 KB) stays resident, so the tile shrinks to 128 px
+    if constexpr (CINP == 80 && NT == 5) { if (a.g.ks == 3) return launch_conv_pf_ks<80, 5, 3, 2>(a, stream, taken); }
+    if constexpr (CINP == 80 && NT == 4) {
+        if (a.g.ks == 3) return launch_conv_pf_ks<80, 4, 3, 2>(a, stream, taken);
+        if (a.g.ks == 1) return launch_conv_pf_ks<80, 4, 1, 2>(a, stream, taken);
+    }
     return MIL_OK;
 }
 
 // 256-px tiles (4 MFMA row tiles per wave) when the halo + a weight chunk fit in LDS, else 64-px tiles.
 template <typename T, int CINP, int NT>
 static int launch_conv_auto(const ConvArgs<T>& a, bool small_tile, hipStream_t stream) {
-    if constexpr (T::DT == MIL_DT_BF16 && CINP <= 64) {
+    if constexpr (T::DT == MIL_DT_BF16) {
         if (!small_tile) {
             bool taken = false;
             const int rc = launch_conv_pf<CINP, NT>(a, stream, &taken);

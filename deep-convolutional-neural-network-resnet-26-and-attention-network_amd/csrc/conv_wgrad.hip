@@ -34,7 +34,7 @@ __device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
 }
 
 template <typename T, int KS, int CINP, int NT, int MSPLIT, bool PF>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs<T> a) {
+__global__ __launch_bounds__(256, (PF && CINP > 40) ? 1 : 0) void wgrad_kernel(WgradArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ESZ = T::ESZ;
     constexpr int PIXB = mil_pix_pitch(CINP, ESZ);
@@ -254,7 +254,7 @@ static int plan_wgrad(ConvGeom& g, WgradPlan& pl, int* lds_z_off) {
     constexpr int RG = KS * KS * (CINP / 8);
     constexpr int MT = (RG + 1) / 2;
     // 256-px tiles when the halo fits comfortably, else 64-px tiles (stride-2 layers, f32 wide layers)
-    constexpr bool PF_OK = (T::DT == MIL_DT_BF16) && CINP <= 40;
+    constexpr bool PF_OK = (T::DT == MIL_DT_BF16);
     for (int lg = 8; lg >= 6; lg -= 2) {
         mil_geom_tiles(g, lg);
         const int xb = ((((g.hh * g.hw) << g.ti_log2) * PIXB) + 15) & ~15;
@@ -290,7 +290,7 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     a.x = (const typename T::elem*)x; a.dz = (const typename T::elem*)dz; a.slab = (float*)ws; a.g = g;
     a.ntiles = g.n_groups * g.tiles_y * g.tiles_x; a.tile_px = 1 << pl.tile_px_log2; a.lds_z_off = lds_z_off;
     // register-prefetch pipeline for the bf16 path when the halo is small enough for its register budget
-    constexpr bool PF_OK = (T::DT == MIL_DT_BF16) && CINP <= 40;      // wider layers: accumulators own the registers
+    constexpr bool PF_OK = (T::DT == MIL_DT_BF16);
     const size_t xb_total = (size_t)g.n_img * g.H * g.W * CINP * T::ESZ;
     const size_t zb_total = (size_t)g.n_img * g.Ho * g.Wo * mil_nt_to_cp(NT) * T::ESZ;
     const bool pf = PF_OK && (((g.hh * g.hw) << g.ti_log2) <= 400) && g.hh < 1024 && g.hw < 1024 &&
