@@ -78,18 +78,27 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(BwdFusedArgs a) 
         const int ky = tap / KS, kx = tap - ky * KS;
         toff[sl] = (ky * g.hw + kx) * PIXB + cg * 16;
     }
-    int pixbase[MTW], o_rel[MTW], o_pos[MTW], x_lds[MTW];
+    int pixbase[MTW];
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
         const int tp = (wave * MTW + m) * 16 + r;
         const int tx = tp & (TW - 1), ty = (tp >> g.tw_log2) & (TH - 1), ti = tp >> (g.tw_log2 + g.th_log2);
         pixbase[m] = ((ti * g.hh + ty) * g.hw + tx) * PIXB;
-        o_rel[m] = ((ti * g.Ho + ty) * g.Wo + tx) * (CX * 2) + gq * 8;
-        o_pos[m] = (ti << 20) | (ty << 10) | tx;
-        x_lds[m] = tp * PIXX + gq * 8;
+    }
+    // paired epilogue layout (see conv_igemm_pf_kernel): after one v_permlane16_swap per accumulator register a
+    // lane holds 8 consecutive channels of pixel (2p + (gq&1), r), channels 16*nt + 8*(gq>>1) ...
+    constexpr int NPAIR = MTW / 2;
+    int o_rel[NPAIR], o_pos[NPAIR], x_lds[NPAIR];
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) {
+        const int tp = (wave * MTW + 2 * p + (gq & 1)) * 16 + r;
+        const int tx = tp & (TW - 1), ty = (tp >> g.tw_log2) & (TH - 1), ti = tp >> (g.tw_log2 + g.th_log2);
+        o_rel[p] = ((ti * g.Ho + ty) * g.Wo + tx) * (CX * 2) + (gq >> 1) * 16;
+        o_pos[p] = (ti << 20) | (ty << 10) | tx;
+        x_lds[p] = tp * PIXX + (gq >> 1) * 16;
     }
     constexpr bool LAST_PARTIAL = (CX % 16) != 0;
-    const bool last_ok = !LAST_PARTIAL || gq < 2;
+    const bool last_ok = !LAST_PARTIAL || (gq >> 1) == 0;
 
     // wgrad: this wave's row tiles mt = wave + 4*i; per-lane tr-read offset inside a dz halo pixel
     const int q4 = (lane & 15) >> 2, p4 = lane & 3;
@@ -108,6 +117,8 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(BwdFusedArgs a) 
         const int rg_lo = 2 * mt, rg_hi = 2 * mt + 1;
         if (mvalid[i] && rg_hi >= CTAP * CG && rg_lo < (CTAP + 1) * CG) bias_i = i;
     }
+    const int wpl0 = mil_pix_base<PIXB>(g, 8 * gq + q4, 1), wpl1 = mil_pix_base<PIXB>(g, 8 * gq + q4 + 4, 1);
+    const int wxl0 = (8 * gq + q4) * PIXX + p4 * 8;
     f32x4_t wacc[MW][NTX];
     f32x4_t bacc = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -132,17 +143,17 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(BwdFusedArgs a) 
         // this tile's x (mask + wgrad operand) and addend, 8 bytes per lane per (row tile, column tile)
         const int obase = ((o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (CX * 2);
         const int ylim = g.Ho - o.oy0, xlim = g.Wo - o.ox0, ilim = g.n_img - o.img0;
-        unsigned ooff[MTW];
-        u32x2_t rxc[MTW][NTX], radd[MTW][NTX];
+        unsigned ooff[NPAIR];
+        u32x4_t rxc[NPAIR][NTX], radd[NPAIR][NTX];
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) {
-            const bool ok = (o_pos[m] >> 20) < ilim && ((o_pos[m] >> 10) & 1023) < ylim && (o_pos[m] & 1023) < xlim;
-            ooff[m] = ok ? (unsigned)(obase + o_rel[m]) : MIL_OOB;
+        for (int p = 0; p < NPAIR; ++p) {
+            const bool ok = (o_pos[p] >> 20) < ilim && ((o_pos[p] >> 10) & 1023) < ylim && (o_pos[p] & 1023) < xlim;
+            ooff[p] = ok ? (unsigned)(obase + o_rel[p]) : MIL_OOB;
 #pragma unroll
             for (int nt = 0; nt < NTX; ++nt) {
-                const unsigned off = (LAST_PARTIAL && nt == NTX - 1 && !last_ok) ? MIL_OOB : ooff[m] + nt * 32;
-                rxc[m][nt] = __builtin_amdgcn_raw_buffer_load_b64(rs_x, off, 0, 0);
-                if (a.addend) radd[m][nt] = __builtin_amdgcn_raw_buffer_load_b64(rs_add, off, 0, 0);
+                const unsigned off = (LAST_PARTIAL && nt == NTX - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 32;
+                rxc[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+                if (a.addend) radd[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, off, 0, 0);
             }
         }
         __syncthreads();                       // dz halo visible
@@ -170,46 +181,52 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(BwdFusedArgs a) 
 
         // x centre tile -> LDS [pixel][CX] (zeros outside the image: no contribution to dW)
 #pragma unroll
-        for (int m = 0; m < MTW; ++m)
+        for (int p = 0; p < NPAIR; ++p)
 #pragma unroll
             for (int nt = 0; nt < NTX; ++nt)
                 if (!(LAST_PARTIAL && nt == NTX - 1) || last_ok)
-                    *reinterpret_cast<u32x2_t*>(ldsX + x_lds[m] + nt * 32) = rxc[m][nt];
+                    *reinterpret_cast<u32x4_t*>(ldsX + x_lds[p] + nt * 32) = rxc[p][nt];
 
-        // ---- data-gradient epilogue from registers ---------------------------------------------------
+        // ---- data-gradient epilogue from registers, 8 channels per lane --------------------------------
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) {
+        for (int p = 0; p < NPAIR; ++p) {
 #pragma unroll
             for (int nt = 0; nt < NTX; ++nt) {
-                float v[4];
+                float v[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = acc[m][nt][i];
+                for (int i = 0; i < 4; ++i) {
+                    float lo = acc[2 * p][nt][i], hi = acc[2 * p + 1][nt][i];
+                    if (i == 0) mil_swap16<true>(lo, hi); else mil_swap16<false>(lo, hi);
+                    v[i] = lo;
+                    v[4 + i] = hi;
+                }
                 if (a.addend) {
-                    const bf16x4_t t = __builtin_bit_cast(bf16x4_t, radd[m][nt]);
+                    const bf16x8_t t = __builtin_bit_cast(bf16x8_t, radd[p][nt]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += (float)t[i];
+                    for (int i = 0; i < 8; ++i) v[i] += (float)t[i];
                 }
                 if (a.apply_mask) {
-                    const bf16x4_t t = __builtin_bit_cast(bf16x4_t, rxc[m][nt]);
+                    const bf16x8_t t = __builtin_bit_cast(bf16x8_t, rxc[p][nt]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] *= ((float)t[i] > 0.f ? 1.f : a.slope);
+                    for (int i = 0; i < 8; ++i) v[i] *= ((float)t[i] > 0.f ? 1.f : a.slope);
                 }
-                bf16x4_t ov;
+                bf16x8_t ov;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ov[i] = (__bf16)v[i];
-                const unsigned off = (LAST_PARTIAL && nt == NTX - 1 && !last_ok) ? MIL_OOB : ooff[m] + nt * 32;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, ov), rs_dx, off, 0, 0);
+                for (int i = 0; i < 8; ++i) ov[i] = (__bf16)v[i];
+                const unsigned off = (LAST_PARTIAL && nt == NTX - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 32;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), rs_dx, off, 0, 0);
             }
         }
         __syncthreads();                       // x centre tile visible
 
         // ---- weight gradient: rows (tap', dz channel), cols x channel, K = the tile's 256 pixels -------
         for (int k32 = 0; k32 < 256; k32 += 32) {
-            const int tp0 = k32 + 8 * gq + q4, tp1 = tp0 + 4;
-            const int pb0 = mil_pix_base<PIXB>(g, tp0, 1);
-            const int pb1 = mil_pix_base<PIXB>(g, tp1, 1);
-            const char* x0 = ldsX + tp0 * PIXX + p4 * 8;
-            const char* x1 = ldsX + tp1 * PIXX + p4 * 8;
+            // pixel k = k32 + (8*gq + q4 [+4]): the halo offset is additive in the two parts (no carries between
+            // their bit fields), so the lane part is tile-invariant and the k32 part is wave-uniform (scalar unit)
+            const int kb = mil_pix_base<PIXB>(g, k32, 1);
+            const int pb0 = kb + wpl0, pb1 = kb + wpl1;
+            const char* x0 = ldsX + k32 * PIXX + wxl0;
+            const char* x1 = x0 + 4 * PIXX;
             bf16x8_t xf[NTX];
 #pragma unroll
             for (int nt = 0; nt < NTX; ++nt) xf[nt] = mil_tr_pair(x0 + nt * 32, x1 + nt * 32);

@@ -317,10 +317,10 @@ __global__ __launch_bounds__(256, ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 40 ? 
                 float v[8];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, acc[2 * p][nt][i]),
-                                                                     __builtin_bit_cast(unsigned, acc[2 * p + 1][nt][i]), false, false);
-                    v[i] = __builtin_bit_cast(float, sw[0]);
-                    v[4 + i] = __builtin_bit_cast(float, sw[1]);
+                    float lo = acc[2 * p][nt][i], hi = acc[2 * p + 1][nt][i];
+                    if (i == 0) mil_swap16<true>(lo, hi); else mil_swap16<false>(lo, hi);
+                    v[i] = lo;
+                    v[4 + i] = hi;
                 }
                 if (a.res) {
                     const bf16x8_t t = __builtin_bit_cast(bf16x8_t, rres[p][nt]);
@@ -388,6 +388,14 @@ static int launch_conv(const ConvArgs<T>& a0, hipStream_t stream) {
 }
 
 
+// Persistent launches need enough tiles to amortise the per-workgroup filter load; MIL_PF_MIN_TILES overrides the
+// threshold (the parity tests set it to 1 so that small cases run the persistent kernels too).
+#include <cstdlib>
+static int mil_pf_min_tiles() {
+    const char* e = getenv("MIL_PF_MIN_TILES");
+    return e ? atoi(e) : 512;
+}
+
 #ifndef MIL_PF_WG_PER_CU
 #define MIL_PF_WG_PER_CU 4
 #endif
@@ -408,7 +416,7 @@ static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool*
     const int lds = a_bytes + w_bytes;
     if (lds > 160 * 1024) return MIL_OK;
     if (a.g.hh >= 1024 || a.g.hw >= 1024 || a.slope <= 0.f || a.slope >= 1.f) return MIL_OK;
-    if ((a.g.n_groups * a.g.tiles_y * a.g.tiles_x) < 512) return MIL_OK;    // too few tiles for a persistent launch
+    if ((a.g.n_groups * a.g.tiles_y * a.g.tiles_x) < mil_pf_min_tiles()) return MIL_OK;    // too few tiles for a persistent launch
     a.kc = a.nsteps;
     a.lds_w_off = a_bytes;
     auto kern = conv_igemm_pf_kernel<CINP, NT, KS, MTW>;

@@ -124,12 +124,13 @@ __global__ __launch_bounds__(256, (PF && CINP > 40) ? 1 : 0) void wgrad_kernel(W
             bf16x8_t ones;
 #pragma unroll
             for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+            const int wpl0 = mil_pix_base<PIXB>(g, 8 * gq + q4, g.stride), wpl1 = mil_pix_base<PIXB>(g, 8 * gq + q4 + 4, g.stride);
             for (int k32 = 0; k32 < a.tile_px; k32 += 32) {
-                const int tp0 = k32 + 8 * gq + q4, tp1 = tp0 + 4;
-                const int pb0 = mil_pix_base<PIXB>(g, tp0, g.stride);
-                const int pb1 = mil_pix_base<PIXB>(g, tp1, g.stride);
-                const char* z0 = ldsZ + tp0 * PIXZ + p * 8;
-                const char* z1 = ldsZ + tp1 * PIXZ + p * 8;
+                // halo offset of pixel k32 + lane part: additive (disjoint bit fields), k32 part is wave-uniform
+                const int kb = mil_pix_base<PIXB>(g, k32, g.stride);
+                const int pb0 = kb + wpl0, pb1 = kb + wpl1;
+                const char* z0 = ldsZ + (k32 + 8 * gq + q4) * PIXZ + p * 8;
+                const char* z1 = z0 + 4 * PIXZ;
                 bf16x8_t bf[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bf[nt] = tr_pair(z0 + nt * 32, z1 + nt * 32);

@@ -145,6 +145,18 @@ __device__ __forceinline__ void mil_commit_otile(const u32x4_t (&rz)[NP], char* 
         if (t.pos[i] >= 0) *reinterpret_cast<u32x4_t*>(lds + t.lds[i]) = rz[i];
 }
 
+// v_permlane16_swap: odd 16-lane rows of `a` <-> even rows of `b` (a' = [a.r0 b.r0 a.r2 b.r2], b' = [a.r1 b.r1
+// a.r3 b.r3]; checked on hardware).  Inline asm on purpose: with ROCm 7.2's hipcc the builtin
+// (__builtin_amdgcn_permlane16_swap) called on several elements of an ext_vector is collapsed into ONE swap whose
+// result is reused for all of them (wrong values, no diagnostic).  `pad` inserts the wait states an MFMA result
+// needs before a VALU instruction may read it: the compiler does not pad inside asm and may schedule MFMAs of the
+// other row tiles right in front of this statement.
+template <bool PAD>
+__device__ __forceinline__ void mil_swap16(float& a, float& b) {
+    if constexpr (PAD) asm volatile("s_nop 7\n\ts_nop 7\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    else asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
 __device__ __forceinline__ bf16x8_t mil_tr_pair(const char* p0, const char* p1) {
     typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
     s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));

@@ -47,9 +47,17 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=["generic", "persistent"])
+def kernel_path(request, monkeypatch):
+    """Run a case through the generic kernels (as small launches would) and through the persistent
+    prefetch-pipelined kernels that large launches use (MIL_PF_MIN_TILES lowers their tile-count threshold)."""
+    monkeypatch.setenv("MIL_PF_MIN_TILES", "1" if request.param == "persistent" else "1000000000")
+    return request.param
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_forward_epilogues(ops, dtype, case):
+def test_conv_forward_epilogues(ops, dtype, case, kernel_path):
     L = _lib()
     cin, cout, ks, stride, n, h, w = case
     g = torch.Generator().manual_seed(hash(case) % 10000)
@@ -76,7 +84,7 @@ def test_conv_forward_epilogues(ops, dtype, case):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_dgrad_and_wgrad(ops, dtype, case):
+def test_conv_dgrad_and_wgrad(ops, dtype, case, kernel_path):
     L = _lib()
     cin, cout, ks, stride, n, h, w = case
     g = torch.Generator().manual_seed(1 + hash(case) % 10000)
@@ -112,7 +120,7 @@ def test_conv_dgrad_and_wgrad(ops, dtype, case):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(2, 32, 32), (3, 50, 70), (1, 37, 41), (2, 64, 64)])
-def test_stem_conv_and_wgrad(ops, dtype, shape):
+def test_stem_conv_and_wgrad(ops, dtype, shape, kernel_path):
     L = _lib()
     n, h, w = shape
     g = torch.Generator().manual_seed(7 + h)

@@ -19,6 +19,14 @@ OUT_KEYS = ["Aterm", "wROIs", "Bterm", "Mterm", "Fterm", "Aterm_mu", "Aterm_var"
 CASES = ["eval_n8_64", "eval_n8_64_cw", "eval_n5_50x70", "train_n40_64", "eval_n2_256"]
 
 
+@pytest.fixture(autouse=True, params=["generic", "persistent"])
+def kernel_path(request, monkeypatch):
+    """Every model-level case runs twice: through the generic kernels (what these small launches would pick) and
+    through the persistent prefetch-pipelined kernels that benchmark-sized launches use."""
+    monkeypatch.setenv("MIL_PF_MIN_TILES", "1" if request.param == "persistent" else "1000000000")
+    return request.param
+
+
 def _model(golden_dir, dtype, class_weights=None):
     import mil_amd
     w = np.load(os.path.join(golden_dir, "weights.npz"))
@@ -257,3 +265,32 @@ def test_flat_adam_matches_torch_adam(golden_dir):
     fresh.load_state_dict(net.state_dict())
     a, b = net(x, y), fresh(x, y)
     assert torch.allclose(a["Mterm"], b["Mterm"], rtol=1e-6, atol=1e-7)
+
+
+def test_benchmark_sized_launch_properties(golden_dir, monkeypatch):
+    """Size-independent checks at a launch size that takes the persistent kernels on its own (2 bags x 256 tiles
+    @256x256, default tile-count threshold): every attention map sums to 1; features of a tile do not depend on
+    which other tiles share the launch (same tiles re-encoded alone through the generic kernels, fp32 exactly
+    comparable up to accumulation order); two runs are bitwise identical (no atomics anywhere)."""
+    monkeypatch.delenv("MIL_PF_MIN_TILES", raising=False)
+    gen = torch.Generator(device="cuda").manual_seed(123)
+    x = torch.randn((512, 3, 256, 256), generator=gen, device="cuda").clamp_(-1, 1)
+    labels = torch.tensor([0, 2])
+    for dtype, tol in ((torch.float32, 2e-4), (torch.bfloat16, 3e-2)):
+        net = _model(golden_dir, dtype).eval()
+        outs = net.forward_bags((x, [256, 256]), labels)
+        torch.stack([o["loss"] for o in outs]).sum().backward()
+        g1 = [p.grad.clone() for p in net.parameters()]
+        for o in outs:
+            assert torch.allclose(o["Aterm"].sum(dim=1), torch.ones(3, device="cuda"), atol=1e-5)
+            assert torch.isfinite(o["loss"]) and torch.isfinite(o["Fterm"]).all()
+        assert all(torch.isfinite(g).all() for g in g1)
+        with torch.no_grad():
+            small = net.cnn(x[:6])                      # 6 tiles: far below the persistent-kernel threshold
+        big = outs[0]["Fterm"][:6]
+        assert float((small - big).abs().max() / big.abs().max()) < tol, dtype
+        net.zero_grad(set_to_none=True)
+        outs2 = net.forward_bags((x, [256, 256]), labels)
+        torch.stack([o["loss"] for o in outs2]).sum().backward()
+        assert all(torch.equal(a, p.grad) for a, p in zip(g1, net.parameters()))
+        assert torch.equal(outs[1]["Aterm"], outs2[1]["Aterm"])
