@@ -90,3 +90,37 @@ def test_bag_layout_and_sharding():
         BagLayout([], torch.device("cpu"))
     assert shard_bags(10, 1, 4) == [1, 5, 9]
     assert sorted(sum((shard_bags(10, r, 4) for r in range(4)), [])) == list(range(10))
+
+
+def test_lr_schedule_matches_reference_setstage():
+    """gbm/classify_combined.py:110-138: warm-up base/(10-epoch), main base, check base/2, freeze base/10, stop >340."""
+    from mil_amd.train import stage_for_epoch
+    base = 2e-4
+    assert stage_for_epoch(0) == ("Warmup", base / 10, True, False)
+    assert stage_for_epoch(9) == ("Warmup", base / 1, True, False)
+    assert stage_for_epoch(10) == ("Main", base, True, False)
+    assert stage_for_epoch(149) == ("Main", base, True, False)
+    assert stage_for_epoch(150) == ("Check", base / 2, True, False)
+    assert stage_for_epoch(150, test=True) == ("Check", base / 2, False, False)
+    assert stage_for_epoch(250, test=True) == ("Freeze", base / 10, False, False)
+    assert stage_for_epoch(339) == ("Freeze", base / 10, True, False)
+    assert stage_for_epoch(340) == ("Hold", None, None, False)
+    assert stage_for_epoch(341)[3] is True
+
+
+def test_set_stage_and_attention_map_export(tmp_path):
+    import mil_amd
+    from mil_amd.train import set_stage, write_attention_map
+    net = mil_amd.Attention(3, device="cpu")
+    opt = torch.optim.Adam(net.parameters(), lr=1.0)
+    name, stop = set_stage(opt, net, 3)
+    assert name == "Warmup" and not stop and abs(opt.param_groups[0]["lr"] - 2e-4 / 7) < 1e-12 and net.training
+    set_stage(opt, net, 200, test=True)
+    assert not net.training and abs(opt.param_groups[0]["lr"] - 1e-4) < 1e-12
+    path = tmp_path / "prediction-AGMIL-ATTN.slide.dla"
+    write_attention_map(str(path), [(0, 5), (1, 6), (2, 7)], torch.tensor([0.2, 0.6, 0.4]))
+    lines = path.read_text().strip().split("\n")
+    assert [ln.split()[:2] for ln in lines] == [["5", "0"], ["6", "1"], ["7", "2"]]
+    assert [round(float(ln.split()[2]), 6) for ln in lines] == [0.0, 1.0, 0.5]
+    with pytest.raises(ValueError):
+        write_attention_map(str(path), [(0, 0)], torch.tensor([0.1, 0.2]))
