@@ -40,13 +40,13 @@ _SIGS = {
     "mil_pack_conv_weights": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "mil_conv_igemm": ([_vp] * 6 + [_i] * 12 + [_f, _i, _vp], _i),
     "mil_conv_wgrad_workspace": ([_c.POINTER(_sz)] + [_i] * 12, _i),
-    "mil_conv_wgrad": ([_vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 12 + [_vp], _i),
+    "mil_conv_wgrad": ([_vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 13 + [_vp], _i),
     "mil_conv_bwd_fused_workspace": ([_c.POINTER(_sz)] + [_i] * 8, _i),
-    "mil_conv_bwd_fused": ([_vp] * 8 + [_sz] + [_i] * 8 + [_f, _i, _vp], _i),
+    "mil_conv_bwd_fused": ([_vp] * 8 + [_sz] + [_i] * 9 + [_f, _i, _vp], _i),
     "mil_maxpool_fwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "mil_maxpool_bwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
     "mil_avgpool_fc_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
-    "mil_avgpool_fc_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
+    "mil_avgpool_fc_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
     "mil_adam_step": ([_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp], _i),
     "mil_pack_job_bytes": ([], _i),
     "mil_pack_job_fill": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i], _i),

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(BwdFusedArgs a) 
 __global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const float* __restrict__ slab, int nslab, size_t slab_elems,
                                                              int slab_cols, int n_rows, float* __restrict__ dw,
                                                              float* __restrict__ db, int cout, int cin, int ks, int czp,
-                                                             int bias_off) {
+                                                             int bias_off, int accumulate) {
     __shared__ float part[8][32];
     const int c = threadIdx.x & 31, gq = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + c;
@@ -291,18 +291,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const float* __rest
     for (int k = 0; k < 8; ++k) v += part[k][c];
     if (e >= n_rows * slab_cols) {
         const int co = e - n_rows * slab_cols;
-        if (co < cout && db) db[co] = v;
+        if (co < cout && db) db[co] = accumulate ? db[co] + v : v;
         return;
     }
     const int row = e / slab_cols, ci = e - row * slab_cols;
     const int tapf = row / czp, co = row - tapf * czp;
     if (ci >= cin || co >= cout) return;
-    dw[((size_t)co * cin + ci) * (ks * ks) + (ks * ks - 1 - tapf)] = v;
+    float* q = dw + ((size_t)co * cin + ci) * (ks * ks) + (ks * ks - 1 - tapf);
+    *q = accumulate ? *q + v : v;
 }
 
 // ---------------------------------------------------------------------------------------------
 template <int CZ, int NTX, int KS>
-static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t ws_bytes, int cout, int cin, bool query,
+static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t ws_bytes, int cout, int cin, int accumulate, bool query,
                          size_t* need, hipStream_t stream) {
     constexpr int PIXB = mil_pix_pitch(CZ, 2);
     constexpr int CX = mil_nt_to_cp(NTX);
@@ -341,14 +342,14 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
     const int n_rows = KS * KS * CZ;
     const int total = n_rows * NTX * 16 + CZ;
     hipLaunchKernelGGL(wgrad_reduce_t_kernel, dim3((total + 31) / 32), dim3(256), 0, stream, (const float*)ws, grid, slab_elems,
-                       NTX * 16, n_rows, dw, db, cout, cin, KS, CZ, MT * 16 * NTX * 16);
+                       NTX * 16, n_rows, dw, db, cout, cin, KS, CZ, MT * 16 * NTX * 16, accumulate);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
 
 static int bwd_fused_entry(const void* dz, const void* wpack, const void* x, const void* addend, void* dx, float* dw,
                            float* db, void* ws, size_t ws_bytes, int n_img, int H, int W, int cout, int cin, int ks,
-                           int pad, int apply_mask, float slope, int dtype, bool query, size_t* need, void* stream) {
+                           int pad, int apply_mask, int accumulate, float slope, int dtype, bool query, size_t* need, void* stream) {
     if (dtype != MIL_DT_BF16 || ks != 3 || pad != 1) return MIL_ERR_UNSUPPORTED;
     if (n_img <= 0 || H <= 0 || W <= 0) return MIL_ERR_ARG;
     if (slope <= 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
@@ -358,7 +359,7 @@ static int bwd_fused_entry(const void* dz, const void* wpack, const void* x, con
     a.g.n_img = n_img; a.g.H = H; a.g.W = W; a.g.Ho = H; a.g.Wo = W; a.g.ks = ks; a.g.stride = 1; a.g.pad = pad; a.g.zins = 0;
     const int czp = mil_cpad(cout), cxp = mil_cpad(cin);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (czp == 24 && cxp == 24) return run_bwd_fused<24, 2, 3>(a, dw, db, ws, ws_bytes, cout, cin, query, need, st);
+    if (czp == 24 && cxp == 24) return run_bwd_fused<24, 2, 3>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st);
     return MIL_ERR_UNSUPPORTED;
 }
 
@@ -366,14 +367,15 @@ extern "C" int mil_conv_bwd_fused_workspace(size_t* bytes, int n_img, int H, int
                                             int dtype) {
     if (!bytes) return MIL_ERR_ARG;
     return bwd_fused_entry(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_img, H, W, cout, cin,
-                           ks, pad, 0, 0.1f, dtype, true, bytes, nullptr);
+                           ks, pad, 0, 0, 0.1f, dtype, true, bytes, nullptr);
 }
 
 extern "C" int mil_conv_bwd_fused(const void* dz, const void* wpack_dgrad, const void* x, const void* addend, void* dx,
                                   float* dw, float* db, void* workspace, size_t workspace_bytes, int n_img, int H, int W,
-                                  int cout, int cin, int ks, int pad, int apply_mask, float slope, int dtype, void* stream) {
+                                  int cout, int cin, int ks, int pad, int apply_mask, int accumulate, float slope, int dtype,
+                                  void* stream) {
     if (!dz || !wpack_dgrad || !x || !dx || !dw) return MIL_ERR_ARG;
     size_t need = 0;
     return bwd_fused_entry(dz, wpack_dgrad, x, addend, dx, dw, db, workspace, workspace_bytes, n_img, H, W, cout, cin, ks,
-                           pad, apply_mask, slope, dtype, false, &need, stream);
+                           pad, apply_mask, accumulate, slope, dtype, false, &need, stream);
 }

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, (PF && CINP > 40) ? 1 : 0) void wgrad_kernel(W
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, size_t slab_elems,
                                                            int slab_cols, int n_rows, float* __restrict__ dw,
                                                            float* __restrict__ db, int cout, int cin, int ks, int cinp,
-                                                           int stem_mode, int bias_row) {
+                                                           int stem_mode, int bias_row, int accumulate) {
     __shared__ float part[8][32];
     const int c = threadIdx.x & 31, gq = threadIdx.x >> 5;
     // rows [0, n_rows) are weight rows, row n_rows stands for the bias row
@@ -230,17 +230,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (int k = 0; k < 8; ++k) v += part[k][c];
     const int row = e / slab_cols, co = e - row * slab_cols;
     if (co >= cout) return;
-    if (row == n_rows) { if (db) db[co] = v; return; }
+    if (row == n_rows) { if (db) db[co] = accumulate ? db[co] + v : v; return; }
     const int tap = row / cinp, ch = row - tap * cinp;
     if (stem_mode) {
         if (ch >= 12) return;
         const int ci = ch >> 2, dy = (ch >> 1) & 1, dx = ch & 1;
         const int ky = 2 * (tap >> 2) + dy - 1, kx = 2 * (tap & 3) + dx - 1;
         if (ky < 0 || ky >= 7 || kx < 0 || kx >= 7) return;
-        dw[(((size_t)co * 3 + ci) * 7 + ky) * 7 + kx] = v;
+        float* q = dw + (((size_t)co * 3 + ci) * 7 + ky) * 7 + kx;
+        *q = accumulate ? *q + v : v;
     } else {
         if (ch >= cin) return;
-        dw[((size_t)co * cin + ch) * (ks * ks) + tap] = v;
+        float* q = dw + ((size_t)co * cin + ch) * (ks * ks) + tap;
+        *q = accumulate ? *q + v : v;
     }
 }
 
@@ -279,7 +281,7 @@ static int plan_wgrad(ConvGeom& g, WgradPlan& pl, int* lds_z_off) {
 
 template <typename T, int KS, int CINP, int NT, int MSPLIT>
 static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* ws, size_t ws_bytes, ConvGeom g,
-                     int cout, int cin, int stem_mode, bool query, size_t* need, hipStream_t stream) {
+                     int cout, int cin, int stem_mode, int accumulate, bool query, size_t* need, hipStream_t stream) {
     WgradPlan pl{};
     int lds_z_off = 0;
     int rc = plan_wgrad<T, KS, CINP, NT, MSPLIT>(g, pl, &lds_z_off);
@@ -307,17 +309,17 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     const int n_rows = KS * KS * CINP;
     const int total = (n_rows + 1) * pl.slab_cols;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, stream, (const float*)ws, pl.grid_x,
-                       pl.slab_elems, pl.slab_cols, n_rows, dw, db, cout, cin, KS, CINP, stem_mode, pl.mt * 16);
+                       pl.slab_elems, pl.slab_cols, n_rows, dw, db, cout, cin, KS, CINP, stem_mode, pl.mt * 16, accumulate);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
 
 template <typename T>
 static int dispatch_wgrad(const void* x, const void* dz, float* dw, float* db, void* ws, size_t ws_bytes,
-                          const ConvGeom& g, int cout, int cin, int stem_mode, bool query, size_t* need,
+                          const ConvGeom& g, int cout, int cin, int stem_mode, int accumulate, bool query, size_t* need,
                           hipStream_t st) {
     const int cinp = stem_mode ? 16 : mil_cpad(cin), coutp = mil_cpad(cout);
-#define MIL_WG(KSV, CI, NTV, MS) return run_wgrad<T, KSV, CI, NTV, MS>(x, dz, dw, db, ws, ws_bytes, g, cout, cin, stem_mode, query, need, st)
+#define MIL_WG(KSV, CI, NTV, MS) return run_wgrad<T, KSV, CI, NTV, MS>(x, dz, dw, db, ws, ws_bytes, g, cout, cin, stem_mode, accumulate, query, need, st)
     if (g.ks == 4 && cinp == 16 && coutp == 24) MIL_WG(4, 16, 2, 1);
     if (g.ks == 3) {
         if (cinp == 24 && coutp == 24) MIL_WG(3, 24, 2, 1);
@@ -339,13 +341,13 @@ static int dispatch_wgrad(const void* x, const void* dz, float* dw, float* db, v
 
 static int wgrad_entry(const void* x, const void* dz, float* dw, float* db, void* ws, size_t ws_bytes, int n_img,
                        int H, int W, int cin, int Ho, int Wo, int cout, int ks, int stride, int pad, int stem_mode,
-                       int dtype, bool query, size_t* need, void* stream) {
+                       int accumulate, int dtype, bool query, size_t* need, void* stream) {
     if (n_img < 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return MIL_ERR_ARG;
     ConvGeom g{};
     g.n_img = n_img; g.H = H; g.W = W; g.Ho = Ho; g.Wo = Wo; g.ks = ks; g.stride = stride; g.pad = pad; g.zins = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MIL_DT_BF16) return dispatch_wgrad<BF16>(x, dz, dw, db, ws, ws_bytes, g, cout, cin, stem_mode, query, need, st);
-    if (dtype == MIL_DT_F32) return dispatch_wgrad<F32>(x, dz, dw, db, ws, ws_bytes, g, cout, cin, stem_mode, query, need, st);
+    if (dtype == MIL_DT_BF16) return dispatch_wgrad<BF16>(x, dz, dw, db, ws, ws_bytes, g, cout, cin, stem_mode, accumulate, query, need, st);
+    if (dtype == MIL_DT_F32) return dispatch_wgrad<F32>(x, dz, dw, db, ws, ws_bytes, g, cout, cin, stem_mode, accumulate, query, need, st);
     return MIL_ERR_ARG;
 }
 
@@ -353,14 +355,14 @@ extern "C" int mil_conv_wgrad_workspace(size_t* bytes, int n_img, int H, int W, 
                                         int ks, int stride, int pad, int stem_mode, int dtype) {
     if (!bytes) return MIL_ERR_ARG;
     return wgrad_entry(nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_img, H, W, cin, Ho, Wo, cout, ks, stride, pad,
-                       stem_mode, dtype, true, bytes, nullptr);
+                       stem_mode, 0, dtype, true, bytes, nullptr);
 }
 
 extern "C" int mil_conv_wgrad(const void* x, const void* dz, float* dw, float* db, void* workspace,
                               size_t workspace_bytes, int n_img, int H, int W, int cin, int Ho, int Wo, int cout,
-                              int ks, int stride, int pad, int stem_mode, int dtype, void* stream) {
+                              int ks, int stride, int pad, int stem_mode, int accumulate, int dtype, void* stream) {
     if (!x || !dz || !dw) return MIL_ERR_ARG;
     size_t need = 0;
     return wgrad_entry(x, dz, dw, db, workspace, workspace_bytes, n_img, H, W, cin, Ho, Wo, cout, ks, stride, pad,
-                       stem_mode, dtype, false, &need, stream);
+                       stem_mode, accumulate, dtype, false, &need, stream);
 }

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(128) void avgpool_fc_bwd_kernel(const float* __rest
 // dWfc[o][i] = sum_t dfeats[t][o] * pooled[t][i].  One wave per output element: lanes stride the tiles,
 // then a fixed shuffle tree (deterministic).
 __global__ __launch_bounds__(256) void fc_wgrad_kernel(const float* __restrict__ dfeats, const float* __restrict__ pooled,
-                                                       float* __restrict__ dw, int n, int C, int NF) {
+                                                       float* __restrict__ dw, int n, int C, int NF, int accumulate) {
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (idx >= NF * C) return;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void fc_wgrad_kernel(const float* __restrict__
     float s = 0.f;
     for (int t = lane; t < n; t += 64) s += dfeats[(size_t)t * NF + o] * pooled[(size_t)t * C + i];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) dw[idx] = s;
+    if (lane == 0) dw[idx] = accumulate ? dw[idx] + s : s;
 }
 
 extern "C" int mil_avgpool_fc_fwd(const void* x, const float* wfc, float* pooled, float* feats, int n, int hw, int cp,
@@ -349,7 +349,8 @@ extern "C" int mil_avgpool_fc_fwd(const void* x, const float* wfc, float* pooled
 }
 
 extern "C" int mil_avgpool_fc_bwd(const float* dfeats, const float* wfc, const float* pooled, const void* act, void* dz,
-                                  float* dwfc, int n, int hw, int cp, int c, int nf, float slope, int dtype, void* stream) {
+                                  float* dwfc, int n, int hw, int cp, int c, int nf, int accumulate, float slope, int dtype,
+                                  void* stream) {
     if (!dfeats || !wfc || !pooled || !dz || !dwfc || c > 128 || nf > 128 || cp > 128 || hw <= 0) return MIL_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (n > 0) {
@@ -358,7 +359,7 @@ extern "C" int mil_avgpool_fc_bwd(const float* dfeats, const float* wfc, const f
         else return MIL_ERR_ARG;
         MIL_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(fc_wgrad_kernel, dim3((nf * c + 3) / 4), dim3(256), 0, st, dfeats, pooled, dwfc, n, c, nf);
+    hipLaunchKernelGGL(fc_wgrad_kernel, dim3((nf * c + 3) / 4), dim3(256), 0, st, dfeats, pooled, dwfc, n, c, nf, accumulate);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

@@ -38,6 +38,11 @@ class FlatParams:
                 p.grad = self.flat_grad[off:off + n].view(p.shape)
                 off += n
         self.numel = total
+        # gradients now have a fixed home: let the encoder's backward accumulate into it directly (saves one
+        # torch add launch and one temporary per parameter per backward)
+        for m in module.modules():
+            if hasattr(m, "direct_grad"):
+                m.direct_grad = True
 
     def zero_grad(self):
         self.flat_grad.zero_()

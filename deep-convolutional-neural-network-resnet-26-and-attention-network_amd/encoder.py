@@ -56,6 +56,7 @@ class ResNet(nn.Module):
         self.fc = nn.Linear(STAGE_WIDTHS[-1], num_classes, bias=False)
         self.compute_dtype = compute_dtype
         self.overlap_wgrad = True
+        self.direct_grad = False        # accumulate parameter gradients straight into existing .grad tensors
         self.n_side_streams = 1
         self.fuse_backward = True
         self._pack_table = None
@@ -180,7 +181,8 @@ def encoder_backward(net, saved, dfeats, dtype):
     grads = {}
     last_out = saved["blocks"][-1][2]
     dz, dwfc = ops.avgpool_fc_bwd(dfeats.contiguous(), net.fc.weight.detach(), saved["pooled"], last_out,
-                                  STAGE_WIDTHS[-1])
+                                  STAGE_WIDTHS[-1],
+                                  out=net.fc.weight.grad if (net.direct_grad and net.fc.weight.grad is not None) else None)
     # Weight gradients only consume (x, dz) and nothing downstream waits for them, so they run on side
     # streams (round-robin, one slab workspace each) beside the sequential dgrad chain: the small late-layer
     # and stride-2 launches do not fill 256 CUs alone.
@@ -189,6 +191,12 @@ def encoder_backward(net, saved, dfeats, dtype):
     use_side = net.overlap_wgrad
     ws = [None] * (len(sides) + 1)
     rr = [0]
+
+    direct = net.direct_grad and all(p.grad is not None and p.grad.is_contiguous() for p in net.encoder_params())
+
+    def gout(*params):
+        """Destination gradient tensors (the parameters' own .grad) when accumulating in place, else None."""
+        return tuple(None if p is None else p.grad for p in params) if direct else None
 
     def wgrad(xin, dzz, cin, cout, **kw):
         n, h, w, _ = xin.shape
@@ -213,7 +221,7 @@ def encoder_backward(net, saved, dfeats, dtype):
 
     fws = None
 
-    def fused_bwd(dzz, wd, xin, cin, cout, addend, mask):
+    def fused_bwd(dzz, wd, xin, cin, cout, addend, mask, out):
         nonlocal fws
         n, h, w, _ = dzz.shape
         need = ops.bwd_fused_workspace_bytes(n, h, w, cout, cin, 3, 1, dzz.dtype)
@@ -221,29 +229,30 @@ def encoder_backward(net, saved, dfeats, dtype):
             return None
         if fws is None or fws.numel() * 4 < need:
             fws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dzz.device)
-        return ops.conv_bwd_fused(dzz, wd, xin, cin, cout, addend=addend, mask=mask, workspace=fws)
+        return ops.conv_bwd_fused(dzz, wd, xin, cin, cout, addend=addend, mask=mask, workspace=fws, out=out)
 
     for bi in range(len(blocks) - 1, -1, -1):
         blk = blocks[bi]
         xin, o1, _out = saved["blocks"][bi]
         cin, cout, s = blk.conv1.in_channels, blk.conv1.out_channels, blk.stride
         w2d, _ = net._packed(f"b{bi}.c2", blk.conv2.weight, None, L.PACK_DGRAD, dtype)
-        fused = fused_bwd(dz, w2d, o1, cout, cout, None, True) if net.fuse_backward else None
+        fused = fused_bwd(dz, w2d, o1, cout, cout, None, True, gout(blk.conv2.weight, blk.conv2.bias)) if net.fuse_backward else None
         if fused is not None:                       # one pass: dz1 and dW2/db2
             dz1, grads[f"b{bi}.c2"] = fused[0], (fused[1], fused[2])
         else:
-            grads[f"b{bi}.c2"] = wgrad(o1, dz, cout, cout, ks=3, stride=1, pad=1)
+            grads[f"b{bi}.c2"] = wgrad(o1, dz, cout, cout, ks=3, stride=1, pad=1, out=gout(blk.conv2.weight, blk.conv2.bias))
             dz1 = ops.conv(dz, w2d, None, ops.cpad(cout), ks=3, stride=1, pad=1, act=o1)
         w1d, _ = net._packed(f"b{bi}.c1", blk.conv1.weight, None, L.PACK_DGRAD, dtype)
         mask = xin if bi > 0 else None          # block 0 reads the max-pool output (no activation in between)
         if s == 1 and blk.downsample is None and net.fuse_backward:
-            fused = fused_bwd(dz1, w1d, xin, cin, cout, dz, mask is not None)
+            fused = fused_bwd(dz1, w1d, xin, cin, cout, dz, mask is not None, gout(blk.conv1.weight, blk.conv1.bias))
             if fused is not None:                   # one pass: previous block's dz and dW1/db1
                 dz, grads[f"b{bi}.c1"] = fused[0], (fused[1], fused[2])
                 continue
-        grads[f"b{bi}.c1"] = wgrad(xin, dz1, cin, cout, ks=3, stride=s, pad=1)
+        grads[f"b{bi}.c1"] = wgrad(xin, dz1, cin, cout, ks=3, stride=s, pad=1, out=gout(blk.conv1.weight, blk.conv1.bias))
         if blk.downsample is not None:
-            grads[f"b{bi}.ds"] = wgrad(xin, dz, cin, cout, ks=1, stride=s, pad=0, want_bias=False)
+            grads[f"b{bi}.ds"] = wgrad(xin, dz, cin, cout, ks=1, stride=s, pad=0, want_bias=False,
+                                       out=gout(blk.downsample[0].weight, None))
             wdd, _ = net._packed(f"b{bi}.ds", blk.downsample[0].weight, None, L.PACK_DGRAD, dtype)
             if s == 2:
                 addend = ops.conv(dz, wdd, None, ops.cpad(cin), ks=1, stride=1, pad=0, zero_insert=True,
@@ -258,7 +267,8 @@ def encoder_backward(net, saved, dfeats, dtype):
         else:
             dz = ops.conv(dz1, w1d, None, ops.cpad(cin), ks=3, stride=1, pad=1, res=addend, act=mask)
     dstem = ops.maxpool_bwd(dz, saved["widx"], saved["stem_hw"])
-    grads["stem"] = wgrad(saved["xs"], dstem, 3, STEM_WIDTH, ks=4, stride=1, pad=2, stem=True)
+    grads["stem"] = wgrad(saved["xs"], dstem, 3, STEM_WIDTH, ks=4, stride=1, pad=2, stem=True,
+                          out=gout(net.conv1.weight, net.conv1.bias))
 
     if use_side:
         for side in sides:
@@ -269,6 +279,8 @@ def encoder_backward(net, saved, dfeats, dtype):
         if blk.downsample is not None:
             flat.append(grads[f"b{bi}.ds"][0])
     flat.append(dwfc)
+    if direct:
+        return [None] * len(flat)          # already accumulated into the parameters' .grad tensors
     return flat
 
 

@@ -110,7 +110,7 @@ def wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, ks, stride, pad, stem, dty
     return need.value
 
 
-def conv_wgrad(x, dz, cin, cout, *, ks, stride, pad, stem=False, want_bias=True, workspace=None):
+def conv_wgrad(x, dz, cin, cout, *, ks, stride, pad, stem=False, want_bias=True, workspace=None, out=None):
     """(dW [cout,cin,k,k] fp32, db [cout] fp32 or None) — see mil_conv_wgrad."""
     n, h, w, cin_p = x.shape
     _, ho, wo, cout_p = dz.shape
@@ -120,11 +120,17 @@ def conv_wgrad(x, dz, cin, cout, *, ks, stride, pad, stem=False, want_bias=True,
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
     kk = 7 if stem else ks
-    dw = torch.empty((cout, cin, kk, kk), dtype=torch.float32, device=x.device)
-    db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
+    if out is None:
+        dw = torch.empty((cout, cin, kk, kk), dtype=torch.float32, device=x.device)
+        db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
+    else:                         # accumulate straight into caller-owned gradient tensors (p.grad views)
+        dw, db = out
+        _need(dw, (cout, cin, kk, kk), torch.float32, "dw")
+        _need(db, (cout,), torch.float32, "db")
     L.check(L.lib().mil_conv_wgrad(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), L.ptr(db), workspace.data_ptr(),
                                    workspace.numel() * workspace.element_size(), n, h, w, cin, ho, wo, cout, ks, stride,
-                                   pad, 1 if stem else 0, L.dt_code(x.dtype), L.stream_ptr()), "mil_conv_wgrad")
+                                   pad, 1 if stem else 0, 0 if out is None else 1, L.dt_code(x.dtype), L.stream_ptr()),
+            "mil_conv_wgrad")
     return dw, db
 
 
@@ -138,7 +144,8 @@ def bwd_fused_workspace_bytes(n, h, w, cout, cin, ks, pad, dtype):
     return need.value
 
 
-def conv_bwd_fused(dz, wpack_dgrad, x, cin, cout, *, addend=None, mask=True, ks=3, pad=1, workspace=None, slope=LEAK):
+def conv_bwd_fused(dz, wpack_dgrad, x, cin, cout, *, addend=None, mask=True, ks=3, pad=1, workspace=None, slope=LEAK,
+                   out=None):
     """(dx, dW, db) of a 3x3 stride-1 conv in one pass, or None if unsupported — see mil_conv_bwd_fused."""
     n, h, w, _ = dz.shape
     need = bwd_fused_workspace_bytes(n, h, w, cout, cin, ks, pad, dz.dtype)
@@ -150,13 +157,19 @@ def conv_bwd_fused(dz, wpack_dgrad, x, cin, cout, *, addend=None, mask=True, ks=
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=dz.device)
     dx = torch.empty_like(x)
-    dw = torch.empty((cout, cin, ks, ks), dtype=torch.float32, device=dz.device)
-    db = torch.empty(cout, dtype=torch.float32, device=dz.device)
+    if out is None:
+        dw = torch.empty((cout, cin, ks, ks), dtype=torch.float32, device=dz.device)
+        db = torch.empty(cout, dtype=torch.float32, device=dz.device)
+    else:
+        dw, db = out
+        _need(dw, (cout, cin, ks, ks), torch.float32, "dw")
+        _need(db, (cout,), torch.float32, "db")
     end = TIMER.bracket(("bwd_fused", cpad(cout), cpad(cin), ks, 1, False, n, h, w)) if TIMER else None
     L.check(L.lib().mil_conv_bwd_fused(dz.data_ptr(), wpack_dgrad.data_ptr(), x.data_ptr(), L.ptr(addend), dx.data_ptr(),
                                        dw.data_ptr(), db.data_ptr(), workspace.data_ptr(),
                                        workspace.numel() * workspace.element_size(), n, h, w, cout, cin, ks, pad,
-                                       1 if mask else 0, slope, L.dt_code(dz.dtype), L.stream_ptr()), "mil_conv_bwd_fused")
+                                       1 if mask else 0, 0 if out is None else 1, slope, L.dt_code(dz.dtype), L.stream_ptr()),
+            "mil_conv_bwd_fused")
     if end is not None:
         end.record()
     return dx, dw, db
@@ -197,13 +210,15 @@ def avgpool_fc_fwd(x, wfc, c):
     return pooled, feats
 
 
-def avgpool_fc_bwd(dfeats, wfc, pooled, act, c, slope=LEAK):
+def avgpool_fc_bwd(dfeats, wfc, pooled, act, c, slope=LEAK, out=None):
     n, h, w, cp = act.shape
     nf = wfc.shape[0]
     _need(dfeats, (n, nf), torch.float32, "dfeats")
     dz = torch.empty_like(act)
-    dwfc = torch.empty((nf, c), dtype=torch.float32, device=act.device)
+    dwfc = torch.empty((nf, c), dtype=torch.float32, device=act.device) if out is None else out
+    _need(dwfc, (nf, c), torch.float32, "dwfc")
     L.check(L.lib().mil_avgpool_fc_bwd(dfeats.data_ptr(), wfc.data_ptr(), pooled.data_ptr(), act.data_ptr(), dz.data_ptr(),
-                                       dwfc.data_ptr(), n, h * w, cp, c, nf, slope, L.dt_code(act.dtype), L.stream_ptr()),
+                                       dwfc.data_ptr(), n, h * w, cp, c, nf, 0 if out is None else 1, slope,
+                                       L.dt_code(act.dtype), L.stream_ptr()),
             "mil_avgpool_fc_bwd")
     return dz, dwfc

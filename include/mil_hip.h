@@ -74,12 +74,13 @@ int mil_conv_igemm(const void* x, const void* wpack, const float* bias_pad, cons
  * accumulated) in the reference layout [cout][cin][k][k] fp32 (k = 7 when stem_mode), db [cout]
  * (may be null).  x [n,H,W,cpad(cin)] (or the 16-channel s2d tensor when stem_mode), dz
  * [n,Ho,Wo,cpad(cout)].  Split-K over workgroups with a fixed-order second pass: bitwise
- * reproducible.  `workspace` must hold mil_conv_wgrad_workspace() bytes. */
+ * reproducible.  `workspace` must hold mil_conv_wgrad_workspace() bytes.  accumulate=1 adds into dw/db
+ * (gradient accumulation straight into the flat gradient bucket) instead of overwriting them. */
 int mil_conv_wgrad_workspace(size_t* bytes, int n_img, int H, int W, int cin, int Ho, int Wo, int cout, int ks,
                              int stride, int pad, int stem_mode, int dtype);
 int mil_conv_wgrad(const void* x, const void* dz, float* dw, float* db, void* workspace, size_t workspace_bytes,
                    int n_img, int H, int W, int cin, int Ho, int Wo, int cout, int ks, int stride, int pad,
-                   int stem_mode, int dtype, void* stream);
+                   int stem_mode, int accumulate, int dtype, void* stream);
 
 /* ---- fused backward of a 3x3 stride-1 conv (bf16 path, narrow layers) --------------------------
  * One pass over dz and x yields BOTH autograd results of nn.Conv2d (nnBlocks.py:169-171):
@@ -90,7 +91,7 @@ int mil_conv_wgrad(const void* x, const void* dz, float* dw, float* db, void* wo
 int mil_conv_bwd_fused_workspace(size_t* bytes, int n_img, int H, int W, int cout, int cin, int ks, int pad, int dtype);
 int mil_conv_bwd_fused(const void* dz, const void* wpack_dgrad, const void* x, const void* addend, void* dx, float* dw,
                        float* db, void* workspace, size_t workspace_bytes, int n_img, int H, int W, int cout, int cin,
-                       int ks, int pad, int apply_mask, float slope, int dtype, void* stream);
+                       int ks, int pad, int apply_mask, int accumulate, float slope, int dtype, void* stream);
 
 /* ---- pooling -------------------------------------------------------------------------------
  * MaxPool2d(3, stride 2, pad 1) (gbm/model.py:26,53): y [n,Ho,Wo,cp], Ho=(H-1)/2+1; `widx` records per
@@ -108,7 +109,8 @@ int mil_maxpool_bwd(const void* gy, const uint8_t* widx, void* gx, int n, int H,
 int mil_avgpool_fc_fwd(const void* x, const float* wfc, float* pooled, float* feats, int n, int hw, int cp, int c,
                        int nf, int dtype, void* stream);
 int mil_avgpool_fc_bwd(const float* dfeats, const float* wfc, const float* pooled, const void* act, void* dz,
-                       float* dwfc, int n, int hw, int cp, int c, int nf, float slope, int dtype, void* stream);
+                       float* dwfc, int n, int hw, int cp, int c, int nf, int accumulate, float slope, int dtype,
+                       void* stream);
 
 /* ---- attention-MIL head --------------------------------------------------------------------
  * Replaces everything after the backbone in Attention.forward (gbm/model.py:198-246): ContextLayer

@@ -357,3 +357,23 @@ def test_large_bag_attention_map_inference(golden_dir):
         H = torch.cat(parts)
         _loss, _l2, a1, *_ = head_apply(H, BagLayout([n], H.device), y.cuda(), None, None, net.head_weights())
     assert torch.allclose(a1.t(), out["Aterm"], rtol=1e-4, atol=1e-7)
+
+
+def test_direct_gradient_accumulation_equals_autograd(golden_dir):
+    """FlatParams switches the encoder to accumulate weight gradients straight into the flat bucket; two backward
+    passes must leave exactly the sum autograd's own accumulation would (and twice one pass)."""
+    import mil_amd
+    g = np.load(os.path.join(golden_dir, "eval_n8_64.npz"))
+    x, y = torch.tensor(g["x"]).cuda(), torch.tensor(g["y"]).cuda()
+    ref = _model(golden_dir, torch.float32).eval()
+    for _ in range(2):
+        ref(x, y)["loss"].backward()
+    net = _model(golden_dir, torch.float32).eval()
+    flat = mil_amd.FlatParams(net)
+    assert net.cnn.module.direct_grad
+    flat.zero_grad()
+    for _ in range(2):
+        net(x, y)["loss"].backward()
+    for (k, p), q in zip(net.named_parameters(), ref.parameters()):
+        assert p.grad.data_ptr() >= flat.flat_grad.data_ptr()
+        assert _grad_close(k, p.grad.cpu().numpy(), q.grad.cpu().numpy(), 1e-5), k
