@@ -89,8 +89,15 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # one process per GPU over RCCL; MIL_DIST_BACKEND=gloo (+ ranks sharing a device) exists only to rehearse the
+        # multi-process path on a one-GPU box
+        backend = os.environ.get("MIL_DIST_BACKEND", "nccl")
+        local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     elif args.gpus != 1:
         raise SystemExit("--gpus N>1 must be launched through torch.distributed.run (one process per GPU)")
     else:
@@ -163,7 +170,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    loss_val = float(torch.stack([o["loss"] for o in outs]).mean())
+    loss_val = float(torch.stack([o["loss"].detach() for o in outs]).mean())
     if not np.isfinite(loss_val):
         raise SystemExit("non-finite loss in benchmark step")
 
