@@ -351,6 +351,288 @@ static int wgrad_entry(const void* x, const void* dz, float* dw, float* db, void
     return MIL_ERR_ARG;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused backward of the stem (gbm/model.py:24-26,51-53): max-pool backward + LeakyReLU backward + the
+// 7x7 conv's weight/bias gradient in ONE pass.  The dz tile that the weight-gradient MFMA loop reads from
+// LDS is not loaded from HBM: it is built in LDS from the pooled-output gradient and the winner records of
+// the (TH/2+1)x(TW/2+1) pooling windows that cover the tile (deterministic gather, one thread per 2x2 pixel
+// block as in maxpool_bwd_kernel).  The 4x-larger d(stem output) tensor is never written or read.
+struct StemBwdArgs {
+    const __bf16* xs;        // [n,H2,W2,16] space-to-depth input
+    const __bf16* gp;        // [n,Hp,Wp,24] gradient of the pooled output
+    const uint8_t* widx;     // [n,Hp,Wp,24] winner tap (bits 0-3) + "winner <= 0" (bit 4)
+    float* slab;
+    ConvGeom g;              // geometry of the stem conv as executed (ks 4, stride 1, pad 2, Ho=H2, Wo=W2)
+    int Hp, Wp;
+    int ntiles;
+    int lds_z_off, lds_g_off, lds_i_off;
+    unsigned xs_bytes, gp_bytes, wi_bytes;
+    float slope;
+};
+
+__global__ __launch_bounds__(256) void stem_bwd_fused_kernel(StemBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CINP = 16, NT = 2, KS = 4, COUTP = 24;
+    constexpr int PIXB = mil_pix_pitch(CINP, 2);
+    constexpr int PIXZ = mil_pix_pitch(COUTP, 2);           // 48: dz tile and pooled-gradient tile
+    constexpr int CG = CINP / 8, RG = KS * KS * CG, MT = (RG + 1) / 2, MW = (MT + 3) / 4;
+    constexpr int NPX = mil_halo_np(CINP, 2);
+    constexpr int NPW = 2;                                  // pooled-window pieces per thread (<= 144 windows x 3)
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* ldsX = smem;
+    char* ldsZ = smem + a.lds_z_off;
+    char* ldsG = smem + a.lds_g_off;
+    char* ldsI = smem + a.lds_i_off;
+    const int TW = 1 << g.tw_log2, TH = 1 << g.th_log2;
+    const int WH = TH / 2 + 1, WW = TW / 2 + 1;             // pooling windows per image of the tile
+    const int nwin = (WH * WW) << g.ti_log2;
+
+    const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.xs, a.xs_bytes);
+    const __amdgpu_buffer_rsrc_t rs_g = mil_rsrc(a.gp, a.gp_bytes);
+    const __amdgpu_buffer_rsrc_t rs_i = mil_rsrc(a.widx, a.wi_bytes);
+    HaloTables<NPX> ht;
+    mil_build_halo_tables<CINP, NPX>(ht, g, tid);
+    // pooled-window pieces: item = window*3 + j; gradient piece = 16 B (8 channels), winner piece = 8 B
+    int w_pos[NPW], w_rel[NPW], w_lds[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int idx = tid + 256 * i;
+        w_pos[i] = -1; w_rel[i] = 0; w_lds[i] = 0;
+        if (idx < nwin * 3) {
+            const int win = idx / 3, j = idx - win * 3;
+            const int ti = win / (WH * WW), rem = win - ti * (WH * WW);
+            const int wy = rem / WW, wx = rem - wy * WW;
+            w_pos[i] = (ti << 20) | (wy << 10) | wx;
+            w_rel[i] = ((ti * a.Hp + wy) * a.Wp + wx) * COUTP + j * 8;      // in channels (= bytes of widx, x2 for g)
+            w_lds[i] = win * COUTP + j * 8;
+        }
+    }
+    auto fetch_win = [&](u32x4_t (&rg)[NPW], u32x2_t (&ri)[NPW], const TileOrigin& o) {
+        const int py0 = o.oy0 >> 1, px0 = o.ox0 >> 1;
+        const int base = ((o.img0 * a.Hp + py0) * a.Wp + px0) * COUTP;
+        const int ylim = a.Hp - py0, xlim = a.Wp - px0, ilim = g.n_img - o.img0;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int p = w_pos[i];
+            const bool ok = p >= 0 && (p >> 20) < ilim && ((p >> 10) & 1023) < ylim && (p & 1023) < xlim;
+            const unsigned off = ok ? (unsigned)(base + w_rel[i]) : MIL_OOB;
+            rg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, ok ? off * 2u : MIL_OOB, 0, 0);
+            ri[i] = __builtin_amdgcn_raw_buffer_load_b64(rs_i, off, 0, 0);
+        }
+    };
+
+    // per-lane tr-read offsets of this wave's row tiles (rows = (tap, 8 s2d channels))
+    int toff[MW];
+    bool mvalid[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+        const int mt = wave + 4 * i;
+        mvalid[i] = mt < MT;
+        const int p = lane & 3;
+        int rg = 2 * mt + (p >> 1);
+        if (rg >= RG) rg = 0;
+        const int tap = rg / CG, cg = rg - tap * CG;
+        toff[i] = ((tap / KS) * g.hw + (tap % KS)) * PIXB + cg * 16 + (p & 1) * 8;
+    }
+    const bool bias_wave = wave == 0;
+    f32x4_t acc[MW][NT], accb[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        accb[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MW; ++i) acc[i][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    bf16x8_t ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, gq = lane >> 4;
+    const int wpl0 = mil_pix_base<PIXB>(g, 8 * gq + q4, 1), wpl1 = mil_pix_base<PIXB>(g, 8 * gq + q4 + 4, 1);
+    // dz builder: thread -> (2x2 pixel block, 8-channel group) of the tile
+    const int nblk = 64;                                     // 256 px / 4
+    const int bitem = tid / 3, bc8 = tid - bitem * 3;
+    const bool builder = bitem < nblk;
+    const int bW = TW / 2, bH = TH / 2;
+    const int b_ti = bitem / (bW * bH), b_rem = bitem - b_ti * (bW * bH);
+    const int b_y = b_rem / bW, b_x = b_rem - b_y * bW;
+
+    TileWalker cur, nxt;
+    cur.init(g, blockIdx.x, gridDim.x);
+    nxt = cur; nxt.advance();
+    u32x4_t rx[NPX], rgp[NPW];
+    u32x2_t rwi[NPW];
+    if ((int)blockIdx.x < a.ntiles) {
+        mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, cur.origin(g));
+        fetch_win(rgp, rwi, cur.origin(g));
+    }
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        __syncthreads();                         // previous tile's MFMA loop is done with ldsX / ldsZ
+        mil_commit_halo<NPX>(rx, ldsX, ht);
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            if (w_pos[i] >= 0) {
+                *reinterpret_cast<u32x4_t*>(ldsG + w_lds[i] * 2) = rgp[i];
+                *reinterpret_cast<u32x2_t*>(ldsI + w_lds[i]) = rwi[i];
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.ntiles) {
+            mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, nxt.origin(g));
+            fetch_win(rgp, rwi, nxt.origin(g));
+        }
+        cur = nxt; nxt.advance();
+
+        // ---- dz tile = lrelu'(stem) * maxpool^T(g): gather over the 4 windows that cover a 2x2 block --------
+        if (builder) {
+            float gsum[2][2][8];
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) gsum[dy][dx][j] = 0.f;
+#pragma unroll
+            for (int wy = 0; wy < 2; ++wy) {
+#pragma unroll
+                for (int wx = 0; wx < 2; ++wx) {
+                    const int win = (b_ti * WH + b_y + wy) * WW + b_x + wx;
+                    const uint2 packed = *reinterpret_cast<const uint2*>(ldsI + win * COUTP + bc8 * 8);
+                    const bf16x8_t gv = *reinterpret_cast<const bf16x8_t*>(ldsG + win * PIXZ + bc8 * 16);
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy) {
+                        const int ky = dy + 1 - 2 * wy;          // tap row of pixel 2*b_y+dy inside window b_y+wy
+                        if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const int kx = dx + 1 - 2 * wx;
+                            if (kx < 0 || kx > 2) continue;
+                            const uint32_t me = (uint32_t)(ky * 3 + kx);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const uint32_t w = ((j < 4 ? packed.x : packed.y) >> (8 * (j & 3))) & 0xffu;
+                                const float gj = (float)gv[j];
+                                if ((w & 15u) == me) gsum[dy][dx][j] += (w & 16u) ? gj * a.slope : gj;
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int tp = (b_ti << (g.tw_log2 + g.th_log2)) + ((2 * b_y + dy) << g.tw_log2) + 2 * b_x + dx;
+                    bf16x8_t ov;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ov[j] = (__bf16)gsum[dy][dx][j];
+                    *reinterpret_cast<bf16x8_t*>(ldsZ + tp * PIXZ + bc8 * 16) = ov;
+                }
+        }
+        __syncthreads();
+
+        // ---- weight gradient: rows (tap, s2d channel), cols stem channel, K = the tile's 256 pixels ---------
+        for (int k32 = 0; k32 < 256; k32 += 32) {
+            const int kb = mil_pix_base<PIXB>(g, k32, 1);
+            const int pb0 = kb + wpl0, pb1 = kb + wpl1;
+            const char* z0 = ldsZ + (k32 + 8 * gq + q4) * PIXZ + p4 * 8;
+            const char* z1 = z0 + 4 * PIXZ;
+            bf16x8_t bf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bf[nt] = mil_tr_pair(z0 + nt * 32, z1 + nt * 32);
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+                if (mvalid[i]) {
+                    const bf16x8_t af = mil_tr_pair(ldsX + pb0 + toff[i], ldsX + pb1 + toff[i]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[nt], acc[i][nt], 0, 0, 0);
+                }
+            }
+            if (bias_wave) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    accb[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bf[nt], accb[nt], 0, 0, 0);
+            }
+        }
+    }
+
+    constexpr int SLAB_COLS = NT * 16;
+    constexpr size_t SLAB_ELEMS = (size_t)(MT + 1) * 16 * SLAB_COLS;
+    float* slab = a.slab + (size_t)blockIdx.x * SLAB_ELEMS;
+    const int col = lane & 15;
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+        if (!mvalid[i]) continue;
+        const int mt = wave + 4 * i;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                slab[(size_t)(mt * 16 + gq * 4 + e) * SLAB_COLS + nt * 16 + col] = acc[i][nt][e];
+    }
+    if (bias_wave) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                slab[(size_t)(MT * 16 + gq * 4 + e) * SLAB_COLS + nt * 16 + col] = accb[nt][e];
+    }
+}
+
+static int stem_bwd_entry(const void* xs, const void* gp, const uint8_t* widx, float* dw, float* db, void* ws,
+                          size_t ws_bytes, int n, int H2, int W2, float slope, int accumulate, int dtype, bool query,
+                          size_t* need, void* stream) {
+    if (dtype != MIL_DT_BF16) return MIL_ERR_UNSUPPORTED;
+    if (n <= 0 || H2 <= 0 || W2 <= 0) return MIL_ERR_ARG;
+    constexpr int PIXB = mil_pix_pitch(16, 2), PIXZ = mil_pix_pitch(24, 2);
+    constexpr int MT = 16;
+    StemBwdArgs a{};
+    ConvGeom& g = a.g;
+    g.n_img = n; g.H = H2; g.W = W2; g.Ho = H2; g.Wo = W2; g.ks = 4; g.stride = 1; g.pad = 2; g.zins = 0;
+    mil_geom_tiles(g, 8);
+    a.Hp = (H2 - 1) / 2 + 1; a.Wp = (W2 - 1) / 2 + 1;
+    const int halo_px = (g.hh * g.hw) << g.ti_log2;
+    const int nwin = (((1 << g.th_log2) / 2 + 1) * ((1 << g.tw_log2) / 2 + 1)) << g.ti_log2;
+    const size_t xs_b = (size_t)n * H2 * W2 * 32, gp_b = (size_t)n * a.Hp * a.Wp * 48;
+    if (halo_px > 400 || nwin * 3 > 512 || xs_b >= ((size_t)1 << 31) || gp_b >= ((size_t)1 << 31)) return MIL_ERR_UNSUPPORTED;
+    const int xb = (halo_px * PIXB + 15) & ~15, zb = 256 * PIXZ, gb = (nwin * PIXZ + 15) & ~15, ib = (nwin * 24 + 15) & ~15;
+    const int lds = xb + zb + gb + ib;
+    const int ntiles = g.n_groups * g.tiles_y * g.tiles_x;
+    int grid = 1024;
+    if (grid > ntiles) grid = ntiles;
+    const size_t slab_elems = (size_t)(MT + 1) * 16 * 32;
+    const size_t bytes = slab_elems * grid * sizeof(float);
+    if (query) { *need = bytes; return MIL_OK; }
+    if (!ws || ws_bytes < bytes) return MIL_ERR_ARG;
+    a.xs = (const __bf16*)xs; a.gp = (const __bf16*)gp; a.widx = widx; a.slab = (float*)ws;
+    a.ntiles = ntiles; a.lds_z_off = xb; a.lds_g_off = xb + zb; a.lds_i_off = xb + zb + gb;
+    a.xs_bytes = (unsigned)xs_b; a.gp_bytes = (unsigned)gp_b; a.wi_bytes = (unsigned)(gp_b / 2); a.slope = slope;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(stem_bwd_fused_kernel, dim3(grid), dim3(256), lds, st, a);
+    MIL_CHECK_LAUNCH();
+    const int n_rows = 16 * 16;
+    const int total = (n_rows + 1) * 32;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, st, (const float*)ws, grid, slab_elems, 32,
+                       n_rows, dw, db, 20, 3, 7, 16, 1, MT * 16, accumulate);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+extern "C" int mil_stem_bwd_fused_workspace(size_t* bytes, int n, int H2, int W2, int dtype) {
+    if (!bytes) return MIL_ERR_ARG;
+    return stem_bwd_entry(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n, H2, W2, 0.1f, 0, dtype, true, bytes, nullptr);
+}
+
+extern "C" int mil_stem_bwd_fused(const void* xs, const void* g_pool, const uint8_t* widx, float* dw, float* db,
+                                  void* workspace, size_t workspace_bytes, int n, int H2, int W2, float slope,
+                                  int accumulate, int dtype, void* stream) {
+    if (!xs || !g_pool || !widx || !dw || !db) return MIL_ERR_ARG;
+    size_t need = 0;
+    return stem_bwd_entry(xs, g_pool, widx, dw, db, workspace, workspace_bytes, n, H2, W2, slope, accumulate, dtype, false,
+                          &need, stream);
+}
+
 extern "C" int mil_conv_wgrad_workspace(size_t* bytes, int n_img, int H, int W, int cin, int Ho, int Wo, int cout,
                                         int ks, int stride, int pad, int stem_mode, int dtype) {
     if (!bytes) return MIL_ERR_ARG;

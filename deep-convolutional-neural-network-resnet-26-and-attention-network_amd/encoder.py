@@ -266,9 +266,15 @@ def encoder_backward(net, saved, dfeats, dtype):
                           out_hw=xin.shape[1:3], res=addend, act=mask)
         else:
             dz = ops.conv(dz1, w1d, None, ops.cpad(cin), ks=3, stride=1, pad=1, res=addend, act=mask)
-    dstem = ops.maxpool_bwd(dz, saved["widx"], saved["stem_hw"])
-    grads["stem"] = wgrad(saved["xs"], dstem, 3, STEM_WIDTH, ks=4, stride=1, pad=2, stem=True,
-                          out=gout(net.conv1.weight, net.conv1.bias))
+    fused_stem = None
+    if net.fuse_backward:               # pool backward + lrelu backward + stem wgrad in one pass (bf16 path)
+        fused_stem = ops.stem_bwd_fused(saved["xs"], dz, saved["widx"], out=gout(net.conv1.weight, net.conv1.bias))
+    if fused_stem is not None:
+        grads["stem"] = fused_stem
+    else:
+        dstem = ops.maxpool_bwd(dz, saved["widx"], saved["stem_hw"])
+        grads["stem"] = wgrad(saved["xs"], dstem, 3, STEM_WIDTH, ks=4, stride=1, pad=2, stem=True,
+                              out=gout(net.conv1.weight, net.conv1.bias))
 
     if use_side:
         for side in sides:

@@ -199,6 +199,35 @@ def maxpool_bwd(gy, widx, in_hw, lrelu_mask=True, slope=LEAK):
     return gx
 
 
+def stem_bwd_fused(xs, g_pool, widx, *, workspace=None, out=None, slope=LEAK):
+    """(dW [20,3,7,7], db [20]) of the stem from the pooled-output gradient in one pass (see mil_stem_bwd_fused),
+    or None when the shape/dtype has no fused kernel."""
+    n, h2, w2, c = xs.shape
+    need = ctypes.c_size_t(0)
+    rc = L.lib().mil_stem_bwd_fused_workspace(ctypes.byref(need), n, h2, w2, L.dt_code(xs.dtype))
+    if rc == 2:
+        return None
+    L.check(rc, "mil_stem_bwd_fused_workspace")
+    hp, wp = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
+    _need(xs, (n, h2, w2, 16), xs.dtype, "xs")
+    _need(g_pool, (n, hp, wp, 24), xs.dtype, "g_pool")
+    _need(widx, (n, hp, wp, 24), torch.uint8, "widx")
+    if workspace is None or workspace.numel() * workspace.element_size() < need.value:
+        workspace = torch.empty((need.value + 3) // 4, dtype=torch.float32, device=xs.device)
+    if out is None:
+        dw = torch.empty((20, 3, 7, 7), dtype=torch.float32, device=xs.device)
+        db = torch.empty(20, dtype=torch.float32, device=xs.device)
+    else:
+        dw, db = out
+        _need(dw, (20, 3, 7, 7), torch.float32, "dw")
+        _need(db, (20,), torch.float32, "db")
+    L.check(L.lib().mil_stem_bwd_fused(xs.data_ptr(), g_pool.data_ptr(), widx.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                       workspace.data_ptr(), workspace.numel() * workspace.element_size(), n, h2, w2,
+                                       slope, 0 if out is None else 1, L.dt_code(xs.dtype), L.stream_ptr()),
+            "mil_stem_bwd_fused")
+    return dw, db
+
+
 def avgpool_fc_fwd(x, wfc, c):
     n, h, w, cp = x.shape
     nf = wfc.shape[0]

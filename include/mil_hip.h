@@ -103,6 +103,15 @@ int mil_maxpool_fwd(const void* x, void* y, uint8_t* widx, int n, int H, int W, 
 int mil_maxpool_bwd(const void* gy, const uint8_t* widx, void* gx, int n, int H, int W, int cp,
                     int apply_lrelu_mask, float slope, int dtype, void* stream);
 
+/* Fused backward of the whole stem (bf16 path): max-pool backward + LeakyReLU backward + the 7x7 conv's weight
+ * and bias gradient in one pass over xs [n,H2,W2,16] (mil_stem_s2d output), g_pool [n,Hp,Wp,24] (gradient of
+ * the pooled output) and widx (mil_maxpool_fwd's winner records).  Replaces mil_maxpool_bwd + mil_conv_wgrad
+ * (stem_mode) and the 4x-larger d(stem output) tensor between them.  dw [20,3,7,7], db [20] fp32. */
+int mil_stem_bwd_fused_workspace(size_t* bytes, int n, int H2, int W2, int dtype);
+int mil_stem_bwd_fused(const void* xs, const void* g_pool, const uint8_t* widx, float* dw, float* db, void* workspace,
+                       size_t workspace_bytes, int n, int H2, int W2, float slope, int accumulate, int dtype,
+                       void* stream);
+
 /* AdaptiveAvgPool2d((1,1)) + flatten + Linear(80,L,bias=False) (gbm/model.py:31-32,58-60).
  * x [n,hw,cp] -> pooled [n,c] fp32 (kept for backward), feats [n,nf] fp32 = pooled @ wfc^T.
  * Backward: dz [n,hw,cp] = lrelu'(act) * (dfeats @ wfc)/hw, dwfc [nf,c] = dfeats^T @ pooled. */

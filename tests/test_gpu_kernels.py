@@ -215,3 +215,35 @@ def test_fused_backward_equals_dgrad_plus_wgrad(ops, shape, with_addend, mask):
     out2 = ops.conv_bwd_fused(to_nhwc(dz, dtype), wd, to_nhwc(x.detach(), dtype), cin, cout,
                               addend=None if addend is None else to_nhwc(addend, dtype), mask=mask)
     assert torch.equal(dw, out2[1]) and torch.equal(db, out2[2]) and torch.equal(dx, out2[0])
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 32), (2, 50, 70), (5, 16, 16), (1, 37, 41), (18, 8, 8)])
+def test_stem_backward_fused_equals_pool_bwd_plus_wgrad(ops, shape):
+    """mil_stem_bwd_fused against autograd of conv7x7/s2 -> LeakyReLU -> MaxPool(3,2,1) (bf16 path)."""
+    L = _lib()
+    dtype = torch.bfloat16
+    n, h, w = shape                                   # s2d / stem-output dims are (h, w): the image is (2h, 2w)
+    g = torch.Generator().manual_seed(40 + h)
+    x = round_to(torch.randn(n, 3, 2 * h, 2 * w, generator=g).clamp_(-1, 1), dtype)
+    wt = round_to(torch.randn(20, 3, 7, 7, generator=g) / 147 ** 0.5, dtype).requires_grad_(True)
+    b = (torch.randn(20, generator=g) * 0.1).requires_grad_(True)
+    stem = F.leaky_relu(F.conv2d(x, wt, b, stride=2, padding=3), LEAK)
+    # what the HIP path pools is the bf16-rounded stem output: do the same so that winners and signs agree
+    stem_q = stem + (round_to(stem.detach(), dtype) - stem.detach())
+    pooled = F.max_pool2d(stem_q, 3, 2, 1)
+    gp = round_to(torch.randn(pooled.shape, generator=g), dtype)
+    pooled.backward(gp)
+    xs = ops.stem_s2d(x.cuda(), dtype)
+    wp, bp = ops.pack_weights(wt.detach().cuda(), b.detach().cuda(), L.PACK_STEM, dtype)
+    stem_g = ops.conv(xs, wp, bp, 24, ks=4, stride=1, pad=2, lrelu=True)
+    pool_g, widx = ops.maxpool_fwd(stem_g)
+    out = ops.stem_bwd_fused(xs, to_nhwc(gp, dtype), widx)
+    if out is None:
+        assert h <= 8, "fused stem backward must exist for real tile sizes"
+        pytest.skip("no fused kernel for 8x8 stem maps (the encoder falls back to pool-bwd + wgrad)")
+    dw, db = out
+    # reference path on the device: unfused pool backward + stem wgrad (dz rounded to bf16 in between)
+    dstem = ops.maxpool_bwd(to_nhwc(gp, dtype), widx, (h, w))
+    dw2, db2 = ops.conv_wgrad(xs, dstem, 3, 20, ks=4, stride=1, pad=2, stem=True)
+    assert rel_err(dw.cpu(), dw2.cpu()) < 1e-5 and rel_err(db.cpu(), db2.cpu()) < 1e-5
+    assert rel_err(dw.cpu(), wt.grad) < 2e-2 and rel_err(db.cpu(), b.grad) < 2e-2     # vs autograd (bf16 stem rounding)
