@@ -415,7 +415,7 @@ static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool*
     const int w_bytes = a.nsteps * NT * 64 * 16;
     const int lds = a_bytes + w_bytes;
     if (lds > 160 * 1024) return MIL_OK;
-    if (a.g.hh >= 1024 || a.g.hw >= 1024 || a.slope <= 0.f || a.slope >= 1.f) return MIL_OK;
+    if (a.g.hh >= 1024 || a.g.hw >= 1024 || a.slope < 0.f || a.slope >= 1.f) return MIL_OK;   // max(v, slope*v) form
     if ((a.g.n_groups * a.g.tiles_y * a.g.tiles_x) < mil_pf_min_tiles()) return MIL_OK;    // too few tiles for a persistent launch
     a.kc = a.nsteps;
     a.lds_w_off = a_bytes;
@@ -495,6 +495,7 @@ static int dispatch_conv(const ConvArgs<T>& a, int cin_p, int cout_p, hipStream_
     const bool small_tile = (a.g.stride == 2 && !a.g.zins);     // stride-2 forward: the halo is 4x the tile
 #define MIL_CONV_CASE(CI, NTV) return launch_conv_auto<T, CI, NTV>(a, small_tile, stream)
     if (cin_p == 16 && cout_p == 24) MIL_CONV_CASE(16, 2);
+    if (cin_p == 16 && cout_p == 64) MIL_CONV_CASE(16, 4);   // alt_resnet stem (3 -> 64)
     if (cin_p == 24 && cout_p == 24) MIL_CONV_CASE(24, 2);
     if (cin_p == 40 && cout_p == 40) MIL_CONV_CASE(40, 3);
     if (cin_p == 64 && cout_p == 64) MIL_CONV_CASE(64, 4);

@@ -321,6 +321,7 @@ static int dispatch_wgrad(const void* x, const void* dz, float* dw, float* db, v
     const int cinp = stem_mode ? 16 : mil_cpad(cin), coutp = mil_cpad(cout);
 #define MIL_WG(KSV, CI, NTV, MS) return run_wgrad<T, KSV, CI, NTV, MS>(x, dz, dw, db, ws, ws_bytes, g, cout, cin, stem_mode, accumulate, query, need, st)
     if (g.ks == 4 && cinp == 16 && coutp == 24) MIL_WG(4, 16, 2, 1);
+    if (g.ks == 4 && cinp == 16 && coutp == 64) MIL_WG(4, 16, 4, 1);     // alt_resnet stem
     if (g.ks == 3) {
         if (cinp == 24 && coutp == 24) MIL_WG(3, 24, 2, 1);
         if (cinp == 40 && coutp == 40) MIL_WG(3, 40, 3, 1);

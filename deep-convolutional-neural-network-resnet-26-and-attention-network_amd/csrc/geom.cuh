@@ -16,6 +16,7 @@ struct ConvGeom {
     int hh, hw;         // halo tile extent in input pixels
 };
 
+__host__ inline void mil_geom_set(ConvGeom& g, int tw, int th, int ti);
 __host__ inline void mil_geom_tiles(ConvGeom& g, int tile_px_log2) {
     // choose TW x TH x TI = 2^tile_px_log2 output pixels
     int tw, th;
@@ -31,7 +32,11 @@ __host__ inline void mil_geom_tiles(ConvGeom& g, int tile_px_log2) {
         if (g.Wo > 4 || g.Ho > 4) { tw = 3; th = 3; }
         else { tw = 2; th = 2; }
     }
-    g.tw_log2 = tw; g.th_log2 = th; g.ti_log2 = tile_px_log2 - tw - th;
+    mil_geom_set(g, tw, th, tile_px_log2 - tw - th);
+}
+
+__host__ inline void mil_geom_set(ConvGeom& g, int tw, int th, int ti) {
+    g.tw_log2 = tw; g.th_log2 = th; g.ti_log2 = ti;
     g.tiles_x = (g.Wo + (1 << tw) - 1) >> tw;
     g.tiles_y = (g.Ho + (1 << th) - 1) >> th;
     g.n_groups = (g.n_img + (1 << g.ti_log2) - 1) >> g.ti_log2;

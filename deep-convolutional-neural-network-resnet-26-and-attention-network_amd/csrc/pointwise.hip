@@ -274,13 +274,15 @@ extern "C" int mil_maxpool_bwd(const void* gy, const uint8_t* widx, void* gx, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// Global average pool over h*w + bias-free linear: feats[t][o] = sum_i mean_p(x[t][p][i]) * Wfc[o][i].
-// One 128-thread workgroup per tile; pooled means are kept (fp32) for the backward pass.
+// Global average pool over h*w + linear: feats[t][o] = bias[o]? + sum_i mean_p(x[t][p][i]) * Wfc[o][i].
+// One workgroup per tile (blockDim = max(C, NF) rounded up to a wave, <= 512); pooled means are kept (fp32)
+// for the backward pass.  gbm/model.py:31-32,58-60 (C = 80, no bias); alt_resnet.py:92-93,139-143 (C = 512, bias).
+#define POOL_MAXC 512
 template <typename T>
-__global__ __launch_bounds__(128) void avgpool_fc_fwd_kernel(const typename T::elem* __restrict__ x,
-                                                             const float* __restrict__ wfc, float* __restrict__ pooled,
-                                                             float* __restrict__ feats, int hw, int CP, int C, int NF) {
-    __shared__ float sp[128];
+__global__ void avgpool_fc_fwd_kernel(const typename T::elem* __restrict__ x, const float* __restrict__ wfc,
+                                      const float* __restrict__ bias, float* __restrict__ pooled,
+                                      float* __restrict__ feats, int hw, int CP, int C, int NF) {
+    __shared__ float sp[POOL_MAXC];
     const int t = blockIdx.x, c = threadIdx.x;
     float s = 0.f;
     if (c < C) {
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(128) void avgpool_fc_fwd_kernel(const typename T::e
     sp[c] = s;
     __syncthreads();
     if (c < NF) {
-        float acc = 0.f;
+        float acc = bias ? bias[c] : 0.f;
         for (int i = 0; i < C; ++i) acc += sp[i] * wfc[(size_t)c * C + i];
         feats[(size_t)t * NF + c] = acc;
     }
@@ -300,11 +302,10 @@ __global__ __launch_bounds__(128) void avgpool_fc_fwd_kernel(const typename T::e
 
 // dz[t][p][c] = lrelu'(act[t][p][c]) * (sum_o dfeats[t][o] * Wfc[o][c]) / hw      (padded channels -> 0)
 template <typename T>
-__global__ __launch_bounds__(128) void avgpool_fc_bwd_kernel(const float* __restrict__ dfeats, const float* __restrict__ wfc,
-                                                             const typename T::elem* __restrict__ act,
-                                                             typename T::elem* __restrict__ dz, int hw, int CP, int C, int NF,
-                                                             float slope) {
-    __shared__ float sd[128];
+__global__ void avgpool_fc_bwd_kernel(const float* __restrict__ dfeats, const float* __restrict__ wfc,
+                                      const typename T::elem* __restrict__ act, typename T::elem* __restrict__ dz, int hw,
+                                      int CP, int C, int NF, float slope) {
+    __shared__ float sd[POOL_MAXC];
     const int t = blockIdx.x, c = threadIdx.x;
     sd[c] = (c < NF) ? dfeats[(size_t)t * NF + c] : 0.f;
     __syncthreads();
@@ -322,44 +323,62 @@ __global__ __launch_bounds__(128) void avgpool_fc_bwd_kernel(const float* __rest
     }
 }
 
-// dWfc[o][i] = sum_t dfeats[t][o] * pooled[t][i].  One wave per output element: lanes stride the tiles,
-// then a fixed shuffle tree (deterministic).
+// dWfc[o][i] = sum_t dfeats[t][o] * pooled[t][i]; elements [NF*C, NF*C+NF) are dbias[o] = sum_t dfeats[t][o].
+// One wave per output element: lanes stride the tiles, then a fixed shuffle tree (deterministic).
 __global__ __launch_bounds__(256) void fc_wgrad_kernel(const float* __restrict__ dfeats, const float* __restrict__ pooled,
-                                                       float* __restrict__ dw, int n, int C, int NF, int accumulate) {
+                                                       float* __restrict__ dw, float* __restrict__ dbias, int n, int C, int NF,
+                                                       int accumulate) {
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (idx >= NF * C) return;
-    const int o = idx / C, i = idx - o * C;
+    const int nw = NF * C;
+    if (idx >= nw + (dbias ? NF : 0)) return;
     float s = 0.f;
-    for (int t = lane; t < n; t += 64) s += dfeats[(size_t)t * NF + o] * pooled[(size_t)t * C + i];
+    if (idx < nw) {
+        const int o = idx / C, i = idx - o * C;
+        for (int t = lane; t < n; t += 64) s += dfeats[(size_t)t * NF + o] * pooled[(size_t)t * C + i];
+    } else {
+        const int o = idx - nw;
+        for (int t = lane; t < n; t += 64) s += dfeats[(size_t)t * NF + o];
+    }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) dw[idx] = accumulate ? dw[idx] + s : s;
+    if (lane != 0) return;
+    float* q = idx < nw ? dw + idx : dbias + (idx - nw);
+    *q = accumulate ? *q + s : s;
 }
 
-extern "C" int mil_avgpool_fc_fwd(const void* x, const float* wfc, float* pooled, float* feats, int n, int hw, int cp,
-                                  int c, int nf, int dtype, void* stream) {
-    if (!x || !wfc || !pooled || !feats || c > 128 || nf > 128 || cp > 128 || hw <= 0) return MIL_ERR_ARG;
+static int pool_block(int c, int nf, int cp) {
+    int m = c > nf ? c : nf;
+    if (cp > m) m = cp;
+    return (m + 63) / 64 * 64;
+}
+
+extern "C" int mil_avgpool_fc_fwd(const void* x, const float* wfc, const float* bias, float* pooled, float* feats, int n,
+                                  int hw, int cp, int c, int nf, int dtype, void* stream) {
+    if (!x || !wfc || !pooled || !feats || c > POOL_MAXC || nf > POOL_MAXC || cp > POOL_MAXC || hw <= 0) return MIL_ERR_ARG;
     if (n == 0) return MIL_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MIL_DT_BF16) hipLaunchKernelGGL(avgpool_fc_fwd_kernel<BF16>, dim3(n), dim3(128), 0, st, (const __bf16*)x, wfc, pooled, feats, hw, cp, c, nf);
-    else if (dtype == MIL_DT_F32) hipLaunchKernelGGL(avgpool_fc_fwd_kernel<F32>, dim3(n), dim3(128), 0, st, (const float*)x, wfc, pooled, feats, hw, cp, c, nf);
+    const int bd = pool_block(c, nf, cp);
+    if (dtype == MIL_DT_BF16) hipLaunchKernelGGL(avgpool_fc_fwd_kernel<BF16>, dim3(n), dim3(bd), 0, st, (const __bf16*)x, wfc, bias, pooled, feats, hw, cp, c, nf);
+    else if (dtype == MIL_DT_F32) hipLaunchKernelGGL(avgpool_fc_fwd_kernel<F32>, dim3(n), dim3(bd), 0, st, (const float*)x, wfc, bias, pooled, feats, hw, cp, c, nf);
     else return MIL_ERR_ARG;
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
 
 extern "C" int mil_avgpool_fc_bwd(const float* dfeats, const float* wfc, const float* pooled, const void* act, void* dz,
-                                  float* dwfc, int n, int hw, int cp, int c, int nf, int accumulate, float slope, int dtype,
-                                  void* stream) {
-    if (!dfeats || !wfc || !pooled || !dz || !dwfc || c > 128 || nf > 128 || cp > 128 || hw <= 0) return MIL_ERR_ARG;
+                                  float* dwfc, float* dbias, int n, int hw, int cp, int c, int nf, int accumulate, float slope,
+                                  int dtype, void* stream) {
+    if (!dfeats || !wfc || !pooled || !dz || !dwfc || c > POOL_MAXC || nf > POOL_MAXC || cp > POOL_MAXC || hw <= 0) return MIL_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int bd = pool_block(c, nf, cp);
     if (n > 0) {
-        if (dtype == MIL_DT_BF16) hipLaunchKernelGGL(avgpool_fc_bwd_kernel<BF16>, dim3(n), dim3(128), 0, st, dfeats, wfc, (const __bf16*)act, (__bf16*)dz, hw, cp, c, nf, slope);
-        else if (dtype == MIL_DT_F32) hipLaunchKernelGGL(avgpool_fc_bwd_kernel<F32>, dim3(n), dim3(128), 0, st, dfeats, wfc, (const float*)act, (float*)dz, hw, cp, c, nf, slope);
+        if (dtype == MIL_DT_BF16) hipLaunchKernelGGL(avgpool_fc_bwd_kernel<BF16>, dim3(n), dim3(bd), 0, st, dfeats, wfc, (const __bf16*)act, (__bf16*)dz, hw, cp, c, nf, slope);
+        else if (dtype == MIL_DT_F32) hipLaunchKernelGGL(avgpool_fc_bwd_kernel<F32>, dim3(n), dim3(bd), 0, st, dfeats, wfc, (const float*)act, (float*)dz, hw, cp, c, nf, slope);
         else return MIL_ERR_ARG;
         MIL_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(fc_wgrad_kernel, dim3((nf * c + 3) / 4), dim3(256), 0, st, dfeats, pooled, dwfc, n, c, nf, accumulate);
+    const int total = nf * c + (dbias ? nf : 0);
+    hipLaunchKernelGGL(fc_wgrad_kernel, dim3((total + 3) / 4), dim3(256), 0, st, dfeats, pooled, dwfc, dbias, n, c, nf, accumulate);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

@@ -228,26 +228,78 @@ def stem_bwd_fused(xs, g_pool, widx, *, workspace=None, out=None, slope=LEAK):
     return dw, db
 
 
-def avgpool_fc_fwd(x, wfc, c):
+def avgpool_fc_fwd(x, wfc, c, bias=None):
     n, h, w, cp = x.shape
     nf = wfc.shape[0]
     _need(wfc, (nf, c), torch.float32, "fc.weight")
+    _need(bias, (nf,), torch.float32, "fc.bias")
     pooled = torch.empty((n, c), dtype=torch.float32, device=x.device)
     feats = torch.empty((n, nf), dtype=torch.float32, device=x.device)
-    L.check(L.lib().mil_avgpool_fc_fwd(x.data_ptr(), wfc.data_ptr(), pooled.data_ptr(), feats.data_ptr(), n, h * w, cp, c,
-                                       nf, L.dt_code(x.dtype), L.stream_ptr()), "mil_avgpool_fc_fwd")
+    L.check(L.lib().mil_avgpool_fc_fwd(x.data_ptr(), wfc.data_ptr(), L.ptr(bias), pooled.data_ptr(), feats.data_ptr(), n,
+                                       h * w, cp, c, nf, L.dt_code(x.dtype), L.stream_ptr()), "mil_avgpool_fc_fwd")
     return pooled, feats
 
 
-def avgpool_fc_bwd(dfeats, wfc, pooled, act, c, slope=LEAK, out=None):
+def avgpool_fc_bwd(dfeats, wfc, pooled, act, c, slope=LEAK, out=None, want_bias=False, out_bias=None):
     n, h, w, cp = act.shape
     nf = wfc.shape[0]
     _need(dfeats, (n, nf), torch.float32, "dfeats")
     dz = torch.empty_like(act)
     dwfc = torch.empty((nf, c), dtype=torch.float32, device=act.device) if out is None else out
     _need(dwfc, (nf, c), torch.float32, "dwfc")
+    dbias = None
+    if want_bias:
+        dbias = torch.empty(nf, dtype=torch.float32, device=act.device) if out_bias is None else out_bias
     L.check(L.lib().mil_avgpool_fc_bwd(dfeats.data_ptr(), wfc.data_ptr(), pooled.data_ptr(), act.data_ptr(), dz.data_ptr(),
-                                       dwfc.data_ptr(), n, h * w, cp, c, nf, 0 if out is None else 1, slope,
+                                       dwfc.data_ptr(), L.ptr(dbias), n, h * w, cp, c, nf, 0 if out is None else 1, slope,
                                        L.dt_code(act.dtype), L.stream_ptr()),
             "mil_avgpool_fc_bwd")
+    if want_bias:
+        return dz, dwfc, dbias
     return dz, dwfc
+
+
+# ---- wide (multiples of 64 channels) layers: the alt_resnet configuration -----------------------------------
+def wide_pack_weights(w, mode, dtype):
+    w = w.detach().contiguous()
+    cout, cin, ks, _ = w.shape
+    elems = ctypes.c_size_t(0)
+    L.check(L.lib().mil_wide_packed_elems(ctypes.byref(elems), cout, cin, ks, mode), "mil_wide_packed_elems")
+    packed = torch.empty(elems.value, dtype=dtype, device=w.device)
+    L.check(L.lib().mil_wide_pack_weights(w.data_ptr(), packed.data_ptr(), cout, cin, ks, mode, L.dt_code(dtype),
+                                          L.stream_ptr()), "mil_wide_pack_weights")
+    return packed
+
+
+def wide_conv(x, wpack, cout, *, ks, stride, pad, out_hw=None, res=None, act=None, relu=False, zero_insert=False,
+              slope=0.0, bias=None):
+    n, h, w, cin = x.shape
+    if zero_insert:
+        ho, wo = out_hw
+    else:
+        ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+    y = torch.empty((n, ho, wo, cout), dtype=x.dtype, device=x.device)
+    _need(res, y.shape, x.dtype, "res")
+    _need(act, y.shape, x.dtype, "act")
+    L.check(L.lib().mil_wide_conv(x.data_ptr(), wpack.data_ptr(), L.ptr(bias), L.ptr(res), L.ptr(act), y.data_ptr(), n, h, w,
+                                  cin, ho, wo, cout, ks, 1 if zero_insert else stride, pad, 1 if zero_insert else 0,
+                                  1 if relu else 0, slope, L.dt_code(x.dtype), L.stream_ptr()), "mil_wide_conv")
+    return y
+
+
+def wide_wgrad(x, dz, cin, cout, *, ks, stride, pad, workspace=None, out=None):
+    n, h, w, _ = x.shape
+    _, ho, wo, _ = dz.shape
+    _need(x, (n, h, w, cin), x.dtype, "x")
+    _need(dz, (n, ho, wo, cout), x.dtype, "dz")
+    need = ctypes.c_size_t(0)
+    L.check(L.lib().mil_wide_wgrad_workspace(ctypes.byref(need), n, h, w, cin, ho, wo, cout, ks, stride, pad,
+                                             L.dt_code(x.dtype)), "mil_wide_wgrad_workspace")
+    if workspace is None or workspace.numel() * workspace.element_size() < need.value:
+        workspace = torch.empty((need.value + 3) // 4, dtype=torch.float32, device=x.device)
+    dw = torch.empty((cout, cin, ks, ks), dtype=torch.float32, device=x.device) if out is None else out
+    _need(dw, (cout, cin, ks, ks), torch.float32, "dw")
+    L.check(L.lib().mil_wide_wgrad(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), workspace.data_ptr(),
+                                   workspace.numel() * workspace.element_size(), n, h, w, cin, ho, wo, cout, ks, stride, pad,
+                                   0 if out is None else 1, L.dt_code(x.dtype), L.stream_ptr()), "mil_wide_wgrad")
+    return dw, workspace

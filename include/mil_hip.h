@@ -113,13 +113,14 @@ int mil_stem_bwd_fused(const void* xs, const void* g_pool, const uint8_t* widx, 
                        void* stream);
 
 /* AdaptiveAvgPool2d((1,1)) + flatten + Linear(80,L,bias=False) (gbm/model.py:31-32,58-60).
- * x [n,hw,cp] -> pooled [n,c] fp32 (kept for backward), feats [n,nf] fp32 = pooled @ wfc^T.
- * Backward: dz [n,hw,cp] = lrelu'(act) * (dfeats @ wfc)/hw, dwfc [nf,c] = dfeats^T @ pooled. */
-int mil_avgpool_fc_fwd(const void* x, const float* wfc, float* pooled, float* feats, int n, int hw, int cp, int c,
-                       int nf, int dtype, void* stream);
+ * x [n,hw,cp] -> pooled [n,c] fp32 (kept for backward), feats [n,nf] fp32 = pooled @ wfc^T (+ bias when given:
+ * alt_resnet.py:93's Linear(512,num_classes) has one).  c, nf, cp <= 512.
+ * Backward: dz [n,hw,cp] = lrelu'(act) * (dfeats @ wfc)/hw, dwfc [nf,c] = dfeats^T @ pooled, dbias [nf] (nullable). */
+int mil_avgpool_fc_fwd(const void* x, const float* wfc, const float* bias, float* pooled, float* feats, int n, int hw,
+                       int cp, int c, int nf, int dtype, void* stream);
 int mil_avgpool_fc_bwd(const float* dfeats, const float* wfc, const float* pooled, const void* act, void* dz,
-                       float* dwfc, int n, int hw, int cp, int c, int nf, int accumulate, float slope, int dtype,
-                       void* stream);
+                       float* dwfc, float* dbias, int n, int hw, int cp, int c, int nf, int accumulate, float slope,
+                       int dtype, void* stream);
 
 /* ---- attention-MIL head --------------------------------------------------------------------
  * Replaces everything after the backbone in Attention.forward (gbm/model.py:198-246): ContextLayer
@@ -148,6 +149,21 @@ int mil_head_bwd(const float* H, const int* bag_offsets, const int* inst_bag, co
                  const float* const* weights, float* workspace, const float* bterm, const float* rec,
                  const float* grad_loss, const float* grad_l2, float* dH, float* grads, int ntot, int nbags,
                  float slope, float drop_p, void* stream);
+
+/* ---- wide (64..512-channel) layers: the alt_resnet.py configuration -----------------------------
+ * Channel-blocked implicit GEMM (64-wide output blocks x 32-wide input chunks staged through LDS) for channel
+ * counts that do not fit the resident-filter kernels above.  Replaces conv3x3 / conv1x1 of alt_resnet.py:24-33
+ * (bias-free, ReLU = slope 0) forward, data-gradient (MIL_PACK_DGRAD packing + zero_insert for stride 2) and
+ * weight-gradient.  cin % 32 == 0, cout % 64 == 0; same tensor layout and epilogue semantics as mil_conv_igemm. */
+int mil_wide_packed_elems(size_t* elems, int cout, int cin, int ks, int mode);
+int mil_wide_pack_weights(const float* w, void* wpack, int cout, int cin, int ks, int mode, int dtype, void* stream);
+int mil_wide_conv(const void* x, const void* wpack, const float* bias, const void* res, const void* act, void* y, int n_img,
+                  int H, int W, int cin, int Ho, int Wo, int cout, int ks, int stride, int pad, int zero_insert,
+                  int apply_relu, float slope, int dtype, void* stream);
+int mil_wide_wgrad_workspace(size_t* bytes, int n_img, int H, int W, int cin, int Ho, int Wo, int cout, int ks, int stride,
+                             int pad, int dtype);
+int mil_wide_wgrad(const void* x, const void* dz, float* dw, void* workspace, size_t workspace_bytes, int n_img, int H, int W,
+                   int cin, int Ho, int Wo, int cout, int ks, int stride, int pad, int accumulate, int dtype, void* stream);
 
 /* ---- training-step closure ---------------------------------------------------
  * mil_adam_step: torch.optim.Adam (gbm/classify_combined.py:519, stepped at :450-454) over the flat fp32

@@ -197,3 +197,56 @@ def load_state(npz, requires_grad=False):
     for k, _shape in state_dict_spec():
         sd[k] = torch.tensor(npz[k], dtype=torch.float32, requires_grad=requires_grad)
     return sd
+
+
+# ---- second backbone configuration: alt_resnet.py (BatchNorm-free torchvision ResNet, widths 64..512) ----------
+ALT_WIDTHS = (64, 128, 256, 512)            # alt_resnet.py:86-89
+
+
+def alt_state_dict_spec(layers, num_classes):
+    """Ordered (key, shape) list of alt_resnet.ResNet(BasicBlock, layers, num_classes).state_dict()."""
+    spec = [("conv1.weight", (64, 3, 7, 7))]
+    cin = 64
+    for li, (planes, depth) in enumerate(zip(ALT_WIDTHS, layers), start=1):
+        for b in range(depth):
+            c_in = cin if b == 0 else planes
+            spec += [(f"layer{li}.{b}.conv1.weight", (planes, c_in, 3, 3)), (f"layer{li}.{b}.conv2.weight", (planes, planes, 3, 3))]
+            if b == 0 and (li > 1 or c_in != planes):
+                spec.append((f"layer{li}.{b}.downsample.0.weight", (planes, c_in, 1, 1)))
+        cin = planes
+    spec += [("fc.weight", (num_classes, 512)), ("fc.bias", (num_classes,))]
+    return spec
+
+
+def alt_seeded_state(layers, num_classes, seed, requires_grad=False):
+    """Deterministic weights (He-scaled normal from a seeded CPU generator) so that 5-20 M parameters never have to be
+    stored: the golden generator loads exactly these into the reference model, the tests regenerate them."""
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+    for k, shape in alt_state_dict_spec(layers, num_classes):
+        if k.endswith("bias"):
+            t = 0.05 * torch.randn(shape, generator=g)
+        else:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            t = torch.randn(shape, generator=g) * (2.0 / fan_in) ** 0.5
+        sd[k] = t.requires_grad_(requires_grad)
+    return sd
+
+
+def alt_backbone(sd, x, layers):
+    """alt_resnet.py:128-145 (`_forward_impl`) with BasicBlock of :54-66: conv-relu-conv-(+identity/projection)-relu."""
+    t = F.relu(F.conv2d(x, sd["conv1.weight"], None, stride=2, padding=3))
+    t = F.max_pool2d(t, kernel_size=3, stride=2, padding=1)
+    for li, depth in enumerate(layers, start=1):
+        for b in range(depth):
+            p = f"layer{li}.{b}."
+            stride = 2 if (b == 0 and li > 1) else 1
+            o = F.relu(F.conv2d(t, sd[p + "conv1.weight"], None, stride=stride, padding=1))
+            o = F.conv2d(o, sd[p + "conv2.weight"], None, stride=1, padding=1)
+            key = p + "downsample.0.weight"
+            shortcut = F.conv2d(t, sd[key], None, stride=stride) if key in sd else t
+            t = F.relu(o + shortcut)
+    t = t.mean(dim=(2, 3))
+    return t @ sd["fc.weight"].t() + sd["fc.bias"]

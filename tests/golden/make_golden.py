@@ -134,7 +134,55 @@ def run_case(model, net, name, x, y, *, train=False, seed=None, class_weights=No
           f"|Fterm|max={out['Fterm'].abs().max().item():.4f}")
 
 
+def load_reference_alt():
+    """alt_resnet.py has a relative import of `.utils` (a URL loader it only needs for pretrained=True): give it a
+    package context with a stub whose loader raises."""
+    import importlib.util
+    pkg = types.ModuleType("refpkg")
+    pkg.__path__ = [REF]
+    sys.modules["refpkg"] = pkg
+    utils = types.ModuleType("refpkg.utils")
+
+    def _offline(*_a, **_k):
+        raise RuntimeError("pretrained weights are a network fetch; unavailable offline")
+    utils.load_state_dict_from_url = _offline
+    sys.modules["refpkg.utils"] = utils
+    spec = importlib.util.spec_from_file_location("refpkg.alt_resnet", os.path.join(REF, "alt_resnet.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["refpkg.alt_resnet"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def run_alt_case(alt, name, layers, num_classes, wseed, x):
+    """Reference alt_resnet on seeded weights (oracle/mil_oracle.alt_seeded_state regenerates them, nothing to store)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import mil_oracle as orc
+    net = alt.ResNet(alt.BasicBlock, list(layers), num_classes=num_classes)
+    sd = orc.alt_seeded_state(layers, num_classes, wseed)
+    assert list(sd.keys()) == list(net.state_dict().keys())
+    net.load_state_dict(sd)
+    feats = net(x)
+    g = torch.Generator().manual_seed(wseed + 1)
+    dfe = torch.randn(feats.shape, generator=g)
+    feats.backward(dfe)
+    names, norms = [], []
+    for k, p in net.named_parameters():
+        names.append(k)
+        norms.append(float(p.grad.double().norm()))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), x=x.numpy(), feats=feats.detach().numpy(), dfeats=dfe.numpy(),
+                        layers=np.array(layers), num_classes=np.array(num_classes), wseed=np.array(wseed),
+                        **{"gradnorm.names": np.array(names), "gradnorm.l2": np.array(norms, dtype=np.float64),
+                           "grad.conv1.weight": net.conv1.weight.grad.numpy(),
+                           "grad.layer2.0.downsample.0.weight": net.layer2[0].downsample[0].weight.grad.numpy(),
+                           "grad.fc.bias": net.fc.bias.grad.numpy()})
+    print(f"{name}: |feats|max={feats.abs().max().item():.4f}")
+
+
 def main():
+    alt = load_reference_alt()
+    run_alt_case(alt, "alt_l1111_n4_64", (1, 1, 1, 1), 80, 555, synth_bag(4, 64, 64, 20260201))
+    run_alt_case(alt, "alt_l2222_n2_96x80", (2, 2, 2, 2), 80, 556, synth_bag(2, 96, 80, 20260202))
     model = load_reference()
     net = make_weights(model)
     np.savez_compressed(os.path.join(HERE, "weights.npz"),

@@ -1,0 +1,75 @@
+"""-m gpu parity of the wide tile-encoder configuration (reference alt_resnet.py) against golden outputs captured
+from the reference itself (tests/golden/make_golden.py: run_alt_case) and against the oracle restatement."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import mil_amd
+from oracle import mil_oracle as orc
+
+pytestmark = pytest.mark.gpu
+CASES = ["alt_l1111_n4_64", "alt_l2222_n2_96x80"]
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    layers = tuple(int(v) for v in z["layers"])
+    return z, layers, int(z["num_classes"]), int(z["wseed"])
+
+
+def _net(layers, num_classes, wseed, dtype):
+    net = mil_amd.alt_resnet.ResNet(mil_amd.alt_resnet.BasicBlock, list(layers), num_classes=num_classes, compute_dtype=dtype)
+    sd = orc.alt_seeded_state(layers, num_classes, wseed)
+    assert list(sd.keys()) == list(net.state_dict().keys())
+    net.load_state_dict(sd)
+    return net.cuda()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_alt_resnet_fp32_matches_reference_golden(golden_dir, name):
+    z, layers, nc, wseed = _load(golden_dir, name)
+    net = _net(layers, nc, wseed, torch.float32)
+    feats = net(torch.from_numpy(z["x"]).cuda())
+    ref = torch.from_numpy(z["feats"])
+    # fp32 accumulation-order differences only; the features reach |47|
+    assert float((feats.detach().cpu() - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()))
+    feats.backward(torch.from_numpy(z["dfeats"]).cuda())
+    norms = dict(zip([str(k) for k in z["gradnorm.names"]], z["gradnorm.l2"]))
+    for k, p in net.named_parameters():
+        got = float(p.grad.double().norm())
+        assert abs(got - norms[k]) <= 1e-3 * norms[k] + 1e-6, (k, got, norms[k])
+    for k in ("conv1.weight", "layer2.0.downsample.0.weight", "fc.bias"):
+        ref_g = torch.from_numpy(z["grad." + k])
+        got_g = dict(net.named_parameters())[k].grad.cpu()
+        assert float((got_g - ref_g).abs().max()) <= 1e-3 * float(ref_g.abs().max()), k
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_alt_resnet_bf16_stated_tolerance(golden_dir, name):
+    """bf16 storage between layers: 2^-9 relative rounding per stored activation over up to 18 layers; stated tolerance
+    3e-2 of the feature range and cosine >= 0.97 on every parameter gradient against the fp32 oracle."""
+    z, layers, nc, wseed = _load(golden_dir, name)
+    net = _net(layers, nc, wseed, torch.bfloat16)
+    x = torch.from_numpy(z["x"])
+    feats = net(x.cuda())
+    ref = torch.from_numpy(z["feats"])
+    assert float((feats.detach().cpu() - ref).abs().max()) <= 3e-2 * float(ref.abs().max())
+    feats.backward(torch.from_numpy(z["dfeats"]).cuda())
+    sd = orc.alt_seeded_state(layers, nc, wseed, requires_grad=True)
+    orc.alt_backbone(sd, x, layers).backward(torch.from_numpy(z["dfeats"]))
+    for k, p in net.named_parameters():
+        a, b = p.grad.cpu().double().flatten(), sd[k].grad.double().flatten()
+        cos = float(a @ b / (a.norm() * b.norm()).clamp_min(1e-30))
+        assert cos >= 0.97, (k, cos)      # ReLU gates of near-zero activations flip under bf16 storage (2 tiles only)
+
+
+def test_alt_resnet18_module_surface():
+    net = mil_amd.alt_resnet.resnet18(num_classes=80)
+    keys = [k for k, _ in orc.alt_state_dict_spec((2, 2, 2, 2), 80)]
+    assert list(net.state_dict().keys()) == keys
+    with pytest.raises(RuntimeError):
+        mil_amd.alt_resnet.resnet18(pretrained=True)
+    with pytest.raises(AttributeError):
+        mil_amd.alt_resnet.ResNet(zero_init_residual=True)

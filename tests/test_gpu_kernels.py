@@ -247,3 +247,50 @@ def test_stem_backward_fused_equals_pool_bwd_plus_wgrad(ops, shape):
     dw2, db2 = ops.conv_wgrad(xs, dstem, 3, 20, ks=4, stride=1, pad=2, stem=True)
     assert rel_err(dw.cpu(), dw2.cpu()) < 1e-5 and rel_err(db.cpu(), db2.cpu()) < 1e-5
     assert rel_err(dw.cpu(), wt.grad) < 2e-2 and rel_err(db.cpu(), b.grad) < 2e-2     # vs autograd (bf16 stem rounding)
+
+
+WIDE_CASES = [
+    # cin, cout, ks, stride, n, H, W
+    (64, 128, 3, 2, 3, 16, 16),
+    (64, 128, 1, 2, 2, 16, 16),
+    (128, 128, 3, 1, 2, 16, 16),
+    (128, 128, 3, 1, 3, 9, 11),
+    (128, 256, 3, 2, 2, 10, 10),
+    (128, 256, 3, 2, 4, 8, 8),          # fp32: 8 images of 9x9 halo per tile do not fit -> smaller-group fallback
+    (256, 256, 3, 1, 5, 8, 8),
+    (256, 512, 1, 2, 3, 8, 8),
+    (512, 512, 3, 1, 9, 4, 4),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_wide_conv_forward_dgrad_wgrad(ops, dtype, case):
+    """Channel-blocked kernels for the alt_resnet widths (bias-free convs, ReLU) against F.conv2d + autograd."""
+    L = _lib()
+    cin, cout, ks, stride, n, h, w = case
+    g = torch.Generator().manual_seed(3 + cin + cout + ks)
+    pad = 1 if ks == 3 else 0
+    x = round_to(torch.randn(n, cin, h, w, generator=g), dtype).requires_grad_(True)
+    wt = round_to(torch.randn(cout, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5, dtype).requires_grad_(True)
+    lin = F.conv2d(x, wt, None, stride=stride, padding=pad)
+    res = round_to(torch.randn(lin.shape, generator=g), dtype)
+    xg = to_nhwc(x.detach(), dtype)
+    wp = ops.wide_pack_weights(wt.detach().cuda(), L.PACK_FWD, dtype)
+    y = ops.wide_conv(xg, wp, cout, ks=ks, stride=stride, pad=pad, res=to_nhwc(res, dtype), relu=True)
+    assert rel_err(from_nhwc(y, cout), F.relu(lin.detach() + res)) < TOL[dtype]
+    dz = round_to(torch.randn(lin.shape, generator=g), dtype)
+    lin.backward(dz)
+    act = round_to(torch.randn(x.shape, generator=g), dtype)
+    want = x.grad * (act > 0)
+    wd = ops.wide_pack_weights(wt.detach().cuda(), L.PACK_DGRAD, dtype)
+    dzg = to_nhwc(dz, dtype)
+    if stride == 2:
+        dx = ops.wide_conv(dzg, wd, cin, ks=ks, stride=1, pad=pad, zero_insert=True, out_hw=(h, w), act=to_nhwc(act, dtype))
+    else:
+        dx = ops.wide_conv(dzg, wd, cin, ks=ks, stride=1, pad=pad, act=to_nhwc(act, dtype))
+    assert rel_err(from_nhwc(dx, cin), want) < TOL[dtype]
+    dw, _ws = ops.wide_wgrad(xg, dzg, cin, cout, ks=ks, stride=stride, pad=pad)
+    assert rel_err(dw.cpu(), wt.grad) < 3e-5
+    dw2, _ws = ops.wide_wgrad(xg, dzg, cin, cout, ks=ks, stride=stride, pad=pad)
+    assert torch.equal(dw, dw2)

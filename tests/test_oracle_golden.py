@@ -97,3 +97,17 @@ def test_single_instance_bag_raises(golden_dir):
     sd = orc.load_state(w)
     with pytest.raises(ValueError):
         orc.attention_forward(sd, torch.zeros(1, 3, 32, 32), torch.tensor([0]))
+
+
+@pytest.mark.parametrize("name", ["alt_l1111_n4_64", "alt_l2222_n2_96x80"])
+def test_alt_backbone_oracle_matches_reference_golden(golden_dir, name):
+    """Second encoder configuration (alt_resnet.py): restatement vs outputs of the reference itself."""
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    layers = tuple(int(v) for v in z["layers"])
+    sd = orc.alt_seeded_state(layers, int(z["num_classes"]), int(z["wseed"]), requires_grad=True)
+    feats = orc.alt_backbone(sd, torch.from_numpy(z["x"]), layers)
+    ref = torch.from_numpy(z["feats"])
+    assert float((feats.detach() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    feats.backward(torch.from_numpy(z["dfeats"]))
+    for k, v in zip([str(k) for k in z["gradnorm.names"]], z["gradnorm.l2"]):
+        assert abs(float(sd[k].grad.double().norm()) - v) <= 1e-5 * v, k
