@@ -125,11 +125,17 @@ class ResNet(nn.Module):
 
 
 def _forward(net, x, dtype):
-    xs = ops.stem_s2d(x, dtype)
     wp, bp = ops.pack_weights(net.conv1.weight, None, L.PACK_STEM, dtype)
-    stem = ops.conv(xs, wp, bp, 64, ks=4, stride=1, pad=2, lrelu=True, slope=0.0)
-    pool, widx = ops.maxpool_fwd(stem)
-    saved = {"xs": xs, "stem_hw": tuple(stem.shape[1:3]), "widx": widx, "blocks": []}
+    fused = ops.stem_fwd_fused(x, wp, bp, 64, slope=0.0, dtype=dtype)
+    if fused is not None:
+        xs, pool, widx = fused
+        stem_hw = tuple(xs.shape[1:3])
+    else:
+        xs = ops.stem_s2d(x, dtype)
+        stem = ops.conv(xs, wp, bp, 64, ks=4, stride=1, pad=2, lrelu=True, slope=0.0)
+        pool, widx = ops.maxpool_fwd(stem)
+        stem_hw = tuple(stem.shape[1:3])
+    saved = {"xs": xs, "stem_hw": stem_hw, "widx": widx, "blocks": []}
     t = pool
     for blk in net.blocks():
         c1, c2 = _Conv(blk.conv1, dtype), _Conv(blk.conv2, dtype)

@@ -1,0 +1,297 @@
+// Fused stem forward: fp32 NCHW tiles -> space-to-depth (kept for the backward) -> 7x7/s2 conv + bias +
+// LeakyReLU -> MaxPool2d(3,2,1) + winner records, in ONE pass (reference ops gbm/model.py:24-26,51-53).
+//
+// The unfused chain writes and re-reads the s2d tensor (1.07 GB at T=2048, 256x256) and the stem activation
+// (1.6 GB + 1.6 GB) through HBM; here the fp32 input is read once, the s2d tile and the stem tile live in LDS,
+// and only what later kernels need is written: the s2d tensor (stem weight gradient), the pooled map and the
+// 1-byte winner records.  Arithmetic is the same as the unfused kernels' (same packed filter, same k order,
+// bias-initialised accumulators, bf16 rounding of the stem activation before the pool), so results are
+// bit-identical to stem_s2d -> conv_igemm -> maxpool_fwd.
+//
+// Tile = 8x16 pooled pixels of one image  <- 17x33 stem pixels <- 20x36 s2d pixels (loaded as 20x38 so that the
+// fp32 input is fetched in aligned 16-byte pieces) <- 40x76 input pixels x 3 colours.  Workgroups are persistent;
+// each XCD walks its own contiguous range of tiles so that neighbouring tiles (which share halo rows/columns)
+// are in flight on the same L2.
+#include "pf_common.cuh"
+
+struct StemFwdArgs {
+    const float* x;            // [n,3,H,W]
+    const __bf16* w;           // MIL_PACK_STEM fragments [8][NT][64][8]
+    const float* bias;         // [NT*16]
+    __bf16* xs;                // [n,H2,W2,16]
+    __bf16* pool;              // [n,Ho,Wo,COUTP]
+    uint8_t* widx;             // [n,Ho,Wo,COUTP]
+    int n_img, H, W, H2, W2, Ho, Wo, tiles_x, tiles_y, ntiles;
+    float slope;
+};
+
+constexpr int SF_SH = 17, SF_SW = 33;               // stem tile
+constexpr int SF_XH = 20, SF_XW = 38, SF_NPAIR = 19;  // s2d tile; a "pair" = 2 s2d pixels = 4 input columns
+constexpr int SF_XPIX = 48;                         // 16 ch bf16 = 32 B at an odd 16-B slot pitch
+constexpr int SF_XBYTES = SF_XH * SF_XW * SF_XPIX;  // 36480
+constexpr int SF_NITEM = SF_XH * SF_NPAIR * 3;      // (row, pair, colour) load items
+constexpr int SF_NLOAD = (SF_NITEM + 255) / 256;    // 5
+constexpr int SF_NSTEM = SF_SH * SF_SW;             // 561
+constexpr int SF_MT = 9;                            // 16-pixel row tiles per wave (4*9*16 = 576 >= 561)
+
+template <int NT>
+__host__ __device__ constexpr int sf_lds_bytes() {
+    return SF_XBYTES + ((SF_NSTEM * mil_pix_pitch(mil_nt_to_cp(NT), 2) + 15) & ~15) + 8 * NT * 64 * 16;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void stem_fwd_fused_kernel(StemFwdArgs a) {
+    constexpr int COUTP = mil_nt_to_cp(NT);
+    constexpr int NG = COUTP / 8;
+    constexpr int SPIX = mil_pix_pitch(COUTP, 2);
+    constexpr int KSTEPS = 8;
+    constexpr int NPOOL = (128 * NG + 255) / 256;
+    constexpr bool LAST_PARTIAL = (COUTP % 16) != 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ldsX = smem;
+    char* ldsS = smem + SF_XBYTES;
+    char* ldsW = ldsS + ((SF_NSTEM * SPIX + 15) & ~15);
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, gq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    {
+        const char* src = reinterpret_cast<const char*>(a.w);
+        for (int i = tid * 16; i < KSTEPS * NT * 64 * 16; i += 256 * 16)
+            *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(src + i);
+        for (int i = tid * 16; i < SF_XBYTES; i += 256 * 16)           // channels 12..15 of every s2d pixel stay zero
+            *reinterpret_cast<uint4*>(ldsX + i) = make_uint4(0, 0, 0, 0);
+    }
+    const int H = a.H, W = a.W, H2 = a.H2, W2 = a.W2, Ho = a.Ho, Wo = a.Wo;
+    const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, (unsigned)((size_t)a.n_img * 3 * H * W * 4));
+    const __amdgpu_buffer_rsrc_t rs_xs = mil_rsrc(a.xs, (unsigned)((size_t)a.n_img * H2 * W2 * 32));
+    const __amdgpu_buffer_rsrc_t rs_p = mil_rsrc(a.pool, (unsigned)((size_t)a.n_img * Ho * Wo * COUTP * 2));
+    const __amdgpu_buffer_rsrc_t rs_i = mil_rsrc(a.widx, (unsigned)((size_t)a.n_img * Ho * Wo * COUTP));
+
+    // ---- tile-invariant tables --------------------------------------------------------------------
+    int l_lds[SF_NLOAD], l_rel[SF_NLOAD], l_pos[SF_NLOAD];       // input -> s2d tile
+#pragma unroll
+    for (int i = 0; i < SF_NLOAD; ++i) {
+        const int idx = tid + 256 * i;
+        l_pos[i] = -1; l_lds[i] = 0; l_rel[i] = 0;
+        if (idx < SF_NITEM) {
+            const int pair = idx % SF_NPAIR, t = idx / SF_NPAIR;
+            const int c = t % 3, row = t / 3;
+            l_pos[i] = (row << 10) | pair;
+            l_lds[i] = (row * SF_XW + 2 * pair) * SF_XPIX + c * 8;
+            l_rel[i] = ((c * H + 2 * row) * W + 4 * pair) * 4;
+        }
+    }
+    int x_lds[4], x_rel[4], x_pos[4];                            // s2d tile interior -> xs tensor (16-B pieces)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + 256 * i;
+        const int half = id & 1, px = id >> 1, row = px >> 5, col = px & 31;
+        x_lds[i] = ((row + 3) * SF_XW + col + 4) * SF_XPIX + half * 16;
+        x_rel[i] = (row * W2 + col) * 32 + half * 16;
+        x_pos[i] = (row << 10) | col;
+    }
+    int pixbase[SF_MT], sdst[SF_MT];                             // MFMA row tiles of the stem tile
+#pragma unroll
+    for (int m = 0; m < SF_MT; ++m) {
+        const int tp = (wave * SF_MT + m) * 16 + r;
+        const bool ok = tp < SF_NSTEM;
+        const int sy = tp / SF_SW, sx = tp - sy * SF_SW;
+        pixbase[m] = ok ? (sy * SF_XW + sx + 1) * SF_XPIX : 0;
+        sdst[m] = ok ? tp * SPIX + gq * 8 : -1;
+    }
+    int toff[KSTEPS];
+#pragma unroll
+    for (int sl = 0; sl < KSTEPS; ++sl) {
+        const int q = 4 * sl + gq, tap = q >> 1, cg = q & 1;
+        toff[sl] = ((tap >> 2) * SF_XW + (tap & 3)) * SF_XPIX + cg * 16;
+    }
+    int p_lds[NPOOL], p_rel[NPOOL], p_pos[NPOOL];                // pooled pixels x 8-channel groups
+#pragma unroll
+    for (int i = 0; i < NPOOL; ++i) {
+        const int id = tid + 256 * i;
+        p_pos[i] = -1; p_lds[i] = 0; p_rel[i] = 0;
+        if (id < 128 * NG) {
+            const int c8 = id % NG, pp = id / NG, py = pp >> 4, px = pp & 15;
+            p_pos[i] = (py << 10) | px;
+            p_lds[i] = ((2 * py) * SF_SW + 2 * px) * SPIX + c8 * 16;
+            p_rel[i] = (py * Wo + px) * COUTP + c8 * 8;
+        }
+    }
+    f32x4_t bias_r[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias_r[nt][i] = a.bias ? a.bias[nt * 16 + gq * 4 + i] : 0.f;
+
+    // ---- tile walk: XCD x (= blockIdx & 7) owns tiles [x*per, (x+1)*per) ---------------------------
+    const int G8 = gridDim.x >> 3, per = (a.ntiles + 7) >> 3;
+    const int t_begin = (blockIdx.x & 7) * per;
+    const int t_end = min(t_begin + per, a.ntiles);
+    int tile = t_begin + (blockIdx.x >> 3);
+
+    u32x4_t r0[SF_NLOAD], r1[SF_NLOAD];
+    auto fetch = [&](int t) {
+        const int tx = t % a.tiles_x, q = t / a.tiles_x, ty = q % a.tiles_y, img = q / a.tiles_y;
+        const int y0 = 16 * ty - 3, c0 = 64 * tx - 8;            // first s2d row / first input column of the tile
+        const int base = (((img * 3) * H + 2 * y0) * W + c0) * 4;
+#pragma unroll
+        for (int i = 0; i < SF_NLOAD; ++i) {
+            const int p = l_pos[i];
+            const bool ok = p >= 0 && (unsigned)(y0 + (p >> 10)) < (unsigned)H2 && (unsigned)(c0 + 4 * (p & 1023)) < (unsigned)W;
+            const unsigned off = ok ? (unsigned)(base + l_rel[i]) : MIL_OOB;
+            r0[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+            r1[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off + (unsigned)(W * 4), 0, 0);
+        }
+    };
+    if (tile < t_end) fetch(tile);
+    __syncthreads();
+
+    for (; tile < t_end; tile += G8) {
+        const int tx = tile % a.tiles_x, tq = tile / a.tiles_x, ty = tq % a.tiles_y, img = tq / a.tiles_y;
+        // ---- s2d tile: fp32 -> bf16, channel = c*4 + dy*2 + dx --------------------------------------
+#pragma unroll
+        for (int i = 0; i < SF_NLOAD; ++i) {
+            if (l_pos[i] >= 0) {
+                const f32x4_t v0 = __builtin_bit_cast(f32x4_t, r0[i]), v1 = __builtin_bit_cast(f32x4_t, r1[i]);
+                bf16x4_t pa, pb;
+                pa[0] = (__bf16)v0[0]; pa[1] = (__bf16)v0[1]; pa[2] = (__bf16)v1[0]; pa[3] = (__bf16)v1[1];
+                pb[0] = (__bf16)v0[2]; pb[1] = (__bf16)v0[3]; pb[2] = (__bf16)v1[2]; pb[3] = (__bf16)v1[3];
+                *reinterpret_cast<bf16x4_t*>(ldsX + l_lds[i]) = pa;
+                *reinterpret_cast<bf16x4_t*>(ldsX + l_lds[i] + SF_XPIX) = pb;
+            }
+        }
+        __syncthreads();
+        if (tile + G8 < t_end) fetch(tile + G8);
+        // ---- the tile's own 16x32 s2d pixels go to the xs tensor ------------------------------------
+        {
+            const int xbase = ((img * H2 + 16 * ty) * W2 + 32 * tx) * 32;
+            const int ylim = H2 - 16 * ty, xlim = W2 - 32 * tx;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = (x_pos[i] >> 10) < ylim && (x_pos[i] & 1023) < xlim;
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(ldsX + x_lds[i]);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_xs, ok ? (unsigned)(xbase + x_rel[i]) : MIL_OOB, 0, 0);
+            }
+        }
+        // ---- 4x4 s1 implicit GEMM over the s2d tile, D[channel][pixel] ------------------------------
+        f32x4_t acc[SF_MT][NT];
+#pragma unroll
+        for (int m = 0; m < SF_MT; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = bias_r[nt];
+#pragma unroll
+        for (int sl = 0; sl < KSTEPS; ++sl) {
+            Frag8<BF16> wf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<BF16>(ldsW + ((sl * NT + nt) * 64 + lane) * 16);
+#pragma unroll
+            for (int m = 0; m < SF_MT; ++m) {
+                const Frag8<BF16> xf = lds_frag<BF16>(ldsX + pixbase[m] + toff[sl]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wf[nt], xf, acc[m][nt]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < SF_MT; ++m) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (LAST_PARTIAL && nt == NT - 1 && gq >= 2) continue;        // channels COUTP.. do not exist
+                bf16x4_t o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const float v = acc[m][nt][i]; o[i] = (__bf16)fmaxf(v, v * a.slope); }
+                if (sdst[m] >= 0) *reinterpret_cast<bf16x4_t*>(ldsS + sdst[m] + nt * 32) = o;
+            }
+        }
+        __syncthreads();
+        // ---- 3x3 s2 max-pool of the stem tile; stem pixels outside the image are -inf padding ---------
+        {
+            const int sy0 = 16 * ty - 1, sx0 = 32 * tx - 1;       // image coordinates of stem-tile pixel (0,0)
+            const int obase = ((img * Ho + 8 * ty) * Wo + 16 * tx) * COUTP;
+            const int ylim = Ho - 8 * ty, xlim = Wo - 16 * tx;
+#pragma unroll
+            for (int it = 0; it < NPOOL; ++it) {
+                const int p = p_pos[it];
+                if (p < 0) continue;
+                const int py = p >> 10, px = p & 1023;
+                float best[8];
+                unsigned bi[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        if ((unsigned)(sy0 + 2 * py + ky) < (unsigned)H2 && (unsigned)(sx0 + 2 * px + kx) < (unsigned)W2) {
+                            const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(ldsS + p_lds[it] + (ky * SF_SW + kx) * SPIX);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const float v = (float)t[j];
+                                if (v > best[j]) { best[j] = v; bi[j] = ky * 3 + kx; }
+                            }
+                        }
+                    }
+                }
+                const bool ok = py < ylim && px < xlim;
+                bf16x8_t ov;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { ov[j] = (__bf16)best[j]; bi[j] |= (best[j] > 0.f) ? 0u : 16u; }
+                u32x2_t rec;
+                rec[0] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+                rec[1] = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+                const unsigned eoff = (unsigned)(obase + p_rel[it]);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), rs_p, ok ? eoff * 2u : MIL_OOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(rec, rs_i, ok ? eoff : MIL_OOB, 0, 0);
+            }
+        }
+    }
+}
+
+template <int NT>
+static int launch_stem_fwd(StemFwdArgs a, hipStream_t st) {
+    constexpr int COUTP = mil_nt_to_cp(NT);
+    const int lds = sf_lds_bytes<NT>();
+    auto kern = stem_fwd_fused_kernel<NT>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return MIL_ERR_LAUNCH;
+    // every tensor is addressed with 32-bit offsets below 2 GiB: split the launch by images
+    size_t per_img = (size_t)3 * a.H * a.W * 4;
+    const size_t xs_img = (size_t)a.H2 * a.W2 * 32, p_img = (size_t)a.Ho * a.Wo * COUTP * 2;
+    if (xs_img > per_img) per_img = xs_img;
+    if (p_img > per_img) per_img = p_img;
+    const int chunk = mil_imgs_under_2g(per_img);
+    const int n_total = a.n_img;
+    for (int i0 = 0; i0 < n_total; i0 += chunk) {
+        StemFwdArgs b = a;
+        b.n_img = n_total - i0 < chunk ? n_total - i0 : chunk;
+        b.x = a.x + (size_t)i0 * 3 * a.H * a.W;
+        b.xs = a.xs + (size_t)i0 * a.H2 * a.W2 * 16;
+        b.pool = a.pool + (size_t)i0 * a.Ho * a.Wo * COUTP;
+        b.widx = a.widx + (size_t)i0 * a.Ho * a.Wo * COUTP;
+        b.ntiles = b.n_img * a.tiles_y * a.tiles_x;
+        int grid = (b.ntiles + 7) & ~7;
+        const int cap = 256 * (NT <= 2 ? 2 : 1);
+        if (grid > cap) grid = cap;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, b);
+        MIL_CHECK_LAUNCH();
+    }
+    return MIL_OK;
+}
+
+// xs = s2d(x); pool, widx = maxpool(lrelu(conv7x7s2(x) + bias)).  bf16 only; needs H even, W a multiple of 4 and a
+// 16-byte aligned x (otherwise MIL_ERR_UNSUPPORTED: the caller runs mil_stem_s2d / mil_conv_igemm / mil_maxpool_fwd).
+extern "C" int mil_stem_fwd_fused(const float* x_nchw, const void* wpack, const float* bias_pad, void* xs, void* pool,
+                                  uint8_t* widx, int n_img, int H, int W, int cout_p, float slope, int dtype, void* stream) {
+    if (!x_nchw || !wpack || !xs || !pool || !widx || n_img < 0 || H <= 0 || W <= 0) return MIL_ERR_ARG;
+    if (dtype != MIL_DT_BF16 || (H & 1) || (W & 3) || (reinterpret_cast<uintptr_t>(x_nchw) & 15) || slope < 0.f || slope >= 1.f)
+        return MIL_ERR_UNSUPPORTED;
+    if (cout_p != 24 && cout_p != 64) return MIL_ERR_UNSUPPORTED;
+    if (n_img == 0) return MIL_OK;
+    StemFwdArgs a{};
+    a.x = x_nchw; a.w = (const __bf16*)wpack; a.bias = bias_pad; a.xs = (__bf16*)xs; a.pool = (__bf16*)pool; a.widx = widx;
+    a.n_img = n_img; a.H = H; a.W = W; a.H2 = H / 2; a.W2 = W / 2;
+    a.Ho = (a.H2 - 1) / 2 + 1; a.Wo = (a.W2 - 1) / 2 + 1;
+    a.tiles_y = (a.Ho + 7) / 8; a.tiles_x = (a.Wo + 15) / 16;
+    a.slope = slope;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return cout_p == 24 ? launch_stem_fwd<2>(a, st) : launch_stem_fwd<4>(a, st);
+}

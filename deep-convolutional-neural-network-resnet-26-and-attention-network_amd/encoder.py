@@ -59,6 +59,7 @@ class ResNet(nn.Module):
         self.direct_grad = False        # accumulate parameter gradients straight into existing .grad tensors
         self.n_side_streams = 1
         self.fuse_backward = True
+        self.fuse_stem_forward = True
         self._pack_table = None
         self._pack_version = None
         self._side = None
@@ -149,11 +150,17 @@ class ResNet(nn.Module):
 def encoder_forward(net, x, dtype):
     """Runs the kernels; returns (feats [T,80] fp32, saved-state dict for the backward)."""
     net.refresh_packed(dtype)
-    xs = ops.stem_s2d(x, dtype)
     wp, bp = net._packed("stem", net.conv1.weight, net.conv1.bias, L.PACK_STEM, dtype)
-    stem = ops.conv(xs, wp, bp, ops.cpad(STEM_WIDTH), ks=4, stride=1, pad=2, lrelu=True)
-    pool, widx = ops.maxpool_fwd(stem)
-    saved = {"xs": xs, "stem_hw": tuple(stem.shape[1:3]), "widx": widx, "blocks": []}      # the stem output itself is not kept
+    fused = ops.stem_fwd_fused(x, wp, bp, ops.cpad(STEM_WIDTH), dtype=dtype) if net.fuse_stem_forward else None
+    if fused is not None:
+        xs, pool, widx = fused
+        stem_hw = tuple(xs.shape[1:3])
+    else:
+        xs = ops.stem_s2d(x, dtype)
+        stem = ops.conv(xs, wp, bp, ops.cpad(STEM_WIDTH), ks=4, stride=1, pad=2, lrelu=True)
+        pool, widx = ops.maxpool_fwd(stem)
+        stem_hw = tuple(stem.shape[1:3])
+    saved = {"xs": xs, "stem_hw": stem_hw, "widx": widx, "blocks": []}      # the stem output itself is not kept
     t = pool
     for bi, blk in enumerate(net.blocks()):
         cout = blk.conv1.out_channels

@@ -199,6 +199,31 @@ def maxpool_bwd(gy, widx, in_hw, lrelu_mask=True, slope=LEAK):
     return gx
 
 
+def stem_fwd_fused(x, wpack, bias_pad, cout_p, *, slope=LEAK, dtype=torch.bfloat16):
+    """(xs, pool, widx) of the whole stem in one pass over the fp32 NCHW tiles (see mil_stem_fwd_fused), or None when
+    the shape/dtype has no fused kernel (the caller then runs stem_s2d / conv / maxpool_fwd)."""
+    if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or not x.is_cuda:
+        raise ValueError(f"expected a CUDA fp32 [N,3,H,W] tile stack, got {tuple(x.shape)} {x.dtype} on {x.device}")
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    if dtype != torch.bfloat16 or h % 2 or w % 4 or cout_p not in (24, 64) or x.data_ptr() % 16:
+        return None
+    h2, w2 = h // 2, w // 2
+    hp, wp = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
+    xs = torch.empty((n, h2, w2, 16), dtype=dtype, device=x.device)
+    pool = torch.empty((n, hp, wp, cout_p), dtype=dtype, device=x.device)
+    widx = torch.empty((n, hp, wp, cout_p), dtype=torch.uint8, device=x.device)
+    end = TIMER.bracket(("stem_fwd", cout_p, n, h, w)) if TIMER else None
+    rc = L.lib().mil_stem_fwd_fused(x.data_ptr(), wpack.data_ptr(), L.ptr(bias_pad), xs.data_ptr(), pool.data_ptr(),
+                                    widx.data_ptr(), n, h, w, cout_p, slope, L.dt_code(dtype), L.stream_ptr())
+    if rc == 2:
+        return None
+    L.check(rc, "mil_stem_fwd_fused")
+    if end is not None:
+        end.record()
+    return xs, pool, widx
+
+
 def stem_bwd_fused(xs, g_pool, widx, *, workspace=None, out=None, slope=LEAK):
     """(dW [20,3,7,7], db [20]) of the stem from the pooled-output gradient in one pass (see mil_stem_bwd_fused),
     or None when the shape/dtype has no fused kernel."""

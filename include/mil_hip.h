@@ -103,6 +103,15 @@ int mil_maxpool_fwd(const void* x, void* y, uint8_t* widx, int n, int H, int W, 
 int mil_maxpool_bwd(const void* gy, const uint8_t* widx, void* gx, int n, int H, int W, int cp,
                     int apply_lrelu_mask, float slope, int dtype, void* stream);
 
+/* Fused forward of the whole stem (bf16 path): space-to-depth + Conv2d(3,C,7,2,3) + bias + LeakyReLU +
+ * MaxPool2d(3,2,1) in one pass over the fp32 NCHW tiles (gbm/model.py:24-26,51-53; alt_resnet.py:81-84,128-131
+ * with slope 0).  Writes xs [n,H/2,W/2,16] (kept for the stem weight gradient), pool [n,Hp,Wp,cout_p] and the
+ * winner records widx; bit-identical to mil_stem_s2d -> mil_conv_igemm(ks=4) -> mil_maxpool_fwd, whose
+ * intermediate tensors are never materialised.  cout_p 24 or 64; H even, W % 4 == 0, x 16-byte aligned,
+ * otherwise MIL_ERR_UNSUPPORTED (the caller then uses the three calls). */
+int mil_stem_fwd_fused(const float* x_nchw, const void* wpack, const float* bias_pad, void* xs, void* pool,
+                       uint8_t* widx, int n_img, int H, int W, int cout_p, float slope, int dtype, void* stream);
+
 /* Fused backward of the whole stem (bf16 path): max-pool backward + LeakyReLU backward + the 7x7 conv's weight
  * and bias gradient in one pass over xs [n,H2,W2,16] (mil_stem_s2d output), g_pool [n,Hp,Wp,24] (gradient of
  * the pooled output) and widx (mil_maxpool_fwd's winner records).  Replaces mil_maxpool_bwd + mil_conv_wgrad

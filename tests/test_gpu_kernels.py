@@ -294,3 +294,49 @@ def test_wide_conv_forward_dgrad_wgrad(ops, dtype, case):
     assert rel_err(dw.cpu(), wt.grad) < 3e-5
     dw2, _ws = ops.wide_wgrad(xg, dzg, cin, cout, ks=ks, stride=stride, pad=pad)
     assert torch.equal(dw, dw2)
+
+
+STEM_FUSED_CASES = [
+    # n, H, W, cout, slope
+    (3, 64, 64, 20, LEAK),
+    (2, 256, 256, 20, LEAK),
+    (5, 36, 52, 20, LEAK),          # ragged: 9x13 pooled pixels, partly filled tiles in both directions
+    (9, 30, 132, 20, LEAK),         # three tile columns, odd pooled height
+    (2, 96, 80, 64, 0.0),           # alt_resnet stem: 64 channels, ReLU
+]
+
+
+@pytest.mark.parametrize("case", STEM_FUSED_CASES)
+def test_stem_forward_fused_is_bit_identical_to_the_three_kernels(ops, case):
+    """s2d + 7x7/s2 conv + bias + LeakyReLU + max-pool in one pass must reproduce the unfused chain exactly (same packed
+    filter, same accumulation order, same bf16 roundings); the unfused kernels are checked against torch above."""
+    L = _lib()
+    n, h, w, cout, slope = case
+    g = torch.Generator().manual_seed(17 + h + w)
+    x = torch.randn(n, 3, h, w, generator=g).cuda()
+    wt = (torch.randn(cout, 3, 7, 7, generator=g) * 0.1).cuda()
+    b = (torch.randn(cout, generator=g) * 0.1).cuda()
+    dt = torch.bfloat16
+    wp, bp = ops.pack_weights(wt, b, L.PACK_STEM, dt)
+    cp = cpad(cout)
+    xs0 = ops.stem_s2d(x, dt)
+    stem = ops.conv(xs0, wp, bp, cp, ks=4, stride=1, pad=2, lrelu=True, slope=slope)
+    pool0, widx0 = ops.maxpool_fwd(stem)
+    fused = ops.stem_fwd_fused(x, wp, bp, cp, slope=slope, dtype=dt)
+    assert fused is not None
+    xs1, pool1, widx1 = fused
+    torch.cuda.synchronize()
+    assert torch.equal(xs0, xs1)
+    assert torch.equal(pool0.view(torch.int16), pool1.view(torch.int16))
+    assert torch.equal(widx0, widx1)
+    # and against torch directly (bf16 operands, fp32 accumulate)
+    ref = F.max_pool2d(F.leaky_relu(F.conv2d(round_to(x.cpu(), dt), round_to(wt.cpu(), dt), b.cpu(), stride=2, padding=3), slope), 3, 2, 1)
+    assert rel_err(from_nhwc(pool1, cout), ref) < TOL[dt]
+
+
+def test_stem_forward_fused_declines_unsupported_shapes(ops):
+    L = _lib()
+    wt, b = torch.randn(20, 3, 7, 7).cuda(), torch.zeros(20).cuda()
+    wp, bp = ops.pack_weights(wt, b, L.PACK_STEM, torch.bfloat16)
+    assert ops.stem_fwd_fused(torch.randn(2, 3, 50, 70).cuda(), wp, bp, 24) is None          # W % 4 != 0
+    assert ops.stem_fwd_fused(torch.randn(2, 3, 64, 64).cuda(), wp, bp, 24, dtype=torch.float32) is None
