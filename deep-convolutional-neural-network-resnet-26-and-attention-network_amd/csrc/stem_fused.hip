@@ -36,7 +36,7 @@ constexpr int SF_MT = 9;                            // 16-pixel row tiles per wa
 
 template <int NT>
 __host__ __device__ constexpr int sf_lds_bytes() {
-    return SF_XBYTES + ((SF_NSTEM * mil_pix_pitch(mil_nt_to_cp(NT), 2) + 15) & ~15) + 8 * NT * 64 * 16;
+    return SF_XBYTES + ((SF_NSTEM * mil_pix_pitch(mil_nt_to_cp(NT), 2) + 15) & ~15) + 8 * NT * 64 * 16 + 256;   // + dump slot
 }
 
 template <int NT>
@@ -45,12 +45,16 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void stem_fwd_fused_kernel(St
     constexpr int NG = COUTP / 8;
     constexpr int SPIX = mil_pix_pitch(COUTP, 2);
     constexpr int KSTEPS = 8;
-    constexpr int NPOOL = (128 * NG + 255) / 256;
+    constexpr int NG4 = COUTP / 4;
+    constexpr int NPOOL = (128 * NG4 + 255) / 256;           // (pooled pixel, 4-channel group) items per thread
     constexpr bool LAST_PARTIAL = (COUTP % 16) != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ldsX = smem;
     char* ldsS = smem + SF_XBYTES;
     char* ldsW = ldsS + ((SF_NSTEM * SPIX + 15) & ~15);
+    // LDS writes of unused slots (the last partial rounds of the tables below) go to a dump area instead of being
+    // branched around: a divergent branch per store costs more than the store.
+    const int dump = sf_lds_bytes<NT>() - 256;
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, gq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -68,53 +72,42 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void stem_fwd_fused_kernel(St
     const __amdgpu_buffer_rsrc_t rs_i = mil_rsrc(a.widx, (unsigned)((size_t)a.n_img * Ho * Wo * COUTP));
 
     // ---- tile-invariant tables --------------------------------------------------------------------
-    int l_lds[SF_NLOAD], l_rel[SF_NLOAD], l_pos[SF_NLOAD];       // input -> s2d tile
+    int l_lds[SF_NLOAD], l_rel[SF_NLOAD];       // input -> s2d tile; l_lds = LDS offset | row << 18 | pair << 24 (row 31 = unused)
 #pragma unroll
     for (int i = 0; i < SF_NLOAD; ++i) {
         const int idx = tid + 256 * i;
-        l_pos[i] = -1; l_lds[i] = 0; l_rel[i] = 0;
+        l_lds[i] = dump | (31 << 18); l_rel[i] = 0;
         if (idx < SF_NITEM) {
             const int pair = idx % SF_NPAIR, t = idx / SF_NPAIR;
             const int c = t % 3, row = t / 3;
-            l_pos[i] = (row << 10) | pair;
-            l_lds[i] = (row * SF_XW + 2 * pair) * SF_XPIX + c * 8;
+            l_lds[i] = ((row * SF_XW + 2 * pair) * SF_XPIX + c * 8) | (row << 18) | (pair << 24);
             l_rel[i] = ((c * H + 2 * row) * W + 4 * pair) * 4;
         }
     }
-    int x_lds[4], x_rel[4], x_pos[4];                            // s2d tile interior -> xs tensor (16-B pieces)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int id = tid + 256 * i;
-        const int half = id & 1, px = id >> 1, row = px >> 5, col = px & 31;
-        x_lds[i] = ((row + 3) * SF_XW + col + 4) * SF_XPIX + half * 16;
-        x_rel[i] = (row * W2 + col) * 32 + half * 16;
-        x_pos[i] = (row << 10) | col;
-    }
+    // s2d tile interior -> xs tensor: 16-B piece id = tid + 256*i -> (row 4*i + tid>>6, col (tid>>1)&31, half tid&1)
+    const int x_row0 = tid >> 6, x_col = (tid >> 1) & 31;
+    const int x_lds0 = ((x_row0 + 3) * SF_XW + x_col + 4) * SF_XPIX + (tid & 1) * 16;
+    const int x_rel0 = (x_row0 * W2 + x_col) * 32 + (tid & 1) * 16;
     int pixbase[SF_MT], sdst[SF_MT];                             // MFMA row tiles of the stem tile
 #pragma unroll
     for (int m = 0; m < SF_MT; ++m) {
         const int tp = (wave * SF_MT + m) * 16 + r;
         const bool ok = tp < SF_NSTEM;
         const int sy = tp / SF_SW, sx = tp - sy * SF_SW;
-        pixbase[m] = ok ? (sy * SF_XW + sx + 1) * SF_XPIX : 0;
-        sdst[m] = ok ? tp * SPIX + gq * 8 : -1;
+        // k-group q = 4*step + gq is tap 2*step + (gq>>1), channel group gq&1: the lane-dependent part of the tap offset
+        // ((gq>>1) pixels + (gq&1) pieces) is folded in here, the step-dependent part is a compile-time immediate below
+        pixbase[m] = (ok ? (sy * SF_XW + sx + 1) * SF_XPIX : 0) + (gq >> 1) * SF_XPIX + (gq & 1) * 16;
+        sdst[m] = (ok ? SF_XBYTES + tp * SPIX : dump) + gq * 8;
     }
-    int toff[KSTEPS];
-#pragma unroll
-    for (int sl = 0; sl < KSTEPS; ++sl) {
-        const int q = 4 * sl + gq, tap = q >> 1, cg = q & 1;
-        toff[sl] = ((tap >> 2) * SF_XW + (tap & 3)) * SF_XPIX + cg * 16;
-    }
-    int p_lds[NPOOL], p_rel[NPOOL], p_pos[NPOOL];                // pooled pixels x 8-channel groups
+    int p_lds[NPOOL], p_rel[NPOOL];          // pooled pixels x 4-channel groups; p_lds = LDS offset | py << 20 | px << 24 (py 15 = unused)
 #pragma unroll
     for (int i = 0; i < NPOOL; ++i) {
         const int id = tid + 256 * i;
-        p_pos[i] = -1; p_lds[i] = 0; p_rel[i] = 0;
-        if (id < 128 * NG) {
-            const int c8 = id % NG, pp = id / NG, py = pp >> 4, px = pp & 15;
-            p_pos[i] = (py << 10) | px;
-            p_lds[i] = ((2 * py) * SF_SW + 2 * px) * SPIX + c8 * 16;
-            p_rel[i] = (py * Wo + px) * COUTP + c8 * 8;
+        p_lds[i] = 15 << 20; p_rel[i] = 0;
+        if (id < 128 * NG4) {
+            const int c4 = id % NG4, pp = id / NG4, py = pp >> 4, px = pp & 15;
+            p_lds[i] = (((2 * py) * SF_SW + 2 * px) * SPIX + c4 * 8) | (py << 20) | (px << 24);
+            p_rel[i] = (py * Wo + px) * COUTP + c4 * 4;
         }
     }
     f32x4_t bias_r[NT];
@@ -136,8 +129,8 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void stem_fwd_fused_kernel(St
         const int base = (((img * 3) * H + 2 * y0) * W + c0) * 4;
 #pragma unroll
         for (int i = 0; i < SF_NLOAD; ++i) {
-            const int p = l_pos[i];
-            const bool ok = p >= 0 && (unsigned)(y0 + (p >> 10)) < (unsigned)H2 && (unsigned)(c0 + 4 * (p & 1023)) < (unsigned)W;
+            const int row = (l_lds[i] >> 18) & 31, pair = l_lds[i] >> 24;
+            const bool ok = (unsigned)(y0 + row) < (unsigned)H2 && (unsigned)(c0 + 4 * pair) < (unsigned)W;      // row 31 is never inside
             const unsigned off = ok ? (unsigned)(base + l_rel[i]) : MIL_OOB;
             r0[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
             r1[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off + (unsigned)(W * 4), 0, 0);
@@ -151,14 +144,13 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void stem_fwd_fused_kernel(St
         // ---- s2d tile: fp32 -> bf16, channel = c*4 + dy*2 + dx --------------------------------------
 #pragma unroll
         for (int i = 0; i < SF_NLOAD; ++i) {
-            if (l_pos[i] >= 0) {
-                const f32x4_t v0 = __builtin_bit_cast(f32x4_t, r0[i]), v1 = __builtin_bit_cast(f32x4_t, r1[i]);
-                bf16x4_t pa, pb;
-                pa[0] = (__bf16)v0[0]; pa[1] = (__bf16)v0[1]; pa[2] = (__bf16)v1[0]; pa[3] = (__bf16)v1[1];
-                pb[0] = (__bf16)v0[2]; pb[1] = (__bf16)v0[3]; pb[2] = (__bf16)v1[2]; pb[3] = (__bf16)v1[3];
-                *reinterpret_cast<bf16x4_t*>(ldsX + l_lds[i]) = pa;
-                *reinterpret_cast<bf16x4_t*>(ldsX + l_lds[i] + SF_XPIX) = pb;
-            }
+            const f32x4_t v0 = __builtin_bit_cast(f32x4_t, r0[i]), v1 = __builtin_bit_cast(f32x4_t, r1[i]);
+            bf16x4_t pa, pb;
+            pa[0] = (__bf16)v0[0]; pa[1] = (__bf16)v0[1]; pa[2] = (__bf16)v1[0]; pa[3] = (__bf16)v1[1];
+            pb[0] = (__bf16)v0[2]; pb[1] = (__bf16)v0[3]; pb[2] = (__bf16)v1[2]; pb[3] = (__bf16)v1[3];
+            char* dst = smem + (l_lds[i] & 0x3FFFF);
+            *reinterpret_cast<bf16x4_t*>(dst) = pa;
+            *reinterpret_cast<bf16x4_t*>(dst + SF_XPIX) = pb;
         }
         __syncthreads();
         if (tile + G8 < t_end) fetch(tile + G8);
@@ -168,9 +160,9 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void stem_fwd_fused_kernel(St
             const int ylim = H2 - 16 * ty, xlim = W2 - 32 * tx;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const bool ok = (x_pos[i] >> 10) < ylim && (x_pos[i] & 1023) < xlim;
-                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(ldsX + x_lds[i]);
-                __builtin_amdgcn_raw_buffer_store_b128(v, rs_xs, ok ? (unsigned)(xbase + x_rel[i]) : MIL_OOB, 0, 0);
+                const bool ok = x_row0 + 4 * i < ylim && x_col < xlim;
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(ldsX + x_lds0 + i * (4 * SF_XW * SF_XPIX));
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_xs, ok ? (unsigned)(xbase + x_rel0 + i * (4 * W2 * 32)) : MIL_OOB, 0, 0);
             }
         }
         // ---- 4x4 s1 implicit GEMM over the s2d tile, D[channel][pixel] ------------------------------
@@ -186,61 +178,68 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void stem_fwd_fused_kernel(St
             for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<BF16>(ldsW + ((sl * NT + nt) * 64 + lane) * 16);
 #pragma unroll
             for (int m = 0; m < SF_MT; ++m) {
-                const Frag8<BF16> xf = lds_frag<BF16>(ldsX + pixbase[m] + toff[sl]);
+                const Frag8<BF16> xf = lds_frag<BF16>(ldsX + pixbase[m] + ((sl >> 1) * SF_XW + 2 * (sl & 1)) * SF_XPIX);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wf[nt], xf, acc[m][nt]);
             }
         }
+        // Stem pixels outside the image are the pool's -inf padding: written as such, so that the pool phase below
+        // needs no per-tap bounds tests (only tiles on the image border have any).
+        const int sy0 = 16 * ty - 1, sx0 = 32 * tx - 1;           // image coordinates of stem-tile pixel (0,0)
+        const bool border = sy0 < 0 || sx0 < 0 || sy0 + SF_SH > H2 || sx0 + SF_SW > W2;
 #pragma unroll
         for (int m = 0; m < SF_MT; ++m) {
+            bool inside = true;
+            if (border) {                                     // rare: recompute the pixel's tile coordinates instead of keeping a table
+                const int tp = (wave * SF_MT + m) * 16 + r, sy = (tp * 1986) >> 16, sx = tp - sy * SF_SW;      // tp / 33 for tp < 1024
+                inside = (unsigned)(sy0 + sy) < (unsigned)H2 && (unsigned)(sx0 + sx) < (unsigned)W2;
+            }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if (LAST_PARTIAL && nt == NT - 1 && gq >= 2) continue;        // channels COUTP.. do not exist
                 bf16x4_t o;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { const float v = acc[m][nt][i]; o[i] = (__bf16)fmaxf(v, v * a.slope); }
-                if (sdst[m] >= 0) *reinterpret_cast<bf16x4_t*>(ldsS + sdst[m] + nt * 32) = o;
+                u32x2_t ou = __builtin_bit_cast(u32x2_t, o);
+                if (border) { ou[0] = inside ? ou[0] : 0xFF80FF80u; ou[1] = inside ? ou[1] : 0xFF80FF80u; }
+                *reinterpret_cast<u32x2_t*>(smem + sdst[m] + nt * 32) = ou;
             }
         }
         __syncthreads();
-        // ---- 3x3 s2 max-pool of the stem tile; stem pixels outside the image are -inf padding ---------
+        // ---- 3x3 s2 max-pool of the stem tile: first maximum in (ky,kx) scan order wins ---------------------
         {
-            const int sy0 = 16 * ty - 1, sx0 = 32 * tx - 1;       // image coordinates of stem-tile pixel (0,0)
             const int obase = ((img * Ho + 8 * ty) * Wo + 16 * tx) * COUTP;
             const int ylim = Ho - 8 * ty, xlim = Wo - 16 * tx;
 #pragma unroll
             for (int it = 0; it < NPOOL; ++it) {
-                const int p = p_pos[it];
-                if (p < 0) continue;
-                const int py = p >> 10, px = p & 1023;
-                float best[8];
-                unsigned bi[8];
+                const int py = (p_lds[it] >> 20) & 15, px = p_lds[it] >> 24;
+                const char* src = ldsS + (p_lds[it] & 0xFFFFF);
+                u32x2_t t[9];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+                for (int k = 0; k < 9; ++k) t[k] = *reinterpret_cast<const u32x2_t*>(src + ((k / 3) * SF_SW + (k % 3)) * SPIX);
+                float best[4];
+                unsigned bi[4];
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
+                for (int j = 0; j < 4; ++j) { best[j] = -INFINITY; bi[j] = 0; }
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        if ((unsigned)(sy0 + 2 * py + ky) < (unsigned)H2 && (unsigned)(sx0 + 2 * px + kx) < (unsigned)W2) {
-                            const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(ldsS + p_lds[it] + (ky * SF_SW + kx) * SPIX);
+                for (int k = 0; k < 9; ++k) {
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const float v = (float)t[j];
-                                if (v > best[j]) { best[j] = v; bi[j] = ky * 3 + kx; }
-                            }
-                        }
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned d = t[k][j >> 1];
+                        const float v = __uint_as_float((j & 1) ? (d & 0xFFFF0000u) : (d << 16));
+                        if (v > best[j]) { best[j] = v; bi[j] = k; }
                     }
                 }
-                const bool ok = py < ylim && px < xlim;
-                bf16x8_t ov;
+                const bool ok = py < ylim && px < xlim;                 // py 15 (unused slot) is never inside: ylim <= 8
+                u32x2_t ov;
+                ov[0] = (__float_as_uint(best[0]) >> 16) | (__float_as_uint(best[1]) & 0xFFFF0000u);
+                ov[1] = (__float_as_uint(best[2]) >> 16) | (__float_as_uint(best[3]) & 0xFFFF0000u);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { ov[j] = (__bf16)best[j]; bi[j] |= (best[j] > 0.f) ? 0u : 16u; }
-                u32x2_t rec;
-                rec[0] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
-                rec[1] = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+                for (int j = 0; j < 4; ++j) bi[j] |= (best[j] > 0.f) ? 0u : 16u;
+                const unsigned rec = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
                 const unsigned eoff = (unsigned)(obase + p_rel[it]);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), rs_p, ok ? eoff * 2u : MIL_OOB, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(rec, rs_i, ok ? eoff : MIL_OOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(ov, rs_p, ok ? eoff * 2u : MIL_OOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(rec, rs_i, ok ? eoff : MIL_OOB, 0, 0);
             }
         }
     }
