@@ -105,6 +105,46 @@ class FlatAdam:
     def state_dict(self):
         return {"t": self.t, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr}
 
+    def torch_state_dict(self):
+        """The same state in `torch.optim.Adam.state_dict()` form (what the reference stores under 'optimizer',
+        gbm/classify_combined.py:468-474): per-parameter step / exp_avg / exp_avg_sq, one param group."""
+        state, off = {}, 0
+        for i, p in enumerate(self.flat.params):
+            n = p.numel()
+            if self.t > 0:
+                state[i] = {"step": torch.tensor(float(self.t)),
+                            "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+            off += n
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "decoupled_weight_decay": False, "params": list(range(len(self.flat.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_torch_state_dict(self, sd):
+        """Inverse of torch_state_dict(); accepts a checkpoint written by the reference's torch.optim.Adam over the same
+        parameter list (parameters without state yet start from zero moments)."""
+        group = sd["param_groups"][0]
+        if len(group["params"]) != len(self.flat.params):
+            raise ValueError(f"optimizer state has {len(group['params'])} parameters, the model has {len(self.flat.params)}")
+        self.lr, self.betas, self.eps = float(group["lr"]), tuple(group["betas"]), float(group["eps"])
+        self.weight_decay = float(group.get("weight_decay", 0.0))
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+        steps, off = set(), 0
+        for i, p in enumerate(self.flat.params):
+            n = p.numel()
+            st = sd["state"].get(group["params"][i])
+            if st is not None:
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state {i}: shape {tuple(st['exp_avg'].shape)} != parameter {tuple(p.shape)}")
+                self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(st["step"]))
+            off += n
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): not a state the fused step can continue")
+        self.t = steps.pop() if steps else 0
+
     def load_state_dict(self, sd):
         self.t = int(sd["t"]); self.lr = float(sd.get("lr", self.lr))
         self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])

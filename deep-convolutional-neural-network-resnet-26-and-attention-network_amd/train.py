@@ -80,3 +80,29 @@ def write_attention_map(path, raster, weights, normalise=True):
     with open(path, "w") as f:
         for (row, col), v in zip(raster, w.tolist()):
             f.write(f"{col} {row} {v}\n")
+
+
+def save_checkpoint(path, model, optimizer):
+    """`{'classifier': state_dict, 'optimizer': Adam state}` exactly as the reference writes it per epoch
+    (gbm/classify_combined.py:468-474): its own `torch.load(...)['classifier']` / `optimizer.load_state_dict` read it."""
+    opt = optimizer.torch_state_dict() if hasattr(optimizer, "torch_state_dict") else optimizer.state_dict()
+    torch.save({"classifier": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "optimizer": opt}, path)
+
+
+def load_checkpoint(path, model, optimizer=None, transfer=False):
+    """gbm/classify_combined.py:521-535: full load (`strict=False`), or with `transfer` only the encoder's conv
+    tensors (keys containing both 'cnn' and 'conv').  Returns the (missing, unexpected) key lists."""
+    from .encoder import WEIGHT_EPOCH
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    sd = ckpt["classifier"]
+    if transfer:
+        sd = {k: v for k, v in sd.items() if "cnn" in k and "conv" in k}
+    with torch.no_grad():
+        result = model.load_state_dict(sd, strict=False)
+    WEIGHT_EPOCH[0] += 1                     # packed filter copies are stale
+    if optimizer is not None and not transfer and "optimizer" in ckpt:
+        if hasattr(optimizer, "load_torch_state_dict"):
+            optimizer.load_torch_state_dict(ckpt["optimizer"])
+        else:
+            optimizer.load_state_dict(ckpt["optimizer"])
+    return list(result.missing_keys), list(result.unexpected_keys)

@@ -124,3 +124,52 @@ def test_set_stage_and_attention_map_export(tmp_path):
     assert [round(float(ln.split()[2]), 6) for ln in lines] == [0.0, 1.0, 0.5]
     with pytest.raises(ValueError):
         write_attention_map(str(path), [(0, 0)], torch.tensor([0.1, 0.2]))
+
+
+def test_checkpoint_roundtrip_in_reference_format(tmp_path):
+    """gbm/classify_combined.py:468-474 writes {'classifier', 'optimizer'}; :521-535 reads it (full / conv-only transfer).
+    The file written here must load into a plain torch.optim.Adam over the same parameters, and back."""
+    import torch
+    import mil_amd
+    from mil_amd import train
+    torch.manual_seed(5)
+    model = mil_amd.Attention(3, device="cpu")
+    flat = mil_amd.FlatParams(model)
+    opt = mil_amd.FlatAdam(flat, lr=1e-4)
+    opt.t = 7
+    opt.exp_avg.normal_()
+    opt.exp_avg_sq.uniform_()
+    path = str(tmp_path / "train_step-001.model")
+    train.save_checkpoint(path, model, opt)
+
+    ckpt = torch.load(path, weights_only=True)
+    assert set(ckpt) == {"classifier", "optimizer"}
+    assert list(ckpt["classifier"].keys()) == list(model.state_dict().keys())
+    ref_model = mil_amd.Attention(3, device="cpu")
+    ref_model.load_state_dict(ckpt["classifier"], strict=False)
+    ref_opt = torch.optim.Adam(ref_model.parameters(), betas=(0.9, 0.999), lr=0.0002)      # the reference's optimizer
+    ref_opt.load_state_dict(ckpt["optimizer"])
+    p0 = next(iter(ref_model.parameters()))
+    assert float(ref_opt.state[p0]["step"]) == 7 and ref_opt.param_groups[0]["lr"] == 1e-4
+    n0 = p0.numel()
+    assert torch.equal(ref_opt.state[p0]["exp_avg"].reshape(-1), opt.exp_avg[:n0])
+
+    # a checkpoint written by torch's Adam loads into the fused optimizer
+    path2 = str(tmp_path / "from_torch.model")
+    torch.save({"classifier": ref_model.state_dict(), "optimizer": ref_opt.state_dict()}, path2)
+    model2 = mil_amd.Attention(3, device="cpu")
+    flat2 = mil_amd.FlatParams(model2)
+    opt2 = mil_amd.FlatAdam(flat2)
+    missing, unexpected = train.load_checkpoint(path2, model2, opt2)
+    assert not missing and not unexpected
+    assert torch.equal(flat2.flat, flat.flat) and opt2.t == 7 and opt2.lr == 1e-4
+    assert torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+    assert all(p.data_ptr() >= flat2.flat.data_ptr() for p in model2.parameters())         # still views of the bucket
+
+    # transfer: only the encoder's conv tensors move
+    model3 = mil_amd.Attention(3, device="cpu")
+    before = {k: v.clone() for k, v in model3.state_dict().items()}
+    train.load_checkpoint(path, model3, transfer=True)
+    for k, v in model3.state_dict().items():
+        moved = "cnn" in k and "conv" in k
+        assert torch.equal(v, ckpt["classifier"][k]) if moved else torch.equal(v, before[k]), k
