@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmil_hip.so")
 
 MIL_DT_F32, MIL_DT_BF16 = 0, 1
-PACK_FWD, PACK_DGRAD, PACK_STEM = 0, 1, 2
+PACK_FWD, PACK_DGRAD, PACK_STEM, PACK_DGRAD_S2 = 0, 1, 2, 3
 _ERR = {1: "invalid argument", 2: "unsupported shape / channel configuration", 3: "kernel launch failed"}
 
 
@@ -45,6 +45,7 @@ _SIGS = {
     "mil_conv_bwd_fused": ([_vp] * 8 + [_sz] + [_i] * 9 + [_f, _i, _vp], _i),
     "mil_maxpool_fwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "mil_maxpool_bwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
+    "mil_conv_dgrad_s2": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
     "mil_stem_fwd_fused": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp], _i),
     "mil_stem_bwd_fused_workspace": ([_c.POINTER(_sz), _i, _i, _i, _i], _i),
     "mil_stem_bwd_fused": ([_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _f, _i, _i, _vp], _i),

@@ -130,12 +130,13 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(BwdFusedArgs a) 
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
     TileWalker cur, nxt;
-    cur.init(g, blockIdx.x, gridDim.x);
+    const int bid = mil_xcd_block_id();
+    cur.init(g, bid, gridDim.x);
     nxt = cur; nxt.advance();
     u32x4_t rx[NPX];
-    if ((int)blockIdx.x < a.ntiles) mil_fetch_halo<CZ, NPX>(rx, rs_z, ht, g, cur.origin(g));
+    if (bid < a.ntiles) mil_fetch_halo<CZ, NPX>(rx, rs_z, ht, g, cur.origin(g));
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    for (int tile = bid; tile < a.ntiles; tile += gridDim.x) {
         const TileOrigin o = cur.origin(g);
         __syncthreads();                       // previous tile: all reads of ldsA / ldsX are done
         mil_commit_halo<NPX>(rx, ldsA, ht);

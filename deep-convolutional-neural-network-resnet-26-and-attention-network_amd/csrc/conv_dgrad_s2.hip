@@ -1,0 +1,265 @@
+// Data gradient of a stage-entry block's input (bf16 path): the transposed 3x3 stride-2 conv of dz1 PLUS the
+// transposed 1x1 stride-2 projection of dz, times the lrelu' mask of the block input — one pass
+// (reference: autograd of nnBlocks.py:175-189 for the blocks built at gbm/model.py:37-41).
+//
+// The zero-insert form (conv_igemm with zero_insert=1) stages a halo tile that is 3/4 zeros, multiplies all 9
+// taps against it, and needs a second launch plus a full-resolution temporary for the projection.  Here the 256
+// output pixels of a tile are split by parity class (py,px) = (y&1, x&1): each class is a 1/2/2/4-tap conv over
+// the COMPACT dz map (geom.cuh: mil_s2_group), so the LDS tile is 81 pixels instead of 324, the MFMA work drops
+// from 9 to 2.25 taps per output pixel, and the projection is 5..10 more K-groups of class (0,0) read from a
+// second compact tile.  Wave w owns row tile w (16 pixels) of every class; the paired 16-byte register epilogue
+// of the persistent conv kernel then stores two horizontally adjacent output pixels per lane pair.
+#include "pf_common.cuh"
+
+struct DgradS2Args {
+    const __bf16* dz1;      // [n,h,w,CZ]   gradient of the 3x3/s2 conv's output
+    const __bf16* dz2;      // [n,h,w,CZ]   gradient of the block output (input of the projection's transposed conv), or null
+    const __bf16* w;        // MIL_PACK_DGRAD_S2 fragments [mil_s2_nsteps][NT][64][8]
+    const __bf16* act;      // [n,H,W,CXP]  block input (lrelu' mask), or null
+    __bf16* y;              // [n,H,W,CXP]
+    ConvGeom g;             // output tiling: Ho=H, Wo=W (dx), H=h, W=w (dz)
+    int ch, cw;             // compact halo extent per image: TH/2+1, TW/2+1
+    int lds_z2_off, lds_w_off;
+    float slope;
+};
+
+template <int CZ, int NT>
+__global__ __launch_bounds__(256, CZ <= 40 ? 2 : 1) void conv_dgrad_s2_kernel(DgradS2Args a, int ntiles, unsigned z_bytes, unsigned y_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CG = CZ / 8;
+    constexpr int PIXZ = mil_pix_pitch(CZ, 2);
+    constexpr int CXP = mil_nt_to_cp(NT);
+    constexpr int NS = mil_s2_nsteps(CG);
+    constexpr int NPZ = (144 * CG + 255) / 256;              // <= 144 compact halo pixels (16 images of 3x3)
+    constexpr bool LAST_PARTIAL = (CXP % 16) != 0;
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, gq = lane >> 4;
+    char* ldsZ = smem;
+    char* ldsW = smem + a.lds_w_off;
+    {
+        const char* src = reinterpret_cast<const char*>(a.w);
+        for (int i = tid * 16; i < NS * NT * 64 * 16; i += 256 * 16)
+            *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(src + i);
+    }
+    const __amdgpu_buffer_rsrc_t rs_z1 = mil_rsrc(a.dz1, z_bytes);
+    const __amdgpu_buffer_rsrc_t rs_z2 = mil_rsrc(a.dz2, a.dz2 ? z_bytes : 0);
+    const __amdgpu_buffer_rsrc_t rs_act = mil_rsrc(a.act, a.act ? y_bytes : 0);
+    const __amdgpu_buffer_rsrc_t rs_y = mil_rsrc(a.y, y_bytes);
+    const int CH = a.ch, CW = a.cw, h = g.H, w = g.W, H = g.Ho, W = g.Wo;
+    const int TW = 1 << g.tw_log2, TH = 1 << g.th_log2;
+
+    // ---- tile-invariant tables ---------------------------------------------------------------------
+    int z_pos[NPZ], z_lds[NPZ], z_rel[NPZ];                  // compact halo pieces (same for both sources)
+    {
+        const int total = ((CH * CW) << g.ti_log2) * CG;
+#pragma unroll
+        for (int i = 0; i < NPZ; ++i) {
+            const int idx = tid + 256 * i;
+            z_pos[i] = -1; z_lds[i] = 0; z_rel[i] = 0;
+            if (idx < total) {
+                const int p = idx / CG, j = idx - p * CG;
+                const int cx = p % CW, t = p / CW, cy = t % CH, ti = t / CH;
+                z_pos[i] = (ti << 20) | (cy << 10) | cx;
+                z_lds[i] = p * PIXZ + j * 16;
+                z_rel[i] = ((ti * h + cy) * w + cx) * (CZ * 2) + j * 16;
+            }
+        }
+    }
+    // class pixel of this lane: index wave*16 + r of the 64 (ti, i, j) positions; the same for all four classes
+    const int cp = wave * 16 + r;
+    const int cj = cp & (TW / 2 - 1), ci = (cp >> (g.tw_log2 - 1)) & (TH / 2 - 1), cti = cp >> (g.tw_log2 + g.th_log2 - 2);
+    const int pixbase = ((cti * CH + ci) * CW + cj) * PIXZ;
+    int toff[NS];
+    {
+        int s = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int sl = 0; sl < mil_s2_steps(c, CG); ++sl, ++s) {
+                const S2Group gr = mil_s2_group(c, 4 * sl + gq, CG);
+                toff[s] = gr.valid ? gr.src * a.lds_z2_off + (gr.di * CW + gr.dj) * PIXZ + gr.cg * 16 : 0;
+            }
+        }
+    }
+    // epilogue: after one v_permlane16_swap per accumulator register between classes 2p and 2p+1 a lane holds 8
+    // consecutive channels (16*nt + 8*(gq>>1) ...) of output pixel (2i + p, 2j + (gq&1))
+    int o_rel[2], o_pos[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int oy = 2 * ci + p, ox = 2 * cj + (gq & 1);
+        o_rel[p] = ((cti * H + oy) * W + ox) * (CXP * 2) + (gq >> 1) * 16;
+        o_pos[p] = (cti << 20) | (oy << 10) | ox;
+    }
+    const bool last_ok = !LAST_PARTIAL || (gq >> 1) == 0;
+
+    TileWalker cur, nxt;
+    const int bid = mil_xcd_block_id();
+    cur.init(g, bid, gridDim.x);
+    nxt = cur; nxt.advance();
+    auto fetch_z = [&](u32x4_t (&r1)[NPZ], u32x4_t (&r2)[NPZ], const TileOrigin& o) {
+        const int i0 = o.oy0 >> 1, j0 = o.ox0 >> 1;
+        const int base = ((o.img0 * h + i0) * w + j0) * (CZ * 2);
+        const int ylim = h - i0, xlim = w - j0, ilim = g.n_img - o.img0;
+#pragma unroll
+        for (int i = 0; i < NPZ; ++i) {
+            const int p = z_pos[i];
+            const bool ok = p >= 0 && (p >> 20) < ilim && ((p >> 10) & 1023) < ylim && (p & 1023) < xlim;
+            const unsigned off = ok ? (unsigned)(base + z_rel[i]) : MIL_OOB;
+            r1[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_z1, off, 0, 0);
+            r2[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_z2, off, 0, 0);
+        }
+    };
+    auto fetch_epi = [&](const TileOrigin& o, unsigned (&ooff)[2], u32x4_t (&ract)[2][NT]) {
+        const int obase = ((o.img0 * H + o.oy0) * W + o.ox0) * (CXP * 2);
+        const int ylim = H - o.oy0, xlim = W - o.ox0, ilim = g.n_img - o.img0;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const bool ok = (o_pos[p] >> 20) < ilim && ((o_pos[p] >> 10) & 1023) < ylim && (o_pos[p] & 1023) < xlim;
+            ooff[p] = ok ? (unsigned)(obase + o_rel[p]) : MIL_OOB;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 32;
+                if (a.act) ract[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, off, 0, 0);
+            }
+        }
+    };
+
+    u32x4_t rz1[NPZ], rz2[NPZ];
+    unsigned ooff_n[2];
+    u32x4_t ract_n[2][NT];
+    if (bid < ntiles) {
+        fetch_z(rz1, rz2, cur.origin(g));
+        fetch_epi(cur.origin(g), ooff_n, ract_n);
+    }
+    const int G = gridDim.x;
+    for (int tile = bid; tile < ntiles; tile += G) {
+        __syncthreads();                       // every wave has finished reading the compact tiles of the previous tile
+#pragma unroll
+        for (int i = 0; i < NPZ; ++i) {
+            if (z_pos[i] >= 0) {
+                *reinterpret_cast<u32x4_t*>(ldsZ + z_lds[i]) = rz1[i];
+                *reinterpret_cast<u32x4_t*>(ldsZ + a.lds_z2_off + z_lds[i]) = rz2[i];
+            }
+        }
+        unsigned ooff[2];
+        u32x4_t ract[2][NT];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            ooff[p] = ooff_n[p];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) ract[p][nt] = ract_n[p][nt];
+        }
+        __syncthreads();
+        if (tile + G < ntiles) {
+            fetch_z(rz1, rz2, nxt.origin(g));
+            fetch_epi(nxt.origin(g), ooff_n, ract_n);
+        }
+        cur = nxt; nxt.advance();
+
+        f32x4_t acc[4][NT];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[c][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        {
+            int s = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int sl = 0; sl < mil_s2_steps(c, CG); ++sl, ++s) {
+                    const Frag8<BF16> xf = lds_frag<BF16>(ldsZ + pixbase + toff[s]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const Frag8<BF16> wf = lds_frag<BF16>(ldsW + ((s * NT + nt) * 64 + lane) * 16);
+                        acc[c][nt] = mma8(wf, xf, acc[c][nt]);          // D[channel][pixel]
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float lo = acc[2 * p][nt][i], hi = acc[2 * p + 1][nt][i];
+                    if (i == 0) mil_swap16<true>(lo, hi); else mil_swap16<false>(lo, hi);
+                    v[i] = lo;
+                    v[4 + i] = hi;
+                }
+                if (a.act) {
+                    const bf16x8_t t = __builtin_bit_cast(bf16x8_t, ract[p][nt]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] *= ((float)t[i] > 0.f ? 1.f : a.slope);
+                }
+                bf16x8_t ov;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ov[i] = (__bf16)v[i];
+                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 32;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), rs_y, off, 0, 0);
+            }
+        }
+    }
+}
+
+template <int CZ, int NT>
+static int launch_dgrad_s2(DgradS2Args a, hipStream_t st) {
+    constexpr int CG = CZ / 8, PIXZ = mil_pix_pitch(CZ, 2), CXP = mil_nt_to_cp(NT);
+    mil_geom_tiles(a.g, 8);
+    if (a.g.tw_log2 < 1 || a.g.th_log2 < 1) return MIL_ERR_UNSUPPORTED;
+    a.ch = (1 << a.g.th_log2) / 2 + 1; a.cw = (1 << a.g.tw_log2) / 2 + 1;
+    const int npx = (a.ch * a.cw) << a.g.ti_log2;
+    if (npx > 144) return MIL_ERR_UNSUPPORTED;
+    const int z_bytes = (npx * PIXZ + 15) & ~15;
+    const int w_bytes = mil_s2_nsteps(CG) * NT * 64 * 16;
+    a.lds_z2_off = z_bytes; a.lds_w_off = 2 * z_bytes;
+    const int lds = 2 * z_bytes + w_bytes;
+    if (lds > 160 * 1024) return MIL_ERR_UNSUPPORTED;
+    auto kern = conv_dgrad_s2_kernel<CZ, NT>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return MIL_ERR_LAUNCH;
+    int per_cu = (160 * 1024) / lds;
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    const size_t z_img = (size_t)a.g.H * a.g.W * CZ * 2, y_img = (size_t)a.g.Ho * a.g.Wo * CXP * 2;
+    int chunk = mil_imgs_under_2g(z_img > y_img ? z_img : y_img);
+    if (chunk >= 16) chunk &= ~15;
+    const int n_total = a.g.n_img;
+    for (int i0 = 0; i0 < n_total; i0 += chunk) {
+        const int n = (n_total - i0 < chunk) ? n_total - i0 : chunk;
+        DgradS2Args c = a;
+        c.g.n_img = n;
+        c.g.n_groups = (n + (1 << c.g.ti_log2) - 1) >> c.g.ti_log2;
+        c.dz1 = a.dz1 + (size_t)i0 * (z_img / 2);
+        if (a.dz2) c.dz2 = a.dz2 + (size_t)i0 * (z_img / 2);
+        if (a.act) c.act = a.act + (size_t)i0 * (y_img / 2);
+        c.y = a.y + (size_t)i0 * (y_img / 2);
+        const int ntiles = c.g.n_groups * c.g.tiles_y * c.g.tiles_x;
+        int grid = 256 * per_cu;
+        if (grid > ntiles) grid = ntiles;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, c, ntiles, (unsigned)(z_img * n), (unsigned)(y_img * n));
+        MIL_CHECK_LAUNCH();
+    }
+    return MIL_OK;
+}
+
+// y[n,H,W,cx_p] = lrelu'(act) * ( conv3x3_s2^T(dz1) + conv1x1_s2^T(dz2) ), with wpack from
+// mil_pack_conv_weights(mode MIL_PACK_DGRAD_S2: w = the 3x3 weight, bias argument = the 1x1 projection weight or null).
+// dz1/dz2 [n,h,w,cz_p] with h = (H-1)/2+1, w = (W-1)/2+1.  bf16, (cz_p,cx_p) in {(40,24),(64,40),(80,64)}.
+extern "C" int mil_conv_dgrad_s2(const void* dz1, const void* dz2, const void* wpack, const void* act, void* y, int n_img,
+                                 int h, int w, int cz_p, int H, int W, int cx_p, float slope, int dtype, void* stream) {
+    if (!dz1 || !wpack || !y || n_img < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return MIL_ERR_ARG;
+    if (dtype != MIL_DT_BF16 || h != (H - 1) / 2 + 1 || w != (W - 1) / 2 + 1 || slope < 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
+    if (n_img == 0) return MIL_OK;
+    DgradS2Args a{};
+    a.dz1 = (const __bf16*)dz1; a.dz2 = (const __bf16*)dz2; a.w = (const __bf16*)wpack; a.act = (const __bf16*)act; a.y = (__bf16*)y;
+    a.g.n_img = n_img; a.g.H = h; a.g.W = w; a.g.Ho = H; a.g.Wo = W; a.g.ks = 3; a.g.stride = 1; a.g.pad = 1; a.g.zins = 1;
+    a.slope = slope;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (cz_p == 40 && cx_p == 24) return launch_dgrad_s2<40, 2>(a, st);
+    if (cz_p == 64 && cx_p == 40) return launch_dgrad_s2<64, 3>(a, st);
+    if (cz_p == 80 && cx_p == 64) return launch_dgrad_s2<80, 4>(a, st);
+    return MIL_ERR_UNSUPPORTED;
+}

@@ -228,7 +228,8 @@ __global__ __launch_bounds__(256, ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 40 ? 
         for (int i = 0; i < 4; ++i) bias_r[nt][i] = a.bias ? a.bias[nt * 16 + gq * 4 + i] : 0.f;
 
     TileWalker cur, nxt;
-    cur.init(g, blockIdx.x, gridDim.x);
+    const int bid = mil_xcd_block_id();
+    cur.init(g, bid, gridDim.x);
     nxt = cur; nxt.advance();
     // epilogue operand offsets + loads of one tile (16 bytes = 8 channels per lane per (row-tile pair, column tile))
     auto fetch_epi = [&](const TileOrigin& o, unsigned (&ooff)[NPAIR], u32x4_t (&rres)[NPAIR][NT], u32x4_t (&ract)[NPAIR][NT]) {
@@ -260,12 +261,12 @@ __global__ __launch_bounds__(256, ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 40 ? 
     u32x4_t rxA[NPX], rxB[DEPTH == 2 ? NPX : 1];
     unsigned ooff_n[EPI_AHEAD ? NPAIR : 1];
     u32x4_t rres_n[EPI_AHEAD ? NPAIR : 1][NT], ract_n[EPI_AHEAD ? NPAIR : 1][NT];
-    if ((int)blockIdx.x < ntiles) {
+    if (bid < ntiles) {
         mil_fetch_halo<CINP, NPX>(rxA, rs_x, ht, g, cur.origin(g));
         if constexpr (EPI_AHEAD) fetch_epi(cur.origin(g), ooff_n, rres_n, ract_n);
     }
     if constexpr (DEPTH == 2) {
-        if ((int)blockIdx.x + G < ntiles) mil_fetch_halo<CINP, NPX>(rxB, rs_x, ht, g, nxt.origin(g));
+        if (bid + G < ntiles) mil_fetch_halo<CINP, NPX>(rxB, rs_x, ht, g, nxt.origin(g));
     }
 
     auto do_tile = [&](u32x4_t (&rx)[NPX], int tile) {
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(256, ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 40 ? 
         }
     };
 
-    for (int tile = blockIdx.x; tile < ntiles;) {
+    for (int tile = bid; tile < ntiles;) {
         do_tile(rxA, tile);
         tile += G;
         if constexpr (DEPTH == 2) {

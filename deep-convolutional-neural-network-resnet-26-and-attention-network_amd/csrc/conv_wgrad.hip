@@ -91,19 +91,20 @@ __global__ __launch_bounds__(256, (PF && CINP > 40) ? 1 : 0) void wgrad_kernel(W
     OtileTables<NPZ> zt;
     TileWalker cur, nxt;
     __amdgpu_buffer_rsrc_t rs_x, rs_z;
+    const int bid = mil_xcd_block_id();
     if constexpr (PF) {
         rs_x = mil_rsrc(a.x, a.x_bytes);
         rs_z = mil_rsrc(a.dz, a.z_bytes);
         mil_build_halo_tables<CINP, NPX>(ht, g, tid);
         mil_build_otile_tables<COUTP, NPZ>(zt, g, tid, a.tile_px);
-        cur.init(g, blockIdx.x, gridDim.x);
+        cur.init(g, bid, gridDim.x);
         nxt = cur; nxt.advance();
-        if ((int)blockIdx.x < a.ntiles) {
+        if (bid < a.ntiles) {
             mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, cur.origin(g));
             mil_fetch_otile<COUTP, NPZ>(rz, rs_z, zt, g, cur.origin(g));
         }
     }
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    for (int tile = bid; tile < a.ntiles; tile += gridDim.x) {
         __syncthreads();
         if constexpr (PF) {
             mil_commit_halo<NPX>(rx, ldsX, ht);
@@ -459,15 +460,16 @@ __global__ __launch_bounds__(256) void stem_bwd_fused_kernel(StemBwdArgs a) {
     const int b_y = b_rem / bW, b_x = b_rem - b_y * bW;
 
     TileWalker cur, nxt;
-    cur.init(g, blockIdx.x, gridDim.x);
+    const int bid = mil_xcd_block_id();
+    cur.init(g, bid, gridDim.x);
     nxt = cur; nxt.advance();
     u32x4_t rx[NPX], rgp[NPW];
     u32x2_t rwi[NPW];
-    if ((int)blockIdx.x < a.ntiles) {
+    if (bid < a.ntiles) {
         mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, cur.origin(g));
         fetch_win(rgp, rwi, cur.origin(g));
     }
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    for (int tile = bid; tile < a.ntiles; tile += gridDim.x) {
         __syncthreads();                         // previous tile's MFMA loop is done with ldsX / ldsZ
         mil_commit_halo<NPX>(rx, ldsX, ht);
 #pragma unroll

@@ -212,3 +212,41 @@ __host__ __device__ constexpr int mil_halo_np(int cinp, int esz) { return (400 *
 // same for 128-px tiles: 10x18, 2 x 10x10 and 8 x 6x6 halos (<= 288 pixels)
 __host__ __device__ constexpr int mil_halo_px_max(int mtw) { return mtw == 4 ? 400 : 288; }
 __host__ __device__ constexpr int mil_halo_np_mtw(int cinp, int esz, int mtw) { return (mil_halo_px_max(mtw) * (cinp * esz / 16) + 255) / 256; }
+
+// ---- stride-2 transposed conv (3x3, pad 1) by output parity class ---------------------------------------------
+// dx(2i+py, 2j+px) only sees the taps (ky,kx) of the zero-insert form whose source coordinate is even:
+// py=0 -> ky=1 (dz row i);  py=1 -> ky=0 (row i), ky=2 (row i+1); same for columns.  Class c = py*2+px therefore
+// is a 1-, 2-, 2- or 4-tap conv over the COMPACT dz map; the 1x1/s2 projection's transposed conv lands on class 0
+// only (second source).  K-groups of a class: (tap, 8-channel group) in tap order, then the projection's groups.
+#define MIL_PACK_DGRAD_S2 3
+struct S2Group { int src, ky, kx, di, dj, cg; bool valid; };
+__host__ __device__ inline S2Group mil_s2_group(int c, int q, int CG) {
+    S2Group gr{0, 0, 0, 0, 0, 0, false};
+    const int py = c >> 1, px = c & 1;
+    const int nkx = px ? 2 : 1, ntap = (py ? 2 : 1) * nkx;
+    if (q < ntap * CG) {
+        const int t = q / CG;
+        gr.cg = q - t * CG;
+        const int iy = t / nkx, ix = t - iy * nkx;
+        gr.ky = py ? 2 * iy : 1; gr.kx = px ? 2 * ix : 1;
+        gr.di = (py + gr.ky - 1) >> 1; gr.dj = (px + gr.kx - 1) >> 1;
+        gr.valid = true;
+    } else if (c == 0 && q < 2 * CG) {
+        gr.src = 1; gr.cg = q - CG; gr.valid = true;
+    }
+    return gr;
+}
+__host__ __device__ constexpr int mil_s2_steps(int c, int CG) { return c == 3 ? CG : (CG + 1) / 2; }
+__host__ __device__ constexpr int mil_s2_nsteps(int CG) { return 3 * ((CG + 1) / 2) + CG; }
+// packed element (global k-step s, lane, e, column tile nt) of the class-ordered filter: w1 [cout][cin][3][3] is the
+// forward conv's weight, wproj [cout][cin] the 1x1 projection's (or null); k = its output channel, n = its input channel
+__host__ __device__ inline float mil_s2_pack_value(const float* w1, const float* wproj, int s, int lane, int e, int nt,
+                                                   int cout, int cin, int CG) {
+    int c = 0;
+    while (s >= mil_s2_steps(c, CG)) { s -= mil_s2_steps(c, CG); ++c; }
+    const S2Group gr = mil_s2_group(c, 4 * s + (lane >> 4), CG);
+    const int kin = gr.cg * 8 + e, nout = nt * 16 + (lane & 15);
+    if (!gr.valid || kin >= cout || nout >= cin) return 0.f;
+    if (gr.src == 1) return wproj ? wproj[(size_t)kin * cin + nout] : 0.f;
+    return w1[((size_t)kin * cin + nout) * 9 + (2 - gr.ky) * 3 + (2 - gr.kx)];
+}

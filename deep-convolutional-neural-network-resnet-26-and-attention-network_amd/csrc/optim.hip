@@ -2,7 +2,7 @@
 // gradient buckets (one launch for all 640,967 parameters; reference: torch.optim.Adam(lr=2e-4) at
 // gbm/classify_combined.py:519, stepped every few bags at :450-454) and a single-launch re-pack of every
 // convolution filter into MFMA fragment order after the weights changed.
-#include "common.cuh"
+#include "geom.cuh"
 
 // torch.optim.Adam semantics (no amsgrad, L2 weight decay folded into the gradient):
 //   g += wd*p;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;
@@ -53,13 +53,19 @@ __global__ void pack_all_kernel(const PackJob* __restrict__ jobs) {
     const PackJob j = jobs[blockIdx.y];
     const int total = j.nsteps * j.NT * 64 * 8;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        if (idx < j.NT * 16 && j.bias_pad) {
+        if (idx < j.NT * 16 && j.bias_pad && j.mode != MIL_PACK_DGRAD_S2) {
             const int n_out = (j.mode == 1) ? j.cin : j.cout;
             j.bias_pad[idx] = (j.bias && idx < n_out) ? j.bias[idx] : 0.f;
         }
         const int e = idx & 7, lane = (idx >> 3) & 63;
         const int t = idx >> 9;
         const int nt = t % j.NT, s = t / j.NT;
+        if (j.mode == MIL_PACK_DGRAD_S2) {      // `bias` carries the projection's weight for this mode
+            const float v = mil_s2_pack_value(j.w, j.bias, s, lane, e, nt, j.cout, j.cin, j.CG);
+            if (j.dtype == MIL_DT_BF16) reinterpret_cast<__bf16*>(j.out)[idx] = (__bf16)v;
+            else reinterpret_cast<float*>(j.out)[idx] = v;
+            continue;
+        }
         const int q = 4 * s + (lane >> 4);
         const int tap = q / j.CG, cg = q - tap * j.CG;
         const int kin = cg * 8 + e, nout = nt * 16 + (lane & 15);
@@ -86,7 +92,7 @@ extern "C" int mil_pack_job_bytes(void) { return (int)sizeof(PackJob); }
 
 extern "C" int mil_pack_job_fill(void* job_host, const float* w, const float* bias, void* out, float* bias_pad, int cout,
                                  int cin, int ks, int mode, int dtype) {
-    if (!job_host || !w || !out || mode < 0 || mode > 2) return MIL_ERR_ARG;
+    if (!job_host || !w || !out || mode < 0 || mode > 3) return MIL_ERR_ARG;
     PackJob* j = reinterpret_cast<PackJob*>(job_host);
     int cin_exec, cout_exec, ks_exec;
     if (mode == 2) { cin_exec = 16; cout_exec = mil_cpad(cout); ks_exec = 4; }
@@ -96,6 +102,7 @@ extern "C" int mil_pack_job_fill(void* job_host, const float* w, const float* bi
     j->cout = cout; j->cin = cin; j->ks = ks; j->mode = mode;
     j->CG = cin_exec / 8; j->NT = (cout_exec + 15) / 16;
     j->nsteps = (ks_exec * ks_exec * j->CG + 3) / 4; j->dtype = dtype;
+    if (mode == MIL_PACK_DGRAD_S2) { j->CG = mil_cpad(cout) / 8; j->NT = (mil_cpad(cin) + 15) / 16; j->nsteps = mil_s2_nsteps(j->CG); }
     return MIL_OK;
 }
 

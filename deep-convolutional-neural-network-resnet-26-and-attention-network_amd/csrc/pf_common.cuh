@@ -40,6 +40,15 @@ struct TileWalker {
     }
 };
 
+// Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2.  Persistent tile walks start from this
+// id instead of blockIdx.x, so that the G/8 workgroups resident on ONE XCD work on consecutive tiles (= neighbouring
+// tiles of the same images) at any time and the halo rows/columns neighbouring tiles share are L2 hits there
+// instead of a second HBM/MALL fetch from another XCD.
+__device__ __forceinline__ int mil_xcd_block_id() {
+    const int b = blockIdx.x, G = gridDim.x;
+    return (G & 7) ? b : (b & 7) * (G >> 3) + (b >> 3);
+}
+
 // Halo pieces (16 B) owned by a thread: flat piece id = tid + 256*i.
 //   pos = (ti<<20)|(hy<<10)|hx, or -1 when the slot is unused;  lds = byte offset in the LDS halo tile;
 //   rel = byte offset of the piece relative to the halo origin pixel of image img0 (plain loader only)

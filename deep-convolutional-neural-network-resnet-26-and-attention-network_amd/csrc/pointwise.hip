@@ -2,7 +2,7 @@
 // MFMA fragment order, max-pool (fwd + bwd fused with the stem's LeakyReLU mask), global average pool
 // + bias-free linear (fwd + bwd).  Reference ops: gbm/model.py:24-26 (stem conv/LeakyReLU/MaxPool2d),
 // gbm/model.py:31-32,58-60 (AdaptiveAvgPool2d + fc).
-#include "common.cuh"
+#include "geom.cuh"
 
 // ---------------------------------------------------------------------------------------------
 // fp32 NCHW [n,3,H,W]  ->  NHWC space-to-depth [n, ceil(H/2), ceil(W/2), 16]; channel = c*4 + dy*2 + dx
@@ -63,7 +63,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, const float* __
                                     int ks, int mode, int CG, int NT, int nsteps) {
     const int total = nsteps * NT * 64 * 8;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < NT * 16 && bias_pad) {
+    if (idx < NT * 16 && bias_pad && mode != MIL_PACK_DGRAD_S2) {
         const int n_out = (mode == MIL_PACK_DGRAD) ? cin : cout;
         bias_pad[idx] = (bias && idx < n_out) ? bias[idx] : 0.f;
     }
@@ -71,6 +71,10 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, const float* __
     const int j = idx & 7, lane = (idx >> 3) & 63;
     const int t = idx >> 9;
     const int nt = t % NT, s = t / NT;
+    if (mode == MIL_PACK_DGRAD_S2) {            // `bias` carries the projection's weight for this mode
+        out[idx] = (typename T::elem)mil_s2_pack_value(w, bias, s, lane, j, nt, cout, cin, CG);
+        return;
+    }
     const int q = 4 * s + (lane >> 4);
     const int tap = q / CG, cg = q - tap * CG;
     const int kin = cg * 8 + j, nout = nt * 16 + (lane & 15);
@@ -97,6 +101,7 @@ static void pack_dims(int cout, int cin, int ks, int mode, int* CG, int* NT, int
     *CG = cin_exec / 8;
     *NT = (cout_exec + 15) / 16;
     *nsteps = (ks_exec * ks_exec * (*CG) + 3) / 4;
+    if (mode == MIL_PACK_DGRAD_S2) { *CG = mil_cpad(cout) / 8; *NT = (mil_cpad(cin) + 15) / 16; *nsteps = mil_s2_nsteps(*CG); }
 }
 
 extern "C" int mil_packed_weight_elems(size_t* elems, int cout, int cin, int ks, int mode) {
@@ -109,7 +114,7 @@ extern "C" int mil_packed_weight_elems(size_t* elems, int cout, int cin, int ks,
 
 extern "C" int mil_pack_conv_weights(const float* w, const float* bias, void* wpack, float* bias_pad, int cout, int cin,
                                      int ks, int mode, int dtype, void* stream) {
-    if (!w || !wpack || cout <= 0 || cin <= 0 || mode < 0 || mode > 2) return MIL_ERR_ARG;
+    if (!w || !wpack || cout <= 0 || cin <= 0 || mode < 0 || mode > 3 || (mode == 3 && ks != 3)) return MIL_ERR_ARG;
     int CG, NT, nsteps;
     pack_dims(cout, cin, ks, mode, &CG, &NT, &nsteps);
     const int total = nsteps * NT * 64 * 8;

@@ -105,6 +105,8 @@ class ResNet(nn.Module):
             if blk.downsample is not None:
                 specs.append((f"b{bi}.ds", blk.downsample[0].weight, None, L.PACK_FWD))
                 specs.append((f"b{bi}.ds", blk.downsample[0].weight, None, L.PACK_DGRAD))
+                if blk.stride == 2:       # conv1's and the projection's transposed convs in one parity-class filter
+                    specs.append((f"b{bi}.c1", blk.conv1.weight, blk.downsample[0].weight, L.PACK_DGRAD_S2))
         return specs
 
     def refresh_packed(self, dtype):
@@ -260,6 +262,12 @@ def encoder_backward(net, saved, dfeats, dtype):
         if blk.downsample is not None:
             grads[f"b{bi}.ds"] = wgrad(xin, dz, cin, cout, ks=1, stride=s, pad=0, want_bias=False,
                                        out=gout(blk.downsample[0].weight, None))
+            if s == 2 and net.fuse_backward:     # both transposed convs + the mask in one pass over the compact dz maps
+                ws2, _ = net._packed(f"b{bi}.c1", blk.conv1.weight, blk.downsample[0].weight, L.PACK_DGRAD_S2, dtype)
+                fused = ops.conv_dgrad_s2(dz1, dz, ws2, ops.cpad(cin), xin.shape[1:3], act=mask)
+                if fused is not None:
+                    dz = fused
+                    continue
             wdd, _ = net._packed(f"b{bi}.ds", blk.downsample[0].weight, None, L.PACK_DGRAD, dtype)
             if s == 2:
                 addend = ops.conv(dz, wdd, None, ops.cpad(cin), ks=1, stride=1, pad=0, zero_insert=True,

@@ -199,6 +199,28 @@ def maxpool_bwd(gy, widx, in_hw, lrelu_mask=True, slope=LEAK):
     return gx
 
 
+def conv_dgrad_s2(dz1, dz2, wpack, cx_p, out_hw, *, act=None, slope=LEAK):
+    """lrelu'(act) * (conv3x3_s2^T(dz1) + conv1x1_s2^T(dz2)) in one pass (see mil_conv_dgrad_s2), or None when the
+    shape/dtype has no such kernel."""
+    n, h, w, cz_p = dz1.shape
+    hh, ww = out_hw
+    if dz1.dtype != torch.bfloat16:
+        return None
+    _need(dz1, dz1.shape, dz1.dtype, "dz1")
+    _need(dz2, dz1.shape, dz1.dtype, "dz2")
+    y = torch.empty((n, hh, ww, cx_p), dtype=dz1.dtype, device=dz1.device)
+    _need(act, y.shape, dz1.dtype, "act")
+    end = TIMER.bracket(("dgrad_s2", cz_p, cx_p, n, hh, ww)) if TIMER else None
+    rc = L.lib().mil_conv_dgrad_s2(dz1.data_ptr(), L.ptr(dz2), wpack.data_ptr(), L.ptr(act), y.data_ptr(), n, h, w, cz_p,
+                                   hh, ww, cx_p, slope, L.dt_code(dz1.dtype), L.stream_ptr())
+    if rc == 2:
+        return None
+    L.check(rc, "mil_conv_dgrad_s2")
+    if end is not None:
+        end.record()
+    return y
+
+
 def stem_fwd_fused(x, wpack, bias_pad, cout_p, *, slope=LEAK, dtype=torch.bfloat16):
     """(xs, pool, widx) of the whole stem in one pass over the fp32 NCHW tiles (see mil_stem_fwd_fused), or None when
     the shape/dtype has no fused kernel (the caller then runs stem_s2d / conv / maxpool_fwd)."""

@@ -38,6 +38,7 @@ extern "C" {
 #define MIL_PACK_FWD 0   /* B[(tap,ci)][co] = W[co][ci][ky][kx]                     */
 #define MIL_PACK_DGRAD 1 /* B[(tap,co)][ci] = W[co][ci][k-1-ky][k-1-kx]             */
 #define MIL_PACK_STEM 2  /* 7x7/s2 filter as a 4x4/s1 filter over space-to-depth x  */
+#define MIL_PACK_DGRAD_S2 3 /* parity-class order for mil_conv_dgrad_s2; `bias` = 1x1 projection weight */
 
 /* ABI version of this header (bumped on any signature change). */
 int mil_abi_version(void);
@@ -102,6 +103,17 @@ int mil_conv_bwd_fused(const void* dz, const void* wpack_dgrad, const void* x, c
 int mil_maxpool_fwd(const void* x, void* y, uint8_t* widx, int n, int H, int W, int cp, int dtype, void* stream);
 int mil_maxpool_bwd(const void* gy, const uint8_t* widx, void* gx, int n, int H, int W, int cp,
                     int apply_lrelu_mask, float slope, int dtype, void* stream);
+
+/* Data gradient of a stage-entry block's input in one pass (bf16 path; autograd of nnBlocks.py:175-189 for the
+ * blocks built with stride 2 + projection at gbm/model.py:37-41):
+ *   y = lrelu'(act) * ( conv3x3_s2^T(dz1) + conv1x1_s2^T(dz2) )
+ * computed per output parity class over the compact dz maps (no zero-insert halo, no full-resolution temporary for
+ * the projection term).  wpack: mil_pack_conv_weights(..., mode MIL_PACK_DGRAD_S2) of the 3x3 weight with the 1x1
+ * projection weight passed in the `bias` argument (or null).  dz1/dz2 [n,h,w,cz_p], act/y [n,H,W,cx_p],
+ * h = (H-1)/2+1; (cz_p,cx_p) in {(40,24),(64,40),(80,64)}; otherwise MIL_ERR_UNSUPPORTED (caller: two
+ * mil_conv_igemm calls with zero_insert). */
+int mil_conv_dgrad_s2(const void* dz1, const void* dz2, const void* wpack, const void* act, void* y, int n_img,
+                      int h, int w, int cz_p, int H, int W, int cx_p, float slope, int dtype, void* stream);
 
 /* Fused forward of the whole stem (bf16 path): space-to-depth + Conv2d(3,C,7,2,3) + bias + LeakyReLU +
  * MaxPool2d(3,2,1) in one pass over the fp32 NCHW tiles (gbm/model.py:24-26,51-53; alt_resnet.py:81-84,128-131

@@ -340,3 +340,48 @@ def test_stem_forward_fused_declines_unsupported_shapes(ops):
     wp, bp = ops.pack_weights(wt, b, L.PACK_STEM, torch.bfloat16)
     assert ops.stem_fwd_fused(torch.randn(2, 3, 50, 70).cuda(), wp, bp, 24) is None          # W % 4 != 0
     assert ops.stem_fwd_fused(torch.randn(2, 3, 64, 64).cuda(), wp, bp, 24, dtype=torch.float32) is None
+
+
+DGRAD_S2_CASES = [
+    # cin, cout, n, H, W   (dx is [n,H,W,cin]; dz1/dz2 are [n,(H-1)//2+1,(W-1)//2+1,cout])
+    (20, 40, 3, 16, 16),
+    (20, 40, 2, 19, 13),            # odd extents: the last dz row/column only feeds even output rows/columns
+    (20, 40, 2, 64, 48),            # several tiles per image
+    (40, 60, 5, 8, 8),              # 4 images per tile
+    (60, 80, 17, 4, 4),             # 16 images per tile, ragged last group
+    (60, 80, 2, 16, 16),
+]
+
+
+@pytest.mark.parametrize("with_proj", [True, False])
+@pytest.mark.parametrize("case", DGRAD_S2_CASES)
+def test_stage_entry_data_gradient_one_pass(ops, case, with_proj):
+    """mask * (conv3x3_s2^T(dz1) + conv1x1_s2^T(dz2)) by output parity class vs autograd, and vs the two zero-insert
+    launches it replaces."""
+    L = _lib()
+    cin, cout, n, h, w = case
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(101 + cin + h)
+    x = round_to(torch.randn(n, cin, h, w, generator=g), dt).requires_grad_(True)
+    w1 = round_to(torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5, dt)
+    wp = round_to(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5, dt)
+    y1 = F.conv2d(x, w1, None, stride=2, padding=1)
+    y2 = F.conv2d(x, wp, None, stride=2)
+    dz1 = round_to(torch.randn(y1.shape, generator=g), dt)
+    dz2 = round_to(torch.randn(y2.shape, generator=g), dt)
+    ((y1 * dz1).sum() + ((y2 * dz2).sum() if with_proj else 0.0)).backward()
+    act = round_to(torch.randn(x.shape, generator=g), dt)
+    want = x.grad * torch.where(act > 0, 1.0, LEAK)
+    ws2, _ = ops.pack_weights(w1.cuda(), wp.cuda() if with_proj else None, L.PACK_DGRAD_S2, dt)
+    d1, d2, ag = to_nhwc(dz1, dt), to_nhwc(dz2, dt), to_nhwc(act, dt)
+    got = ops.conv_dgrad_s2(d1, d2 if with_proj else None, ws2, cpad(cin), (h, w), act=ag)
+    assert got is not None
+    assert rel_err(from_nhwc(got, cin), want) < TOL[dt]
+    assert float(got[..., cin:].float().abs().max()) == 0.0 if cpad(cin) > cin else True       # padded channels stay zero
+    if with_proj:
+        wd1, _ = ops.pack_weights(w1.cuda(), None, L.PACK_DGRAD, dt)
+        wdp, _ = ops.pack_weights(wp.cuda(), None, L.PACK_DGRAD, dt)
+        addend = ops.conv(d2, wdp, None, cpad(cin), ks=1, stride=1, pad=0, zero_insert=True, out_hw=(h, w))
+        two = ops.conv(d1, wd1, None, cpad(cin), ks=3, stride=1, pad=1, zero_insert=True, out_hw=(h, w), res=addend, act=ag)
+        # the unfused path rounds the projection term to bf16 before adding it; allow that one rounding
+        assert rel_err(got.float().cpu(), two.float().cpu()) < 2 * TOL[dt]
