@@ -138,7 +138,7 @@ def main():
             return infer_step()
         flat.zero_grad()
         outs = net.forward_bags((x_all, sizes), labels)
-        torch.stack([o["loss"] for o in outs]).sum().backward()
+        outs.loss.sum().backward()      # == sum of the per-bag o["loss"] (the reference accumulates bag gradients un-normalised)
         flat.allreduce_grads()
         opt.step()                      # weights change every step: the next forward re-packs all filters
         return outs

@@ -270,11 +270,11 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(BwdFusedArgs a) 
 
 // Fixed-order slab reduction for the fused kernel's layout: row = tap'*CZ + co (tap' = flipped tap),
 // col = ci  ->  dW[co][ci][k*k-1-tap'];  db from the extra row tile.
-__global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const float* __restrict__ slab, int nslab, size_t slab_elems,
+__global__ __launch_bounds__(32 * MIL_RED_GROUPS) void wgrad_reduce_t_kernel(const float* __restrict__ slab, int nslab, size_t slab_elems,
                                                              int slab_cols, int n_rows, float* __restrict__ dw,
                                                              float* __restrict__ db, int cout, int cin, int ks, int czp,
                                                              int bias_off, int accumulate) {
-    __shared__ float part[8][32];
+    __shared__ float part[MIL_RED_GROUPS][32];
     const int c = threadIdx.x & 31, gq = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + c;
     const int total = n_rows * slab_cols + czp;           // weight elements, then czp bias sums
@@ -282,14 +282,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const float* __rest
     const bool live = e < total;
     if (live) {
         const size_t src = e < n_rows * slab_cols ? (size_t)e : (size_t)bias_off + (e - n_rows * slab_cols);
-        for (int i = gq; i < nslab; i += 8) s += slab[(size_t)i * slab_elems + src];
+        s = mil_slab_partial(slab, slab_elems, src, gq, nslab);
     }
     part[gq][c] = s;
     __syncthreads();
     if (gq != 0 || !live) return;
     float v = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v += part[k][c];
+    for (int k = 0; k < MIL_RED_GROUPS; ++k) v += part[k][c];
     if (e >= n_rows * slab_cols) {
         const int co = e - n_rows * slab_cols;
         if (co < cout && db) db[co] = accumulate ? db[co] + v : v;
@@ -342,7 +342,7 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
     MIL_CHECK_LAUNCH();
     const int n_rows = KS * KS * CZ;
     const int total = n_rows * NTX * 16 + CZ;
-    hipLaunchKernelGGL(wgrad_reduce_t_kernel, dim3((total + 31) / 32), dim3(256), 0, stream, (const float*)ws, grid, slab_elems,
+    hipLaunchKernelGGL(wgrad_reduce_t_kernel, dim3((total + 31) / 32), dim3(32 * MIL_RED_GROUPS), 0, stream, (const float*)ws, grid, slab_elems,
                        NTX * 16, n_rows, dw, db, cout, cin, KS, CZ, MT * 16 * NTX * 16, accumulate);
     MIL_CHECK_LAUNCH();
     return MIL_OK;

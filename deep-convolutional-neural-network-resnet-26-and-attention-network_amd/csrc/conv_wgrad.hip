@@ -206,11 +206,11 @@ __global__ __launch_bounds__(256, (PF && CINP > 40) ? 1 : 0) void wgrad_kernel(W
 // its 8 thread groups each sum every 8th slab, then group 0 adds the 8 partials in order: the summation
 // tree is fixed, so results are bitwise reproducible.  stem_mode maps the 4x4 space-to-depth taps back
 // onto the 7x7 filter.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, size_t slab_elems,
+__global__ __launch_bounds__(32 * MIL_RED_GROUPS) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, size_t slab_elems,
                                                            int slab_cols, int n_rows, float* __restrict__ dw,
                                                            float* __restrict__ db, int cout, int cin, int ks, int cinp,
                                                            int stem_mode, int bias_row, int accumulate) {
-    __shared__ float part[8][32];
+    __shared__ float part[MIL_RED_GROUPS][32];
     const int c = threadIdx.x & 31, gq = threadIdx.x >> 5;
     // rows [0, n_rows) are weight rows, row n_rows stands for the bias row
     const int e = blockIdx.x * 32 + c;
@@ -221,14 +221,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (live) {
         const int row = e / slab_cols, col = e - row * slab_cols;
         src = (size_t)(row == n_rows ? bias_row : row) * slab_cols + col;
-        for (int i = gq; i < nslab; i += 8) s += slab[(size_t)i * slab_elems + src];
+        s = mil_slab_partial(slab, slab_elems, src, gq, nslab);
     }
     part[gq][c] = s;
     __syncthreads();
     if (gq != 0 || !live) return;
     float v = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v += part[k][c];
+    for (int k = 0; k < MIL_RED_GROUPS; ++k) v += part[k][c];
     const int row = e / slab_cols, co = e - row * slab_cols;
     if (co >= cout) return;
     if (row == n_rows) { if (db) db[co] = accumulate ? db[co] + v : v; return; }
@@ -273,7 +273,11 @@ static int plan_wgrad(ConvGeom& g, WgradPlan& pl, int* lds_z_off) {
     pl.msplit = MSPLIT; pl.mt = MT; pl.slab_cols = NT * 16;
     pl.slab_elems = (size_t)(MT + 1) * 16 * NT * 16;
     const int ntiles = g.n_groups * g.tiles_y * g.tiles_x;
-    int gx = 512 / MSPLIT;
+    // one fp32 slab per workgroup: no more workgroups than can be resident (the 64/80-channel slabs are 150-235 KB —
+    // a second round of workgroups would only double the slab traffic, which already rivals the activation traffic)
+    int per_cu = (160 * 1024) / pl.lds;
+    per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+    int gx = 256 * per_cu / MSPLIT;
     if (gx > ntiles) gx = ntiles;
     if (gx < 1) gx = 1;
     pl.grid_x = gx;
@@ -309,7 +313,7 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     MIL_CHECK_LAUNCH();
     const int n_rows = KS * KS * CINP;
     const int total = (n_rows + 1) * pl.slab_cols;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, stream, (const float*)ws, pl.grid_x,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(32 * MIL_RED_GROUPS), 0, stream, (const float*)ws, pl.grid_x,
                        pl.slab_elems, pl.slab_cols, n_rows, dw, db, cout, cin, KS, CINP, stem_mode, pl.mt * 16, accumulate);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
@@ -616,7 +620,7 @@ static int stem_bwd_entry(const void* xs, const void* gp, const uint8_t* widx, f
     MIL_CHECK_LAUNCH();
     const int n_rows = 16 * 16;
     const int total = (n_rows + 1) * 32;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, st, (const float*)ws, grid, slab_elems, 32,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(32 * MIL_RED_GROUPS), 0, st, (const float*)ws, grid, slab_elems, 32,
                        n_rows, dw, db, 20, 3, 7, 16, 1, MT * 16, accumulate);
     MIL_CHECK_LAUNCH();
     return MIL_OK;

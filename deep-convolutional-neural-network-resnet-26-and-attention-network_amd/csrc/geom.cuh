@@ -250,3 +250,21 @@ __host__ __device__ inline float mil_s2_pack_value(const float* w1, const float*
     if (gr.src == 1) return wproj ? wproj[(size_t)kin * cin + nout] : 0.f;
     return w1[((size_t)kin * cin + nout) * 9 + (2 - gr.ky) * 3 + (2 - gr.kx)];
 }
+
+// Fixed-order sum over slabs for the weight-gradient reductions: thread group gq of MIL_RED_GROUPS sums slabs gq,
+// gq+G, gq+2G, ... (8 independent loads in flight per thread, added in index order), group 0 then adds the G partial
+// sums in order.  The tree depends only on (nslab, G): bitwise reproducible run to run.
+#define MIL_RED_GROUPS 32
+__device__ __forceinline__ float mil_slab_partial(const float* __restrict__ slab, size_t slab_elems, size_t src, int gq, int nslab) {
+    float s = 0.f;
+    int i = gq;
+    for (; i + 7 * MIL_RED_GROUPS < nslab; i += 8 * MIL_RED_GROUPS) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = slab[(size_t)(i + k * MIL_RED_GROUPS) * slab_elems + src];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; i < nslab; i += MIL_RED_GROUPS) s += slab[(size_t)i * slab_elems + src];
+    return s;
+}

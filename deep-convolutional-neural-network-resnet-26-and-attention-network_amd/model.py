@@ -58,6 +58,13 @@ class TileParallel(nn.Module):
         return self.module(x)
 
 
+class BagOutputs(list):
+    """The per-bag output dicts of `forward_bags`, plus the un-split loss vector: summing `o["loss"]` over the dicts
+    back-propagates through one select per bag, `outs.loss.sum()` through none."""
+    loss = None
+    l2 = None
+
+
 class Attention(nn.Module):
     def __init__(self, n_classes, class_weights=None, *, compute_dtype=torch.bfloat16, device="cuda"):
         super().__init__()
@@ -176,7 +183,8 @@ class Attention(nn.Module):
         H = self.cnn(x_all)
         loss, l2, a1, wrois, bterm, kld, rec = head_apply(H, layout, y, keep, cw, self.head_weights())
         Hd = H.detach()
-        outs = []
+        outs = BagOutputs()
+        outs.loss, outs.l2 = loss, l2          # [n_bags] / [] with grad: `outs.loss.sum().backward()` is one backward for all bags
         for b in range(layout.nbags):
             n0, n1 = layout.offsets_host[b], layout.offsets_host[b + 1]
             r = rec[b]

@@ -182,6 +182,12 @@ def test_batched_bags_equal_per_bag_calls(golden_dir):
     torch.stack([o["loss"] for o in outs]).sum().backward()
     g_batched = {k: p.grad.clone() for k, p in net.named_parameters()}
     net.zero_grad(set_to_none=True)
+    outs2 = net.forward_bags(bags, labels)              # the un-split loss vector: same values, same gradients
+    assert torch.equal(outs2.loss.detach(), torch.stack([o["loss"].detach() for o in outs]))
+    outs2.loss.sum().backward()
+    for k, p in net.named_parameters():
+        assert torch.equal(p.grad, g_batched[k]), k
+    net.zero_grad(set_to_none=True)
     for b, (xb, yb) in enumerate(zip(bags, labels)):
         o = net(xb, yb.view(1))
         o["loss"].backward()
