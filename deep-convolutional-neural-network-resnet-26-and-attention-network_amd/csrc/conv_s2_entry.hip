@@ -1,0 +1,209 @@
+// Forward of a stage-entry block's two stride-2 convs in one pass (bf16 path):
+//   o1    = lrelu(conv3x3_s2(x) + b1)      (nnBlocks.py:176-177 with stride 2)
+//   short = conv1x1_s2(x)                  (the bias-free projection shortcut, gbm/model.py:38-40; nnBlocks.py:182-183)
+// Both read the same block input; run separately each of them fetches the full-resolution tensor from HBM (the
+// projection to use a quarter of it).  Here the input halo tile is staged once per 128-pixel output tile and feeds
+// two accumulator sets: the 3x3 filter over all taps, the 1x1 filter over the centre tap.  Persistent workgroups,
+// register prefetch of the next halo, paired 16-byte register epilogue — the structure of conv_igemm_pf_kernel.
+#include "pf_common.cuh"
+
+struct S2EntryArgs {
+    const __bf16* x;        // [n,H,W,CINP]
+    const __bf16* w1;       // MIL_PACK_FWD fragments of the 3x3 filter  [ceil(9*CG/4)][NT][64][8]
+    const __bf16* wp;       // MIL_PACK_FWD fragments of the 1x1 filter  [ceil(CG/4)][NT][64][8]
+    const float* bias;      // [NT*16] bias of the 3x3 conv, or null
+    __bf16* y1;             // [n,Ho,Wo,COUTP]
+    __bf16* y2;             // [n,Ho,Wo,COUTP]
+    ConvGeom g;
+    int lds_w_off;
+    float slope;
+};
+
+template <int CINP, int NT>
+__global__ __launch_bounds__(256, CINP <= 24 ? 2 : 1) void conv_s2_entry_kernel(S2EntryArgs a, int ntiles, unsigned x_bytes, unsigned y_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PIXB = mil_pix_pitch(CINP, 2);
+    constexpr int CG = CINP / 8;
+    constexpr int COUTP = mil_nt_to_cp(NT);
+    constexpr int K1 = (9 * CG + 3) / 4, K2 = (CG + 3) / 4;
+    constexpr int NPX = (648 * CG + 255) / 256;                 // halos of 128-px tiles at stride 2: 17x33, 2 x 17x17, 8 x 9x9
+    constexpr bool LAST_PARTIAL = (COUTP % 16) != 0;
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, gq = lane >> 4;
+    char* ldsA = smem;
+    char* ldsW = smem + a.lds_w_off;
+    {
+        const char* s1 = reinterpret_cast<const char*>(a.w1);
+        for (int i = tid * 16; i < K1 * NT * 64 * 16; i += 256 * 16)
+            *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(s1 + i);
+        const char* s2 = reinterpret_cast<const char*>(a.wp);
+        for (int i = tid * 16; i < K2 * NT * 64 * 16; i += 256 * 16)
+            *reinterpret_cast<uint4*>(ldsW + K1 * NT * 64 * 16 + i) = *reinterpret_cast<const uint4*>(s2 + i);
+    }
+    const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, x_bytes);
+    const __amdgpu_buffer_rsrc_t rs_y1 = mil_rsrc(a.y1, y_bytes);
+    const __amdgpu_buffer_rsrc_t rs_y2 = mil_rsrc(a.y2, y_bytes);
+    const int TW = 1 << g.tw_log2, TH = 1 << g.th_log2;
+
+    HaloTables<NPX> ht;
+    mil_build_halo_tables<CINP, NPX>(ht, g, tid);
+    int toff[K1], toff2[K2];
+#pragma unroll
+    for (int sl = 0; sl < K1; ++sl) {
+        const int q = 4 * sl + gq;
+        int tap = q / CG, cg = q - tap * CG;
+        if (tap >= 9) { tap = 0; cg = 0; }
+        toff[sl] = ((tap / 3) * g.hw + (tap % 3)) * PIXB + cg * 16;
+    }
+#pragma unroll
+    for (int sl = 0; sl < K2; ++sl) {
+        const int q = 4 * sl + gq;
+        toff2[sl] = (g.hw + 1) * PIXB + (q < CG ? q : 0) * 16;     // centre tap of the 3x3 window = the 1x1/s2 sample
+    }
+    int pixbase[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int tp = (wave * 2 + m) * 16 + r;
+        const int tx = tp & (TW - 1), ty = (tp >> g.tw_log2) & (TH - 1), ti = tp >> (g.tw_log2 + g.th_log2);
+        pixbase[m] = ((ti * g.hh + ty * 2) * g.hw + tx * 2) * PIXB;
+    }
+    // after the swap between row tiles 0 and 1 a lane holds channels 16*nt + 8*(gq>>1) .. +8 of pixel ((gq&1), r)
+    int o_rel, o_pos;
+    {
+        const int tp = (wave * 2 + (gq & 1)) * 16 + r;
+        const int tx = tp & (TW - 1), ty = (tp >> g.tw_log2) & (TH - 1), ti = tp >> (g.tw_log2 + g.th_log2);
+        o_rel = ((ti * g.Ho + ty) * g.Wo + tx) * (COUTP * 2) + (gq >> 1) * 16;
+        o_pos = (ti << 20) | (ty << 10) | tx;
+    }
+    const bool last_ok = !LAST_PARTIAL || (gq >> 1) == 0;
+    f32x4_t bias_r[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias_r[nt][i] = a.bias ? a.bias[nt * 16 + gq * 4 + i] : 0.f;
+
+    TileWalker cur, nxt;
+    const int bid = mil_xcd_block_id();
+    cur.init(g, bid, gridDim.x);
+    nxt = cur; nxt.advance();
+    u32x4_t rx[NPX];
+    if (bid < ntiles) mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, cur.origin(g));
+    const int G = gridDim.x;
+    for (int tile = bid; tile < ntiles; tile += G) {
+        __syncthreads();
+        mil_commit_halo<NPX>(rx, ldsA, ht);
+        const TileOrigin o = cur.origin(g);
+        __syncthreads();
+        if (tile + G < ntiles) mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, nxt.origin(g));
+        cur = nxt; nxt.advance();
+
+        f32x4_t acc1[2][NT], acc2[2][NT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { acc1[m][nt] = bias_r[nt]; acc2[m][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int sl = 0; sl < K1; ++sl) {
+            Frag8<BF16> wf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<BF16>(ldsW + ((sl * NT + nt) * 64 + lane) * 16);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const Frag8<BF16> xf = lds_frag<BF16>(ldsA + pixbase[m] + toff[sl]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc1[m][nt] = mma8(wf[nt], xf, acc1[m][nt]);
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < K2; ++sl) {
+            Frag8<BF16> wf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<BF16>(ldsW + (((K1 + sl) * NT + nt) * 64 + lane) * 16);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const Frag8<BF16> xf = lds_frag<BF16>(ldsA + pixbase[m] + toff2[sl]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc2[m][nt] = mma8(wf[nt], xf, acc2[m][nt]);
+            }
+        }
+        const int obase = ((o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (COUTP * 2);
+        const bool ok = (o_pos >> 20) < g.n_img - o.img0 && ((o_pos >> 10) & 1023) < g.Ho - o.oy0 && (o_pos & 1023) < g.Wo - o.ox0;
+        const unsigned ooff = ok ? (unsigned)(obase + o_rel) : MIL_OOB;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float v[8], u[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float lo = acc1[0][nt][i], hi = acc1[1][nt][i];
+                if (i == 0) mil_swap16<true>(lo, hi); else mil_swap16<false>(lo, hi);
+                v[i] = lo; v[4 + i] = hi;
+                float lo2 = acc2[0][nt][i], hi2 = acc2[1][nt][i];
+                if (i == 0) mil_swap16<true>(lo2, hi2); else mil_swap16<false>(lo2, hi2);
+                u[i] = lo2; u[4 + i] = hi2;
+            }
+            bf16x8_t ov, ou;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { ov[i] = (__bf16)fmaxf(v[i], v[i] * a.slope); ou[i] = (__bf16)u[i]; }
+            const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff + nt * 32;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), rs_y1, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ou), rs_y2, off, 0, 0);
+        }
+    }
+}
+
+template <int CINP, int NT>
+static int launch_s2_entry(S2EntryArgs a, hipStream_t st) {
+    constexpr int CG = CINP / 8, PIXB = mil_pix_pitch(CINP, 2), COUTP = mil_nt_to_cp(NT);
+    constexpr int K1 = (9 * CG + 3) / 4, K2 = (CG + 3) / 4;
+    mil_geom_tiles(a.g, 7);
+    const int halo_px = (a.g.hh * a.g.hw) << a.g.ti_log2;
+    if (halo_px > 648 || a.g.hh >= 1024 || a.g.hw >= 1024) return MIL_ERR_UNSUPPORTED;
+    const int a_bytes = (halo_px * PIXB + 15) & ~15;
+    const int lds = a_bytes + (K1 + K2) * NT * 64 * 16;
+    if (lds > 160 * 1024) return MIL_ERR_UNSUPPORTED;
+    a.lds_w_off = a_bytes;
+    auto kern = conv_s2_entry_kernel<CINP, NT>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return MIL_ERR_LAUNCH;
+    int per_cu = (160 * 1024) / lds;
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    const size_t x_img = (size_t)a.g.H * a.g.W * CINP * 2, y_img = (size_t)a.g.Ho * a.g.Wo * COUTP * 2;
+    int chunk = mil_imgs_under_2g(x_img > y_img ? x_img : y_img);
+    if (chunk >= 16) chunk &= ~15;
+    const int n_total = a.g.n_img;
+    for (int i0 = 0; i0 < n_total; i0 += chunk) {
+        const int n = (n_total - i0 < chunk) ? n_total - i0 : chunk;
+        S2EntryArgs c = a;
+        c.g.n_img = n;
+        c.g.n_groups = (n + (1 << c.g.ti_log2) - 1) >> c.g.ti_log2;
+        c.x = a.x + (size_t)i0 * (x_img / 2);
+        c.y1 = a.y1 + (size_t)i0 * (y_img / 2);
+        c.y2 = a.y2 + (size_t)i0 * (y_img / 2);
+        const int ntiles = c.g.n_groups * c.g.tiles_y * c.g.tiles_x;
+        int grid = 256 * per_cu;
+        if (grid > ntiles) grid = ntiles;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, c, ntiles, (unsigned)(x_img * n), (unsigned)(y_img * n));
+        MIL_CHECK_LAUNCH();
+    }
+    return MIL_OK;
+}
+
+// y1 = lrelu(conv3x3_s2(x) + bias), y2 = conv1x1_s2(x); x [n,H,W,cin_p], y1/y2 [n,(H-1)/2+1,(W-1)/2+1,cout_p].
+// bf16, (cin_p,cout_p) in {(24,40),(40,64)}; otherwise MIL_ERR_UNSUPPORTED (caller: two mil_conv_igemm calls).
+extern "C" int mil_conv_s2_entry(const void* x, const void* wpack3, const float* bias_pad, const void* wpack1, void* y1, void* y2,
+                                 int n_img, int H, int W, int cin_p, int cout_p, float slope, int dtype, void* stream) {
+    if (!x || !wpack3 || !wpack1 || !y1 || !y2 || n_img < 0 || H <= 0 || W <= 0) return MIL_ERR_ARG;
+    if (dtype != MIL_DT_BF16 || slope < 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
+    if (n_img == 0) return MIL_OK;
+    S2EntryArgs a{};
+    a.x = (const __bf16*)x; a.w1 = (const __bf16*)wpack3; a.wp = (const __bf16*)wpack1; a.bias = bias_pad;
+    a.y1 = (__bf16*)y1; a.y2 = (__bf16*)y2; a.slope = slope;
+    a.g.n_img = n_img; a.g.H = H; a.g.W = W; a.g.Ho = (H - 1) / 2 + 1; a.g.Wo = (W - 1) / 2 + 1;
+    a.g.ks = 3; a.g.stride = 2; a.g.pad = 1; a.g.zins = 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (cin_p == 24 && cout_p == 40) return launch_s2_entry<24, 3>(a, st);
+    if (cin_p == 40 && cout_p == 64) return launch_s2_entry<40, 4>(a, st);
+    return MIL_ERR_UNSUPPORTED;
+}

@@ -60,6 +60,7 @@ class ResNet(nn.Module):
         self.n_side_streams = 1
         self.fuse_backward = True
         self.fuse_stem_forward = True
+        self.fuse_stage_entry = True
         self._pack_table = None
         self._pack_version = None
         self._side = None
@@ -169,12 +170,16 @@ def encoder_forward(net, x, dtype):
         s = blk.stride
         w1, b1 = net._packed(f"b{bi}.c1", blk.conv1.weight, blk.conv1.bias, L.PACK_FWD, dtype)
         w2, b2 = net._packed(f"b{bi}.c2", blk.conv2.weight, blk.conv2.bias, L.PACK_FWD, dtype)
-        o1 = ops.conv(t, w1, b1, ops.cpad(cout), ks=3, stride=s, pad=1, lrelu=True)
+        pair = None
         if blk.downsample is not None:
             wd, _ = net._packed(f"b{bi}.ds", blk.downsample[0].weight, None, L.PACK_FWD, dtype)
-            short = ops.conv(t, wd, None, ops.cpad(cout), ks=1, stride=s, pad=0)
+            if s == 2 and net.fuse_stage_entry:          # both stride-2 convs in one pass over the block input
+                pair = ops.conv_s2_entry(t, w1, b1, wd, ops.cpad(cout))
+        if pair is not None:
+            o1, short = pair
         else:
-            short = t
+            o1 = ops.conv(t, w1, b1, ops.cpad(cout), ks=3, stride=s, pad=1, lrelu=True)
+            short = ops.conv(t, wd, None, ops.cpad(cout), ks=1, stride=s, pad=0) if blk.downsample is not None else t
         out = ops.conv(o1, w2, b2, ops.cpad(cout), ks=3, stride=1, pad=1, res=short, lrelu=True)
         saved["blocks"].append((t, o1, out))
         t = out

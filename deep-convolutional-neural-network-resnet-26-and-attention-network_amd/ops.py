@@ -199,6 +199,27 @@ def maxpool_bwd(gy, widx, in_hw, lrelu_mask=True, slope=LEAK):
     return gx
 
 
+def conv_s2_entry(x, wpack3, bias_pad, wpack1, cout_p, *, slope=LEAK):
+    """(lrelu(conv3x3_s2(x)+b), conv1x1_s2(x)) in one pass over x (see mil_conv_s2_entry), or None when the shape/dtype
+    has no such kernel."""
+    n, h, w, cin_p = x.shape
+    if x.dtype != torch.bfloat16:
+        return None
+    _need(x, x.shape, x.dtype, "x")
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y1 = torch.empty((n, ho, wo, cout_p), dtype=x.dtype, device=x.device)
+    y2 = torch.empty_like(y1)
+    end = TIMER.bracket(("s2_entry", cin_p, cout_p, n, h, w)) if TIMER else None
+    rc = L.lib().mil_conv_s2_entry(x.data_ptr(), wpack3.data_ptr(), L.ptr(bias_pad), wpack1.data_ptr(), y1.data_ptr(),
+                                   y2.data_ptr(), n, h, w, cin_p, cout_p, slope, L.dt_code(x.dtype), L.stream_ptr())
+    if rc == 2:
+        return None
+    L.check(rc, "mil_conv_s2_entry")
+    if end is not None:
+        end.record()
+    return y1, y2
+
+
 def conv_dgrad_s2(dz1, dz2, wpack, cx_p, out_hw, *, act=None, slope=LEAK):
     """lrelu'(act) * (conv3x3_s2^T(dz1) + conv1x1_s2^T(dz2)) in one pass (see mil_conv_dgrad_s2), or None when the
     shape/dtype has no such kernel."""

@@ -104,6 +104,13 @@ int mil_maxpool_fwd(const void* x, void* y, uint8_t* widx, int n, int H, int W, 
 int mil_maxpool_bwd(const void* gy, const uint8_t* widx, void* gx, int n, int H, int W, int cp,
                     int apply_lrelu_mask, float slope, int dtype, void* stream);
 
+/* Forward of a stage-entry block's two stride-2 convs in one pass over the block input (bf16 path):
+ *   y1 = lrelu(conv3x3_s2(x) + bias)   (nnBlocks.py:176-177)      y2 = conv1x1_s2(x)   (gbm/model.py:38-40)
+ * wpack3 / wpack1: MIL_PACK_FWD fragments of the two filters.  (cin_p,cout_p) in {(24,40),(40,64)}; otherwise
+ * MIL_ERR_UNSUPPORTED (caller: two mil_conv_igemm calls). */
+int mil_conv_s2_entry(const void* x, const void* wpack3, const float* bias_pad, const void* wpack1, void* y1, void* y2,
+                      int n_img, int H, int W, int cin_p, int cout_p, float slope, int dtype, void* stream);
+
 /* Data gradient of a stage-entry block's input in one pass (bf16 path; autograd of nnBlocks.py:175-189 for the
  * blocks built with stride 2 + projection at gbm/model.py:37-41):
  *   y = lrelu'(act) * ( conv3x3_s2^T(dz1) + conv1x1_s2^T(dz2) )

@@ -377,7 +377,8 @@ def test_stage_entry_data_gradient_one_pass(ops, case, with_proj):
     got = ops.conv_dgrad_s2(d1, d2 if with_proj else None, ws2, cpad(cin), (h, w), act=ag)
     assert got is not None
     assert rel_err(from_nhwc(got, cin), want) < TOL[dt]
-    assert float(got[..., cin:].float().abs().max()) == 0.0 if cpad(cin) > cin else True       # padded channels stay zero
+    if cpad(cin) > cin:                                     # padded channels stay exactly zero
+        assert float(got[..., cin:].float().abs().max()) == 0.0
     if with_proj:
         wd1, _ = ops.pack_weights(w1.cuda(), None, L.PACK_DGRAD, dt)
         wdp, _ = ops.pack_weights(wp.cuda(), None, L.PACK_DGRAD, dt)
@@ -385,3 +386,40 @@ def test_stage_entry_data_gradient_one_pass(ops, case, with_proj):
         two = ops.conv(d1, wd1, None, cpad(cin), ks=3, stride=1, pad=1, zero_insert=True, out_hw=(h, w), res=addend, act=ag)
         # the unfused path rounds the projection term to bf16 before adding it; allow that one rounding
         assert rel_err(got.float().cpu(), two.float().cpu()) < 2 * TOL[dt]
+
+
+S2_ENTRY_CASES = [
+    # cin, cout, n, H, W
+    (20, 40, 3, 16, 16),
+    (20, 40, 2, 19, 13),
+    (20, 40, 2, 64, 48),
+    (40, 60, 5, 8, 8),
+    (40, 60, 3, 32, 32),
+    (40, 60, 9, 6, 6),
+]
+
+
+@pytest.mark.parametrize("case", S2_ENTRY_CASES)
+def test_stage_entry_forward_pair_one_pass(ops, case):
+    """lrelu(conv3x3_s2(x)+b) and the 1x1/s2 projection from one staged input tile vs torch and vs the two launches."""
+    L = _lib()
+    cin, cout, n, h, w = case
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(211 + cin + h)
+    x = round_to(torch.randn(n, cin, h, w, generator=g), dt)
+    w3 = round_to(torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5, dt)
+    w1 = round_to(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5, dt)
+    b = torch.randn(cout, generator=g) * 0.1
+    xg = to_nhwc(x, dt)
+    p3, bp = ops.pack_weights(w3.cuda(), b.cuda(), L.PACK_FWD, dt)
+    p1, _ = ops.pack_weights(w1.cuda(), None, L.PACK_FWD, dt)
+    pair = ops.conv_s2_entry(xg, p3, bp, p1, cpad(cout))
+    assert pair is not None
+    y1, y2 = pair
+    assert rel_err(from_nhwc(y1, cout), F.leaky_relu(F.conv2d(x, w3, b, stride=2, padding=1), LEAK)) < TOL[dt]
+    assert rel_err(from_nhwc(y2, cout), F.conv2d(x, w1, None, stride=2)) < TOL[dt]
+    z1 = ops.conv(xg, p3, bp, cpad(cout), ks=3, stride=2, pad=1, lrelu=True)
+    z2 = ops.conv(xg, p1, None, cpad(cout), ks=1, stride=2, pad=0)
+    assert rel_err(y1.float().cpu(), z1.float().cpu()) < TOL[dt] and rel_err(y2.float().cpu(), z2.float().cpu()) < TOL[dt]
+    if cpad(cout) > cout:                                   # padded channels stay exactly zero
+        assert float(y1[..., cout:].float().abs().max()) == 0.0 and float(y2[..., cout:].float().abs().max()) == 0.0
