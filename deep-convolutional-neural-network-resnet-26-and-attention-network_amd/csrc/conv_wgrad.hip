@@ -455,10 +455,8 @@ __global__ __launch_bounds__(256) void stem_bwd_fused_kernel(StemBwdArgs a) {
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
     const int q4 = (lane & 15) >> 2, p4 = lane & 3, gq = lane >> 4;
     const int wpl0 = mil_pix_base<PIXB>(g, 8 * gq + q4, 1), wpl1 = mil_pix_base<PIXB>(g, 8 * gq + q4 + 4, 1);
-    // dz builder: thread -> (2x2 pixel block, 8-channel group) of the tile
-    const int nblk = 64;                                     // 256 px / 4
-    const int bitem = tid / 3, bc8 = tid - bitem * 3;
-    const bool builder = bitem < nblk;
+    // dz builder: thread -> (2x2 pixel block, 6-channel group) of the tile: 64 blocks x 4 groups = all 256 threads
+    const int bitem = tid >> 2, bc6 = tid & 3;
     const int bW = TW / 2, bH = TH / 2;
     const int b_ti = bitem / (bW * bH), b_rem = bitem - b_ti * (bW * bH);
     const int b_y = b_rem / bW, b_x = b_rem - b_y * bW;
@@ -491,35 +489,41 @@ __global__ __launch_bounds__(256) void stem_bwd_fused_kernel(StemBwdArgs a) {
         cur = nxt; nxt.advance();
 
         // ---- dz tile = lrelu'(stem) * maxpool^T(g): gather over the 4 windows that cover a 2x2 block --------
-        if (builder) {
-            float gsum[2][2][8];
+        // A window's gradient goes to exactly one pixel (its recorded winner tap); per (window, channel) the tap and
+        // the masked gradient are decoded once, then tested against the (at most 4) taps this block's pixels have in
+        // that window: 9 (window, pixel) pairs in all.
+        {
+            float gsum[2][2][6];
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) gsum[dy][dx][j] = 0.f;
+                    for (int j = 0; j < 6; ++j) gsum[dy][dx][j] = 0.f;
 #pragma unroll
             for (int wy = 0; wy < 2; ++wy) {
 #pragma unroll
                 for (int wx = 0; wx < 2; ++wx) {
                     const int win = (b_ti * WH + b_y + wy) * WW + b_x + wx;
-                    const uint2 packed = *reinterpret_cast<const uint2*>(ldsI + win * COUTP + bc8 * 8);
-                    const bf16x8_t gv = *reinterpret_cast<const bf16x8_t*>(ldsG + win * PIXZ + bc8 * 16);
+                    const unsigned short* wi = reinterpret_cast<const unsigned short*>(ldsI + win * COUTP + bc6 * 6);
+                    const unsigned* gp = reinterpret_cast<const unsigned*>(ldsG + win * PIXZ + bc6 * 12);
+                    const unsigned wpk[3] = {wi[0], wi[1], wi[2]};
+                    const unsigned gpk[3] = {gp[0], gp[1], gp[2]};
 #pragma unroll
-                    for (int dy = 0; dy < 2; ++dy) {
-                        const int ky = dy + 1 - 2 * wy;          // tap row of pixel 2*b_y+dy inside window b_y+wy
-                        if (ky < 0 || ky > 2) continue;
+                    for (int j = 0; j < 6; ++j) {
+                        const unsigned wb = (wpk[j >> 1] >> (8 * (j & 1))) & 0xffu;
+                        const float gj = __uint_as_float((j & 1) ? (gpk[j >> 1] & 0xffff0000u) : (gpk[j >> 1] << 16));
+                        const float gm = (wb & 16u) ? gj * a.slope : gj;
+                        const unsigned t = wb & 15u;
 #pragma unroll
-                        for (int dx = 0; dx < 2; ++dx) {
-                            const int kx = dx + 1 - 2 * wx;
-                            if (kx < 0 || kx > 2) continue;
-                            const uint32_t me = (uint32_t)(ky * 3 + kx);
+                        for (int dy = 0; dy < 2; ++dy) {
+                            const int ky = dy + 1 - 2 * wy;          // tap row of pixel 2*b_y+dy inside window b_y+wy
+                            if (ky < 0 || ky > 2) continue;
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const uint32_t w = ((j < 4 ? packed.x : packed.y) >> (8 * (j & 3))) & 0xffu;
-                                const float gj = (float)gv[j];
-                                if ((w & 15u) == me) gsum[dy][dx][j] += (w & 16u) ? gj * a.slope : gj;
+                            for (int dx = 0; dx < 2; ++dx) {
+                                const int kx = dx + 1 - 2 * wx;
+                                if (kx < 0 || kx > 2) continue;
+                                gsum[dy][dx][j] += (t == (unsigned)(ky * 3 + kx)) ? gm : 0.f;
                             }
                         }
                     }
@@ -530,10 +534,14 @@ __global__ __launch_bounds__(256) void stem_bwd_fused_kernel(StemBwdArgs a) {
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
                     const int tp = (b_ti << (g.tw_log2 + g.th_log2)) + ((2 * b_y + dy) << g.tw_log2) + 2 * b_x + dx;
-                    bf16x8_t ov;
+                    unsigned* dst = reinterpret_cast<unsigned*>(ldsZ + tp * PIXZ + bc6 * 12);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) ov[j] = (__bf16)gsum[dy][dx][j];
-                    *reinterpret_cast<bf16x8_t*>(ldsZ + tp * PIXZ + bc8 * 16) = ov;
+                    for (int k = 0; k < 3; ++k) {
+                        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+                        bf16x2_t pr;
+                        pr[0] = (__bf16)gsum[dy][dx][2 * k]; pr[1] = (__bf16)gsum[dy][dx][2 * k + 1];
+                        dst[k] = __builtin_bit_cast(unsigned, pr);
+                    }
                 }
         }
         __syncthreads();
