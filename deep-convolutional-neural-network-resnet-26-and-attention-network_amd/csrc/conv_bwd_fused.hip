@@ -23,13 +23,13 @@ struct BwdFusedArgs {
     float* slab;            // [gridDim.x][(MT+1)*16][NTX*16]
     ConvGeom g;
     int ntiles;
-    int lds_w_off, lds_x_off;
+    int lds_w_off, lds_x_off, lds_dump_off;
     int apply_mask;
     float slope;
     unsigned z_bytes, x_bytes;      // byte sizes of dz and of x/addend/dx (buffer descriptors)
 };
 
-template <int CZ, int NTX, int KS>
+template <int CZ, int NTX, int KS, bool ADD, bool MASK>
 __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(BwdFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIXB = mil_pix_pitch(CZ, 2);            // dz halo pixel pitch
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(BwdFusedArgs a) 
     // ---- tile-invariant tables (see conv_igemm_pf_kernel) -------------------------------------------
     HaloTables<NPX> ht;
     mil_build_halo_tables<CZ, NPX>(ht, g, tid);
+    mil_halo_tables_use_dump<NPX>(ht, a.lds_dump_off);
     int toff[KSTEPS];
 #pragma unroll
     for (int sl = 0; sl < KSTEPS; ++sl) {
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(BwdFusedArgs a) 
     for (int tile = bid; tile < a.ntiles; tile += gridDim.x) {
         const TileOrigin o = cur.origin(g);
         __syncthreads();                       // previous tile: all reads of ldsA / ldsX are done
-        mil_commit_halo<NPX>(rx, ldsA, ht);
+        mil_commit_halo_all<NPX>(rx, ldsA, ht);
 
         // this tile's x (mask + wgrad operand) and addend, 8 bytes per lane per (row tile, column tile)
         const int obase = ((o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (CX * 2);
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(BwdFusedArgs a) 
             for (int nt = 0; nt < NTX; ++nt) {
                 const unsigned off = (LAST_PARTIAL && nt == NTX - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 32;
                 rxc[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
-                if (a.addend) radd[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, off, 0, 0);
+                if constexpr (ADD) radd[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, off, 0, 0);
             }
         }
         __syncthreads();                       // dz halo visible
@@ -185,8 +186,11 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(BwdFusedArgs a) 
         for (int p = 0; p < NPAIR; ++p)
 #pragma unroll
             for (int nt = 0; nt < NTX; ++nt)
-                if (!(LAST_PARTIAL && nt == NTX - 1) || last_ok)
-                    *reinterpret_cast<u32x4_t*>(ldsX + x_lds[p] + nt * 32) = rxc[p][nt];
+            {
+                // lanes whose channels of the last column tile do not exist write to the dump slot instead of branching
+                const int dst = (LAST_PARTIAL && nt == NTX - 1 && !last_ok) ? a.lds_dump_off : a.lds_x_off + x_lds[p] + nt * 32;
+                *reinterpret_cast<u32x4_t*>(smem + dst) = rxc[p][nt];
+            }
 
         // ---- data-gradient epilogue from registers, 8 channels per lane --------------------------------
 #pragma unroll
@@ -201,12 +205,12 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(BwdFusedArgs a) 
                     v[i] = lo;
                     v[4 + i] = hi;
                 }
-                if (a.addend) {
+                if constexpr (ADD) {
                     const bf16x8_t t = __builtin_bit_cast(bf16x8_t, radd[p][nt]);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] += (float)t[i];
                 }
-                if (a.apply_mask) {
+                if constexpr (MASK) {
                     const bf16x8_t t = __builtin_bit_cast(bf16x8_t, rxc[p][nt]);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] *= ((float)t[i] > 0.f ? 1.f : a.slope);
@@ -221,6 +225,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(BwdFusedArgs a) 
         __syncthreads();                       // x centre tile visible
 
         // ---- weight gradient: rows (tap', dz channel), cols x channel, K = the tile's 256 pixels -------
+#pragma unroll 2
         for (int k32 = 0; k32 < 256; k32 += 32) {
             // pixel k = k32 + (8*gq + q4 [+4]): the halo offset is additive in the two parts (no carries between
             // their bit fields), so the lane part is tile-invariant and the k32 part is wave-uniform (scalar unit)
@@ -319,24 +324,33 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
     const int a_bytes = (halo_px * PIXB + 15) & ~15;
     const int w_bytes = KSTEPS * NTX * 64 * 16;
     const int x_bytes = 256 * PIXX;
-    const int lds = a_bytes + w_bytes + x_bytes;
+    const int lds = a_bytes + w_bytes + x_bytes + 16;          // + dump slot for branch-free LDS writes
     if (lds > 160 * 1024) return MIL_ERR_UNSUPPORTED;
     const int ntiles = a.g.n_groups * a.g.tiles_y * a.g.tiles_x;
-    const int per_cu = (160 * 1024) / lds;
-    int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu));
+    auto kern = a.addend ? (a.apply_mask ? conv_bwd_fused_kernel<CZ, NTX, KS, true, true> : conv_bwd_fused_kernel<CZ, NTX, KS, true, false>)
+                         : (a.apply_mask ? conv_bwd_fused_kernel<CZ, NTX, KS, false, true> : conv_bwd_fused_kernel<CZ, NTX, KS, false, false>);
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return MIL_ERR_LAUNCH;
+    }
+    // the workspace query (no pointers yet) must size for the same grid the launch will use: occupancy does not depend
+    // on the ADD/MASK variant's few registers, but take the minimum over the variants to be safe
+    int per_cu = 3;
+    {
+        const int o1 = mil_resident_per_cu(conv_bwd_fused_kernel<CZ, NTX, KS, true, true>, lds, 3);
+        const int o2 = mil_resident_per_cu(conv_bwd_fused_kernel<CZ, NTX, KS, false, true>, lds, 3);
+        const int o3 = mil_resident_per_cu(conv_bwd_fused_kernel<CZ, NTX, KS, true, false>, lds, 3);
+        per_cu = o1 < o2 ? o1 : o2; per_cu = per_cu < o3 ? per_cu : o3;
+    }
+    int grid = 256 * per_cu;
     if (grid > ntiles) grid = ntiles;
     const size_t slab_elems = (size_t)(MT + 1) * 16 * NTX * 16;
     const size_t bytes = slab_elems * grid * sizeof(float);
     if (query) { *need = bytes; return MIL_OK; }
     if (!ws || ws_bytes < bytes) return MIL_ERR_ARG;
-    a.slab = (float*)ws; a.ntiles = ntiles; a.lds_w_off = a_bytes; a.lds_x_off = a_bytes + w_bytes;
+    a.slab = (float*)ws; a.ntiles = ntiles; a.lds_w_off = a_bytes; a.lds_x_off = a_bytes + w_bytes; a.lds_dump_off = a_bytes + w_bytes + x_bytes;
     a.z_bytes = (unsigned)((size_t)a.g.n_img * a.g.H * a.g.W * CZ * 2);
     a.x_bytes = (unsigned)((size_t)a.g.n_img * a.g.H * a.g.W * CX * 2);
-    auto kern = conv_bwd_fused_kernel<CZ, NTX, KS>;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return MIL_ERR_LAUNCH;
-    }
     if (grid <= 0) return MIL_OK;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
     MIL_CHECK_LAUNCH();

@@ -111,6 +111,19 @@ __device__ __forceinline__ void mil_commit_halo(const u32x4_t (&rx)[NP], char* l
         if (t.pos[i] >= 0) *reinterpret_cast<u32x4_t*>(lds + t.lds[i]) = rx[i];
 }
 
+// Branch-free commit: tables built with mil_halo_tables_use_dump() send the unused slots to a 16-byte dump area, so
+// every slot is written unconditionally (a divergent branch per LDS store costs more than the store).
+template <int NP>
+__device__ __forceinline__ void mil_halo_tables_use_dump(HaloTables<NP>& t, int dump_off) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) if (t.pos[i] < 0) t.lds[i] = dump_off;
+}
+template <int NP>
+__device__ __forceinline__ void mil_commit_halo_all(const u32x4_t (&rx)[NP], char* lds, const HaloTables<NP>& t) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) *reinterpret_cast<u32x4_t*>(lds + t.lds[i]) = rx[i];
+}
+
 // Output-space tile (no halo) pieces owned by a thread: flat piece id = tid + 256*i -> (tile pixel, 16-B piece).
 template <int NP>
 struct OtileTables { int pos[NP], lds[NP], rel[NP]; };
@@ -173,6 +186,16 @@ __device__ __forceinline__ bf16x8_t mil_tr_pair(const char* p0, const char* p1) 
     typedef __attribute__((ext_vector_type(8))) short s16x8_t;
     s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// Workgroups of `kern` (256 threads, `lds` bytes of dynamic LDS) that one CU holds at a time, from the runtime's own
+// occupancy calculation (registers AND LDS).  Persistent launches size their grid to exactly the resident set: a
+// partial second round would leave CUs idle while the stragglers finish.
+template <typename K>
+__host__ inline int mil_resident_per_cu(K kern, int lds, int cap) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, (size_t)lds) != hipSuccess || n < 1) n = 1;
+    return n > cap ? cap : n;
 }
 
 // How many images of `bytes_per_img` bytes fit under the 2 GiB buffer limit.

@@ -42,7 +42,6 @@ __host__ __device__ constexpr int sf_lds_bytes() {
 template <int NT>
 __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void stem_fwd_fused_kernel(StemFwdArgs a) {
     constexpr int COUTP = mil_nt_to_cp(NT);
-    constexpr int NG = COUTP / 8;
     constexpr int SPIX = mil_pix_pitch(COUTP, 2);
     constexpr int KSTEPS = 8;
     constexpr int NG4 = COUTP / 4;
