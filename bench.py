@@ -220,10 +220,10 @@ def main():
                 traffic = None
                 try:                                                       # rocprofv3 PMC passes of this same command
                     pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
-                    key = "conv_bwd_fused_kernel<24, 2, 3>" if fam != "conv" else "conv_igemm_pf_kernel<24, 2, 3, 4>"
-                    hit = [v for k, v in pmc.items() if key in k]
+                    key = "conv_bwd_fused_kernel<24, 2, 3" if fam != "conv" else "conv_igemm_pf_kernel<24, 2, 3, 4>"
+                    hit = [v for k, v in pmc.items() if key in k]           # all template variants of the kernel family
                     if hit and n_img == 2048:
-                        traffic = hit[0]["hbm_bytes"]
+                        traffic = sum(v["hbm_bytes"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit)
                 except (OSError, KeyError, ValueError):
                     traffic = None
                 # Which roof: arithmetic intensity of the kernel's ALGORITHMIC work against the ridge point
