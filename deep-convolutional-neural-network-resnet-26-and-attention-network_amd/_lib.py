@@ -45,6 +45,9 @@ _SIGS = {
     "mil_conv_bwd_fused": ([_vp] * 8 + [_sz] + [_i] * 9 + [_f, _i, _vp], _i),
     "mil_maxpool_fwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "mil_maxpool_bwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
+    "mil_resize_plan": ([_i, _i, _c.POINTER(_i)], _i),
+    "mil_resize_coeffs": ([_i, _i, _vp, _vp], _i),
+    "mil_tile_preprocess": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "mil_conv_s2_entry": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
     "mil_conv_dgrad_s2": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
     "mil_stem_fwd_fused": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp], _i),

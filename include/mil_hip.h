@@ -104,6 +104,17 @@ int mil_maxpool_fwd(const void* x, void* y, uint8_t* widx, int n, int H, int W, 
 int mil_maxpool_bwd(const void* gy, const uint8_t* widx, void* gx, int n, int H, int W, int cp,
                     int apply_lrelu_mask, float slope, int dtype, void* stream);
 
+/* Tile pre-processing on the device (RoiBuilder.py:193-210: Pad(100) -> RandomCrop(roi) -> Resize(res) ->
+ * RandomHorizontalFlip -> RandomVerticalFlip -> ToTensor -> Normalize(.5,.5); `img_finalize_flat` without pad/crop/flips):
+ * uint8 ROIs [T,S,S,3] -> fp32 [T,3,R,R] in [-1,1], the tensor gbm/classify_combined.py:432 hands to the model.  The
+ * resampling is Pillow's two-pass fixed-point bilinear filter, bit-exact.  mil_resize_plan/_coeffs run on the HOST and fill
+ * host arrays (bounds [R*2], kk [R*ksize]) that the caller uploads once per (S,R); params [T,4] = (top, left, hflip,
+ * vflip) drawn by the caller (top/left in [0, 2*pad]) or null for the flat chain. */
+int mil_resize_plan(int in_size, int out_size, int* ksize);
+int mil_resize_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* kk);
+int mil_tile_preprocess(const uint8_t* rois, const int32_t* params, const int32_t* bounds_host, const int32_t* bounds_dev,
+                        const int32_t* kk_dev, float* out, int T, int S, int pad, int R, void* stream);
+
 /* Forward of a stage-entry block's two stride-2 convs in one pass over the block input (bf16 path):
  *   y1 = lrelu(conv3x3_s2(x) + bias)   (nnBlocks.py:176-177)      y2 = conv1x1_s2(x)   (gbm/model.py:38-40)
  * wpack3 / wpack1: MIL_PACK_FWD fragments of the two filters.  (cin_p,cout_p) in {(24,40),(40,64)}; otherwise

@@ -179,7 +179,68 @@ def run_alt_case(alt, name, layers, num_classes, wseed, x):
     print(f"{name}: |feats|max={feats.abs().max().item():.4f}")
 
 
+def run_prep_case(name, n_tiles, roi, pad, res, seed, train, store="f32"):
+    """The tile pre-processing chain of RoiBuilder.py:193-210 run with Pillow itself (the library the reference's
+    torchvision transforms call for PIL images) and torch's own ToTensor/Normalize arithmetic.  torchvision is not
+    importable here, so its PIL-backend calls are spelled out: Pad(p) = ImageOps.expand(border=p, fill=0); RandomCrop =
+    Image.crop; Resize(r) = Image.resize((r, r), BILINEAR); flips = Image.transpose.  Inputs are regenerated from `seed`."""
+    from PIL import Image, ImageOps
+    rng = np.random.default_rng(seed)
+    rois = rng.integers(0, 256, (n_tiles, roi, roi, 3), dtype=np.uint8)
+    # smooth gradients in half of the tiles: resampling bugs that noise hides show up on ramps
+    ramp = (np.add.outer(np.arange(roi), 2 * np.arange(roi)) % 256).astype(np.uint8)
+    rois[::2, :, :, 1] = ramp
+    params = np.zeros((n_tiles, 4), dtype=np.int32)
+    if train:
+        params[:, 0] = rng.integers(0, 2 * pad + 1, n_tiles)
+        params[:, 1] = rng.integers(0, 2 * pad + 1, n_tiles)
+        params[:, 2] = rng.integers(0, 2, n_tiles)
+        params[:, 3] = rng.integers(0, 2, n_tiles)
+        params[0] = (0, 2 * pad, 1, 0)                      # extreme crops: all padding on one side
+        if n_tiles > 1:
+            params[1] = (2 * pad, 0, 0, 1)
+    outs_u8, outs = [], []
+    for t in range(n_tiles):
+        img = Image.fromarray(rois[t])
+        if train:
+            top, left, hf, vf = (int(v) for v in params[t])
+            img = ImageOps.expand(img, border=pad, fill=0)
+            img = img.crop((left, top, left + roi, top + roi))
+        img = img.resize((res, res), Image.BILINEAR)
+        if train and hf:
+            img = img.transpose(Image.FLIP_LEFT_RIGHT)
+        if train and vf:
+            img = img.transpose(Image.FLIP_TOP_BOTTOM)
+        arr = np.array(img)
+        outs_u8.append(arr)
+        ten = torch.from_numpy(arr).permute(2, 0, 1).contiguous().to(torch.float32).div(255)      # ToTensor
+        ten.sub_(0.5).div_(0.5)                                                                   # Normalize(.5,.5)
+        outs.append(ten.numpy())
+    blob = dict(roi=np.array(roi), pad=np.array(pad), res=np.array(res), seed=np.array(seed), train=np.array(int(train)),
+                n_tiles=np.array(n_tiles), params=params)
+    if store == "f32":
+        blob["out"] = np.stack(outs)
+    else:
+        blob["out_u8"] = np.stack(outs_u8)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **blob)
+    print(f"{name}: {n_tiles} tiles {roi}->{res}")
+
+
+def prep_inputs(z):
+    """Regenerate the inputs of a prep_* fixture (same construction as run_prep_case)."""
+    n, roi, seed = int(z["n_tiles"]), int(z["roi"]), int(z["seed"])
+    rng = np.random.default_rng(seed)
+    rois = rng.integers(0, 256, (n, roi, roi, 3), dtype=np.uint8)
+    ramp = (np.add.outer(np.arange(roi), 2 * np.arange(roi)) % 256).astype(np.uint8)
+    rois[::2, :, :, 1] = ramp
+    return rois
+
+
 def main():
+    run_prep_case("prep_s120_r32_train", 6, 120, 10, 32, 31, True)
+    run_prep_case("prep_s100_r37_flat", 3, 100, 10, 37, 32, False)
+    run_prep_case("prep_s50_r80_train", 2, 50, 7, 80, 33, True)                  # up-sampling
+    run_prep_case("prep_s1200_r300_train", 2, 1200, 100, 300, 34, True, store="u8")    # the reference driver's sizes
     alt = load_reference_alt()
     run_alt_case(alt, "alt_l1111_n4_64", (1, 1, 1, 1), 80, 555, synth_bag(4, 64, 64, 20260201))
     run_alt_case(alt, "alt_l2222_n2_96x80", (2, 2, 2, 2), 80, 556, synth_bag(2, 96, 80, 20260202))
