@@ -31,6 +31,7 @@ struct PrepArgs {
 
 __device__ __forceinline__ unsigned prep_clip8(int v) { v >>= PREP_BITS; return (unsigned)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
+template <int KS>
 __global__ __launch_bounds__(256) void tile_preprocess_kernel(PrepArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
     unsigned char* rows = psm;
@@ -52,36 +53,80 @@ __global__ __launch_bounds__(256) void tile_preprocess_kernel(PrepArgs a) {
     const int row_bytes = S * 3;
     const bool wide = (row_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(src_tile) & 3) == 0;
 
+    // Fast path (16-byte aligned rows, <= 4 KB each): the next four source rows are fetched into registers while the
+    // current four are filtered, so the global-load latency is paid once per band instead of once per row group.
+    typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
+    const int ppr = row_bytes >> 4;                                   // 16-byte pieces per source row
+    const bool fast = (row_bytes & 15) == 0 && (a.margin & 15) == 0 && (reinterpret_cast<uintptr_t>(src_tile) & 15) == 0 && ppr <= 256;
+    u4_t pre[PREP_ROWS];
+    auto fetch_rows = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < PREP_ROWS; ++i) {
+            const int id = tid + 256 * i, jj = id / ppr, piece = id - jj * ppr;
+            const int ys = top + y_lo + j0 + jj - pad;
+            const bool ok = jj < PREP_ROWS && j0 + jj < nri && ys >= 0 && ys < S;
+            pre[i] = ok ? *reinterpret_cast<const u4_t*>(src_tile + (size_t)ys * row_bytes + piece * 16) : u4_t{0u, 0u, 0u, 0u};
+        }
+    };
+    if (fast) fetch_rows(0);
+
     for (int j0 = 0; j0 < nri; j0 += PREP_ROWS) {
         // ---- stage up to four source rows (rows of the padded/cropped image; outside the ROI they are zero) ----
-        for (int jj = 0; jj < PREP_ROWS; ++jj) {
-            if (j0 + jj >= nri) break;
-            const int ys = top + y_lo + j0 + jj - pad;
-            const bool inside = ys >= 0 && ys < S;
-            unsigned char* dst = rows + jj * a.row_pitch + a.margin;
-            const unsigned char* src = src_tile + (size_t)(inside ? ys : 0) * row_bytes;
-            if (wide) {
-                for (int b = tid * 4; b < row_bytes; b += 1024)
-                    *reinterpret_cast<unsigned*>(dst + b) = inside ? *reinterpret_cast<const unsigned*>(src + b) : 0u;
-            } else {
-                for (int b = tid; b < row_bytes; b += 256) dst[b] = inside ? src[b] : (unsigned char)0;
+        if (fast) {
+#pragma unroll
+            for (int i = 0; i < PREP_ROWS; ++i) {
+                const int id = tid + 256 * i, jj = id / ppr, piece = id - jj * ppr;
+                if (jj < PREP_ROWS) *reinterpret_cast<u4_t*>(rows + jj * a.row_pitch + a.margin + piece * 16) = pre[i];
             }
+            __syncthreads();
+            if (j0 + PREP_ROWS < nri) fetch_rows(j0 + PREP_ROWS);
+        } else {
+            for (int jj = 0; jj < PREP_ROWS; ++jj) {
+                if (j0 + jj >= nri) break;
+                const int ys = top + y_lo + j0 + jj - pad;
+                const bool inside = ys >= 0 && ys < S;
+                unsigned char* dst = rows + jj * a.row_pitch + a.margin;
+                const unsigned char* src = src_tile + (size_t)(inside ? ys : 0) * row_bytes;
+                if (wide) {
+                    for (int b = tid * 4; b < row_bytes; b += 1024)
+                        *reinterpret_cast<unsigned*>(dst + b) = inside ? *reinterpret_cast<const unsigned*>(src + b) : 0u;
+                } else {
+                    for (int b = tid; b < row_bytes; b += 256) dst[b] = inside ? src[b] : (unsigned char)0;
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
         // ---- horizontal pass of these rows -> strip ------------------------------------------------------------
-        for (int it = tid; it < PREP_ROWS * R; it += 256) {
-            const int jj = it / R, xr = it - jj * R;
-            if (j0 + jj >= nri) break;
-            const int xmin = bds[2 * xr], cnt = bds[2 * xr + 1];
-            const unsigned char* p = rows + jj * a.row_pitch + a.margin + (left - pad + xmin) * 3;
-            const int* w = kks + xr * ksize;
-            int s0 = 1 << (PREP_BITS - 1), s1 = s0, s2 = s0;
-            for (int k = 0; k < cnt; ++k) {
-                const int wk = w[k];
-                s0 += (int)p[3 * k] * wk; s1 += (int)p[3 * k + 1] * wk; s2 += (int)p[3 * k + 2] * wk;
+        // A thread owns output column xr for all staged rows: its KS weights are read once; the 3*KS source bytes of
+        // a row are fetched as aligned dwords and funnel-shifted (v_alignbyte) to the window start, so the taps index
+        // registers at compile-time positions (weights beyond the window are zero, the bytes behind them are slack).
+        for (int xr = tid; xr < R; xr += 256) {
+            constexpr int ND = (3 * KS + 3) / 4;
+            const int xmin = bds[2 * xr];
+            int w[KS];
+#pragma unroll
+            for (int k = 0; k < KS; ++k) w[k] = k < ksize ? kks[xr * ksize + k] : 0;
+            const int b0 = a.margin + (left - pad + xmin) * 3;
+            const int al = b0 & ~3;
+            const unsigned sh = (unsigned)(b0 & 3);
+            for (int jj = 0; jj < PREP_ROWS; ++jj) {
+                if (j0 + jj >= nri) break;
+                const unsigned* q = reinterpret_cast<const unsigned*>(rows + jj * a.row_pitch + al);
+                unsigned d[ND + 1], e[ND];
+#pragma unroll
+                for (int i = 0; i < ND + 1; ++i) d[i] = q[i];
+#pragma unroll
+                for (int i = 0; i < ND; ++i) e[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+                int s0 = 1 << (PREP_BITS - 1), s1 = s0, s2 = s0;
+#pragma unroll
+                for (int k = 0; k < KS; ++k) {
+                    s0 += (int)((e[(3 * k) >> 2] >> (((3 * k) & 3) * 8)) & 0xffu) * w[k];
+                    s1 += (int)((e[(3 * k + 1) >> 2] >> (((3 * k + 1) & 3) * 8)) & 0xffu) * w[k];
+                    s2 += (int)((e[(3 * k + 2) >> 2] >> (((3 * k + 2) & 3) * 8)) & 0xffu) * w[k];
+                }
+                unsigned char* h = hres + ((j0 + jj) * R + xr) * 3;
+                h[0] = (unsigned char)prep_clip8(s0); h[1] = (unsigned char)prep_clip8(s1); h[2] = (unsigned char)prep_clip8(s2);
             }
-            unsigned char* h = hres + ((j0 + jj) * R + xr) * 3;
-            h[0] = (unsigned char)prep_clip8(s0); h[1] = (unsigned char)prep_clip8(s1); h[2] = (unsigned char)prep_clip8(s2);
         }
         __syncthreads();
     }
@@ -167,16 +212,18 @@ extern "C" int mil_tile_preprocess(const uint8_t* rois, const int32_t* params, c
         const int n = bounds_host[2 * (r1 - 1)] + bounds_host[2 * (r1 - 1) + 1] - bounds_host[2 * r0];
         if (n > nri_max) nri_max = n;
     }
-    a.margin = (3 * a.pad + 3) & ~3;
-    a.row_pitch = (a.margin + S * 3 + 3 * a.pad + 3 * a.ksize + 15) & ~15;
+    a.margin = (3 * a.pad + 15) & ~15;
+    a.row_pitch = (a.margin + S * 3 + 3 * a.pad + 3 * 32 + 8 + 15) & ~15;       // + slack read behind the last window
     a.lds_h_off = PREP_ROWS * a.row_pitch;
     a.lds_k_off = (a.lds_h_off + nri_max * R * 3 + 15) & ~15;
     a.lds_b_off = a.lds_k_off + R * a.ksize * 4;
     const int lds = a.lds_b_off + 2 * R * 4;
-    if (lds > 160 * 1024 || T > 65535) return MIL_ERR_UNSUPPORTED;
-    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(tile_preprocess_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (lds > 160 * 1024 || T > 65535 || a.ksize > 32) return MIL_ERR_UNSUPPORTED;
+    auto kern = a.ksize <= 4 ? tile_preprocess_kernel<4> : a.ksize <= 8 ? tile_preprocess_kernel<8> : a.ksize <= 12 ? tile_preprocess_kernel<12>
+              : a.ksize <= 16 ? tile_preprocess_kernel<16> : a.ksize <= 24 ? tile_preprocess_kernel<24> : tile_preprocess_kernel<32>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MIL_ERR_LAUNCH;
-    hipLaunchKernelGGL(tile_preprocess_kernel, dim3((R + PREP_BAND - 1) / PREP_BAND, T), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(kern, dim3((R + PREP_BAND - 1) / PREP_BAND, T), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
