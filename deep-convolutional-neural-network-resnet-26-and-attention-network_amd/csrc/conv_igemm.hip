@@ -157,9 +157,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs<T> a) {
 //     memory goes through buffer descriptors with out-of-range offsets as the predicate (pf_common.cuh):
 //     the per-tile instruction stream is loads, MFMAs and the element-wise epilogue, which is what keeps
 //     the kernel on the HBM roof rather than on the vector-issue roof.
-template <int CINP, int NT, int KS, int MTW>
-__global__ __launch_bounds__(256, ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 40 ? 2 : 1))) void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles,
-                                                                                  unsigned x_bytes, unsigned y_bytes) {
+// FLAGS: -1 = epilogue options read from the arguments at run time; otherwise a bit mask fixed at compile time
+// (1 residual/addend, 2 lrelu' mask, 4 LeakyReLU): the unused operand prefetch registers and branches disappear, which
+// for the 24-channel layers is the difference between two and three resident waves per SIMD.
+#ifndef MIL_PF_WAVES_24
+#define MIL_PF_WAVES_24 3
+#endif
+template <int CINP, int NT, int KS, int MTW, int FLAGS = -1>
+__global__ __launch_bounds__(256, ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 24 && FLAGS >= 0 && FLAGS != 3) ? MIL_PF_WAVES_24 : (CINP <= 40 ? 2 : 1)))
+void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsigned y_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using T = BF16;
     constexpr int PIXB = mil_pix_pitch(CINP, 2);
@@ -174,6 +180,9 @@ __global__ __launch_bounds__(256, ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 40 ? 
     const int r = lane & 15, gq = lane >> 4;
     char* ldsA = smem;
     char* ldsW = smem + a.lds_w_off;
+    const bool has_res = FLAGS < 0 ? (a.res != nullptr) : (FLAGS & 1) != 0;
+    const bool has_act = FLAGS < 0 ? (a.act != nullptr) : (FLAGS & 2) != 0;
+    const bool do_lrelu = FLAGS < 0 ? (a.apply_lrelu != 0) : (FLAGS & 4) != 0;
 
     {
         const int nbytes = KSTEPS * NT * 64 * 16;
@@ -191,6 +200,7 @@ __global__ __launch_bounds__(256, ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 40 ? 
     // ---- tile-invariant tables ---------------------------------------------------------------------
     HaloTables<NPX> ht;
     mil_build_halo_tables<CINP, NPX>(ht, g, tid);
+    mil_halo_tables_use_dump<NPX>(ht, a.lds_w_off + KSTEPS * NT * 64 * 16);      // 16 spare bytes behind the filter
     int toff[KSTEPS];
 #pragma unroll
     for (int sl = 0; sl < KSTEPS; ++sl) {
@@ -242,8 +252,8 @@ __global__ __launch_bounds__(256, ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 40 ? 
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 32;
-                if (a.res) rres[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0);
-                if (a.act) ract[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, off, 0, 0);
+                if (has_res) rres[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0);
+                if (has_act) ract[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, off, 0, 0);
             }
         }
     };
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(256, ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 40 ? 
 
     auto do_tile = [&](u32x4_t (&rx)[NPX], int tile) {
         __syncthreads();                       // every wave has finished reading ldsA for the previous tile
-        mil_commit_halo<NPX>(rx, ldsA, ht);
+        mil_commit_halo_all<NPX>(rx, ldsA, ht);
         // this tile's epilogue operands were requested one tile ago; take them over before re-issuing
         unsigned ooff[NPAIR];
         u32x4_t rres[NPAIR][NT], ract[NPAIR][NT];
@@ -323,16 +333,16 @@ __global__ __launch_bounds__(256, ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 40 ? 
                     v[i] = lo;
                     v[4 + i] = hi;
                 }
-                if (a.res) {
+                if (has_res) {
                     const bf16x8_t t = __builtin_bit_cast(bf16x8_t, rres[p][nt]);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] += (float)t[i];
                 }
-                if (a.apply_lrelu) {
+                if (do_lrelu) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], v[i] * a.slope);      // 0 < slope < 1
                 }
-                if (a.act) {
+                if (has_act) {
                     const bf16x8_t t = __builtin_bit_cast(bf16x8_t, ract[p][nt]);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] *= ((float)t[i] > 0.f ? 1.f : a.slope);
@@ -397,12 +407,20 @@ static int mil_pf_min_tiles() {
     return e ? atoi(e) : 512;
 }
 
+static int mil_pf_rounds() {
+    static const int r = [] { const char* e = getenv("MIL_PF_ROUNDS"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
+    return r;
+}
+
 #ifndef MIL_PF_WG_PER_CU
 #define MIL_PF_WG_PER_CU 4
 #endif
 #ifndef MIL_PF_MTW_24
 #define MIL_PF_MTW_24 4
 #endif
+template <int CINP, int NT, int KS, int MTW, int FLAGS>
+static auto conv_pf_variant() { return conv_igemm_pf_kernel<CINP, NT, KS, MTW, FLAGS>; }
+
 template <int CINP, int NT, int KS, int MTW = 4>
 static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool* taken) {
     ConvArgs<BF16> a = a0;
@@ -414,18 +432,26 @@ static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool*
     if (halo_px > mil_halo_px_max(MTW)) return MIL_OK;
     const int a_bytes = (halo_px * PIXB + 15) & ~15;
     const int w_bytes = a.nsteps * NT * 64 * 16;
-    const int lds = a_bytes + w_bytes;
+    const int lds = a_bytes + w_bytes + 16;                 // + dump slot for the branch-free halo commit
     if (lds > 160 * 1024) return MIL_OK;
     if (a.g.hh >= 1024 || a.g.hw >= 1024 || a.slope < 0.f || a.slope >= 1.f) return MIL_OK;   // max(v, slope*v) form
     if ((a.g.n_groups * a.g.tiles_y * a.g.tiles_x) < mil_pf_min_tiles()) return MIL_OK;    // too few tiles for a persistent launch
     a.kc = a.nsteps;
     a.lds_w_off = a_bytes;
     auto kern = conv_igemm_pf_kernel<CINP, NT, KS, MTW>;
+    // the hot square 3x3 layers get the epilogue options as compile-time constants
+    if constexpr (KS == 3 && ((CINP == 24 && NT == 2) || (CINP == 40 && NT == 3) || (CINP == 64 && NT == 4) || (CINP == 80 && NT == 5))) {
+        const int fl = (a.res ? 1 : 0) | (a.act ? 2 : 0) | (a.apply_lrelu ? 4 : 0);
+        if (fl == 4) kern = conv_pf_variant<CINP, NT, KS, MTW, 4>();
+        else if (fl == 5) kern = conv_pf_variant<CINP, NT, KS, MTW, 5>();
+        else if (fl == 2) kern = conv_pf_variant<CINP, NT, KS, MTW, 2>();
+        else if (fl == 3) kern = conv_pf_variant<CINP, NT, KS, MTW, 3>();
+    }
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return MIL_ERR_LAUNCH;
     }
-    const int per_cu = (160 * 1024) / lds;
+    const int per_cu = mil_resident_per_cu(kern, lds, MIL_PF_WG_PER_CU) * mil_pf_rounds();   // rounds of resident workgroups
     // buffer descriptors address < 2 GiB: split the launch by images when a tensor is larger
     const size_t x_img = (size_t)a.g.H * a.g.W * CINP * 2, y_img = (size_t)a.g.Ho * a.g.Wo * COUTP * 2;
     int chunk = mil_imgs_under_2g(x_img > y_img ? x_img : y_img);
@@ -441,7 +467,7 @@ static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool*
         if (a.res) c.res = a.res + (size_t)i0 * (y_img / 2);
         if (a.act) c.act = a.act + (size_t)i0 * (y_img / 2);
         const int ntiles = c.g.n_groups * c.g.tiles_y * c.g.tiles_x;
-        int grid = 256 * (per_cu < 1 ? 1 : (per_cu > MIL_PF_WG_PER_CU ? MIL_PF_WG_PER_CU : per_cu));
+        int grid = 256 * per_cu;
         if (grid > ntiles) grid = ntiles;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, c, ntiles, (unsigned)(x_img * n), (unsigned)(y_img * n));
         MIL_CHECK_LAUNCH();
