@@ -1,0 +1,273 @@
+// Forward of a whole identity-shortcut residual block in one pass (bf16 path, 24- and 40-channel stages):
+//   o1  = lrelu(conv3x3(x) + b1)                  nnBlocks.py:176-177
+//   out = lrelu(conv3x3(o1) + b2 + x)             nnBlocks.py:179-189 (identity shortcut, in-place add)
+// The two persistent conv launches this replaces are at the device-copy bandwidth on the 64x64 maps (the forward
+// convs move 2 and 3 tensors per launch); fused, the block input is read once (it is both conv1's operand and the
+// residual), the mid activation goes from the accumulators to an LDS tile that conv2 reads directly, and only what
+// the backward needs is written: o1 and out.  5 tensor passes become 3.
+//
+// Tile = 16x16 output pixels of one image <- 18x18 mid pixels (conv1 is recomputed on the one-pixel ring, +27% of
+// its MFMA work, which is not the bottleneck) <- 20x20 input pixels.  Mid pixels outside the image are conv2's zero
+// padding and are written as zeros.  Structure otherwise as conv_igemm_pf_kernel: persistent workgroups, filters
+// resident in LDS, register prefetch of the next input halo, D[channel][pixel] accumulators, paired 16-byte epilogue.
+#include "pf_common.cuh"
+
+struct BlockFwdArgs {
+    const __bf16* x;        // [n,H,W,CP]
+    const __bf16* w1;       // MIL_PACK_FWD fragments [KSTEPS][NT][64][8]
+    const __bf16* w2;
+    const float* b1;        // [NT*16]
+    const float* b2;
+    __bf16* o1;             // [n,H,W,CP]
+    __bf16* y;              // [n,H,W,CP]
+    ConvGeom g;             // 16x16 tiles; halo described as a 5x5 / pad 2 window (20x20 input pixels)
+    int lds_o_off, lds_w_off, lds_dump_off;
+    float slope;
+};
+
+template <int CP, int NT>
+__global__ __launch_bounds__(256, CP <= 24 ? 2 : 1) void conv_block_fwd_kernel(BlockFwdArgs a, int ntiles, unsigned bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PIXB = mil_pix_pitch(CP, 2);
+    constexpr int CG = CP / 8;
+    constexpr int KSTEPS = (9 * CG + 3) / 4;
+    constexpr int NPX = (400 * CG + 255) / 256;
+    constexpr int MT1 = 6;                                   // 4 waves x 6 row tiles x 16 = 384 >= 324 mid pixels
+    constexpr bool LAST_PARTIAL = (CP % 16) != 0;
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, gq = lane >> 4;
+    char* ldsX = smem;
+    char* ldsO = smem + a.lds_o_off;
+    char* ldsW1 = smem + a.lds_w_off;
+    char* ldsW2 = ldsW1 + KSTEPS * NT * 64 * 16;
+    {
+        const char* s1 = reinterpret_cast<const char*>(a.w1);
+        const char* s2 = reinterpret_cast<const char*>(a.w2);
+        for (int i = tid * 16; i < KSTEPS * NT * 64 * 16; i += 256 * 16) {
+            *reinterpret_cast<uint4*>(ldsW1 + i) = *reinterpret_cast<const uint4*>(s1 + i);
+            *reinterpret_cast<uint4*>(ldsW2 + i) = *reinterpret_cast<const uint4*>(s2 + i);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, bytes);
+    const __amdgpu_buffer_rsrc_t rs_o = mil_rsrc(a.o1, bytes);
+    const __amdgpu_buffer_rsrc_t rs_y = mil_rsrc(a.y, bytes);
+    const int H = g.H, W = g.W;
+
+    // ---- tile-invariant tables --------------------------------------------------------------------
+    HaloTables<NPX> ht;
+    mil_build_halo_tables<CP, NPX>(ht, g, tid);
+    mil_halo_tables_use_dump<NPX>(ht, a.lds_dump_off);
+    int toff1[KSTEPS], toff2[KSTEPS];
+#pragma unroll
+    for (int sl = 0; sl < KSTEPS; ++sl) {
+        const int q = 4 * sl + gq;
+        int tap = q / CG, cg = q - tap * CG;
+        if (tap >= 9) { tap = 0; cg = 0; }
+        toff1[sl] = ((tap / 3) * 20 + (tap % 3)) * PIXB + cg * 16;
+        toff2[sl] = ((tap / 3) * 18 + (tap % 3)) * PIXB + cg * 16;
+    }
+    int pixbase1[MT1], sdst1[MT1];                           // conv1: mid pixel (py,px) reads input halo (py+ky, px+kx)
+#pragma unroll
+    for (int i = 0; i < MT1; ++i) {
+        const int tp = (wave + 4 * i) * 16 + r;
+        const bool ok = tp < 324;
+        const int py = tp / 18, px = tp - py * 18;
+        pixbase1[i] = ok ? (py * 20 + px) * PIXB : 0;
+        sdst1[i] = ok ? a.lds_o_off + tp * PIXB + gq * 8 : a.lds_dump_off;
+    }
+    int pixbase2[4];                                         // conv2: output pixel (ty,tx) reads mid (ty+ky, tx+kx)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int tp = (wave * 4 + m) * 16 + r;
+        pixbase2[m] = ((tp >> 4) * 18 + (tp & 15)) * PIXB;
+    }
+    int o_rel[2], o_pos[2], xres[2];                         // paired epilogue: pixel (2p + (gq&1), r) of this wave's four row tiles
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int tp = (wave * 4 + 2 * p + (gq & 1)) * 16 + r;
+        const int ty = tp >> 4, tx = tp & 15;
+        o_rel[p] = (ty * W + tx) * (CP * 2) + (gq >> 1) * 16;
+        o_pos[p] = (ty << 10) | tx;
+        xres[p] = ((ty + 2) * 20 + tx + 2) * PIXB + (gq >> 1) * 16;          // the residual = centre of the input halo tile
+    }
+    // mid-tile centre pieces -> o1 tensor: piece id = tid + 256*i -> (pixel id / CG, piece id % CG)
+    int c_lds[CG], c_rel[CG], c_pos[CG];
+#pragma unroll
+    for (int i = 0; i < CG; ++i) {
+        const int id = tid + 256 * i, px = id / CG, j = id - px * CG;
+        const int ty = px >> 4, tx = px & 15;
+        c_lds[i] = ((ty + 1) * 18 + tx + 1) * PIXB + j * 16;
+        c_rel[i] = (ty * W + tx) * (CP * 2) + j * 16;
+        c_pos[i] = (ty << 10) | tx;
+    }
+    const bool last_ok = !LAST_PARTIAL || (gq >> 1) == 0;
+    f32x4_t b1r[NT], b2r[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            b1r[nt][i] = a.b1 ? a.b1[nt * 16 + gq * 4 + i] : 0.f;
+            b2r[nt][i] = a.b2 ? a.b2[nt * 16 + gq * 4 + i] : 0.f;
+        }
+
+    TileWalker cur, nxt;
+    const int bid = mil_xcd_block_id();
+    cur.init(g, bid, gridDim.x);
+    nxt = cur; nxt.advance();
+    u32x4_t rx[NPX];
+    if (bid < ntiles) mil_fetch_halo<CP, NPX>(rx, rs_x, ht, g, cur.origin(g));
+    const int G = gridDim.x;
+    for (int tile = bid; tile < ntiles; tile += G) {
+        const TileOrigin o = cur.origin(g);
+        __syncthreads();                       // previous tile: residual reads of ldsX and conv2's reads of ldsO are done
+        mil_commit_halo_all<NPX>(rx, ldsX, ht);
+        __syncthreads();
+        if (tile + G < ntiles) mil_fetch_halo<CP, NPX>(rx, rs_x, ht, g, nxt.origin(g));
+        cur = nxt; nxt.advance();
+
+        // ---- conv1 on the 18x18 mid tile -> LDS ------------------------------------------------------
+        {
+            f32x4_t acc[MT1][NT];
+#pragma unroll
+            for (int i = 0; i < MT1; ++i)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[i][nt] = b1r[nt];
+#pragma unroll
+            for (int sl = 0; sl < KSTEPS; ++sl) {
+                Frag8<BF16> wf[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<BF16>(ldsW1 + ((sl * NT + nt) * 64 + lane) * 16);
+#pragma unroll
+                for (int i = 0; i < MT1; ++i) {
+                    const Frag8<BF16> xf = lds_frag<BF16>(ldsX + pixbase1[i] + toff1[sl]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[i][nt] = mma8(wf[nt], xf, acc[i][nt]);
+                }
+            }
+            // mid pixels outside the image are conv2's zero padding (only tiles on the image border have any)
+            const int my0 = o.oy0 - 1, mx0 = o.ox0 - 1;
+            const bool border = my0 < 0 || mx0 < 0 || my0 + 18 > H || mx0 + 18 > W;
+#pragma unroll
+            for (int i = 0; i < MT1; ++i) {
+                bool inside = true;
+                if (border) {
+                    const int tp = (wave + 4 * i) * 16 + r, py = (tp * 3641) >> 16, px = tp - py * 18;      // tp / 18 for tp < 1024
+                    inside = (unsigned)(my0 + py) < (unsigned)H && (unsigned)(mx0 + px) < (unsigned)W;
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    bf16x4_t ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float v = acc[i][nt][e]; ov[e] = (__bf16)fmaxf(v, v * a.slope); }
+                    u32x2_t ou = __builtin_bit_cast(u32x2_t, ov);
+                    if (border) { ou[0] = inside ? ou[0] : 0u; ou[1] = inside ? ou[1] : 0u; }
+                    const int dst = (LAST_PARTIAL && nt == NT - 1 && gq >= 2) ? a.lds_dump_off : sdst1[i] + nt * 32;
+                    *reinterpret_cast<u32x2_t*>(smem + dst) = ou;
+                }
+            }
+        }
+        __syncthreads();                       // mid tile visible
+
+        // ---- the tile's own 16x16 mid pixels -> o1 tensor (kept for the backward) ------------------------
+        const int obase = ((o.img0 * H + o.oy0) * W + o.ox0) * (CP * 2);
+        const int ylim = H - o.oy0, xlim = W - o.ox0;
+#pragma unroll
+        for (int i = 0; i < CG; ++i) {
+            const bool ok = (c_pos[i] >> 10) < ylim && (c_pos[i] & 1023) < xlim;
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(ldsO + c_lds[i]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, ok ? (unsigned)(obase + c_rel[i]) : MIL_OOB, 0, 0);
+        }
+        // ---- conv2 + residual + LeakyReLU ------------------------------------------------------------------
+        f32x4_t acc[4][NT];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = b2r[nt];
+#pragma unroll
+        for (int sl = 0; sl < KSTEPS; ++sl) {
+            Frag8<BF16> wf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<BF16>(ldsW2 + ((sl * NT + nt) * 64 + lane) * 16);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const Frag8<BF16> of = lds_frag<BF16>(ldsO + pixbase2[m] + toff2[sl]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wf[nt], of, acc[m][nt]);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const bool ok = (o_pos[p] >> 10) < ylim && (o_pos[p] & 1023) < xlim;
+            const unsigned ooff = ok ? (unsigned)(obase + o_rel[p]) : MIL_OOB;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float lo = acc[2 * p][nt][i], hi = acc[2 * p + 1][nt][i];
+                    if (i == 0) mil_swap16<true>(lo, hi); else mil_swap16<false>(lo, hi);
+                    v[i] = lo;
+                    v[4 + i] = hi;
+                }
+                const bool chan_ok = !(LAST_PARTIAL && nt == NT - 1) || last_ok;
+                const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(ldsX + (chan_ok ? xres[p] + nt * 32 : 0));
+                bf16x8_t ov;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float s = v[i] + (float)t[i]; ov[i] = (__bf16)fmaxf(s, s * a.slope); }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), rs_y, chan_ok ? ooff + nt * 32 : MIL_OOB, 0, 0);
+            }
+        }
+    }
+}
+
+template <int CP, int NT>
+static int launch_block_fwd(BlockFwdArgs a, hipStream_t st) {
+    constexpr int PIXB = mil_pix_pitch(CP, 2), CG = CP / 8;
+    constexpr int KSTEPS = (9 * CG + 3) / 4;
+    ConvGeom& g = a.g;
+    g.tw_log2 = 4; g.th_log2 = 4; g.ti_log2 = 0;
+    g.tiles_x = (g.W + 15) >> 4; g.tiles_y = (g.H + 15) >> 4; g.n_groups = g.n_img;
+    g.hh = 20; g.hw = 20;
+    const int x_bytes = 400 * PIXB, o_bytes = (324 * PIXB + 15) & ~15, w_bytes = 2 * KSTEPS * NT * 64 * 16;
+    a.lds_o_off = x_bytes; a.lds_w_off = x_bytes + o_bytes; a.lds_dump_off = x_bytes + o_bytes + w_bytes;
+    const int lds = a.lds_dump_off + 64;
+    if (lds > 160 * 1024) return MIL_ERR_UNSUPPORTED;
+    auto kern = conv_block_fwd_kernel<CP, NT>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return MIL_ERR_LAUNCH;
+    const int per_cu = mil_resident_per_cu(kern, lds, 4);
+    const size_t img = (size_t)g.H * g.W * CP * 2;
+    const int chunk = mil_imgs_under_2g(img);
+    const int n_total = g.n_img;
+    for (int i0 = 0; i0 < n_total; i0 += chunk) {
+        const int n = (n_total - i0 < chunk) ? n_total - i0 : chunk;
+        BlockFwdArgs c = a;
+        c.g.n_img = n; c.g.n_groups = n;
+        c.x = a.x + (size_t)i0 * (img / 2); c.o1 = a.o1 + (size_t)i0 * (img / 2); c.y = a.y + (size_t)i0 * (img / 2);
+        const int ntiles = n * g.tiles_y * g.tiles_x;
+        int grid = 256 * per_cu;
+        if (grid > ntiles) grid = ntiles;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, c, ntiles, (unsigned)(img * n));
+        MIL_CHECK_LAUNCH();
+    }
+    return MIL_OK;
+}
+
+// o1 = lrelu(conv3x3(x)+b1), y = lrelu(conv3x3(o1)+b2+x) for an identity-shortcut block; x/o1/y [n,H,W,cp].
+// bf16, cp in {24, 40}, H and W >= 16; otherwise MIL_ERR_UNSUPPORTED (caller: two mil_conv_igemm calls).
+extern "C" int mil_conv_block_fwd(const void* x, const void* wpack1, const float* bias1, const void* wpack2, const float* bias2,
+                                  void* o1, void* y, int n_img, int H, int W, int cp, float slope, int dtype, void* stream) {
+    if (!x || !wpack1 || !wpack2 || !o1 || !y || n_img < 0 || H <= 0 || W <= 0) return MIL_ERR_ARG;
+    if (dtype != MIL_DT_BF16 || H < 16 || W < 16 || H >= 1024 || W >= 1024 || slope < 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
+    if (n_img == 0) return MIL_OK;
+    BlockFwdArgs a{};
+    a.x = (const __bf16*)x; a.w1 = (const __bf16*)wpack1; a.w2 = (const __bf16*)wpack2; a.b1 = bias1; a.b2 = bias2;
+    a.o1 = (__bf16*)o1; a.y = (__bf16*)y; a.slope = slope;
+    a.g.n_img = n_img; a.g.H = H; a.g.W = W; a.g.Ho = H; a.g.Wo = W; a.g.ks = 5; a.g.stride = 1; a.g.pad = 2; a.g.zins = 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (cp == 24) return launch_block_fwd<24, 2>(a, st);
+    if (cp == 40) return launch_block_fwd<40, 3>(a, st);
+    return MIL_ERR_UNSUPPORTED;
+}

@@ -61,6 +61,7 @@ class ResNet(nn.Module):
         self.fuse_backward = True
         self.fuse_stem_forward = True
         self.fuse_stage_entry = True
+        self.fuse_block_forward = True
         self._pack_table = None
         self._pack_version = None
         self._side = None
@@ -170,6 +171,13 @@ def encoder_forward(net, x, dtype):
         s = blk.stride
         w1, b1 = net._packed(f"b{bi}.c1", blk.conv1.weight, blk.conv1.bias, L.PACK_FWD, dtype)
         w2, b2 = net._packed(f"b{bi}.c2", blk.conv2.weight, blk.conv2.bias, L.PACK_FWD, dtype)
+        if s == 1 and blk.downsample is None and net.fuse_block_forward:      # whole block in one pass (24/40 channels)
+            both = ops.conv_block_fwd(t, w1, b1, w2, b2)
+            if both is not None:
+                o1, out = both
+                saved["blocks"].append((t, o1, out))
+                t = out
+                continue
         pair = None
         if blk.downsample is not None:
             wd, _ = net._packed(f"b{bi}.ds", blk.downsample[0].weight, None, L.PACK_FWD, dtype)

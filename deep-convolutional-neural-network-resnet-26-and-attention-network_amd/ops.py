@@ -199,6 +199,26 @@ def maxpool_bwd(gy, widx, in_hw, lrelu_mask=True, slope=LEAK):
     return gx
 
 
+def conv_block_fwd(x, wpack1, bias1, wpack2, bias2, *, slope=LEAK):
+    """(o1, y) of an identity-shortcut residual block in one pass (see mil_conv_block_fwd), or None when the shape/dtype
+    has no such kernel."""
+    n, h, w, cp = x.shape
+    if x.dtype != torch.bfloat16 or cp not in (24, 40) or h < 16 or w < 16:
+        return None
+    _need(x, x.shape, x.dtype, "x")
+    o1 = torch.empty_like(x)
+    y = torch.empty_like(x)
+    end = TIMER.bracket(("block_fwd", cp, n, h, w)) if TIMER else None
+    rc = L.lib().mil_conv_block_fwd(x.data_ptr(), wpack1.data_ptr(), L.ptr(bias1), wpack2.data_ptr(), L.ptr(bias2),
+                                    o1.data_ptr(), y.data_ptr(), n, h, w, cp, slope, L.dt_code(x.dtype), L.stream_ptr())
+    if rc == 2:
+        return None
+    L.check(rc, "mil_conv_block_fwd")
+    if end is not None:
+        end.record()
+    return o1, y
+
+
 def conv_s2_entry(x, wpack3, bias_pad, wpack1, cout_p, *, slope=LEAK):
     """(lrelu(conv3x3_s2(x)+b), conv1x1_s2(x)) in one pass over x (see mil_conv_s2_entry), or None when the shape/dtype
     has no such kernel."""

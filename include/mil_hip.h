@@ -115,6 +115,13 @@ int mil_resize_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* kk);
 int mil_tile_preprocess(const uint8_t* rois, const int32_t* params, const int32_t* bounds_host, const int32_t* bounds_dev,
                         const int32_t* kk_dev, float* out, int T, int S, int pad, int R, void* stream);
 
+/* Forward of a whole identity-shortcut residual block in one pass (bf16 path; nnBlocks.py:175-189 with
+ * downsample=None): o1 = lrelu(conv3x3(x)+b1) — written because the backward needs it — and
+ * y = lrelu(conv3x3(o1)+b2+x).  x is read once (operand and residual), the mid activation feeds conv2 from LDS.
+ * cp in {24, 40}, H and W >= 16; otherwise MIL_ERR_UNSUPPORTED (caller: two mil_conv_igemm calls). */
+int mil_conv_block_fwd(const void* x, const void* wpack1, const float* bias1, const void* wpack2, const float* bias2,
+                       void* o1, void* y, int n_img, int H, int W, int cp, float slope, int dtype, void* stream);
+
 /* Forward of a stage-entry block's two stride-2 convs in one pass over the block input (bf16 path):
  *   y1 = lrelu(conv3x3_s2(x) + bias)   (nnBlocks.py:176-177)      y2 = conv1x1_s2(x)   (gbm/model.py:38-40)
  * wpack3 / wpack1: MIL_PACK_FWD fragments of the two filters.  (cin_p,cout_p) in {(24,40),(40,64)}; otherwise

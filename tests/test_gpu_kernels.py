@@ -423,3 +423,42 @@ def test_stage_entry_forward_pair_one_pass(ops, case):
     assert rel_err(y1.float().cpu(), z1.float().cpu()) < TOL[dt] and rel_err(y2.float().cpu(), z2.float().cpu()) < TOL[dt]
     if cpad(cout) > cout:                                   # padded channels stay exactly zero
         assert float(y1[..., cout:].float().abs().max()) == 0.0 and float(y2[..., cout:].float().abs().max()) == 0.0
+
+
+BLOCK_FWD_CASES = [
+    # c, n, H, W
+    (20, 3, 16, 16),
+    (20, 2, 19, 37),            # ragged tiles in both directions
+    (20, 2, 64, 64),
+    (40, 3, 32, 32),
+    (40, 2, 18, 21),
+]
+
+
+@pytest.mark.parametrize("case", BLOCK_FWD_CASES)
+def test_identity_block_forward_one_pass(ops, case, monkeypatch):
+    """conv1+lrelu -> conv2+residual+lrelu with the mid activation kept in LDS: equals the two persistent conv launches
+    bit for bit (same filters, same accumulation order, same bf16 rounding of the mid activation) and matches torch."""
+    monkeypatch.setenv("MIL_PF_MIN_TILES", "1")          # the reference pair must be the persistent kernels, whatever the size
+    L = _lib()
+    c, n, h, w = case
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(307 + c + h)
+    x = round_to(torch.randn(n, c, h, w, generator=g), dt)
+    w1 = round_to(torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5, dt)
+    w2 = round_to(torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5, dt)
+    b1, b2 = torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1
+    xg = to_nhwc(x, dt)
+    p1, bp1 = ops.pack_weights(w1.cuda(), b1.cuda(), L.PACK_FWD, dt)
+    p2, bp2 = ops.pack_weights(w2.cuda(), b2.cuda(), L.PACK_FWD, dt)
+    both = ops.conv_block_fwd(xg, p1, bp1, p2, bp2)
+    assert both is not None
+    o1, y = both
+    z1 = ops.conv(xg, p1, bp1, cpad(c), ks=3, stride=1, pad=1, lrelu=True)
+    z2 = ops.conv(z1, p2, bp2, cpad(c), ks=3, stride=1, pad=1, res=xg, lrelu=True)
+    torch.cuda.synchronize()
+    assert torch.equal(o1.view(torch.int16), z1.view(torch.int16))
+    assert torch.equal(y.view(torch.int16), z2.view(torch.int16))
+    ref1 = round_to(F.leaky_relu(F.conv2d(x, w1, b1, padding=1), LEAK), dt)
+    ref2 = F.leaky_relu(F.conv2d(ref1, w2, b2, padding=1) + x, LEAK)
+    assert rel_err(from_nhwc(o1, c), ref1) < TOL[dt] and rel_err(from_nhwc(y, c), ref2) < 2 * TOL[dt]
