@@ -11,6 +11,7 @@
 // padding and are written as zeros.  Structure otherwise as conv_igemm_pf_kernel: persistent workgroups, filters
 // resident in LDS, register prefetch of the next input halo, D[channel][pixel] accumulators, paired 16-byte epilogue.
 #include "pf_common.cuh"
+#include <cstdlib>
 
 struct BlockFwdArgs {
     const __bf16* x;        // [n,H,W,CP]
@@ -25,14 +26,21 @@ struct BlockFwdArgs {
     float slope;
 };
 
-template <int CP, int NT>
-__global__ __launch_bounds__(256, CP <= 24 ? 2 : 1) void conv_block_fwd_kernel(BlockFwdArgs a, int ntiles, unsigned bytes) {
+// NW waves per workgroup (4 or 8).  With 8 waves every per-wave quantity halves (3 + 2 row tiles of accumulators, 3 halo
+// pieces in flight), the kernel fits 128 VGPRs and a CU holds 16 waves instead of 8 on the same LDS tiles and filters:
+// kept as an experiment (MIL_BLOCK_WAVES=8): it measured no faster, see mil_block_waves().
+template <int CP, int NT, int NW>
+__global__ __launch_bounds__(64 * NW, (CP <= 24 ? 2 : 1) * (NW == 8 ? 2 : 1)) void conv_block_fwd_kernel(BlockFwdArgs a, int ntiles, unsigned bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIXB = mil_pix_pitch(CP, 2);
     constexpr int CG = CP / 8;
     constexpr int KSTEPS = (9 * CG + 3) / 4;
-    constexpr int NPX = (400 * CG + 255) / 256;
-    constexpr int MT1 = 6;                                   // 4 waves x 6 row tiles x 16 = 384 >= 324 mid pixels
+    constexpr int NTHR = 64 * NW;
+    constexpr int NPX = (400 * CG + NTHR - 1) / NTHR;
+    constexpr int MT1 = 24 / NW;                             // NW waves x MT1 row tiles x 16 = 384 >= 324 mid pixels
+    constexpr int MT2 = 16 / NW;                             // 256 output pixels
+    constexpr int NPAIR = MT2 / 2;
+    constexpr int NPC = (256 * CG + NTHR - 1) / NTHR;
     constexpr bool LAST_PARTIAL = (CP % 16) != 0;
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -45,7 +53,7 @@ __global__ __launch_bounds__(256, CP <= 24 ? 2 : 1) void conv_block_fwd_kernel(B
     {
         const char* s1 = reinterpret_cast<const char*>(a.w1);
         const char* s2 = reinterpret_cast<const char*>(a.w2);
-        for (int i = tid * 16; i < KSTEPS * NT * 64 * 16; i += 256 * 16) {
+        for (int i = tid * 16; i < KSTEPS * NT * 64 * 16; i += NTHR * 16) {
             *reinterpret_cast<uint4*>(ldsW1 + i) = *reinterpret_cast<const uint4*>(s1 + i);
             *reinterpret_cast<uint4*>(ldsW2 + i) = *reinterpret_cast<const uint4*>(s2 + i);
         }
@@ -56,9 +64,18 @@ __global__ __launch_bounds__(256, CP <= 24 ? 2 : 1) void conv_block_fwd_kernel(B
     const int H = g.H, W = g.W;
 
     // ---- tile-invariant tables --------------------------------------------------------------------
-    HaloTables<NPX> ht;
-    mil_build_halo_tables<CP, NPX>(ht, g, tid);
-    mil_halo_tables_use_dump<NPX>(ht, a.lds_dump_off);
+    HaloTables<NPX> ht;                                      // 20x20 input halo pieces: id = tid + NTHR*i -> (row, col, piece)
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+        const int idx = tid + NTHR * i;
+        ht.pos[i] = -1; ht.lds[i] = a.lds_dump_off; ht.rel[i] = 0;
+        if (idx < 400 * CG) {
+            const int px = idx / CG, j = idx - px * CG, hy = px / 20, hx = px - hy * 20;
+            ht.pos[i] = (hy << 10) | hx;
+            ht.lds[i] = px * PIXB + j * 16;
+            ht.rel[i] = (hy * W + hx) * (CP * 2) + j * 16;
+        }
+    }
     int toff1[KSTEPS], toff2[KSTEPS];
 #pragma unroll
     for (int sl = 0; sl < KSTEPS; ++sl) {
@@ -71,36 +88,37 @@ __global__ __launch_bounds__(256, CP <= 24 ? 2 : 1) void conv_block_fwd_kernel(B
     int pixbase1[MT1], sdst1[MT1];                           // conv1: mid pixel (py,px) reads input halo (py+ky, px+kx)
 #pragma unroll
     for (int i = 0; i < MT1; ++i) {
-        const int tp = (wave + 4 * i) * 16 + r;
+        const int tp = (wave + NW * i) * 16 + r;
         const bool ok = tp < 324;
         const int py = tp / 18, px = tp - py * 18;
         pixbase1[i] = ok ? (py * 20 + px) * PIXB : 0;
         sdst1[i] = ok ? a.lds_o_off + tp * PIXB + gq * 8 : a.lds_dump_off;
     }
-    int pixbase2[4];                                         // conv2: output pixel (ty,tx) reads mid (ty+ky, tx+kx)
+    int pixbase2[MT2];                                       // conv2: output pixel (ty,tx) reads mid (ty+ky, tx+kx)
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int tp = (wave * 4 + m) * 16 + r;
+    for (int m = 0; m < MT2; ++m) {
+        const int tp = (wave * MT2 + m) * 16 + r;
         pixbase2[m] = ((tp >> 4) * 18 + (tp & 15)) * PIXB;
     }
-    int o_rel[2], o_pos[2], xres[2];                         // paired epilogue: pixel (2p + (gq&1), r) of this wave's four row tiles
+    int o_rel[NPAIR], o_pos[NPAIR], xres[NPAIR];             // paired epilogue: pixel (2p + (gq&1), r) of this wave's row tiles
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int tp = (wave * 4 + 2 * p + (gq & 1)) * 16 + r;
+    for (int p = 0; p < NPAIR; ++p) {
+        const int tp = (wave * MT2 + 2 * p + (gq & 1)) * 16 + r;
         const int ty = tp >> 4, tx = tp & 15;
         o_rel[p] = (ty * W + tx) * (CP * 2) + (gq >> 1) * 16;
         o_pos[p] = (ty << 10) | tx;
         xres[p] = ((ty + 2) * 20 + tx + 2) * PIXB + (gq >> 1) * 16;          // the residual = centre of the input halo tile
     }
     // mid-tile centre pieces -> o1 tensor: piece id = tid + 256*i -> (pixel id / CG, piece id % CG)
-    int c_lds[CG], c_rel[CG], c_pos[CG];
+    int c_lds[NPC], c_rel[NPC], c_pos[NPC];
 #pragma unroll
-    for (int i = 0; i < CG; ++i) {
-        const int id = tid + 256 * i, px = id / CG, j = id - px * CG;
+    for (int i = 0; i < NPC; ++i) {
+        const int id = tid + NTHR * i, px = id / CG, j = id - px * CG;
         const int ty = px >> 4, tx = px & 15;
-        c_lds[i] = ((ty + 1) * 18 + tx + 1) * PIXB + j * 16;
+        const bool used = id < 256 * CG;
+        c_lds[i] = used ? ((ty + 1) * 18 + tx + 1) * PIXB + j * 16 : 0;
         c_rel[i] = (ty * W + tx) * (CP * 2) + j * 16;
-        c_pos[i] = (ty << 10) | tx;
+        c_pos[i] = used ? (ty << 10) | tx : (1023 << 10);          // an unused slot is never inside the image
     }
     const bool last_ok = !LAST_PARTIAL || (gq >> 1) == 0;
     f32x4_t b1r[NT], b2r[NT];
@@ -117,14 +135,24 @@ __global__ __launch_bounds__(256, CP <= 24 ? 2 : 1) void conv_block_fwd_kernel(B
     cur.init(g, bid, gridDim.x);
     nxt = cur; nxt.advance();
     u32x4_t rx[NPX];
-    if (bid < ntiles) mil_fetch_halo<CP, NPX>(rx, rs_x, ht, g, cur.origin(g));
+    auto fetch = [&](const TileOrigin& o) {
+        const int iy0 = o.oy0 - 2, ix0 = o.ox0 - 2;
+        const int base = ((o.img0 * H + iy0) * W + ix0) * (CP * 2);
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            const int p = ht.pos[i];
+            const bool ok = p >= 0 && (unsigned)(iy0 + (p >> 10)) < (unsigned)H && (unsigned)(ix0 + (p & 1023)) < (unsigned)W;
+            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (unsigned)(base + ht.rel[i]) : MIL_OOB, 0, 0);
+        }
+    };
+    if (bid < ntiles) fetch(cur.origin(g));
     const int G = gridDim.x;
     for (int tile = bid; tile < ntiles; tile += G) {
         const TileOrigin o = cur.origin(g);
         __syncthreads();                       // previous tile: residual reads of ldsX and conv2's reads of ldsO are done
         mil_commit_halo_all<NPX>(rx, ldsX, ht);
         __syncthreads();
-        if (tile + G < ntiles) mil_fetch_halo<CP, NPX>(rx, rs_x, ht, g, nxt.origin(g));
+        if (tile + G < ntiles) fetch(nxt.origin(g));
         cur = nxt; nxt.advance();
 
         // ---- conv1 on the 18x18 mid tile -> LDS ------------------------------------------------------
@@ -153,7 +181,7 @@ __global__ __launch_bounds__(256, CP <= 24 ? 2 : 1) void conv_block_fwd_kernel(B
             for (int i = 0; i < MT1; ++i) {
                 bool inside = true;
                 if (border) {
-                    const int tp = (wave + 4 * i) * 16 + r, py = (tp * 3641) >> 16, px = tp - py * 18;      // tp / 18 for tp < 1024
+                    const int tp = (wave + NW * i) * 16 + r, py = (tp * 3641) >> 16, px = tp - py * 18;      // tp / 18 for tp < 1024
                     inside = (unsigned)(my0 + py) < (unsigned)H && (unsigned)(mx0 + px) < (unsigned)W;
                 }
 #pragma unroll
@@ -174,15 +202,15 @@ __global__ __launch_bounds__(256, CP <= 24 ? 2 : 1) void conv_block_fwd_kernel(B
         const int obase = ((o.img0 * H + o.oy0) * W + o.ox0) * (CP * 2);
         const int ylim = H - o.oy0, xlim = W - o.ox0;
 #pragma unroll
-        for (int i = 0; i < CG; ++i) {
+        for (int i = 0; i < NPC; ++i) {
             const bool ok = (c_pos[i] >> 10) < ylim && (c_pos[i] & 1023) < xlim;
             const u32x4_t v = *reinterpret_cast<const u32x4_t*>(ldsO + c_lds[i]);
             __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, ok ? (unsigned)(obase + c_rel[i]) : MIL_OOB, 0, 0);
         }
         // ---- conv2 + residual + LeakyReLU ------------------------------------------------------------------
-        f32x4_t acc[4][NT];
+        f32x4_t acc[MT2][NT];
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MT2; ++m)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[m][nt] = b2r[nt];
 #pragma unroll
@@ -191,14 +219,14 @@ __global__ __launch_bounds__(256, CP <= 24 ? 2 : 1) void conv_block_fwd_kernel(B
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<BF16>(ldsW2 + ((sl * NT + nt) * 64 + lane) * 16);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MT2; ++m) {
                 const Frag8<BF16> of = lds_frag<BF16>(ldsO + pixbase2[m] + toff2[sl]);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wf[nt], of, acc[m][nt]);
             }
         }
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < NPAIR; ++p) {
             const bool ok = (o_pos[p] >> 10) < ylim && (o_pos[p] & 1023) < xlim;
             const unsigned ooff = ok ? (unsigned)(obase + o_rel[p]) : MIL_OOB;
 #pragma unroll
@@ -222,6 +250,13 @@ __global__ __launch_bounds__(256, CP <= 24 ? 2 : 1) void conv_block_fwd_kernel(B
     }
 }
 
+static int mil_block_waves() {
+    // measured on the 64x64x24 maps: 434 us with 4 waves per workgroup, 446 us with 8 (16 resident waves per CU at 127
+    // VGPRs) — more resident waves do not help: LDS operand bandwidth (~450 KB per tile) and the MFMA pipe set the pace
+    static const int v = [] { const char* e = getenv("MIL_BLOCK_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();
+    return v;
+}
+
 template <int CP, int NT>
 static int launch_block_fwd(BlockFwdArgs a, hipStream_t st) {
     constexpr int PIXB = mil_pix_pitch(CP, 2), CG = CP / 8;
@@ -234,10 +269,13 @@ static int launch_block_fwd(BlockFwdArgs a, hipStream_t st) {
     a.lds_o_off = x_bytes; a.lds_w_off = x_bytes + o_bytes; a.lds_dump_off = x_bytes + o_bytes + w_bytes;
     const int lds = a.lds_dump_off + 64;
     if (lds > 160 * 1024) return MIL_ERR_UNSUPPORTED;
-    auto kern = conv_block_fwd_kernel<CP, NT>;
+    const int nw = mil_block_waves();
+    auto kern = nw == 8 ? conv_block_fwd_kernel<CP, NT, 8> : conv_block_fwd_kernel<CP, NT, 4>;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MIL_ERR_LAUNCH;
-    const int per_cu = mil_resident_per_cu(kern, lds, 4);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * nw, (size_t)lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_cu > 4) per_cu = 4;
     const size_t img = (size_t)g.H * g.W * CP * 2;
     const int chunk = mil_imgs_under_2g(img);
     const int n_total = g.n_img;
@@ -249,7 +287,7 @@ static int launch_block_fwd(BlockFwdArgs a, hipStream_t st) {
         const int ntiles = n * g.tiles_y * g.tiles_x;
         int grid = 256 * per_cu;
         if (grid > ntiles) grid = ntiles;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, c, ntiles, (unsigned)(img * n));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, st, c, ntiles, (unsigned)(img * n));
         MIL_CHECK_LAUNCH();
     }
     return MIL_OK;
