@@ -30,9 +30,23 @@ class BagLayout:
         for s in sizes:
             offs.append(offs[-1] + s)
         self.offsets_host = offs
+        # built on the host and uploaded once (a device-side repeat_interleave has to synchronise to size its output)
+        import numpy as np
         self.offsets = torch.tensor(offs, dtype=torch.int32, device=device)
-        self.inst_bag = torch.repeat_interleave(torch.arange(self.nbags, dtype=torch.int32, device=device),
-                                                torch.tensor(sizes, device=device))
+        self.inst_bag = torch.from_numpy(np.repeat(np.arange(self.nbags, dtype=np.int32), sizes)).to(device)
+
+    _cache = {}
+
+    @classmethod
+    def cached(cls, sizes, device):
+        """Layouts are immutable: training loops present the same bag sizes step after step."""
+        key = (tuple(int(s) for s in sizes), str(device))
+        lay = cls._cache.get(key)
+        if lay is None:
+            if len(cls._cache) > 64:
+                cls._cache.clear()
+            lay = cls._cache[key] = cls(sizes, device)
+        return lay
 
 
 def _weight_array(ws):

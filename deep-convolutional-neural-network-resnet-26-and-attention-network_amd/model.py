@@ -167,7 +167,7 @@ class Attention(nn.Module):
                 x = x[idx.to(x.device)]
             tiles.append(x.to(dev, torch.float32))
             sizes.append(x.shape[0])
-        layout = BagLayout(sizes, dev)
+        layout = BagLayout.cached(sizes, dev)
         x_all = tiles[0] if len(tiles) == 1 else torch.cat(tiles, dim=0)
         if self.training:
             if self.rng_override is not None and "keep_mask" in self.rng_override:
@@ -185,6 +185,7 @@ class Attention(nn.Module):
         Hd = H.detach()
         outs = BagOutputs()
         outs.loss, outs.l2 = loss, l2          # [n_bags] / [] with grad: `outs.loss.sum().backward()` is one backward for all bags
+        y_hat = rec[:, 16].long()              # one conversion for all bags
         for b in range(layout.nbags):
             n0, n1 = layout.offsets_host[b], layout.offsets_host[b + 1]
             r = rec[b]
@@ -200,7 +201,7 @@ class Attention(nn.Module):
                 "l2": l2,
                 "KLD": kld[b],
                 "y_pred": r[3:6].view(1, 3),
-                "y_pred_hat": r[16].long(),
+                "y_pred_hat": y_hat[b],
                 "error": r[7].view(1),
             })
         return outs
