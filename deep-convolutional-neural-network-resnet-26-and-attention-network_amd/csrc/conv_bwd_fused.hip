@@ -136,17 +136,14 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(BwdFusedArgs a) 
     nxt = cur; nxt.advance();
     u32x4_t rx[NPX];
     if (bid < a.ntiles) mil_fetch_halo<CZ, NPX>(rx, rs_z, ht, g, cur.origin(g));
-
-    for (int tile = bid; tile < a.ntiles; tile += gridDim.x) {
-        const TileOrigin o = cur.origin(g);
-        __syncthreads();                       // previous tile: all reads of ldsA / ldsX are done
-        mil_commit_halo_all<NPX>(rx, ldsA, ht);
-
-        // this tile's x (mask + wgrad operand) and addend, 8 bytes per lane per (row tile, column tile)
+    // The tile's x (mask + wgrad operand) and addend are needed only after the data-gradient MFMA loop; their loads are
+    // issued a phase early — behind the previous tile's last barrier, under its weight-gradient loop — into the registers
+    // that tile has just finished with, so the ~2 us round trip is no longer waited for in the middle of the tile.
+    unsigned ooff[NPAIR];
+    u32x4_t rxc[NPAIR][NTX], radd[NPAIR][NTX];
+    auto fetch_xa = [&](const TileOrigin& o) {
         const int obase = ((o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (CX * 2);
         const int ylim = g.Ho - o.oy0, xlim = g.Wo - o.ox0, ilim = g.n_img - o.img0;
-        unsigned ooff[NPAIR];
-        u32x4_t rxc[NPAIR][NTX], radd[NPAIR][NTX];
 #pragma unroll
         for (int p = 0; p < NPAIR; ++p) {
             const bool ok = (o_pos[p] >> 20) < ilim && ((o_pos[p] >> 10) & 1023) < ylim && (o_pos[p] & 1023) < xlim;
@@ -158,8 +155,17 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(BwdFusedArgs a) 
                 if constexpr (ADD) radd[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, off, 0, 0);
             }
         }
+    };
+    if (bid < a.ntiles) fetch_xa(cur.origin(g));
+
+    for (int tile = bid; tile < a.ntiles; tile += gridDim.x) {
+        __syncthreads();                       // previous tile: all reads of ldsA / ldsX are done
+        mil_commit_halo_all<NPX>(rx, ldsA, ht);
+
         __syncthreads();                       // dz halo visible
-        if (tile + (int)gridDim.x < a.ntiles) mil_fetch_halo<CZ, NPX>(rx, rs_z, ht, g, nxt.origin(g));
+        const bool more = tile + (int)gridDim.x < a.ntiles;
+        if (more) mil_fetch_halo<CZ, NPX>(rx, rs_z, ht, g, nxt.origin(g));
+        const TileOrigin o_next = nxt.origin(g);
         cur = nxt; nxt.advance();
 
         // ---- data gradient: D[cx][pixel] -----------------------------------------------------------
@@ -223,6 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(BwdFusedArgs a) 
             }
         }
         __syncthreads();                       // x centre tile visible
+        if (more) fetch_xa(o_next);            // next tile's x / addend: lands while the loop below runs
 
         // ---- weight gradient: rows (tap', dz channel), cols x channel, K = the tile's 256 pixels -------
 #pragma unroll 2

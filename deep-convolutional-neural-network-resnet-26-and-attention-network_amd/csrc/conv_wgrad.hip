@@ -376,7 +376,10 @@ struct StemBwdArgs {
     float slope;
 };
 
-__global__ __launch_bounds__(256) void stem_bwd_fused_kernel(StemBwdArgs a) {
+#ifndef MIL_STEM_BWD_WAVES
+#define MIL_STEM_BWD_WAVES 3       // measured: 1209 us at 2 waves/SIMD, 1161 us at 3 (30 spilled VGPRs), 2102 us at 4
+#endif
+__global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel(StemBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CINP = 16, NT = 2, KS = 4, COUTP = 24;
     constexpr int PIXB = mil_pix_pitch(CINP, 2);
@@ -547,6 +550,7 @@ __global__ __launch_bounds__(256) void stem_bwd_fused_kernel(StemBwdArgs a) {
         __syncthreads();
 
         // ---- weight gradient: rows (tap, s2d channel), cols stem channel, K = the tile's 256 pixels ---------
+#pragma unroll 2
         for (int k32 = 0; k32 < 256; k32 += 32) {
             const int kb = mil_pix_base<PIXB>(g, k32, 1);
             const int pb0 = kb + wpl0, pb1 = kb + wpl1;
@@ -614,7 +618,7 @@ static int stem_bwd_entry(const void* xs, const void* gp, const uint8_t* widx, f
     const int xb = (halo_px * PIXB + 15) & ~15, zb = 256 * PIXZ, gb = (nwin * PIXZ + 15) & ~15, ib = (nwin * 24 + 15) & ~15;
     const int lds = xb + zb + gb + ib;
     const int ntiles = g.n_groups * g.tiles_y * g.tiles_x;
-    int grid = 1024;
+    int grid = 256 * mil_resident_per_cu(stem_bwd_fused_kernel, lds, 4) * 2;          // two rounds of the resident set
     if (grid > ntiles) grid = ntiles;
     const size_t slab_elems = (size_t)(MT + 1) * 16 * 32;
     const size_t bytes = slab_elems * grid * sizeof(float);
