@@ -273,9 +273,14 @@ static int launch_block_fwd(BlockFwdArgs a, hipStream_t st) {
     auto kern = nw == 8 ? conv_block_fwd_kernel<CP, NT, 8> : conv_block_fwd_kernel<CP, NT, 4>;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MIL_ERR_LAUNCH;
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * nw, (size_t)lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (per_cu > 4) per_cu = 4;
+    static thread_local int occ_lds = -1, occ_n = 1;
+    static thread_local const void* occ_k = nullptr;
+    if (occ_k != reinterpret_cast<const void*>(kern) || occ_lds != lds) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 64 * nw, (size_t)lds) != hipSuccess || n < 1) n = 1;
+        occ_k = reinterpret_cast<const void*>(kern); occ_lds = lds; occ_n = n;
+    }
+    const int per_cu = occ_n > 4 ? 4 : occ_n;
     const size_t img = (size_t)g.H * g.W * CP * 2;
     const int chunk = mil_imgs_under_2g(img);
     const int n_total = g.n_img;

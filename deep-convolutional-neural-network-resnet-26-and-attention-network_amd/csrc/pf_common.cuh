@@ -193,9 +193,16 @@ __device__ __forceinline__ bf16x8_t mil_tr_pair(const char* p0, const char* p1) 
 // partial second round would leave CUs idle while the stragglers finish.
 template <typename K>
 __host__ inline int mil_resident_per_cu(K kern, int lds, int cap) {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, (size_t)lds) != hipSuccess || n < 1) n = 1;
-    return n > cap ? cap : n;
+    // the answer depends only on (kernel, lds): remember the last one per kernel instantiation (launch-path cost)
+    static thread_local int last_lds = -1, last_n = 0;
+    static thread_local const void* last_k = nullptr;
+    const void* kp = reinterpret_cast<const void*>(kern);
+    if (kp != last_k || lds != last_lds) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, (size_t)lds) != hipSuccess || n < 1) n = 1;
+        last_k = kp; last_lds = lds; last_n = n;
+    }
+    return last_n > cap ? cap : last_n;
 }
 
 // How many images of `bytes_per_img` bytes fit under the 2 GiB buffer limit.
