@@ -269,11 +269,14 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
     TileWalker nx2 = nxt;
     nx2.advance();
     u32x4_t rxA[NPX], rxB[DEPTH == 2 ? NPX : 1];
-    unsigned ooff_n[EPI_AHEAD ? NPAIR : 1];
-    u32x4_t rres_n[EPI_AHEAD ? NPAIR : 1][NT], ract_n[EPI_AHEAD ? NPAIR : 1][NT];
+    // EPI_AHEAD: a second register set, filled a whole tile ahead.  Otherwise ONE set, refilled for the next tile as soon
+    // as this tile's epilogue has consumed it (the loads then fly under the next tile's barriers and MFMA loop instead of
+    // being issued at its start and waited for right after its MFMA loop).
+    unsigned ooff_n[NPAIR];
+    u32x4_t rres_n[NPAIR][NT], ract_n[NPAIR][NT];
     if (bid < ntiles) {
         mil_fetch_halo<CINP, NPX>(rxA, rs_x, ht, g, cur.origin(g));
-        if constexpr (EPI_AHEAD) fetch_epi(cur.origin(g), ooff_n, rres_n, ract_n);
+        fetch_epi(cur.origin(g), ooff_n, rres_n, ract_n);
     }
     if constexpr (DEPTH == 2) {
         if (bid + G < ntiles) mil_fetch_halo<CINP, NPX>(rxB, rs_x, ht, g, nxt.origin(g));
@@ -283,19 +286,21 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
         __syncthreads();                       // every wave has finished reading ldsA for the previous tile
         mil_commit_halo_all<NPX>(rx, ldsA, ht);
         // this tile's epilogue operands were requested one tile ago; take them over before re-issuing
-        unsigned ooff[NPAIR];
-        u32x4_t rres[NPAIR][NT], ract[NPAIR][NT];
+        unsigned ooff_l[NPAIR];
+        u32x4_t rres_l[NPAIR][NT], ract_l[NPAIR][NT];
         if constexpr (EPI_AHEAD) {
 #pragma unroll
             for (int p = 0; p < NPAIR; ++p) {
-                ooff[p] = ooff_n[p];
+                ooff_l[p] = ooff_n[p];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) { rres[p][nt] = rres_n[p][nt]; ract[p][nt] = ract_n[p][nt]; }
+                for (int nt = 0; nt < NT; ++nt) { rres_l[p][nt] = rres_n[p][nt]; ract_l[p][nt] = ract_n[p][nt]; }
             }
         }
+        auto& ooff = *(EPI_AHEAD ? &ooff_l : &ooff_n);
+        auto& rres = *(EPI_AHEAD ? &rres_l : &rres_n);
+        auto& ract = *(EPI_AHEAD ? &ract_l : &ract_n);
         __syncthreads();
         // issue-early: refill the register set just written to LDS with the halo of the tile DEPTH ahead
-        if constexpr (!EPI_AHEAD) fetch_epi(cur.origin(g), ooff, rres, ract);
         if (tile + DEPTH * G < ntiles) mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, (DEPTH == 2 ? nx2 : nxt).origin(g));
         if constexpr (EPI_AHEAD) {
             if (tile + G < ntiles) fetch_epi(nxt.origin(g), ooff_n, rres_n, ract_n);
@@ -353,6 +358,9 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
                 const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 32;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), rs_y, off, 0, 0);
             }
+        }
+        if constexpr (!EPI_AHEAD) {            // `cur` is the next tile by now
+            if (tile + G < ntiles) fetch_epi(cur.origin(g), ooff_n, rres_n, ract_n);
         }
     };
 
