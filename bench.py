@@ -148,6 +148,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # calibration: what a plain device copy reaches on this box (read + write bytes / time), outside the timed region.
+    # Every rank runs it, for about half a second: it doubles as the clock ramp of a freshly started box (three warm-up
+    # steps are 35 ms of GPU work, far less than the power-state transition).  The W warm-up steps follow directly.
+    copy_gbps = None
+    if not args.no_kernel_timer:
+        src = torch.empty(1 << 28, dtype=torch.float32, device=dev)         # 1 GiB
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        torch.cuda.synchronize()
+        best, t_start = 0.0, time.perf_counter()
+        while time.perf_counter() - t_start < 0.5:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            best = max(best, 20 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        copy_gbps = best
+        del src, dst
     for _ in range(args.warmup):
         step()
     # Candidate dominant kernels, both on the 64x64 maps at 20(24)->20(24) channels (layer 1, 47% of the FLOPs):
@@ -155,20 +175,6 @@ def main():
     #   conv_bwd_fused_kernel<24,2,3>   — their fused backward (data gradient + weight gradient in one pass)
     # Every launch of both is bracketed with HIP events on the launch stream; the one with the larger total time
     # in the timed region is reported as `roofline`.
-    # calibration: what a plain device copy reaches on this box (read + write bytes / time), outside the timed region
-    copy_gbps = None
-    if rank == 0 and not args.no_kernel_timer:
-        src = torch.empty(1 << 28, dtype=torch.float32, device=dev)         # 1 GiB
-        dst = torch.empty_like(src)
-        dst.copy_(src)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            dst.copy_(src)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbps = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del src, dst
     timer = None
     if not args.no_kernel_timer:
         timer = ops.KernelTimer(lambda label: label[:6] in (("conv", 24, 24, 3, 1, False), ("bwd_fused", 24, 24, 3, 1, False)))
