@@ -29,8 +29,11 @@ struct BwdFusedArgs {
     unsigned z_bytes, x_bytes;      // byte sizes of dz and of x/addend/dx (buffer descriptors)
 };
 
+#ifndef MIL_BWD_WAVES
+#define MIL_BWD_WAVES 2
+#endif
 template <int CZ, int NTX, int KS, bool ADD, bool MASK>
-__global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(BwdFusedArgs a) {
+__global__ __launch_bounds__(256, MIL_BWD_WAVES) void conv_bwd_fused_kernel(BwdFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIXB = mil_pix_pitch(CZ, 2);            // dz halo pixel pitch
     constexpr int CG = CZ / 8;

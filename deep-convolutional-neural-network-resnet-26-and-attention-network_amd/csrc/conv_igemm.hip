@@ -163,15 +163,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs<T> a) {
 #ifndef MIL_PF_WAVES_24
 #define MIL_PF_WAVES_24 3
 #endif
-template <int CINP, int NT, int KS, int MTW, int FLAGS = -1>
-__global__ __launch_bounds__(256, ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 24 && FLAGS >= 0 && FLAGS != 3) ? MIL_PF_WAVES_24 : (CINP <= 40 ? 2 : 1)))
+// NW = waves per workgroup: 4, or 8 for the layers whose resident filter leaves room for only ONE workgroup per CU
+// (64 channels: 72 KB of filter) — eight waves on the same LDS tiles give every SIMD a second wave to overlap with.
+template <int CINP, int NT, int KS, int MTW, int FLAGS = -1, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 24 && FLAGS >= 0 && FLAGS != 3) ? MIL_PF_WAVES_24 : (CINP <= 40 ? 2 : 1)))
 void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsigned y_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using T = BF16;
     constexpr int PIXB = mil_pix_pitch(CINP, 2);
     constexpr int CG = CINP / 8;
     constexpr int COUTP = mil_nt_to_cp(NT);
-    constexpr int NPX = mil_halo_np_mtw(CINP, 2, MTW);
+    constexpr int NTHR = 64 * NW;
+    constexpr int NPX = (mil_halo_px_max(NW * MTW == 16 ? 4 : 2) * (CINP * 2 / 16) + NTHR - 1) / NTHR;
     constexpr int KSTEPS = (KS * KS * CG + 3) / 4;
     constexpr bool LAST_PARTIAL = (COUTP % 16) != 0;        // the last column tile holds only 8 channels
     const ConvGeom& g = a.g;
@@ -187,7 +190,7 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
     {
         const int nbytes = KSTEPS * NT * 64 * 16;
         const char* src = reinterpret_cast<const char*>(a.w);
-        for (int i = tid * 16; i < nbytes; i += 256 * 16)
+        for (int i = tid * 16; i < nbytes; i += NTHR * 16)
             *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(src + i);
     }
     const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, x_bytes);
@@ -199,7 +202,7 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
 
     // ---- tile-invariant tables ---------------------------------------------------------------------
     HaloTables<NPX> ht;
-    mil_build_halo_tables<CINP, NPX>(ht, g, tid);
+    mil_build_halo_tables<CINP, NPX, NTHR>(ht, g, tid);
     mil_halo_tables_use_dump<NPX>(ht, a.lds_w_off + KSTEPS * NT * 64 * 16);      // 16 spare bytes behind the filter
     int toff[KSTEPS];
 #pragma unroll
@@ -420,24 +423,29 @@ static int mil_pf_rounds() {
     return r;
 }
 
+static int mil_pf_waves64() {
+    static const int v = [] { const char* e = getenv("MIL_PF_WAVES64"); return (e && atoi(e) == 4) ? 4 : 8; }();
+    return v;
+}
+
 #ifndef MIL_PF_WG_PER_CU
 #define MIL_PF_WG_PER_CU 4
 #endif
 #ifndef MIL_PF_MTW_24
 #define MIL_PF_MTW_24 4
 #endif
-template <int CINP, int NT, int KS, int MTW, int FLAGS>
-static auto conv_pf_variant() { return conv_igemm_pf_kernel<CINP, NT, KS, MTW, FLAGS>; }
+template <int CINP, int NT, int KS, int MTW, int FLAGS, int NW = 4>
+static auto conv_pf_variant() { return conv_igemm_pf_kernel<CINP, NT, KS, MTW, FLAGS, NW>; }
 
-template <int CINP, int NT, int KS, int MTW = 4>
+template <int CINP, int NT, int KS, int MTW = 4, int NW = 4>
 static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool* taken) {
     ConvArgs<BF16> a = a0;
     constexpr int PIXB = mil_pix_pitch(CINP, 2);
     constexpr int COUTP = mil_nt_to_cp(NT);
     *taken = false;
-    mil_geom_tiles(a.g, MTW == 4 ? 8 : 7);
+    mil_geom_tiles(a.g, NW * MTW == 16 ? 8 : 7);
     const int halo_px = (a.g.hh * a.g.hw) << a.g.ti_log2;
-    if (halo_px > mil_halo_px_max(MTW)) return MIL_OK;
+    if (halo_px > mil_halo_px_max(NW * MTW == 16 ? 4 : 2)) return MIL_OK;
     const int a_bytes = (halo_px * PIXB + 15) & ~15;
     const int w_bytes = a.nsteps * NT * 64 * 16;
     const int lds = a_bytes + w_bytes + 16;                 // + dump slot for the branch-free halo commit
@@ -446,20 +454,20 @@ static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool*
     if ((a.g.n_groups * a.g.tiles_y * a.g.tiles_x) < mil_pf_min_tiles()) return MIL_OK;    // too few tiles for a persistent launch
     a.kc = a.nsteps;
     a.lds_w_off = a_bytes;
-    auto kern = conv_igemm_pf_kernel<CINP, NT, KS, MTW>;
+    auto kern = conv_igemm_pf_kernel<CINP, NT, KS, MTW, -1, NW>;
     // the hot square 3x3 layers get the epilogue options as compile-time constants
     if constexpr (KS == 3 && ((CINP == 24 && NT == 2) || (CINP == 40 && NT == 3) || (CINP == 64 && NT == 4) || (CINP == 80 && NT == 5))) {
         const int fl = (a.res ? 1 : 0) | (a.act ? 2 : 0) | (a.apply_lrelu ? 4 : 0);
-        if (fl == 4) kern = conv_pf_variant<CINP, NT, KS, MTW, 4>();
-        else if (fl == 5) kern = conv_pf_variant<CINP, NT, KS, MTW, 5>();
-        else if (fl == 2) kern = conv_pf_variant<CINP, NT, KS, MTW, 2>();
-        else if (fl == 3) kern = conv_pf_variant<CINP, NT, KS, MTW, 3>();
+        if (fl == 4) kern = conv_pf_variant<CINP, NT, KS, MTW, 4, NW>();
+        else if (fl == 5) kern = conv_pf_variant<CINP, NT, KS, MTW, 5, NW>();
+        else if (fl == 2) kern = conv_pf_variant<CINP, NT, KS, MTW, 2, NW>();
+        else if (fl == 3) kern = conv_pf_variant<CINP, NT, KS, MTW, 3, NW>();
     }
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return MIL_ERR_LAUNCH;
     }
-    const int per_cu = mil_resident_per_cu(kern, lds, MIL_PF_WG_PER_CU) * mil_pf_rounds();   // rounds of resident workgroups
+    const int per_cu = mil_resident_per_cu(kern, lds, MIL_PF_WG_PER_CU, 64 * NW) * mil_pf_rounds();   // rounds of resident workgroups
     // buffer descriptors address < 2 GiB: split the launch by images when a tensor is larger
     const size_t x_img = (size_t)a.g.H * a.g.W * CINP * 2, y_img = (size_t)a.g.Ho * a.g.Wo * COUTP * 2;
     int chunk = mil_imgs_under_2g(x_img > y_img ? x_img : y_img);
@@ -477,7 +485,7 @@ static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool*
         const int ntiles = c.g.n_groups * c.g.tiles_y * c.g.tiles_x;
         int grid = 256 * per_cu;
         if (grid > ntiles) grid = ntiles;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, c, ntiles, (unsigned)(x_img * n), (unsigned)(y_img * n));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, c, ntiles, (unsigned)(x_img * n), (unsigned)(y_img * n));
         MIL_CHECK_LAUNCH();
     }
     *taken = true;
@@ -494,7 +502,9 @@ static int launch_conv_pf(const ConvArgs<BF16>& a, hipStream_t stream, bool* tak
         if (a.g.ks == 3) return launch_conv_pf_ks<40, 2, 3>(a, stream, taken);
         if (a.g.ks == 1) return launch_conv_pf_ks<40, 2, 1>(a, stream, taken);
     }
-    if constexpr (CINP == 64 && NT == 4) { if (a.g.ks == 3) return launch_conv_pf_ks<64, 4, 3>(a, stream, taken); }
+    if constexpr (CINP == 64 && NT == 4) {
+        if (a.g.ks == 3) return mil_pf_waves64() == 8 ? launch_conv_pf_ks<64, 4, 3, 2, 8>(a, stream, taken) : launch_conv_pf_ks<64, 4, 3>(a, stream, taken);
+    }
     if constexpr (CINP == 64 && NT == 3) {
         if (a.g.ks == 3) return launch_conv_pf_ks<64, 3, 3>(a, stream, taken);
         if (a.g.ks == 1) return launch_conv_pf_ks<64, 3, 1>(a, stream, taken);

@@ -55,7 +55,7 @@ __device__ __forceinline__ int mil_xcd_block_id() {
 template <int NP>
 struct HaloTables { int pos[NP], lds[NP], rel[NP]; };
 
-template <int CP, int NP>
+template <int CP, int NP, int NTHR = 256>
 __device__ __forceinline__ void mil_build_halo_tables(HaloTables<NP>& t, const ConvGeom& g, int tid) {
     constexpr int N16 = CP / 8;
     constexpr int PIXB = mil_pix_pitch(CP, 2);
@@ -63,7 +63,7 @@ __device__ __forceinline__ void mil_build_halo_tables(HaloTables<NP>& t, const C
     const int total = (g.hh << g.ti_log2) * ppr;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int idx = tid + 256 * i;
+        const int idx = tid + NTHR * i;
         t.pos[i] = -1; t.lds[i] = 0; t.rel[i] = 0;
         if (idx < total) {
             const int row = idx / ppr, piece = idx - row * ppr;
@@ -192,14 +192,14 @@ __device__ __forceinline__ bf16x8_t mil_tr_pair(const char* p0, const char* p1) 
 // occupancy calculation (registers AND LDS).  Persistent launches size their grid to exactly the resident set: a
 // partial second round would leave CUs idle while the stragglers finish.
 template <typename K>
-__host__ inline int mil_resident_per_cu(K kern, int lds, int cap) {
+__host__ inline int mil_resident_per_cu(K kern, int lds, int cap, int threads = 256) {
     // the answer depends only on (kernel, lds): remember the last one per kernel instantiation (launch-path cost)
     static thread_local int last_lds = -1, last_n = 0;
     static thread_local const void* last_k = nullptr;
     const void* kp = reinterpret_cast<const void*>(kern);
     if (kp != last_k || lds != last_lds) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, (size_t)lds) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, threads, (size_t)lds) != hipSuccess || n < 1) n = 1;
         last_k = kp; last_lds = lds; last_n = n;
     }
     return last_n > cap ? cap : last_n;
