@@ -170,14 +170,15 @@ def main():
         del src, dst
     for _ in range(args.warmup):
         step()
-    # Candidate dominant kernels, both on the 64x64 maps at 20(24)->20(24) channels (layer 1, 47% of the FLOPs):
-    #   conv_igemm_pf_kernel<24,2,3,4>  — the forward 3x3 convs
-    #   conv_bwd_fused_kernel<24,2,3>   — their fused backward (data gradient + weight gradient in one pass)
-    # Every launch of both is bracketed with HIP events on the launch stream; the one with the larger total time
+    # Candidate dominant kernels, all on the 64x64 maps at 20(24)->20(24) channels (layer 1, 47% of the FLOPs):
+    #   conv_block_fwd_kernel<24,2,4>   — the forward of a whole identity block (or conv_igemm_pf_kernel<24,2,3,4> per conv)
+    #   conv_bwd_fused_kernel<24,2,3>   — the fused backward of one conv (data gradient + weight gradient in one pass)
+    # Every launch of them is bracketed with HIP events on the launch stream; the one with the larger total time
     # in the timed region is reported as `roofline`.
     timer = None
     if not args.no_kernel_timer:
-        timer = ops.KernelTimer(lambda label: label[:6] in (("conv", 24, 24, 3, 1, False), ("bwd_fused", 24, 24, 3, 1, False)))
+        timer = ops.KernelTimer(lambda label: label[:6] in (("conv", 24, 24, 3, 1, False), ("bwd_fused", 24, 24, 3, 1, False))
+                                or label[:2] == ("block_fwd", 24))
         ops.TIMER = timer
     fence()
     t0 = time.perf_counter()
@@ -209,12 +210,16 @@ def main():
             if fams:
                 fam = max(fams, key=lambda k: sum(d for _l, d in fams[k]))
                 label = fams[fam][0][0]
-                n_img, ho, wo = label[6], label[7], label[8]
+                n_img, ho, wo = (label[2], label[3], label[4]) if fam == "block_fwd" else (label[6], label[7], label[8])
                 avg_ms = float(np.mean([d for _l, d in fams[fam]]))
                 esz = 2 if args.dtype == "bf16" else 4
                 conv_flops = 2.0 * 9 * 20 * 20 * n_img * ho * wo          # algorithmic: 20 real channels in and out
                 px_bytes = n_img * ho * wo * 20 * esz                      # one 20-channel activation tensor
-                if fam == "conv":
+                if fam == "block_fwd":
+                    flops, alg_bytes = 2 * conv_flops, 3 * px_bytes        # two convs; read x once, write o1 and out
+                    kname = (f"conv_block_fwd_kernel<24,2,4> (whole identity block forward: conv-lrelu-conv-add-lrelu, 20 ch, "
+                             f"{ho}x{wo} maps, {n_img} tiles/launch)")
+                elif fam == "conv":
                     flops, alg_bytes = conv_flops, 2 * px_bytes            # read x once, write y once
                     kname = (f"conv_igemm_pf_kernel<24,2,3,4> (3x3 s1 forward conv, 20->20 ch, {ho}x{wo} maps, "
                              f"{n_img} tiles/launch)")
@@ -226,7 +231,7 @@ def main():
                 traffic = None
                 try:                                                       # rocprofv3 PMC passes of this same command
                     pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
-                    key = "conv_bwd_fused_kernel<24, 2, 3" if fam != "conv" else "conv_igemm_pf_kernel<24, 2, 3, 4>"
+                    key = {"conv": "conv_igemm_pf_kernel<24, 2, 3, 4", "block_fwd": "conv_block_fwd_kernel<24, 2"}.get(fam, "conv_bwd_fused_kernel<24, 2, 3")
                     hit = [v for k, v in pmc.items() if key in k]           # all template variants of the kernel family
                     if hit and n_img == 2048:
                         traffic = sum(v["hbm_bytes"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit)
