@@ -23,7 +23,7 @@ struct BwdFusedArgs {
     float* slab;            // [gridDim.x][(MT+1)*16][NTX*16]
     ConvGeom g;
     int ntiles;
-    int lds_w_off, lds_x_off, lds_dump_off;
+    int lds_w_off, lds_x_off, lds_dump_off, lds_a2_off;     // lds_a2_off: second dz-halo buffer (0 = none)
     int apply_mask;
     float slope;
     unsigned z_bytes, x_bytes;      // byte sizes of dz and of x/addend/dx (buffer descriptors)
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, MIL_BWD_WAVES) void conv_bwd_fused_kernel(BwdF
     // ---- tile-invariant tables (see conv_igemm_pf_kernel) -------------------------------------------
     HaloTables<NPX> ht;
     mil_build_halo_tables<CZ, NPX>(ht, g, tid);
-    mil_halo_tables_use_dump<NPX>(ht, a.lds_dump_off);
+    mil_halo_tables_use_dump<NPX>(ht, a.lds_w_off - 16 - a.lds_a2_off);     // 16 spare bytes behind each halo buffer
     int toff[KSTEPS];
 #pragma unroll
     for (int sl = 0; sl < KSTEPS; ++sl) {
@@ -161,9 +161,17 @@ __global__ __launch_bounds__(256, MIL_BWD_WAVES) void conv_bwd_fused_kernel(BwdF
     };
     if (bid < a.ntiles) fetch_xa(cur.origin(g));
 
+    // Two dz-halo buffers: the next tile's halo goes into the buffer of the tile before the current one, which every
+    // wave has left once this wave is past the current tile's barriers — the "all reads are done" barrier at the top of
+    // the tile disappears (two barriers per tile instead of three).  ldsX is written only after the tile's first barrier,
+    // by which time every wave has finished the previous tile's weight-gradient loop.
+    const int buf_step = a.lds_a2_off;
+    int buf = 0;
     for (int tile = bid; tile < a.ntiles; tile += gridDim.x) {
-        __syncthreads();                       // previous tile: all reads of ldsA / ldsX are done
-        mil_commit_halo_all<NPX>(rx, ldsA, ht);
+        if (buf_step == 0) __syncthreads();    // single buffer: previous tile's reads of ldsA are done
+        char* ldsA_t = ldsA + buf;
+        buf = buf_step - buf;
+        mil_commit_halo_all<NPX>(rx, ldsA_t, ht);
 
         __syncthreads();                       // dz halo visible
         const bool more = tile + (int)gridDim.x < a.ntiles;
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(256, MIL_BWD_WAVES) void conv_bwd_fused_kernel(BwdF
             for (int nt = 0; nt < NTX; ++nt) wf[nt] = lds_frag<BF16>(ldsW + ((sl * NTX + nt) * 64 + lane) * 16);
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
-                const Frag8<BF16> zf = lds_frag<BF16>(ldsA + pixbase[m] + toff[sl]);
+                const Frag8<BF16> zf = lds_frag<BF16>(ldsA_t + pixbase[m] + toff[sl]);
 #pragma unroll
                 for (int nt = 0; nt < NTX; ++nt) acc[m][nt] = mma8(wf[nt], zf, acc[m][nt]);
             }
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(256, MIL_BWD_WAVES) void conv_bwd_fused_kernel(BwdF
 #pragma unroll
             for (int i = 0; i < MW; ++i) {
                 if (mvalid[i]) {
-                    const bf16x8_t zf = mil_tr_pair(ldsA + pb0 + wtoff[i], ldsA + pb1 + wtoff[i]);
+                    const bf16x8_t zf = mil_tr_pair(ldsA_t + pb0 + wtoff[i], ldsA_t + pb1 + wtoff[i]);
 #pragma unroll
                     for (int nt = 0; nt < NTX; ++nt)
                         wacc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf, xf[nt], wacc[i][nt], 0, 0, 0);
@@ -331,10 +339,11 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
     const int halo_px = (a.g.hh * a.g.hw) << a.g.ti_log2;
     if (halo_px > 400 || a.g.hh >= 1024 || a.g.hw >= 1024) return MIL_ERR_UNSUPPORTED;
     if ((size_t)a.g.n_img * a.g.H * a.g.W * (CZ > CX ? CZ : CX) * 2 >= ((size_t)1 << 31)) return MIL_ERR_UNSUPPORTED;   // buffer descriptors: < 2 GiB
-    const int a_bytes = (halo_px * PIXB + 15) & ~15;
+    const int a_bytes = ((halo_px * PIXB + 15) & ~15) + 16;   // + dump slot behind the halo for the branch-free commit
     const int w_bytes = KSTEPS * NTX * 64 * 16;
     const int x_bytes = 256 * PIXX;
-    const int lds = a_bytes + w_bytes + x_bytes + 16;          // + dump slot for branch-free LDS writes
+    const bool dbuf = 2 * (2 * a_bytes + w_bytes + x_bytes + 16) <= 160 * 1024;      // second halo buffer if two workgroups still fit
+    const int lds = (dbuf ? 2 : 1) * a_bytes + w_bytes + x_bytes + 16;          // + dump slot for the x-tile writes
     if (lds > 160 * 1024) return MIL_ERR_UNSUPPORTED;
     const int ntiles = a.g.n_groups * a.g.tiles_y * a.g.tiles_x;
     auto kern = a.addend ? (a.apply_mask ? conv_bwd_fused_kernel<CZ, NTX, KS, true, true> : conv_bwd_fused_kernel<CZ, NTX, KS, true, false>)
@@ -358,7 +367,9 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
     const size_t bytes = slab_elems * grid * sizeof(float);
     if (query) { *need = bytes; return MIL_OK; }
     if (!ws || ws_bytes < bytes) return MIL_ERR_ARG;
-    a.slab = (float*)ws; a.ntiles = ntiles; a.lds_w_off = a_bytes; a.lds_x_off = a_bytes + w_bytes; a.lds_dump_off = a_bytes + w_bytes + x_bytes;
+    const int a_tot = (dbuf ? 2 : 1) * a_bytes;
+    a.slab = (float*)ws; a.ntiles = ntiles; a.lds_w_off = a_tot; a.lds_x_off = a_tot + w_bytes; a.lds_dump_off = a_tot + w_bytes + x_bytes;
+    a.lds_a2_off = dbuf ? a_bytes : 0;
     a.z_bytes = (unsigned)((size_t)a.g.n_img * a.g.H * a.g.W * CZ * 2);
     a.x_bytes = (unsigned)((size_t)a.g.n_img * a.g.H * a.g.W * CX * 2);
     if (grid <= 0) return MIL_OK;

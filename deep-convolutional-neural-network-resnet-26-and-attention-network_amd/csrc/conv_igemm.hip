@@ -25,6 +25,7 @@ struct ConvArgs {
     ConvGeom g;
     int nsteps, kc;                 // k-steps total / per weight chunk held in LDS
     int lds_w_off;                  // byte offset of the weight chunk in LDS
+    int lds_a2_off, lds_dump_rel;   // persistent kernels: offset of the second halo buffer (0 = none); dump slot relative to a halo buffer
     int apply_lrelu;
     float slope;
 };
@@ -203,7 +204,7 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
     // ---- tile-invariant tables ---------------------------------------------------------------------
     HaloTables<NPX> ht;
     mil_build_halo_tables<CINP, NPX, NTHR>(ht, g, tid);
-    mil_halo_tables_use_dump<NPX>(ht, a.lds_w_off + KSTEPS * NT * 64 * 16);      // 16 spare bytes behind the filter
+    mil_halo_tables_use_dump<NPX>(ht, a.lds_dump_rel);                           // 16 spare bytes behind each halo buffer
     int toff[KSTEPS];
 #pragma unroll
     for (int sl = 0; sl < KSTEPS; ++sl) {
@@ -285,9 +286,16 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
         if (bid + G < ntiles) mil_fetch_halo<CINP, NPX>(rxB, rs_x, ht, g, nxt.origin(g));
     }
 
+    // Two halo buffers (when LDS allows): the next tile's halo is committed into the buffer the tile BEFORE the current
+    // one used, which every wave has left by the time this wave is past the current tile's only barrier — so the
+    // "everyone has finished reading" barrier of the single-buffer form disappears (one barrier per tile, not two).
+    const int buf_step = a.lds_a2_off;          // 0: single buffer
+    int buf = 0;
     auto do_tile = [&](u32x4_t (&rx)[NPX], int tile) {
-        __syncthreads();                       // every wave has finished reading ldsA for the previous tile
-        mil_commit_halo_all<NPX>(rx, ldsA, ht);
+        if (buf_step == 0) __syncthreads();    // single buffer: every wave has finished reading ldsA for the previous tile
+        char* ldsA_t = ldsA + buf;
+        buf = buf_step - buf;
+        mil_commit_halo_all<NPX>(rx, ldsA_t, ht);
         // this tile's epilogue operands were requested one tile ago; take them over before re-issuing
         unsigned ooff_l[NPAIR];
         u32x4_t rres_l[NPAIR][NT], ract_l[NPAIR][NT];
@@ -322,7 +330,7 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
             for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<T>(ldsW + ((sl * NT + nt) * 64 + lane) * 16);
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
-                const Frag8<T> xf = lds_frag<T>(ldsA + pixbase[m] + toff[sl]);
+                const Frag8<T> xf = lds_frag<T>(ldsA_t + pixbase[m] + toff[sl]);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wf[nt], xf, acc[m][nt]);   // D[channel][pixel]
             }
@@ -423,6 +431,11 @@ static int mil_pf_rounds() {
     return r;
 }
 
+static bool mil_pf_double_buffer() {
+    static const bool v = [] { const char* e = getenv("MIL_PF_DBUF"); return !(e && atoi(e) == 0); }();
+    return v;
+}
+
 static int mil_pf_waves64() {
     static const int v = [] { const char* e = getenv("MIL_PF_WAVES64"); return (e && atoi(e) == 4) ? 4 : 8; }();
     return v;
@@ -446,14 +459,18 @@ static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool*
     mil_geom_tiles(a.g, NW * MTW == 16 ? 8 : 7);
     const int halo_px = (a.g.hh * a.g.hw) << a.g.ti_log2;
     if (halo_px > mil_halo_px_max(NW * MTW == 16 ? 4 : 2)) return MIL_OK;
-    const int a_bytes = (halo_px * PIXB + 15) & ~15;
+    const int a_bytes = ((halo_px * PIXB + 15) & ~15) + 16;  // + dump slot for the branch-free halo commit
     const int w_bytes = a.nsteps * NT * 64 * 16;
-    const int lds = a_bytes + w_bytes + 16;                 // + dump slot for the branch-free halo commit
+    // a second halo buffer (one barrier per tile instead of two) when it does not cost a resident workgroup
+    const bool dbuf = mil_pf_double_buffer() && (160 * 1024) / (2 * a_bytes + w_bytes) >= ((160 * 1024) / (a_bytes + w_bytes) > 2 ? 3 : (160 * 1024) / (a_bytes + w_bytes));
+    const int lds = (dbuf ? 2 : 1) * a_bytes + w_bytes;
     if (lds > 160 * 1024) return MIL_OK;
     if (a.g.hh >= 1024 || a.g.hw >= 1024 || a.slope < 0.f || a.slope >= 1.f) return MIL_OK;   // max(v, slope*v) form
     if ((a.g.n_groups * a.g.tiles_y * a.g.tiles_x) < mil_pf_min_tiles()) return MIL_OK;    // too few tiles for a persistent launch
     a.kc = a.nsteps;
-    a.lds_w_off = a_bytes;
+    a.lds_w_off = (dbuf ? 2 : 1) * a_bytes;
+    a.lds_a2_off = dbuf ? a_bytes : 0;
+    a.lds_dump_rel = a_bytes - 16;
     auto kern = conv_igemm_pf_kernel<CINP, NT, KS, MTW, -1, NW>;
     // the hot square 3x3 layers get the epilogue options as compile-time constants
     if constexpr (KS == 3 && ((CINP == 24 && NT == 2) || (CINP == 40 && NT == 3) || (CINP == 64 && NT == 4) || (CINP == 80 && NT == 5))) {
