@@ -268,7 +268,12 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
     // L2 or HBM, about one tile time, so the narrowest layers keep TWO tiles of halo loads in flight (two
     // register sets, tile loop unrolled by two).
     constexpr bool EPI_AHEAD = CINP <= 24;
-    constexpr int DEPTH = 1;     // measured: a second tile in flight (DEPTH 2, CINP <= 24) is 8% slower — the limit is VMEM issue, not latency
+#ifndef MIL_PF_DEPTH40
+#define MIL_PF_DEPTH40 1
+#endif
+    // measured twice: a second tile of halo loads in flight is 8% slower on the 24-channel layers and no faster on the
+    // 40-channel ones (108 -> 107 us plain, 142 -> 230 us with both epilogue operands: the second register set spills)
+    constexpr int DEPTH = (CINP == 40 && NW == 4) ? MIL_PF_DEPTH40 : 1;
     const int G = gridDim.x;
     TileWalker nx2 = nxt;
     nx2.advance();
