@@ -351,6 +351,76 @@ __global__ __launch_bounds__(256) void fc_wgrad_kernel(const float* __restrict__
     *q = accumulate ? *q + s : s;
 }
 
+// Two-stage form (see head_wgrad_partial_kernel in mil_head.hip): a workgroup stages 64 rows of [dfeats | pooled | 1] in
+// LDS with coalesced loads and accumulates every output element over them in index order; the second stage adds the
+// slices in index order (and accumulates into dw/dbias when asked).
+#define FCS 64
+__global__ __launch_bounds__(1024) void fc_wgrad_partial_kernel(const float* __restrict__ dfeats, const float* __restrict__ pooled,
+                                                               float* __restrict__ partial, int n, int C, int NF, int want_bias) {
+    extern __shared__ float frows[];                        // [FCS][NF + C + 1 (+pad)]
+    const int stride = (NF + C + 2) & ~1;
+    const int tid = threadIdx.x, n0 = blockIdx.x * FCS;
+    for (int idx = tid; idx < FCS * NF; idx += 1024) {
+        const int nl = idx / NF, o = idx - nl * NF;
+        frows[nl * stride + o] = (n0 + nl < n) ? dfeats[(size_t)(n0 + nl) * NF + o] : 0.f;
+    }
+    for (int idx = tid; idx < FCS * C; idx += 1024) {
+        const int nl = idx / C, i = idx - nl * C;
+        frows[nl * stride + NF + i] = (n0 + nl < n) ? pooled[(size_t)(n0 + nl) * C + i] : 0.f;
+    }
+    for (int nl = tid; nl < FCS; nl += 1024) frows[nl * stride + NF + C] = (n0 + nl < n) ? 1.f : 0.f;
+    __syncthreads();
+    const int total = NF * C + (want_bias ? NF : 0);
+    float* out = partial + (size_t)blockIdx.x * total;
+    for (int e = tid; e < total; e += 1024) {
+        int ca, cb;
+        if (e < NF * C) { ca = e / C; cb = NF + (e - ca * C); } else { ca = e - NF * C; cb = NF + C; }
+        float sacc = 0.f;
+#pragma unroll 8
+        for (int nl = 0; nl < FCS; ++nl) sacc += frows[nl * stride + ca] * frows[nl * stride + cb];
+        out[e] = sacc;
+    }
+}
+
+__global__ __launch_bounds__(256) void fc_wgrad_reduce_kernel(const float* __restrict__ partial, int nslices, int total, int nw,
+                                                              float* __restrict__ dw, float* __restrict__ dbias, int accumulate) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    float sacc = 0.f;
+    for (int k = 0; k < nslices; ++k) sacc += partial[(size_t)k * total + e];
+    float* q = e < nw ? dw + e : dbias + (e - nw);
+    *q = accumulate ? *q + sacc : sacc;
+}
+
+extern "C" int mil_fc_wgrad_workspace(size_t* bytes, int n, int c, int nf) {
+    if (!bytes || n < 0 || c <= 0 || nf <= 0) return MIL_ERR_ARG;
+    *bytes = (size_t)((n + FCS - 1) / FCS) * ((size_t)nf * c + nf) * sizeof(float);
+    return MIL_OK;
+}
+
+// dwfc[nf][c] (+)= dfeats^T pooled, dbias[nf] (+)= column sums of dfeats (dbias may be null).
+extern "C" int mil_fc_wgrad(const float* dfeats, const float* pooled, float* dwfc, float* dbias, void* workspace,
+                            size_t workspace_bytes, int n, int c, int nf, int accumulate, void* stream) {
+    if (!dfeats || !pooled || !dwfc || !workspace || n < 0 || c <= 0 || nf <= 0 || c > POOL_MAXC || nf > POOL_MAXC) return MIL_ERR_ARG;
+    size_t need = 0;
+    mil_fc_wgrad_workspace(&need, n, c, nf);
+    if (workspace_bytes < need) return MIL_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int nslices = (n + FCS - 1) / FCS;
+    const int total = nf * c + (dbias ? nf : 0);
+    const int lds = FCS * ((nf + c + 2) & ~1) * 4;
+    if (lds > 160 * 1024) return MIL_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fc_wgrad_partial_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return MIL_ERR_LAUNCH;
+    if (nslices > 0) {
+        hipLaunchKernelGGL(fc_wgrad_partial_kernel, dim3(nslices), dim3(1024), lds, st, dfeats, pooled, (float*)workspace, n, c, nf, dbias ? 1 : 0);
+        MIL_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(fc_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)workspace, nslices, total, nf * c, dwfc, dbias, accumulate);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
 static int pool_block(int c, int nf, int cp) {
     int m = c > nf ? c : nf;
     if (cp > m) m = cp;
@@ -373,7 +443,8 @@ extern "C" int mil_avgpool_fc_fwd(const void* x, const float* wfc, const float* 
 extern "C" int mil_avgpool_fc_bwd(const float* dfeats, const float* wfc, const float* pooled, const void* act, void* dz,
                                   float* dwfc, float* dbias, int n, int hw, int cp, int c, int nf, int accumulate, float slope,
                                   int dtype, void* stream) {
-    if (!dfeats || !wfc || !pooled || !dz || !dwfc || c > POOL_MAXC || nf > POOL_MAXC || cp > POOL_MAXC || hw <= 0) return MIL_ERR_ARG;
+    // dwfc == null: data path only (the parameter gradients then come from mil_fc_wgrad)
+    if (!dfeats || !wfc || !pooled || !dz || c > POOL_MAXC || nf > POOL_MAXC || cp > POOL_MAXC || hw <= 0) return MIL_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int bd = pool_block(c, nf, cp);
     if (n > 0) {
@@ -382,8 +453,10 @@ extern "C" int mil_avgpool_fc_bwd(const float* dfeats, const float* wfc, const f
         else return MIL_ERR_ARG;
         MIL_CHECK_LAUNCH();
     }
-    const int total = nf * c + (dbias ? nf : 0);
-    hipLaunchKernelGGL(fc_wgrad_kernel, dim3((total + 3) / 4), dim3(256), 0, st, dfeats, pooled, dwfc, dbias, n, c, nf, accumulate);
-    MIL_CHECK_LAUNCH();
+    if (dwfc) {
+        const int total = nf * c + (dbias ? nf : 0);
+        hipLaunchKernelGGL(fc_wgrad_kernel, dim3((total + 3) / 4), dim3(256), 0, st, dfeats, pooled, dwfc, dbias, n, c, nf, accumulate);
+        MIL_CHECK_LAUNCH();
+    }
     return MIL_OK;
 }

@@ -344,9 +344,13 @@ def avgpool_fc_bwd(dfeats, wfc, pooled, act, c, slope=LEAK, out=None, want_bias=
     if want_bias:
         dbias = torch.empty(nf, dtype=torch.float32, device=act.device) if out_bias is None else out_bias
     L.check(L.lib().mil_avgpool_fc_bwd(dfeats.data_ptr(), wfc.data_ptr(), pooled.data_ptr(), act.data_ptr(), dz.data_ptr(),
-                                       dwfc.data_ptr(), L.ptr(dbias), n, h * w, cp, c, nf, 0 if out is None else 1, slope,
-                                       L.dt_code(act.dtype), L.stream_ptr()),
+                                       None, None, n, h * w, cp, c, nf, 0, slope, L.dt_code(act.dtype), L.stream_ptr()),
             "mil_avgpool_fc_bwd")
+    need = ctypes.c_size_t(0)
+    L.check(L.lib().mil_fc_wgrad_workspace(ctypes.byref(need), n, c, nf), "mil_fc_wgrad_workspace")
+    ws = torch.empty((need.value + 3) // 4, dtype=torch.float32, device=act.device)
+    L.check(L.lib().mil_fc_wgrad(dfeats.data_ptr(), pooled.data_ptr(), dwfc.data_ptr(), L.ptr(dbias), ws.data_ptr(),
+                                 ws.numel() * 4, n, c, nf, 0 if out is None else 1, L.stream_ptr()), "mil_fc_wgrad")
     if want_bias:
         return dz, dwfc, dbias
     return dz, dwfc

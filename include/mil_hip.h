@@ -167,6 +167,13 @@ int mil_avgpool_fc_fwd(const void* x, const float* wfc, const float* bias, float
 int mil_avgpool_fc_bwd(const float* dfeats, const float* wfc, const float* pooled, const void* act, void* dz,
                        float* dwfc, float* dbias, int n, int hw, int cp, int c, int nf, int accumulate, float slope,
                        int dtype, void* stream);
+/* The parameter gradients of the same layer on their own (two-stage, coalesced): dwfc [nf][c] (+)= dfeats^T pooled,
+ * dbias [nf] (+)= column sums of dfeats (may be null).  mil_avgpool_fc_bwd skips them when its dwfc is null.
+ * Workspace from mil_fc_wgrad_workspace. */
+int mil_fc_wgrad_workspace(size_t* bytes, int n, int c, int nf);
+int mil_fc_wgrad(const float* dfeats, const float* pooled, float* dwfc, float* dbias, void* workspace,
+                 size_t workspace_bytes, int n, int c, int nf, int accumulate, void* stream);
+
 
 /* ---- attention-MIL head --------------------------------------------------------------------
  * Replaces everything after the backbone in Attention.forward (gbm/model.py:198-246): ContextLayer
