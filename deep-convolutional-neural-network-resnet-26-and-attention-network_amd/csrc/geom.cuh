@@ -21,7 +21,17 @@ __host__ inline void mil_geom_tiles(ConvGeom& g, int tile_px_log2) {
     // choose TW x TH x TI = 2^tile_px_log2 output pixels
     int tw, th;
     if (tile_px_log2 == 8) {          // 256 px
-        if (g.Wo > 8 || g.Ho > 8) { tw = 4; th = 4; }
+        if (g.Wo > 8 || g.Ho > 8) {
+            // 16x16 tiles of one image, or 8x8 tiles of four: whichever wastes less on maps that are not a multiple of
+            // 16 (the live driver's 300x300 tiles give 75/38/19/10-pixel maps).  Cost per image ~ tiles x (256 MFMA
+            // pixels + staged halo pixels) / images per tile.
+            const long c16 = (long)((g.Wo + 15) >> 4) * ((g.Ho + 15) >> 4) * (256 + 18 * 18);
+            const long c8 = (long)((g.Wo + 7) >> 3) * ((g.Ho + 7) >> 3) * (256 + 4 * 10 * 10) / 4;
+#ifndef MIL_GEOM_KS_MAX
+#define MIL_GEOM_KS_MAX 3
+#endif
+            if (c8 < c16 && g.stride == 1 && !g.zins && g.ks <= MIL_GEOM_KS_MAX) { tw = 3; th = 3; } else { tw = 4; th = 4; }
+        }
         else if (g.Wo > 4 || g.Ho > 4) { tw = 3; th = 3; }
         else { tw = 2; th = 2; }
     } else if (tile_px_log2 == 7) {   // 128 px
