@@ -41,7 +41,9 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="run weight-gradient launches on the main stream")
+    ap.add_argument("--overlap", action="store_true", help="run the separate weight-gradient launches on a side stream "
+                    "(measured: same throughput on this workload, +2%% at 512 tiles, -24%% at 64 tiles; off by default)")
+    ap.add_argument("--no-overlap", action="store_true", help="(default now) weight-gradient launches on the main stream")
     ap.add_argument("--infer", action="store_true",
                     help="BASELINE config 5 instead of the headline metric: forward only, no_grad (attention-map extraction)")
     return ap.parse_args()
@@ -113,8 +115,7 @@ def main():
     w = np.load(os.path.join(ROOT, "tests", "golden", "weights.npz"))
     net = mil_amd.Attention(3, compute_dtype=dtype, device=dev).eval()     # eval = full-bag path (all tiles encoded)
     net.load_state_dict({k: torch.tensor(w[k]) for k in w.keys()})
-    if args.no_overlap:
-        net.cnn.module.overlap_wgrad = False
+    net.cnn.module.overlap_wgrad = bool(args.overlap) and not args.no_overlap
     flat = mil_amd.FlatParams(net)
     flat.broadcast_params()
     opt = mil_amd.FlatAdam(flat, lr=2e-4)               # reference optimizer: Adam(lr=2e-4), gbm/classify_combined.py:519

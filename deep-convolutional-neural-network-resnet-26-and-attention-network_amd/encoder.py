@@ -55,7 +55,9 @@ class ResNet(nn.Module):
         self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
         self.fc = nn.Linear(STAGE_WIDTHS[-1], num_classes, bias=False)
         self.compute_dtype = compute_dtype
-        self.overlap_wgrad = True
+        # separate weight-gradient launches on a side stream: no longer a win once the hot layers run fused backward
+        # kernels (same throughput at 2048 tiles, slower for small bags) — available, off by default
+        self.overlap_wgrad = False
         self.direct_grad = False        # accumulate parameter gradients straight into existing .grad tensors
         self.n_side_streams = 1
         self.fuse_backward = True

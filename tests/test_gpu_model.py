@@ -407,3 +407,21 @@ def test_whole_step_is_bitwise_reproducible(golden_dir, monkeypatch):
         assert torch.equal(r[0], results[0][0]) and torch.equal(r[1], results[0][1])
         assert torch.equal(r[2], results[0][2])
     assert float(results[0][2].abs().max()) > 0
+
+
+def test_side_stream_weight_gradients_equal_main_stream(golden_dir):
+    """`overlap_wgrad` (separate weight-gradient launches on a side stream) changes scheduling only: same bits."""
+    import mil_amd
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((24, 3, 64, 64), generator=g, device="cuda").clamp_(-1, 1)
+    sizes, labels = [10, 14], torch.tensor([2, 0], device="cuda")
+    grads = []
+    for overlap in (False, True):
+        net = _model(golden_dir, torch.bfloat16).eval()
+        net.cnn.module.overlap_wgrad = overlap
+        flat = mil_amd.FlatParams(net)
+        flat.zero_grad()
+        net.forward_bags((x, sizes), labels).loss.sum().backward()
+        torch.cuda.synchronize()
+        grads.append(flat.flat_grad.clone())
+    assert torch.equal(grads[0], grads[1]) and float(grads[0].abs().max()) > 0
