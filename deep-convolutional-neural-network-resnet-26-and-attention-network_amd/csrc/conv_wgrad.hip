@@ -33,8 +33,11 @@ __device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <typename T, int KS, int CINP, int NT, int MSPLIT, bool PF>
-__global__ __launch_bounds__(256, (PF && CINP > 40) ? 1 : 0) void wgrad_kernel(WgradArgs<T> a) {
+// NW = waves per workgroup: 4, or 8 for the persistent bf16 form of the 64/80-channel layers, whose accumulators
+// (up to 9 row tiles x 5 column tiles per wave) otherwise leave ONE wave per SIMD: eight waves on the same LDS tiles
+// halve every per-wave quantity and give each SIMD a second wave to overlap with.
+template <typename T, int KS, int CINP, int NT, int MSPLIT, bool PF, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0)) void wgrad_kernel(WgradArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ESZ = T::ESZ;
     constexpr int PIXB = mil_pix_pitch(CINP, ESZ);
@@ -44,7 +47,8 @@ __global__ __launch_bounds__(256, (PF && CINP > 40) ? 1 : 0) void wgrad_kernel(W
     constexpr int RG = KS * KS * CG;            // row groups of 8 input channels
     constexpr int MT = (RG + 1) / 2;            // 16-row MFMA tiles over (tap, ci)
     constexpr int MT_S = (MT + MSPLIT - 1) / MSPLIT;
-    constexpr int MW = (MT_S + 3) / 4;          // tiles per wave
+    constexpr int NTHR = 64 * NW;
+    constexpr int MW = (MT_S + NW - 1) / NW;    // tiles per wave
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     // wave id through readfirstlane: provably wave-uniform, so branches on it are scalar branches (an MFMA or a
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(256, (PF && CINP > 40) ? 1 : 0) void wgrad_kernel(W
     bool mvalid[MW];
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
-        const int ml = wave + 4 * i;
+        const int ml = wave + NW * i;
         const int mt = split * MT_S + ml;
         mvalid[i] = (ml < MT_S) && (mt < MT);
         int rg, sub;
@@ -84,8 +88,8 @@ __global__ __launch_bounds__(256, (PF && CINP > 40) ? 1 : 0) void wgrad_kernel(W
     // PF: software pipeline — the next tile's global loads are issued (into registers) before this tile's
     // MFMA loop and written to LDS after the loop's barrier, so HBM latency hides under compute.  Addressing
     // through buffer descriptors + tile-invariant tables (pf_common.cuh) keeps the per-tile VALU work small.
-    constexpr int NPX = PF ? mil_halo_np(CINP, ESZ) : 1;
-    constexpr int NPZ = PF ? COUTP * ESZ / 16 : 1;
+    constexpr int NPX = PF ? (400 * (CINP * ESZ / 16) + NTHR - 1) / NTHR : 1;
+    constexpr int NPZ = PF ? (256 * (COUTP * ESZ / 16) + NTHR - 1) / NTHR : 1;
     u32x4_t rx[NPX], rz[NPZ];
     HaloTables<NPX> ht;
     OtileTables<NPZ> zt;
@@ -95,8 +99,8 @@ __global__ __launch_bounds__(256, (PF && CINP > 40) ? 1 : 0) void wgrad_kernel(W
     if constexpr (PF) {
         rs_x = mil_rsrc(a.x, a.x_bytes);
         rs_z = mil_rsrc(a.dz, a.z_bytes);
-        mil_build_halo_tables<CINP, NPX>(ht, g, tid);
-        mil_build_otile_tables<COUTP, NPZ>(zt, g, tid, a.tile_px);
+        mil_build_halo_tables<CINP, NPX, NTHR>(ht, g, tid);
+        mil_build_otile_tables<COUTP, NPZ, NTHR>(zt, g, tid, a.tile_px);
         cur.init(g, bid, gridDim.x);
         nxt = cur; nxt.advance();
         if (bid < a.ntiles) {
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256, (PF && CINP > 40) ? 1 : 0) void wgrad_kernel(W
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
         if (!mvalid[i]) continue;
-        const int mt = split * MT_S + wave + 4 * i;
+        const int mt = split * MT_S + wave + NW * i;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -304,12 +308,15 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     const bool pf = PF_OK && (((g.hh * g.hw) << g.ti_log2) <= 400) && g.hh < 1024 && g.hw < 1024 &&
                     xb_total < ((size_t)1 << 31) && zb_total < ((size_t)1 << 31);
     a.x_bytes = (unsigned)xb_total; a.z_bytes = (unsigned)zb_total;
-    auto kern = pf ? wgrad_kernel<T, KS, CINP, NT, MSPLIT, PF_OK> : wgrad_kernel<T, KS, CINP, NT, MSPLIT, false>;
+    // 8-wave workgroups where the 4-wave form holds a single wave per SIMD (persistent bf16 form, >= 64 input channels)
+    constexpr int NW = (PF_OK && CINP >= 64) ? 8 : 4;
+    const int nthr = pf ? 64 * NW : 256;
+    auto kern = pf ? wgrad_kernel<T, KS, CINP, NT, MSPLIT, PF_OK, NW> : wgrad_kernel<T, KS, CINP, NT, MSPLIT, false>;
     if (pl.lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds) != hipSuccess)
             return MIL_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3(pl.grid_x, MSPLIT), dim3(256), pl.lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(pl.grid_x, MSPLIT), dim3(nthr), pl.lds, stream, a);
     MIL_CHECK_LAUNCH();
     const int n_rows = KS * KS * CINP;
     const int total = (n_rows + 1) * pl.slab_cols;

@@ -128,14 +128,14 @@ __device__ __forceinline__ void mil_commit_halo_all(const u32x4_t (&rx)[NP], cha
 template <int NP>
 struct OtileTables { int pos[NP], lds[NP], rel[NP]; };
 
-template <int CP, int NP>
+template <int CP, int NP, int NTHR = 256>
 __device__ __forceinline__ void mil_build_otile_tables(OtileTables<NP>& t, const ConvGeom& g, int tid, int tile_px) {
     constexpr int N16 = CP / 8;
     constexpr int PIXZ = mil_pix_pitch(CP, 2);
     const int tw_mask = (1 << g.tw_log2) - 1, th_mask = (1 << g.th_log2) - 1;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int idx = tid + 256 * i;
+        const int idx = tid + NTHR * i;
         t.pos[i] = -1; t.lds[i] = 0; t.rel[i] = 0;
         if (idx < tile_px * N16) {
             const int tp = idx / N16, j = idx - tp * N16;
