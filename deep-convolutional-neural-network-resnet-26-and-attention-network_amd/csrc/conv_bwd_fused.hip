@@ -32,19 +32,23 @@ struct BwdFusedArgs {
 #ifndef MIL_BWD_WAVES
 #define MIL_BWD_WAVES 2
 #endif
-template <int CZ, int NTX, int KS, bool ADD, bool MASK>
-__global__ __launch_bounds__(256, MIL_BWD_WAVES) void conv_bwd_fused_kernel(BwdFusedArgs a) {
+// NW = waves per workgroup: 4 for the 24-channel layers (two workgroups per CU), 8 for the 40/64-channel layers, whose
+// filter + tiles leave one workgroup per CU: eight waves share its LDS, every per-wave quantity halves (two row tiles of
+// data-gradient accumulators, three to five of weight-gradient ones) and each SIMD still holds two waves.
+template <int CZ, int NTX, int KS, bool ADD, bool MASK, int NW = 4>
+__global__ __launch_bounds__(64 * NW, MIL_BWD_WAVES) void conv_bwd_fused_kernel(BwdFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIXB = mil_pix_pitch(CZ, 2);            // dz halo pixel pitch
     constexpr int CG = CZ / 8;
     constexpr int CX = mil_nt_to_cp(NTX);
     constexpr int PIXX = mil_pix_pitch(CX, 2);            // x centre tile pixel pitch
-    constexpr int MTW = 4;
-    constexpr int NPX = mil_halo_np(CZ, 2);
+    constexpr int NTHR = 64 * NW;
+    constexpr int MTW = 16 / NW;                          // data-gradient row tiles per wave (256-pixel tile)
+    constexpr int NPX = (400 * (CZ * 2 / 16) + NTHR - 1) / NTHR;
     constexpr int KSTEPS = (KS * KS * CG + 3) / 4;
     constexpr int RG = KS * KS * CG;                       // wgrad row groups (tap', 8 dz channels)
     constexpr int MT = (RG + 1) / 2;
-    constexpr int MW = (MT + 3) / 4;
+    constexpr int MW = (MT + NW - 1) / NW;
     constexpr int CTAP = (KS * KS) / 2;                    // centre tap
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(256, MIL_BWD_WAVES) void conv_bwd_fused_kernel(BwdF
     {
         const int nbytes = KSTEPS * NTX * 64 * 16;
         const char* src = reinterpret_cast<const char*>(a.w);
-        for (int i = tid * 16; i < nbytes; i += 256 * 16)
+        for (int i = tid * 16; i < nbytes; i += NTHR * 16)
             *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(src + i);
     }
     const int TW = 1 << g.tw_log2, TH = 1 << g.th_log2;
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256, MIL_BWD_WAVES) void conv_bwd_fused_kernel(BwdF
 
     // ---- tile-invariant tables (see conv_igemm_pf_kernel) -------------------------------------------
     HaloTables<NPX> ht;
-    mil_build_halo_tables<CZ, NPX>(ht, g, tid);
+    mil_build_halo_tables<CZ, NPX, NTHR>(ht, g, tid);
     mil_halo_tables_use_dump<NPX>(ht, a.lds_w_off - 16 - a.lds_a2_off);     // 16 spare bytes behind each halo buffer
     int toff[KSTEPS];
 #pragma unroll
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256, MIL_BWD_WAVES) void conv_bwd_fused_kernel(BwdF
     int bias_i = -1;                                       // which owned row tile holds centre-tap rows
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
-        const int mt = wave + 4 * i;
+        const int mt = wave + NW * i;
         mvalid[i] = mt < MT;
         int rg = 2 * mt + (p4 >> 1);
         if (rg >= RG) rg = 0;
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(256, MIL_BWD_WAVES) void conv_bwd_fused_kernel(BwdF
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
         if (!mvalid[i]) continue;
-        const int mt = wave + 4 * i;
+        const int mt = wave + NW * i;
 #pragma unroll
         for (int nt = 0; nt < NTX; ++nt)
 #pragma unroll
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(32 * MIL_RED_GROUPS) void wgrad_reduce_t_kernel(con
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int CZ, int NTX, int KS>
+template <int CZ, int NTX, int KS, int NW = 4>
 static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t ws_bytes, int cout, int cin, int accumulate, bool query,
                          size_t* need, hipStream_t stream) {
     constexpr int PIXB = mil_pix_pitch(CZ, 2);
@@ -336,6 +340,12 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
     constexpr int RG = KS * KS * (CZ / 8);
     constexpr int MT = (RG + 1) / 2;
     mil_geom_tiles(a.g, 8);
+    {   // the 8x8-tiles-of-four-images shape stages 400 halo pixels; where that (plus filter and x tile) does not fit in
+        // LDS but the 16x16 shape's 324 pixels would, take 16x16
+        const int px = (a.g.hh * a.g.hw) << a.g.ti_log2;
+        const int need = ((px * PIXB + 15) & ~15) + 16 + KSTEPS * NTX * 64 * 16 + 256 * PIXX + 16;
+        if (need > 160 * 1024 && a.g.tw_log2 == 3 && a.g.ti_log2 == 2 && (a.g.Wo > 8 || a.g.Ho > 8)) mil_geom_set(a.g, 4, 4, 0);
+    }
     const int halo_px = (a.g.hh * a.g.hw) << a.g.ti_log2;
     if (halo_px > 400 || a.g.hh >= 1024 || a.g.hw >= 1024) return MIL_ERR_UNSUPPORTED;
     if ((size_t)a.g.n_img * a.g.H * a.g.W * (CZ > CX ? CZ : CX) * 2 >= ((size_t)1 << 31)) return MIL_ERR_UNSUPPORTED;   // buffer descriptors: < 2 GiB
@@ -346,8 +356,8 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
     const int lds = (dbuf ? 2 : 1) * a_bytes + w_bytes + x_bytes + 16;          // + dump slot for the x-tile writes
     if (lds > 160 * 1024) return MIL_ERR_UNSUPPORTED;
     const int ntiles = a.g.n_groups * a.g.tiles_y * a.g.tiles_x;
-    auto kern = a.addend ? (a.apply_mask ? conv_bwd_fused_kernel<CZ, NTX, KS, true, true> : conv_bwd_fused_kernel<CZ, NTX, KS, true, false>)
-                         : (a.apply_mask ? conv_bwd_fused_kernel<CZ, NTX, KS, false, true> : conv_bwd_fused_kernel<CZ, NTX, KS, false, false>);
+    auto kern = a.addend ? (a.apply_mask ? conv_bwd_fused_kernel<CZ, NTX, KS, true, true, NW> : conv_bwd_fused_kernel<CZ, NTX, KS, true, false, NW>)
+                         : (a.apply_mask ? conv_bwd_fused_kernel<CZ, NTX, KS, false, true, NW> : conv_bwd_fused_kernel<CZ, NTX, KS, false, false, NW>);
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return MIL_ERR_LAUNCH;
@@ -356,9 +366,9 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
     // on the ADD/MASK variant's few registers, but take the minimum over the variants to be safe
     int per_cu = 3;
     {
-        const int o1 = mil_resident_per_cu(conv_bwd_fused_kernel<CZ, NTX, KS, true, true>, lds, 3);
-        const int o2 = mil_resident_per_cu(conv_bwd_fused_kernel<CZ, NTX, KS, false, true>, lds, 3);
-        const int o3 = mil_resident_per_cu(conv_bwd_fused_kernel<CZ, NTX, KS, true, false>, lds, 3);
+        const int o1 = mil_resident_per_cu(conv_bwd_fused_kernel<CZ, NTX, KS, true, true, NW>, lds, 3, 64 * NW);
+        const int o2 = mil_resident_per_cu(conv_bwd_fused_kernel<CZ, NTX, KS, false, true, NW>, lds, 3, 64 * NW);
+        const int o3 = mil_resident_per_cu(conv_bwd_fused_kernel<CZ, NTX, KS, true, false, NW>, lds, 3, 64 * NW);
         per_cu = o1 < o2 ? o1 : o2; per_cu = per_cu < o3 ? per_cu : o3;
     }
     int grid = 256 * per_cu;
@@ -373,7 +383,7 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
     a.z_bytes = (unsigned)((size_t)a.g.n_img * a.g.H * a.g.W * CZ * 2);
     a.x_bytes = (unsigned)((size_t)a.g.n_img * a.g.H * a.g.W * CX * 2);
     if (grid <= 0) return MIL_OK;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, a);
     MIL_CHECK_LAUNCH();
     const int n_rows = KS * KS * CZ;
     const int total = n_rows * NTX * 16 + CZ;
@@ -396,6 +406,8 @@ static int bwd_fused_entry(const void* dz, const void* wpack, const void* x, con
     const int czp = mil_cpad(cout), cxp = mil_cpad(cin);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (czp == 24 && cxp == 24) return run_bwd_fused<24, 2, 3>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st);
+    if (czp == 40 && cxp == 40) return run_bwd_fused<40, 3, 3, 8>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st);
+    if (czp == 64 && cxp == 64) return run_bwd_fused<64, 4, 3, 8>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st);
     return MIL_ERR_UNSUPPORTED;
 }
 
