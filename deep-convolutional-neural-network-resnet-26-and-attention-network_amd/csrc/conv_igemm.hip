@@ -225,16 +225,20 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
     // tile m.  One v_permlane16_swap per accumulator register between row tiles 2p and 2p+1 turns that into
     // 8 consecutive channels of ONE pixel per lane — pixel (2p + (gq&1), r), channels 16*nt + 8*(gq>>1) ... —
     // so residual / mask loads and the output store are 16-byte accesses (half the VMEM instructions).
-    constexpr int NPAIR = MTW / 2;
+    // With ONE row tile per wave (MTW == 1: the 8-wave form on 128-pixel tiles) there is nothing to pair with: the lane
+    // keeps its 4 channels of pixel r and the epilogue runs on 8-byte accesses.
+    constexpr bool PAIRED = MTW >= 2;
+    constexpr int NPAIR = PAIRED ? MTW / 2 : 1;
     int o_rel[NPAIR], o_pos[NPAIR];
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) {
-        const int tp = (wave * MTW + 2 * p + (gq & 1)) * 16 + r;
+        const int tp = PAIRED ? (wave * MTW + 2 * p + (gq & 1)) * 16 + r : wave * 16 + r;
         const int tx = tp & (TW - 1), ty = (tp >> g.tw_log2) & (TH - 1), ti = tp >> (g.tw_log2 + g.th_log2);
-        o_rel[p] = ((ti * g.Ho + ty) * g.Wo + tx) * (COUTP * 2) + (gq >> 1) * 16;
+        o_rel[p] = ((ti * g.Ho + ty) * g.Wo + tx) * (COUTP * 2) + (PAIRED ? (gq >> 1) * 16 : gq * 8);
         o_pos[p] = (ti << 20) | (ty << 10) | tx;
     }
-    const bool last_ok = !LAST_PARTIAL || (gq >> 1) == 0;   // channels of the last column tile this lane owns exist
+    // channels of the last column tile this lane owns exist
+    const bool last_ok = !LAST_PARTIAL || (PAIRED ? (gq >> 1) == 0 : gq * 4 < COUTP - (NT - 1) * 16);
     f32x4_t bias_r[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -256,8 +260,13 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 32;
-                if (has_res) rres[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0);
-                if (has_act) ract[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, off, 0, 0);
+                if constexpr (PAIRED) {
+                    if (has_res) rres[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0);
+                    if (has_act) ract[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, off, 0, 0);
+                } else {
+                    if (has_res) { const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rs_res, off, 0, 0); rres[p][nt][0] = t[0]; rres[p][nt][1] = t[1]; }
+                    if (has_act) { const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rs_act, off, 0, 0); ract[p][nt][0] = t[0]; ract[p][nt][1] = t[1]; }
+                }
             }
         }
     };
@@ -341,7 +350,34 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
             }
         }
 
-        // register epilogue on 8 channels per lane (see "Epilogue layout" above)
+        // register epilogue on 8 channels per lane (see "Epilogue layout" above); 4 channels per lane when unpaired
+        if constexpr (!PAIRED) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = acc[0][nt][i];
+                if (has_res) {
+                    const bf16x4_t t = __builtin_bit_cast(bf16x4_t, u32x2_t{rres[0][nt][0], rres[0][nt][1]});
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += (float)t[i];
+                }
+                if (do_lrelu) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], v[i] * a.slope);
+                }
+                if (has_act) {
+                    const bf16x4_t t = __builtin_bit_cast(bf16x4_t, u32x2_t{ract[0][nt][0], ract[0][nt][1]});
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] *= ((float)t[i] > 0.f ? 1.f : a.slope);
+                }
+                bf16x4_t ov;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ov[i] = (__bf16)v[i];
+                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[0] + nt * 32;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, ov), rs_y, off, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int p = 0; p < NPAIR; ++p) {
 #pragma unroll
@@ -374,6 +410,7 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
                 const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 32;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), rs_y, off, 0, 0);
             }
+        }
         }
         if constexpr (!EPI_AHEAD) {            // `cur` is the next tile by now
             if (tile + G < ntiles) fetch_epi(cur.origin(g), ooff_n, rres_n, ract_n);
@@ -532,9 +569,12 @@ static int launch_conv_pf(const ConvArgs<BF16>& a, hipStream_t stream, bool* tak
         if (a.g.ks == 1) return launch_conv_pf_ks<64, 3, 1>(a, stream, taken);
     }
     // 80-channel layers: the whole filter (115 KB) stays resident, so the tile shrinks to 128 px
-    if constexpr (CINP == 80 && NT == 5) { if (a.g.ks == 3) return launch_conv_pf_ks<80, 5, 3, 2>(a, stream, taken); }
+    // (eight waves with one row tile each by default: one workgroup per CU either way, but two waves per SIMD)
+    if constexpr (CINP == 80 && NT == 5) {
+        if (a.g.ks == 3) return mil_pf_waves64() == 8 ? launch_conv_pf_ks<80, 5, 3, 1, 8>(a, stream, taken) : launch_conv_pf_ks<80, 5, 3, 2>(a, stream, taken);
+    }
     if constexpr (CINP == 80 && NT == 4) {
-        if (a.g.ks == 3) return launch_conv_pf_ks<80, 4, 3, 2>(a, stream, taken);
+        if (a.g.ks == 3) return mil_pf_waves64() == 8 ? launch_conv_pf_ks<80, 4, 3, 1, 8>(a, stream, taken) : launch_conv_pf_ks<80, 4, 3, 2>(a, stream, taken);
         if (a.g.ks == 1) return launch_conv_pf_ks<80, 4, 1, 2>(a, stream, taken);
     }
     return MIL_OK;
