@@ -22,6 +22,8 @@ struct WgradArgs {
     int tile_px;
     int lds_z_off;
     unsigned x_bytes, z_bytes;   // buffer-descriptor sizes (prefetch-pipelined path)
+    const typename T::elem* dz2; // PROJ: gradient of the 1x1/s2 projection's output (same shape as dz)
+    int lds_z2_off;
 };
 
 __device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
@@ -36,7 +38,11 @@ __device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
 // NW = waves per workgroup: 4, or 8 for the persistent bf16 form of the 64/80-channel layers, whose accumulators
 // (up to 9 row tiles x 5 column tiles per wave) otherwise leave ONE wave per SIMD: eight waves on the same LDS tiles
 // halve every per-wave quantity and give each SIMD a second wave to overlap with.
-template <typename T, int KS, int CINP, int NT, int MSPLIT, bool PF, int NW = 4>
+// PROJ (stage-entry blocks, 3x3/s2 conv + 1x1/s2 projection on the same input): the projection's weight gradient
+// dWp[ci][co] = sum_q x[2q][ci] * dz2[q][co] has the 3x3 conv's CENTRE-TAP rows as its A operand, so the row tiles that
+// hold those rows get a second accumulator set fed by a second dz tile — the block input is read once for both filters
+// instead of once per weight-gradient launch.  Its rows are appended to the slab behind the bias tile.
+template <typename T, int KS, int CINP, int NT, int MSPLIT, bool PF, int NW = 4, bool PROJ = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0)) void wgrad_kernel(WgradArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ESZ = T::ESZ;
@@ -49,6 +55,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0))
     constexpr int MT_S = (MT + MSPLIT - 1) / MSPLIT;
     constexpr int NTHR = 64 * NW;
     constexpr int MW = (MT_S + NW - 1) / NW;    // tiles per wave
+    constexpr int PM0 = 2 * CG, PM1 = (5 * CG - 1) / 2, PMN = PROJ ? PM1 - PM0 + 1 : 0;    // row tiles holding centre-tap rows
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     // wave id through readfirstlane: provably wave-uniform, so branches on it are scalar branches (an MFMA or a
@@ -62,11 +69,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0))
     // per-lane byte offset of this lane's (tap, channel) rows inside a halo pixel, per owned m-tile
     int toff[MW];
     bool mvalid[MW];
+    int proj_i = -1, proj_mt = 0;               // the owned row tile (at most one per wave) that also feeds the projection
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
         const int ml = wave + NW * i;
         const int mt = split * MT_S + ml;
         mvalid[i] = (ml < MT_S) && (mt < MT);
+        if (PROJ && mvalid[i] && mt >= PM0 && mt <= PM1) { proj_i = i; proj_mt = mt; }
         int rg, sub;
         if constexpr (T::DT == MIL_DT_BF16) { const int p = lane & 3; rg = 2 * mt + (p >> 1); sub = (p & 1) * 8; }
         else { const int row = lane & 15; rg = 2 * mt + (row >> 3); sub = (row & 7) * 4; }
@@ -77,10 +86,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0))
     }
 
     f32x4_t acc[MW][NT];
-    f32x4_t accb[NT];
+    f32x4_t accb[NT], accp[PROJ ? NT : 1];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         accb[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if constexpr (PROJ) accp[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < MW; ++i) acc[i][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
@@ -90,7 +100,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0))
     // through buffer descriptors + tile-invariant tables (pf_common.cuh) keeps the per-tile VALU work small.
     constexpr int NPX = PF ? (400 * (CINP * ESZ / 16) + NTHR - 1) / NTHR : 1;
     constexpr int NPZ = PF ? (256 * (COUTP * ESZ / 16) + NTHR - 1) / NTHR : 1;
-    u32x4_t rx[NPX], rz[NPZ];
+    u32x4_t rx[NPX], rz[NPZ], rz2[PROJ ? NPZ : 1];
+    char* ldsZ2 = smem + a.lds_z2_off;
+    __amdgpu_buffer_rsrc_t rs_z2;
     HaloTables<NPX> ht;
     OtileTables<NPZ> zt;
     TileWalker cur, nxt;
@@ -99,6 +111,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0))
     if constexpr (PF) {
         rs_x = mil_rsrc(a.x, a.x_bytes);
         rs_z = mil_rsrc(a.dz, a.z_bytes);
+        if constexpr (PROJ) rs_z2 = mil_rsrc(a.dz2, a.z_bytes);
         mil_build_halo_tables<CINP, NPX, NTHR>(ht, g, tid);
         mil_build_otile_tables<COUTP, NPZ, NTHR>(zt, g, tid, a.tile_px);
         cur.init(g, bid, gridDim.x);
@@ -106,6 +119,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0))
         if (bid < a.ntiles) {
             mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, cur.origin(g));
             mil_fetch_otile<COUTP, NPZ>(rz, rs_z, zt, g, cur.origin(g));
+            if constexpr (PROJ) mil_fetch_otile<COUTP, NPZ>(rz2, rs_z2, zt, g, cur.origin(g));
         }
     }
     for (int tile = bid; tile < a.ntiles; tile += gridDim.x) {
@@ -113,9 +127,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0))
         if constexpr (PF) {
             mil_commit_halo<NPX>(rx, ldsX, ht);
             mil_commit_otile<NPZ>(rz, ldsZ, zt);
+            if constexpr (PROJ) mil_commit_otile<NPZ>(rz2, ldsZ2, zt);
             if (tile + (int)gridDim.x < a.ntiles) {
                 mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, nxt.origin(g));
                 mil_fetch_otile<COUTP, NPZ>(rz, rs_z, zt, g, nxt.origin(g));
+                if constexpr (PROJ) mil_fetch_otile<COUTP, NPZ>(rz2, rs_z2, zt, g, nxt.origin(g));
             }
             cur = nxt; nxt.advance();
         } else {
@@ -136,9 +152,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0))
                 const int pb0 = kb + wpl0, pb1 = kb + wpl1;
                 const char* z0 = ldsZ + (k32 + 8 * gq + q4) * PIXZ + p * 8;
                 const char* z1 = z0 + 4 * PIXZ;
-                bf16x8_t bf[NT];
+                bf16x8_t bf[NT], bf2[PROJ ? NT : 1];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bf[nt] = tr_pair(z0 + nt * 32, z1 + nt * 32);
+                if constexpr (PROJ) {
+                    if (proj_i >= 0) {           // wave-uniform
+                        const char* y0 = ldsZ2 + (k32 + 8 * gq + q4) * PIXZ + p * 8;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) bf2[nt] = tr_pair(y0 + nt * 32, y0 + 4 * PIXZ + nt * 32);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < MW; ++i) {
                     if (mvalid[i]) {             // wave-uniform
@@ -146,6 +169,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0))
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
                             acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[nt], acc[i][nt], 0, 0, 0);
+                        if constexpr (PROJ) {
+                            if (i == proj_i) {
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt)
+                                    accp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf2[nt], accp[nt], 0, 0, 0);
+                            }
+                        }
                     }
                 }
                 if (bias_wave) {
@@ -183,9 +213,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0))
 
     // one slab per workgroup column; row = (tap*CINP + ci), col = co; bias sums live in tile MT
     constexpr int SLAB_COLS = NT * 16;
-    constexpr size_t SLAB_ELEMS = (size_t)(MT + 1) * 16 * SLAB_COLS;
+    constexpr size_t SLAB_ELEMS = (size_t)(MT + 1 + PMN) * 16 * SLAB_COLS;
     float* slab = a.slab + (size_t)blockIdx.x * SLAB_ELEMS;
     const int gq = lane >> 4, col = lane & 15;
+    if constexpr (PROJ) {
+        if (proj_i >= 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    slab[(size_t)((MT + 1 + proj_mt - PM0) * 16 + gq * 4 + e) * SLAB_COLS + nt * 16 + col] = accp[nt][e];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
         if (!mvalid[i]) continue;
@@ -255,7 +294,7 @@ __global__ __launch_bounds__(32 * MIL_RED_GROUPS) void wgrad_reduce_kernel(const
 struct WgradPlan { int grid_x; int msplit; size_t slab_elems; int slab_cols; int mt; int lds; int tile_px_log2; };
 
 template <typename T, int KS, int CINP, int NT, int MSPLIT>
-static int plan_wgrad(ConvGeom& g, WgradPlan& pl, int* lds_z_off) {
+static int plan_wgrad(ConvGeom& g, WgradPlan& pl, int* lds_z_off, bool proj = false) {
     constexpr int ESZ = T::ESZ;
     constexpr int PIXB = mil_pix_pitch(CINP, ESZ);
     constexpr int PIXZ = mil_pix_pitch(mil_nt_to_cp(NT), ESZ);
@@ -266,7 +305,7 @@ static int plan_wgrad(ConvGeom& g, WgradPlan& pl, int* lds_z_off) {
     for (int lg = 8; lg >= 6; lg -= 2) {
         mil_geom_tiles(g, lg);
         const int xb = ((((g.hh * g.hw) << g.ti_log2) * PIXB) + 15) & ~15;
-        const int zb = (1 << lg) * PIXZ;
+        const int zb = (1 << lg) * PIXZ * (proj ? 2 : 1);
         const bool halo_fits_regs = ((g.hh * g.hw) << g.ti_log2) <= 400;
         if ((xb + zb <= 150 * 1024 && (halo_fits_regs || !PF_OK)) || lg == 6) {
             if (xb + zb > 160 * 1024) return MIL_ERR_UNSUPPORTED;
@@ -275,7 +314,11 @@ static int plan_wgrad(ConvGeom& g, WgradPlan& pl, int* lds_z_off) {
         }
     }
     pl.msplit = MSPLIT; pl.mt = MT; pl.slab_cols = NT * 16;
-    pl.slab_elems = (size_t)(MT + 1) * 16 * NT * 16;
+    {
+        constexpr int CGc = CINP / 8;
+        const int pmn = proj ? (5 * CGc - 1) / 2 - 2 * CGc + 1 : 0;
+        pl.slab_elems = (size_t)(MT + 1 + pmn) * 16 * NT * 16;
+    }
     const int ntiles = g.n_groups * g.tiles_y * g.tiles_x;
     // one fp32 slab per workgroup: no more workgroups than can be resident (the 64/80-channel slabs are 150-235 KB —
     // a second round of workgroups would only double the slab traffic, which already rivals the activation traffic)
@@ -288,12 +331,13 @@ static int plan_wgrad(ConvGeom& g, WgradPlan& pl, int* lds_z_off) {
     return MIL_OK;
 }
 
-template <typename T, int KS, int CINP, int NT, int MSPLIT>
+template <typename T, int KS, int CINP, int NT, int MSPLIT, bool PROJ = false>
 static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* ws, size_t ws_bytes, ConvGeom g,
-                     int cout, int cin, int stem_mode, int accumulate, bool query, size_t* need, hipStream_t stream) {
+                     int cout, int cin, int stem_mode, int accumulate, bool query, size_t* need, hipStream_t stream,
+                     const void* dz2 = nullptr, float* dw1 = nullptr) {
     WgradPlan pl{};
     int lds_z_off = 0;
-    int rc = plan_wgrad<T, KS, CINP, NT, MSPLIT>(g, pl, &lds_z_off);
+    int rc = plan_wgrad<T, KS, CINP, NT, MSPLIT>(g, pl, &lds_z_off, PROJ);
     if (rc != MIL_OK) return rc;
     const size_t bytes = pl.slab_elems * pl.grid_x * sizeof(float);
     if (query) { *need = bytes; return MIL_OK; }
@@ -301,6 +345,8 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     WgradArgs<T> a{};
     a.x = (const typename T::elem*)x; a.dz = (const typename T::elem*)dz; a.slab = (float*)ws; a.g = g;
     a.ntiles = g.n_groups * g.tiles_y * g.tiles_x; a.tile_px = 1 << pl.tile_px_log2; a.lds_z_off = lds_z_off;
+    a.dz2 = (const typename T::elem*)dz2;
+    a.lds_z2_off = lds_z_off + (1 << pl.tile_px_log2) * mil_pix_pitch(mil_nt_to_cp(NT), T::ESZ);
     // register-prefetch pipeline for the bf16 path when the halo is small enough for its register budget
     constexpr bool PF_OK = (T::DT == MIL_DT_BF16);
     const size_t xb_total = (size_t)g.n_img * g.H * g.W * CINP * T::ESZ;
@@ -311,7 +357,8 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     // 8-wave workgroups where the 4-wave form holds a single wave per SIMD (persistent bf16 form, >= 64 input channels)
     constexpr int NW = (PF_OK && CINP >= 64) ? 8 : 4;
     const int nthr = pf ? 64 * NW : 256;
-    auto kern = pf ? wgrad_kernel<T, KS, CINP, NT, MSPLIT, PF_OK, NW> : wgrad_kernel<T, KS, CINP, NT, MSPLIT, false>;
+    if (PROJ && !pf) return MIL_ERR_UNSUPPORTED;                 // the paired form exists for the persistent bf16 kernel only
+    auto kern = pf ? wgrad_kernel<T, KS, CINP, NT, MSPLIT, PF_OK, NW, PROJ && PF_OK> : wgrad_kernel<T, KS, CINP, NT, MSPLIT, false>;
     if (pl.lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds) != hipSuccess)
             return MIL_ERR_LAUNCH;
@@ -323,7 +370,29 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(32 * MIL_RED_GROUPS), 0, stream, (const float*)ws, pl.grid_x,
                        pl.slab_elems, pl.slab_cols, n_rows, dw, db, cout, cin, KS, CINP, stem_mode, pl.mt * 16, accumulate);
     MIL_CHECK_LAUNCH();
+    if constexpr (PROJ) {            // the projection's rows sit behind the bias tile: rows = input channel, one tap
+        const int total1 = (CINP + 1) * pl.slab_cols;                // + the (unused, db == null) bias row slot
+        const float* seg = (const float*)ws + (size_t)(pl.mt + 1) * 16 * pl.slab_cols;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total1 + 31) / 32), dim3(32 * MIL_RED_GROUPS), 0, stream, seg, pl.grid_x,
+                           pl.slab_elems, pl.slab_cols, CINP, dw1, (float*)nullptr, cout, cin, 1, CINP, 0, 0, accumulate);
+        MIL_CHECK_LAUNCH();
+    }
     return MIL_OK;
+}
+
+// 3x3/s2 conv + 1x1/s2 projection of a stage-entry block: both weight gradients from one pass over the block input.
+template <typename T>
+static int dispatch_wgrad_pair(const void* x, const void* dz1, const void* dz2, float* dw3, float* db3, float* dw1, void* ws,
+                               size_t ws_bytes, const ConvGeom& g, int cout, int cin, int accumulate, bool query, size_t* need,
+                               hipStream_t st) {
+    if constexpr (T::DT != MIL_DT_BF16) return MIL_ERR_UNSUPPORTED;
+    const int cinp = mil_cpad(cin), coutp = mil_cpad(cout);
+#define MIL_WGP(CI, NTV, MS) return run_wgrad<T, 3, CI, NTV, MS, true>(x, dz1, dw3, db3, ws, ws_bytes, g, cout, cin, 0, accumulate, query, need, st, dz2, dw1)
+    if (cinp == 24 && coutp == 40) MIL_WGP(24, 3, 1);
+    if (cinp == 40 && coutp == 64) MIL_WGP(40, 4, 1);
+    if (cinp == 64 && coutp == 80) MIL_WGP(64, 5, 2);
+#undef MIL_WGP
+    return MIL_ERR_UNSUPPORTED;
 }
 
 template <typename T>
@@ -657,6 +726,34 @@ extern "C" int mil_stem_bwd_fused(const void* xs, const void* g_pool, const uint
     size_t need = 0;
     return stem_bwd_entry(xs, g_pool, widx, dw, db, workspace, workspace_bytes, n, H2, W2, slope, accumulate, dtype, false,
                           &need, stream);
+}
+
+static int wgrad_pair_entry(const void* x, const void* dz1, const void* dz2, float* dw3, float* db3, float* dw1, void* ws,
+                            size_t ws_bytes, int n_img, int H, int W, int cin, int Ho, int Wo, int cout, int accumulate,
+                            int dtype, bool query, size_t* need, void* stream) {
+    if (n_img < 0 || H <= 0 || W <= 0 || Ho != (H - 1) / 2 + 1 || Wo != (W - 1) / 2 + 1) return MIL_ERR_ARG;
+    if (dtype != MIL_DT_BF16) return MIL_ERR_UNSUPPORTED;
+    ConvGeom g{};
+    g.n_img = n_img; g.H = H; g.W = W; g.Ho = Ho; g.Wo = Wo; g.ks = 3; g.stride = 2; g.pad = 1; g.zins = 0;
+    return dispatch_wgrad_pair<BF16>(x, dz1, dz2, dw3, db3, dw1, ws, ws_bytes, g, cout, cin, accumulate, query, need,
+                                     reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int mil_conv_wgrad_pair_workspace(size_t* bytes, int n_img, int H, int W, int cin, int Ho, int Wo, int cout, int dtype) {
+    if (!bytes) return MIL_ERR_ARG;
+    return wgrad_pair_entry(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n_img, H, W, cin, Ho, Wo, cout, 0,
+                            dtype, true, bytes, nullptr);
+}
+
+// Weight gradients of a stage-entry block's two stride-2 convs from ONE pass over the block input x [n,H,W,cpad(cin)]:
+// dw3 [cout,cin,3,3], db3 [cout] from dz1, and dw1 [cout,cin,1,1] from dz2 (both [n,Ho,Wo,cpad(cout)]).  bf16 only.
+extern "C" int mil_conv_wgrad_pair(const void* x, const void* dz1, const void* dz2, float* dw3, float* db3, float* dw1,
+                                   void* workspace, size_t workspace_bytes, int n_img, int H, int W, int cin, int Ho, int Wo,
+                                   int cout, int accumulate, int dtype, void* stream) {
+    if (!x || !dz1 || !dz2 || !dw3 || !dw1 || !workspace) return MIL_ERR_ARG;
+    size_t need = 0;
+    return wgrad_pair_entry(x, dz1, dz2, dw3, db3, dw1, workspace, workspace_bytes, n_img, H, W, cin, Ho, Wo, cout, accumulate,
+                            dtype, false, &need, stream);
 }
 
 extern "C" int mil_conv_wgrad_workspace(size_t* bytes, int n_img, int H, int W, int cin, int Ho, int Wo, int cout,

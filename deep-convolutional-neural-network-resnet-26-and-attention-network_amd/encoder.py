@@ -273,10 +273,20 @@ def encoder_backward(net, saved, dfeats, dtype):
             if fused is not None:                   # one pass: previous block's dz and dW1/db1
                 dz, grads[f"b{bi}.c1"] = fused[0], (fused[1], fused[2])
                 continue
-        grads[f"b{bi}.c1"] = wgrad(xin, dz1, cin, cout, ks=3, stride=s, pad=1, out=gout(blk.conv1.weight, blk.conv1.bias))
+        pair = None
+        if s == 2 and blk.downsample is not None and net.fuse_backward and not use_side:
+            # both weight gradients of the stage-entry convs from one pass over the block input
+            o = gout(blk.conv1.weight, blk.conv1.bias, blk.downsample[0].weight)
+            pair = ops.conv_wgrad_pair(xin, dz1, dz, cin, cout, workspace=ws[-1], out=o)
+        if pair is not None:
+            ws[-1] = pair[3]
+            grads[f"b{bi}.c1"], grads[f"b{bi}.ds"] = (pair[0], pair[1]), (pair[2], None)
+        else:
+            grads[f"b{bi}.c1"] = wgrad(xin, dz1, cin, cout, ks=3, stride=s, pad=1, out=gout(blk.conv1.weight, blk.conv1.bias))
         if blk.downsample is not None:
-            grads[f"b{bi}.ds"] = wgrad(xin, dz, cin, cout, ks=1, stride=s, pad=0, want_bias=False,
-                                       out=gout(blk.downsample[0].weight, None))
+            if pair is None:
+                grads[f"b{bi}.ds"] = wgrad(xin, dz, cin, cout, ks=1, stride=s, pad=0, want_bias=False,
+                                           out=gout(blk.downsample[0].weight, None))
             if s == 2 and net.fuse_backward:     # both transposed convs + the mask in one pass over the compact dz maps
                 ws2, _ = net._packed(f"b{bi}.c1", blk.conv1.weight, blk.downsample[0].weight, L.PACK_DGRAD_S2, dtype)
                 fused = ops.conv_dgrad_s2(dz1, dz, ws2, ops.cpad(cin), xin.shape[1:3], act=mask)

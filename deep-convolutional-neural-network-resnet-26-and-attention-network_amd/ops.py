@@ -245,6 +245,45 @@ def conv_s2_entry(x, wpack3, bias_pad, wpack1, cout_p, *, slope=LEAK):
     return y1, y2
 
 
+import os as _os
+WGRAD_PAIR = _os.environ.get("MIL_WGRAD_PAIR", "1") != "0"      # experiment switch
+
+
+def conv_wgrad_pair(x, dz1, dz2, cin, cout, *, workspace=None, out=None):
+    """(dW3, db3, dW1) of a stage-entry block's 3x3/s2 conv and 1x1/s2 projection from one pass over x (see
+    mil_conv_wgrad_pair), or None when the shape/dtype has no such kernel.  out = (dw3, db3, dw1) accumulates in place."""
+    n, h, w, _ = x.shape
+    _, ho, wo, _ = dz1.shape
+    if x.dtype != torch.bfloat16 or not WGRAD_PAIR:
+        return None
+    _need(x, (n, h, w, cpad(cin)), x.dtype, "x")
+    _need(dz1, (n, ho, wo, cpad(cout)), x.dtype, "dz1")
+    _need(dz2, (n, ho, wo, cpad(cout)), x.dtype, "dz2")
+    need = ctypes.c_size_t(0)
+    rc = L.lib().mil_conv_wgrad_pair_workspace(ctypes.byref(need), n, h, w, cin, ho, wo, cout, L.dt_code(x.dtype))
+    if rc == 2:
+        return None
+    L.check(rc, "mil_conv_wgrad_pair_workspace")
+    if workspace is None or workspace.numel() * workspace.element_size() < need.value:
+        workspace = torch.empty((need.value + 3) // 4, dtype=torch.float32, device=x.device)
+    if out is None:
+        dw3 = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+        db3 = torch.empty(cout, dtype=torch.float32, device=x.device)
+        dw1 = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=x.device)
+    else:
+        dw3, db3, dw1 = out
+        _need(dw3, (cout, cin, 3, 3), torch.float32, "dw3")
+        _need(db3, (cout,), torch.float32, "db3")
+        _need(dw1, (cout, cin, 1, 1), torch.float32, "dw1")
+    rc = L.lib().mil_conv_wgrad_pair(x.data_ptr(), dz1.data_ptr(), dz2.data_ptr(), dw3.data_ptr(), db3.data_ptr(), dw1.data_ptr(),
+                                     workspace.data_ptr(), workspace.numel() * workspace.element_size(), n, h, w, cin, ho, wo,
+                                     cout, 0 if out is None else 1, L.dt_code(x.dtype), L.stream_ptr())
+    if rc == 2:
+        return None
+    L.check(rc, "mil_conv_wgrad_pair")
+    return dw3, db3, dw1, workspace
+
+
 def conv_dgrad_s2(dz1, dz2, wpack, cx_p, out_hw, *, act=None, slope=LEAK):
     """lrelu'(act) * (conv3x3_s2^T(dz1) + conv1x1_s2^T(dz2)) in one pass (see mil_conv_dgrad_s2), or None when the
     shape/dtype has no such kernel."""

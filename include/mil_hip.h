@@ -129,6 +129,16 @@ int mil_conv_block_fwd(const void* x, const void* wpack1, const float* bias1, co
 int mil_conv_s2_entry(const void* x, const void* wpack3, const float* bias_pad, const void* wpack1, void* y1, void* y2,
                       int n_img, int H, int W, int cin_p, int cout_p, float slope, int dtype, void* stream);
 
+/* Weight gradients of a stage-entry block's two stride-2 convs from one pass over the block input (bf16 path; autograd
+ * of the convs built at gbm/model.py:37-41): dw3 [cout,cin,3,3] and db3 [cout] from dz1 (gradient of the 3x3/s2 conv's
+ * output), dw1 [cout,cin,1,1] from dz2 (gradient of the projection's output); x [n,H,W,cpad(cin)], dz1/dz2
+ * [n,Ho,Wo,cpad(cout)].  The projection's A operand is the centre-tap rows the 3x3 weight gradient stages anyway.
+ * (cin,cout) padded in {(24,40),(40,64),(64,80)}; otherwise MIL_ERR_UNSUPPORTED (caller: two mil_conv_wgrad calls). */
+int mil_conv_wgrad_pair_workspace(size_t* bytes, int n_img, int H, int W, int cin, int Ho, int Wo, int cout, int dtype);
+int mil_conv_wgrad_pair(const void* x, const void* dz1, const void* dz2, float* dw3, float* db3, float* dw1,
+                        void* workspace, size_t workspace_bytes, int n_img, int H, int W, int cin, int Ho, int Wo,
+                        int cout, int accumulate, int dtype, void* stream);
+
 /* Data gradient of a stage-entry block's input in one pass (bf16 path; autograd of nnBlocks.py:175-189 for the
  * blocks built with stride 2 + projection at gbm/model.py:37-41):
  *   y = lrelu'(act) * ( conv3x3_s2^T(dz1) + conv1x1_s2^T(dz2) )

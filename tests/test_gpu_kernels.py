@@ -466,3 +466,36 @@ def test_identity_block_forward_one_pass(ops, case, monkeypatch):
     ref1 = round_to(F.leaky_relu(F.conv2d(x, w1, b1, padding=1), LEAK), dt)
     ref2 = F.leaky_relu(F.conv2d(ref1, w2, b2, padding=1) + x, LEAK)
     assert rel_err(from_nhwc(o1, c), ref1) < TOL[dt] and rel_err(from_nhwc(y, c), ref2) < 2 * TOL[dt]
+
+
+@pytest.mark.parametrize("case", [(20, 40, 3, 16, 16), (20, 40, 2, 19, 13), (20, 40, 2, 64, 48), (40, 60, 5, 8, 8),
+                                  (40, 60, 3, 32, 32), (60, 80, 3, 16, 16), (60, 80, 9, 8, 8)])
+def test_stage_entry_weight_gradients_one_pass(ops, case):
+    """dW/db of the 3x3/s2 conv and dW of the 1x1/s2 projection from one pass over the block input (the projection rides
+    on the centre-tap rows) vs autograd, vs the two separate launches, and accumulating into existing gradients."""
+    cin, cout, n, h, w = case
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(401 + cin + h)
+    x = round_to(torch.randn(n, cin, h, w, generator=g), dt)
+    w3 = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    w1 = torch.zeros(cout, cin, 1, 1, requires_grad=True)
+    b3 = torch.zeros(cout, requires_grad=True)
+    y1 = F.conv2d(x, w3, b3, stride=2, padding=1)
+    y2 = F.conv2d(x, w1, None, stride=2)
+    dz1 = round_to(torch.randn(y1.shape, generator=g), dt)
+    dz2 = round_to(torch.randn(y2.shape, generator=g), dt)
+    ((y1 * dz1).sum() + (y2 * dz2).sum()).backward()
+    xg, d1, d2 = to_nhwc(x, dt), to_nhwc(dz1, dt), to_nhwc(dz2, dt)
+    out = ops.conv_wgrad_pair(xg, d1, d2, cin, cout)
+    assert out is not None
+    dw3, db3, dw1, _ws = out
+    assert rel_err(dw3.cpu(), w3.grad) < 3e-5 and rel_err(db3.cpu(), b3.grad) < 3e-5 and rel_err(dw1.cpu(), w1.grad) < 3e-5
+    s3, sb = ops.conv_wgrad(xg, d1, cin, cout, ks=3, stride=2, pad=1)
+    s1, _ = ops.conv_wgrad(xg, d2, cin, cout, ks=1, stride=2, pad=0, want_bias=False)
+    assert rel_err(dw3.cpu(), s3.cpu()) < 1e-5 and rel_err(dw1.cpu(), s1.cpu()) < 1e-5
+    # accumulate on top of existing gradients
+    acc = (dw3.clone(), db3.clone(), dw1.clone())
+    again = ops.conv_wgrad_pair(xg, d1, d2, cin, cout, out=acc)
+    assert rel_err(again[0].cpu(), 2 * dw3.cpu()) < 1e-6 and rel_err(again[2].cpu(), 2 * dw1.cpu()) < 1e-6
+    rerun = ops.conv_wgrad_pair(xg, d1, d2, cin, cout)
+    assert torch.equal(rerun[0], dw3) and torch.equal(rerun[2], dw1) and torch.equal(rerun[1], db3)
