@@ -348,7 +348,12 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
     }
     const int halo_px = (a.g.hh * a.g.hw) << a.g.ti_log2;
     if (halo_px > 400 || a.g.hh >= 1024 || a.g.hw >= 1024) return MIL_ERR_UNSUPPORTED;
-    if ((size_t)a.g.n_img * a.g.H * a.g.W * (CZ > CX ? CZ : CX) * 2 >= ((size_t)1 << 31)) return MIL_ERR_UNSUPPORTED;   // buffer descriptors: < 2 GiB
+    // buffer descriptors address < 2 GiB: larger launches are split by images, later chunks accumulating into dW/db
+    const size_t img_bytes = (size_t)a.g.H * a.g.W * (CZ > CX ? CZ : CX) * 2;
+    int chunk = mil_imgs_under_2g(img_bytes);
+    if (chunk >= 16) chunk &= ~15;
+    const int n_total = a.g.n_img;
+    if (chunk < n_total) { a.g.n_img = chunk; a.g.n_groups = (chunk + (1 << a.g.ti_log2) - 1) >> a.g.ti_log2; }
     const int a_bytes = ((halo_px * PIXB + 15) & ~15) + 16;   // + dump slot behind the halo for the branch-free commit
     const int w_bytes = KSTEPS * NTX * 64 * 16;
     const int x_bytes = 256 * PIXX;
@@ -378,18 +383,30 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
     if (query) { *need = bytes; return MIL_OK; }
     if (!ws || ws_bytes < bytes) return MIL_ERR_ARG;
     const int a_tot = (dbuf ? 2 : 1) * a_bytes;
-    a.slab = (float*)ws; a.ntiles = ntiles; a.lds_w_off = a_tot; a.lds_x_off = a_tot + w_bytes; a.lds_dump_off = a_tot + w_bytes + x_bytes;
+    a.slab = (float*)ws; a.lds_w_off = a_tot; a.lds_x_off = a_tot + w_bytes; a.lds_dump_off = a_tot + w_bytes + x_bytes;
     a.lds_a2_off = dbuf ? a_bytes : 0;
-    a.z_bytes = (unsigned)((size_t)a.g.n_img * a.g.H * a.g.W * CZ * 2);
-    a.x_bytes = (unsigned)((size_t)a.g.n_img * a.g.H * a.g.W * CX * 2);
     if (grid <= 0) return MIL_OK;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, a);
-    MIL_CHECK_LAUNCH();
     const int n_rows = KS * KS * CZ;
     const int total = n_rows * NTX * 16 + CZ;
-    hipLaunchKernelGGL(wgrad_reduce_t_kernel, dim3((total + 31) / 32), dim3(32 * MIL_RED_GROUPS), 0, stream, (const float*)ws, grid, slab_elems,
-                       NTX * 16, n_rows, dw, db, cout, cin, KS, CZ, MT * 16 * NTX * 16, accumulate);
-    MIL_CHECK_LAUNCH();
+    const BwdFusedArgs a0 = a;
+    for (int i0 = 0; i0 < n_total; i0 += chunk) {
+        const int n = n_total - i0 < chunk ? n_total - i0 : chunk;
+        BwdFusedArgs c = a0;
+        c.g.n_img = n;
+        c.g.n_groups = (n + (1 << c.g.ti_log2) - 1) >> c.g.ti_log2;
+        c.ntiles = c.g.n_groups * c.g.tiles_y * c.g.tiles_x;
+        const size_t zo = (size_t)i0 * a.g.H * a.g.W * CZ, xo = (size_t)i0 * a.g.H * a.g.W * CX;
+        c.dz = a0.dz + zo; c.x = a0.x + xo; c.dx = a0.dx + xo;
+        if (a0.addend) c.addend = a0.addend + xo;
+        c.z_bytes = (unsigned)((size_t)n * a.g.H * a.g.W * CZ * 2);
+        c.x_bytes = (unsigned)((size_t)n * a.g.H * a.g.W * CX * 2);
+        int gr = grid < c.ntiles ? grid : c.ntiles;
+        hipLaunchKernelGGL(kern, dim3(gr), dim3(64 * NW), lds, stream, c);
+        MIL_CHECK_LAUNCH();
+        hipLaunchKernelGGL(wgrad_reduce_t_kernel, dim3((total + 31) / 32), dim3(32 * MIL_RED_GROUPS), 0, stream, (const float*)ws, gr, slab_elems,
+                           NTX * 16, n_rows, dw, db, cout, cin, KS, CZ, MT * 16 * NTX * 16, (i0 > 0) ? 1 : accumulate);
+        MIL_CHECK_LAUNCH();
+    }
     return MIL_OK;
 }
 

@@ -499,3 +499,25 @@ def test_stage_entry_weight_gradients_one_pass(ops, case):
     assert rel_err(again[0].cpu(), 2 * dw3.cpu()) < 1e-6 and rel_err(again[2].cpu(), 2 * dw1.cpu()) < 1e-6
     rerun = ops.conv_wgrad_pair(xg, d1, d2, cin, cout)
     assert torch.equal(rerun[0], dw3) and torch.equal(rerun[2], dw1) and torch.equal(rerun[1], db3)
+
+
+def test_fused_backward_splits_launches_above_2gib(ops):
+    """Tensors beyond the 2 GiB reach of a buffer descriptor: the fused backward walks them in image chunks, later chunks
+    accumulating into dW/db.  Checked against two calls on halves that each fit (no CPU reference at this size)."""
+    L = _lib()
+    dt = torch.bfloat16
+    n, h, c = 11200, 64, 20                      # 11200 x 64 x 64 x 24 x 2 B = 2.2 GB per tensor
+    g = torch.Generator(device="cuda").manual_seed(9)
+    def rnd():
+        t = torch.randn((n, h, h, 24), generator=g, device="cuda", dtype=torch.float32).to(dt)
+        t[..., c:] = 0
+        return t
+    dz, x, add = rnd(), rnd(), rnd()
+    wd, _ = ops.pack_weights((torch.randn(c, c, 3, 3, generator=g, device="cuda") * 0.05), None, L.PACK_DGRAD, dt)
+    whole = ops.conv_bwd_fused(dz, wd, x, c, c, addend=add, mask=True)
+    assert whole is not None
+    half = n // 2
+    a = ops.conv_bwd_fused(dz[:half], wd, x[:half], c, c, addend=add[:half], mask=True)
+    b = ops.conv_bwd_fused(dz[half:], wd, x[half:], c, c, addend=add[half:], mask=True)
+    assert torch.equal(whole[0][:half], a[0]) and torch.equal(whole[0][half:], b[0])
+    assert rel_err(whole[1].cpu(), (a[1] + b[1]).cpu()) < 1e-5 and rel_err(whole[2].cpu(), (a[2] + b[2]).cpu()) < 1e-5
