@@ -30,22 +30,28 @@ constexpr int SF_XH = 20, SF_XW = 38, SF_NPAIR = 19;  // s2d tile; a "pair" = 2 
 constexpr int SF_XPIX = 48;                         // 16 ch bf16 = 32 B at an odd 16-B slot pitch
 constexpr int SF_XBYTES = SF_XH * SF_XW * SF_XPIX;  // 36480
 constexpr int SF_NITEM = SF_XH * SF_NPAIR * 3;      // (row, pair, colour) load items
-constexpr int SF_NLOAD = (SF_NITEM + 255) / 256;    // 5
 constexpr int SF_NSTEM = SF_SH * SF_SW;             // 561
-constexpr int SF_MT = 9;                            // 16-pixel row tiles per wave (4*9*16 = 576 >= 561)
+constexpr int SF_MTILES = 36;                       // 16-pixel row tiles of the stem tile (36*16 = 576 >= 561)
 
 template <int NT>
 __host__ __device__ constexpr int sf_lds_bytes() {
     return SF_XBYTES + ((SF_NSTEM * mil_pix_pitch(mil_nt_to_cp(NT), 2) + 15) & ~15) + 8 * NT * 64 * 16 + 256;   // + dump slot
 }
 
-template <int NT>
-__global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void stem_fwd_fused_kernel(StemFwdArgs a) {
+// NW = waves per workgroup.  The kernel is VALU-bound (pool compare/select, activation, conversions) and at 4 waves per
+// workgroup its 238 VGPRs leave two waves per SIMD, which keep the vector pipe only half busy; with 8 waves every
+// per-wave quantity halves (5 row tiles, 3 load items, 2 pool items) and four waves per SIMD fit on the same LDS tiles.
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 2 : 1)) void stem_fwd_fused_kernel(StemFwdArgs a) {
     constexpr int COUTP = mil_nt_to_cp(NT);
     constexpr int SPIX = mil_pix_pitch(COUTP, 2);
     constexpr int KSTEPS = 8;
     constexpr int NG4 = COUTP / 4;
-    constexpr int NPOOL = (128 * NG4 + 255) / 256;           // (pooled pixel, 4-channel group) items per thread
+    constexpr int NTHR = 64 * NW;
+    constexpr int SF_NLOAD = (SF_NITEM + NTHR - 1) / NTHR;
+    constexpr int SF_MT = (SF_MTILES + NW - 1) / NW;          // row tiles per wave
+    constexpr int NXS = 1024 / NTHR;                          // 16-byte pieces of the tile's own 16x32 s2d pixels per thread
+    constexpr int NPOOL = (128 * NG4 + NTHR - 1) / NTHR;      // (pooled pixel, 4-channel group) items per thread
     constexpr bool LAST_PARTIAL = (COUTP % 16) != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ldsX = smem;
@@ -59,9 +65,9 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void stem_fwd_fused_kernel(St
 
     {
         const char* src = reinterpret_cast<const char*>(a.w);
-        for (int i = tid * 16; i < KSTEPS * NT * 64 * 16; i += 256 * 16)
+        for (int i = tid * 16; i < KSTEPS * NT * 64 * 16; i += NTHR * 16)
             *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(src + i);
-        for (int i = tid * 16; i < SF_XBYTES; i += 256 * 16)           // channels 12..15 of every s2d pixel stay zero
+        for (int i = tid * 16; i < SF_XBYTES; i += NTHR * 16)          // channels 12..15 of every s2d pixel stay zero
             *reinterpret_cast<uint4*>(ldsX + i) = make_uint4(0, 0, 0, 0);
     }
     const int H = a.H, W = a.W, H2 = a.H2, W2 = a.W2, Ho = a.Ho, Wo = a.Wo;
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void stem_fwd_fused_kernel(St
     int l_lds[SF_NLOAD], l_rel[SF_NLOAD];       // input -> s2d tile; l_lds = LDS offset | row << 18 | pair << 24 (row 31 = unused)
 #pragma unroll
     for (int i = 0; i < SF_NLOAD; ++i) {
-        const int idx = tid + 256 * i;
+        const int idx = tid + NTHR * i;
         l_lds[i] = dump | (31 << 18); l_rel[i] = 0;
         if (idx < SF_NITEM) {
             const int pair = idx % SF_NPAIR, t = idx / SF_NPAIR;
@@ -83,14 +89,14 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void stem_fwd_fused_kernel(St
             l_rel[i] = ((c * H + 2 * row) * W + 4 * pair) * 4;
         }
     }
-    // s2d tile interior -> xs tensor: 16-B piece id = tid + 256*i -> (row 4*i + tid>>6, col (tid>>1)&31, half tid&1)
+    // s2d tile interior -> xs tensor: 16-B piece id = tid + NTHR*i -> (row (NTHR/64)*i + tid>>6, col (tid>>1)&31, half tid&1)
     const int x_row0 = tid >> 6, x_col = (tid >> 1) & 31;
     const int x_lds0 = ((x_row0 + 3) * SF_XW + x_col + 4) * SF_XPIX + (tid & 1) * 16;
     const int x_rel0 = (x_row0 * W2 + x_col) * 32 + (tid & 1) * 16;
     int pixbase[SF_MT], sdst[SF_MT];                             // MFMA row tiles of the stem tile
 #pragma unroll
     for (int m = 0; m < SF_MT; ++m) {
-        const int tp = (wave * SF_MT + m) * 16 + r;
+        const int tp = (wave + NW * m) * 16 + r;
         const bool ok = tp < SF_NSTEM;
         const int sy = tp / SF_SW, sx = tp - sy * SF_SW;
         // k-group q = 4*step + gq is tap 2*step + (gq>>1), channel group gq&1: the lane-dependent part of the tap offset
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void stem_fwd_fused_kernel(St
     int p_lds[NPOOL], p_rel[NPOOL];          // pooled pixels x 4-channel groups; p_lds = LDS offset | py << 20 | px << 24 (py 15 = unused)
 #pragma unroll
     for (int i = 0; i < NPOOL; ++i) {
-        const int id = tid + 256 * i;
+        const int id = tid + NTHR * i;
         p_lds[i] = 15 << 20; p_rel[i] = 0;
         if (id < 128 * NG4) {
             const int c4 = id % NG4, pp = id / NG4, py = pp >> 4, px = pp & 15;
@@ -158,10 +164,11 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void stem_fwd_fused_kernel(St
             const int xbase = ((img * H2 + 16 * ty) * W2 + 32 * tx) * 32;
             const int ylim = H2 - 16 * ty, xlim = W2 - 32 * tx;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool ok = x_row0 + 4 * i < ylim && x_col < xlim;
-                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(ldsX + x_lds0 + i * (4 * SF_XW * SF_XPIX));
-                __builtin_amdgcn_raw_buffer_store_b128(v, rs_xs, ok ? (unsigned)(xbase + x_rel0 + i * (4 * W2 * 32)) : MIL_OOB, 0, 0);
+            for (int i = 0; i < NXS; ++i) {
+                constexpr int RPI = NTHR / 64;                   // rows covered per round
+                const bool ok = x_row0 + RPI * i < ylim && x_col < xlim;
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(ldsX + x_lds0 + i * (RPI * SF_XW * SF_XPIX));
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_xs, ok ? (unsigned)(xbase + x_rel0 + i * (RPI * W2 * 32)) : MIL_OOB, 0, 0);
             }
         }
         // ---- 4x4 s1 implicit GEMM over the s2d tile, D[channel][pixel] ------------------------------
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void stem_fwd_fused_kernel(St
         for (int m = 0; m < SF_MT; ++m) {
             bool inside = true;
             if (border) {                                     // rare: recompute the pixel's tile coordinates instead of keeping a table
-                const int tp = (wave * SF_MT + m) * 16 + r, sy = (tp * 1986) >> 16, sx = tp - sy * SF_SW;      // tp / 33 for tp < 1024
+                const int tp = (wave + NW * m) * 16 + r, sy = (tp * 1986) >> 16, sx = tp - sy * SF_SW;      // tp / 33 for tp < 1024
                 inside = (unsigned)(sy0 + sy) < (unsigned)H2 && (unsigned)(sx0 + sx) < (unsigned)W2;
             }
 #pragma unroll
@@ -248,7 +255,10 @@ template <int NT>
 static int launch_stem_fwd(StemFwdArgs a, hipStream_t st) {
     constexpr int COUTP = mil_nt_to_cp(NT);
     const int lds = sf_lds_bytes<NT>();
-    auto kern = stem_fwd_fused_kernel<NT>;
+    // measured (24 channels): 1120 us with 4 waves per workgroup at 238 VGPRs, 1428 us with 8 waves squeezed into 128
+    // VGPRs (15 spilled): the 8-wave form is kept as a template option only
+    constexpr int NW = 4;
+    auto kern = stem_fwd_fused_kernel<NT, NW>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MIL_ERR_LAUNCH;
     // every tensor is addressed with 32-bit offsets below 2 GiB: split the launch by images
@@ -269,7 +279,7 @@ static int launch_stem_fwd(StemFwdArgs a, hipStream_t st) {
         int grid = (b.ntiles + 7) & ~7;
         const int cap = 256 * (NT <= 2 ? 2 : 1);
         if (grid > cap) grid = cap;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, b);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, st, b);
         MIL_CHECK_LAUNCH();
     }
     return MIL_OK;
