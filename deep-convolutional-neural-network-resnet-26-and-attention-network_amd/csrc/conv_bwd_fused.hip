@@ -36,7 +36,7 @@ struct BwdFusedArgs {
 // filter + tiles leave one workgroup per CU: eight waves share its LDS, every per-wave quantity halves (two row tiles of
 // data-gradient accumulators, three to five of weight-gradient ones) and each SIMD still holds two waves.
 template <int CZ, int NTX, int KS, bool ADD, bool MASK, int NW = 4>
-__global__ __launch_bounds__(64 * NW, MIL_BWD_WAVES) void conv_bwd_fused_kernel(BwdFusedArgs a) {
+__global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES) void conv_bwd_fused_kernel(BwdFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIXB = mil_pix_pitch(CZ, 2);            // dz halo pixel pitch
     constexpr int CG = CZ / 8;
@@ -422,7 +422,10 @@ static int bwd_fused_entry(const void* dz, const void* wpack, const void* x, con
     a.g.n_img = n_img; a.g.H = H; a.g.W = W; a.g.Ho = H; a.g.Wo = W; a.g.ks = ks; a.g.stride = 1; a.g.pad = pad; a.g.zins = 0;
     const int czp = mil_cpad(cout), cxp = mil_cpad(cin);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (czp == 24 && cxp == 24) return run_bwd_fused<24, 2, 3>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st);
+#ifndef MIL_BWD24_WAVES
+#define MIL_BWD24_WAVES 8       // measured in the model: 397/428/401 us per launch with 4 waves per workgroup (two per SIMD), 356/397/371 us with 8 (four per SIMD, 122-128 VGPRs)
+#endif
+    if (czp == 24 && cxp == 24) return run_bwd_fused<24, 2, 3, MIL_BWD24_WAVES>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st);
     if (czp == 40 && cxp == 40) return run_bwd_fused<40, 3, 3, 8>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st);
     if (czp == 64 && cxp == 64) return run_bwd_fused<64, 4, 3, 8>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st);
     return MIL_ERR_UNSUPPORTED;
