@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs<T> a) {
 // NW = waves per workgroup: 4, or 8 for the layers whose resident filter leaves room for only ONE workgroup per CU
 // (64 channels: 72 KB of filter) — eight waves on the same LDS tiles give every SIMD a second wave to overlap with.
 template <int CINP, int NT, int KS, int MTW, int FLAGS = -1, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 24 && FLAGS >= 0 && FLAGS != 3) ? MIL_PF_WAVES_24 : (CINP <= 40 ? 2 : 1)))
+__global__ __launch_bounds__(64 * NW, NW == 8 ? (CINP <= 40 ? 4 : 2) : ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 24 && FLAGS >= 0 && FLAGS != 3) ? MIL_PF_WAVES_24 : (CINP <= 40 ? 2 : 1)))
 void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsigned y_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using T = BF16;
@@ -556,7 +556,12 @@ static int launch_conv_pf(const ConvArgs<BF16>& a, hipStream_t stream, bool* tak
     *taken = false;
     if constexpr (CINP == 16 && NT == 2) { if (a.g.ks == 4) return launch_conv_pf_ks<16, 2, 4>(a, stream, taken); }
     if constexpr (CINP == 24 && NT == 2) { if (a.g.ks == 3) return launch_conv_pf_ks<24, 2, 3, MIL_PF_MTW_24>(a, stream, taken); }
-    if constexpr (CINP == 40 && NT == 3) { if (a.g.ks == 3) return launch_conv_pf_ks<40, 3, 3>(a, stream, taken); }
+#ifndef MIL_PF40_WAVES
+#define MIL_PF40_WAVES 8        // measured in the model: 122 / 100 us per launch with 4 waves, 114 / 88 us with 8 (four waves per SIMD)
+#endif
+    if constexpr (CINP == 40 && NT == 3) {
+        if (a.g.ks == 3) return MIL_PF40_WAVES == 8 ? launch_conv_pf_ks<40, 3, 3, 2, 8>(a, stream, taken) : launch_conv_pf_ks<40, 3, 3>(a, stream, taken);
+    }
     if constexpr (CINP == 40 && NT == 2) {
         if (a.g.ks == 3) return launch_conv_pf_ks<40, 2, 3>(a, stream, taken);
         if (a.g.ks == 1) return launch_conv_pf_ks<40, 2, 1>(a, stream, taken);
