@@ -8,8 +8,16 @@ bags (BASELINE.json metric, configs[1]: 8 bags x 256 tiles per GPU, bf16 operand
 
 One step = zero the flat gradient bucket, re-pack the filters (they changed), one encoder pass over every tile of
 this rank's bags (full-bag path: all tiles through the backbone, gradients enabled), the segmented MIL head, the
-full backward, — for N>1 — one RCCL all-reduce (sum) of the flat gradient bucket, and one fused Adam step.  Weak scaling: every rank owns 8 bags.
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+full backward, — for N>1 — one RCCL all-reduce (sum) of the flat gradient bucket, and one fused Adam step.  Weak
+scaling: every rank owns 8 bags.  Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`,
+`cpu_baseline` and — at N=1 — two sub-records timed by the same command: `fp32_path` (the exact-fp32 kernels that
+meet the north star's 1e-3 parity gate, same workload) and `alt_resnet_path` (the 64-512-channel encoder of
+alt_resnet.py, the MFMA-bound datapoint).
+
+Other workloads (their own labels, never the headline metric's):
+    --size 512 --tiles 128        BASELINE configs[2]
+    --infer --bags 1 --tiles 4096 BASELINE configs[4]: forward only; with N>1 ONE bag is split over the ranks
+                                  (Attention.forward_tile_parallel: local encode, all-gather of H, replicated head)
 """
 import argparse
 import json
@@ -24,7 +32,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+GFLOP_PER_TILE_FWD_256 = 0.5754
 GFLOP_PER_TILE_FWD_BWD_256 = 1.6298    # fwd + dgrad + wgrad of every conv, no stem dgrad
+ALT_GFLOP_PER_TILE_FWD_BWD_256 = 21.1521   # alt_resnet widths, layers [3,3,3,3]
 MFMA_PEAK_BF16_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA
 MFMA_PEAK_F32_TFLOPS = 157.3
 HBM_PEAK_GBPS = 8000.0
@@ -41,6 +51,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-extra-paths", action="store_true", help="skip the fp32_path / alt_resnet_path sub-records")
     ap.add_argument("--overlap", action="store_true", help="run the separate weight-gradient launches on a side stream "
                     "(measured: same throughput on this workload, +2%% at 512 tiles, -24%% at 64 tiles; off by default)")
     ap.add_argument("--no-overlap", action="store_true", help="(default now) weight-gradient launches on the main stream")
@@ -83,6 +94,196 @@ def cpu_baseline(size, weights_npz):
                       f"fwd+bwd, median of {len(times)} after 1 warm-up"}
 
 
+def workload_label(args, world):
+    """Names the workload that actually ran and the BASELINE.json configuration it corresponds to (if any)."""
+    mode = "fwd-only attention-map extraction (no_grad)" if args.infer else "fwd+bwd full-bag path"
+    if args.infer:
+        split = f"ONE bag of {args.tiles} tiles split over {world} ranks (tile-parallel)" if world > 1 else \
+            f"{args.bags} bag(s) x {args.tiles} tiles on one GPU"
+        cfg = "BASELINE.json configs[4]" if (args.tiles == 4096 and args.size == 256 and (world > 1 or args.bags == 1)) else "no BASELINE config"
+        return f"{split} @{args.size}x{args.size}x3, ResNet-26 (20/40/60/80) + attention-MIL head, {mode} ({cfg})"
+    if (args.bags, args.tiles, args.size) == (8, 256, 256):
+        cfg = "BASELINE.json configs[1]" if world == 1 else "BASELINE.json configs[3]: configs[1] per GPU"
+    elif (args.tiles, args.size) == (128, 512):
+        cfg = "BASELINE.json configs[2]"
+    else:
+        cfg = "no BASELINE config"
+    return (f"{args.bags} bags x {args.tiles} tiles @{args.size}x{args.size}x3 per GPU, ResNet-26 (20/40/60/80) + "
+            f"attention-MIL head, {mode} ({cfg})")
+
+
+def timed_steps(step, steps, warmup, fence):
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step()
+    fence()
+    return time.perf_counter() - t0, out
+
+
+def fp32_path_record(args, w, x_all, sizes, labels, dev):
+    """The exact-fp32 kernel path (v_mfma_f32_16x16x4_f32; the one the 1e-3 parity gate is asserted on everywhere) on
+    the SAME workload, fewer steps: a driver-timed number for the conformant path."""
+    import mil_amd
+    net = mil_amd.Attention(3, compute_dtype=torch.float32, device=dev).eval()
+    net.load_state_dict({k: torch.tensor(w[k]) for k in w.keys()})
+    flat = mil_amd.FlatParams(net)
+    opt = mil_amd.FlatAdam(flat, lr=2e-4)
+
+    def step():
+        flat.zero_grad()
+        outs = net.forward_bags((x_all, sizes), labels)
+        outs.loss.sum().backward()
+        opt.step()
+        return outs
+
+    steps = 3
+    elapsed, outs = timed_steps(step, steps, 1, torch.cuda.synchronize)
+    if not bool(torch.isfinite(outs.loss).all()):
+        raise SystemExit("non-finite loss on the fp32 path")
+    tiles = x_all.shape[0]
+    value = tiles * steps / elapsed
+    tfl = value * GFLOP_PER_TILE_FWD_BWD_256 * (args.size / 256.0) ** 2 / 1e3
+    return {"value": value, "unit": "tiles/s", "dtype": "f32", "steps": steps, "warmup": 1,
+            "ms_per_step": elapsed / steps * 1e3, "model_tflops": tfl, "frac_of_f32_mfma_peak": tfl / MFMA_PEAK_F32_TFLOPS,
+            "note": "same workload and step as `value`, exact-fp32 kernels (the path the 1e-3 parity gate is asserted on)"}
+
+
+def alt_resnet_record(dev):
+    """alt_resnet.py's encoder (widths 64/128/256/512, layers [3,3,3,3], no BN/bias, ReLU) forward+backward on synthetic
+    256x256 tiles: arithmetic intensity 288-2304 FLOP/B, i.e. on the MFMA side of the ridge — priced against the dense
+    bf16 MFMA peak (21.15 GFLOP/tile fwd+bwd)."""
+    import mil_amd
+    torch.manual_seed(77)
+    net = mil_amd.alt_resnet.ResNet(mil_amd.alt_resnet.BasicBlock, [3, 3, 3, 3], num_classes=80,
+                                    compute_dtype=torch.bfloat16).to(dev)
+    tiles = 256
+    gen = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn((tiles, 3, 256, 256), generator=gen, device=dev).clamp_(-1.0, 1.0)
+    dfe = torch.randn((tiles, 80), generator=gen, device=dev)
+
+    def step():
+        for p in net.parameters():
+            p.grad = None
+        feats = net(x)
+        feats.backward(dfe)
+        return feats
+
+    steps = 5
+    elapsed, feats = timed_steps(step, steps, 2, torch.cuda.synchronize)
+    if not bool(torch.isfinite(feats).all()):
+        raise SystemExit("non-finite features on the alt_resnet path")
+    value = tiles * steps / elapsed
+    tfl = value * ALT_GFLOP_PER_TILE_FWD_BWD_256 / 1e3
+    return {"value": value, "unit": "tiles/s", "dtype": "bf16", "steps": steps, "warmup": 2, "tiles_per_step": tiles,
+            "ms_per_step": elapsed / steps * 1e3, "model_tflops": tfl,
+            "roofline": {"bound": "mfma", "achieved": tfl, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tfl / MFMA_PEAK_BF16_TFLOPS},
+            "workload": "alt_resnet.ResNet(BasicBlock,[3,3,3,3]) 64/128/256/512 ch, 256 tiles @256x256x3, fwd+bwd, "
+                        "21.15 GFLOP/tile (SURVEY.md §8d)"}
+
+
+# ---- roofline of the dominant kernel ------------------------------------------------------------------------------
+def _profile_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except (OSError, ValueError):
+        return None
+
+
+def roofline_record(args, spans, peak, copy_gbps, achieved_model_tflops):
+    """`spans` = [(label, ms)] of every bracketed launch (HIP events on the launch stream).  Families, all on the
+    64x64 maps at 20(24)->20(24) channels (layer 1, 47 % of the FLOPs):
+        block_fwd   conv_block_fwd_kernel<24,..>      whole identity block forward            2 convs, 3 tensor passes
+        conv        conv_igemm_pf_kernel<24,2,3,4>    one 3x3 s1 forward conv                 1 conv,  2 passes
+        bwd_fused   conv_bwd_fused_kernel<24,2,3,..>  dx + dW + db of one conv in one pass    2 convs, 3 passes (+1 with addend)
+        block_bwd   conv_block_bwd_kernel<24,..>      backward of a whole identity block      4 convs, 4 passes
+    The family with the largest total time in the timed region is the dominant kernel."""
+    fams = {}
+    for label, d in spans:
+        fams.setdefault(label[0], []).append((label, d))
+    if not fams:
+        return None
+    fam = max(fams, key=lambda k: sum(d for _l, d in fams[k]))
+    esz = 2 if args.dtype == "bf16" else 4
+    flops = alg_bytes = 0.0
+    n_img = ho = wo = 0
+    for label, _d in fams[fam]:
+        if fam == "block_fwd":
+            n_img, ho, wo = label[2], label[3], label[4]
+        elif fam == "block_bwd":
+            n_img, ho, wo = label[2], label[3], label[4]
+        else:
+            n_img, ho, wo = label[6], label[7], label[8]
+        conv_flops = 2.0 * 9 * 20 * 20 * n_img * ho * wo              # algorithmic: 20 real channels in and out
+        px_bytes = n_img * ho * wo * 20 * esz                          # one 20-channel activation tensor
+        if fam == "block_fwd":
+            flops += 2 * conv_flops; alg_bytes += 3 * px_bytes         # read x once, write o1 and out
+        elif fam == "conv":
+            flops += conv_flops; alg_bytes += 2 * px_bytes             # read x once, write y once (SURVEY App. D)
+        elif fam == "block_bwd":
+            flops += 4 * conv_flops; alg_bytes += 4 * px_bytes         # read dz, o1, x once; write dx once
+        else:
+            has_addend = bool(label[9]) if len(label) > 9 else False
+            flops += 2 * conv_flops                                    # dgrad + wgrad
+            alg_bytes += (4 if has_addend else 3) * px_bytes           # read dz, x (+ addend) once, write dx once
+    n_l = len(fams[fam])
+    flops /= n_l
+    alg_bytes /= n_l
+    avg_ms = float(np.mean([d for _l, d in fams[fam]]))
+    kname = {
+        "block_fwd": "conv_block_fwd_kernel<24,..> (whole identity block forward: conv-lrelu-conv-add-lrelu, 20 ch",
+        "conv": "conv_igemm_pf_kernel<24,2,3,4> (3x3 s1 forward conv, 20->20 ch",
+        "bwd_fused": "conv_bwd_fused_kernel<24,2,3,..> (fused data+weight gradient of the 3x3 s1 conv, 20->20 ch",
+        "block_bwd": "conv_block_bwd_kernel<24,..> (backward of a whole identity block: 2x (data+weight gradient), 20 ch",
+    }[fam] + f", {ho}x{wo} maps, {n_img} tiles/launch)"
+    pmc_key = {"conv": "conv_igemm_pf_kernel<24, 2, 3, 4", "block_fwd": "conv_block_fwd_kernel<24,",
+               "bwd_fused": "conv_bwd_fused_kernel<24, 2, 3", "block_bwd": "conv_block_bwd_kernel<24,"}[fam]
+    traffic = None
+    pmc = _profile_json("pmc_traffic.json")                            # rocprofv3 PMC passes of this same command
+    if pmc and n_img == 2048:
+        hit = [v for k, v in pmc.get("kernels", {}).items() if pmc_key in k]      # all template variants of the family
+        if hit:
+            traffic = sum(v["hbm_bytes"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit)
+    sq = _profile_json("sq_counters.json")                             # SQ PMC passes of this same command
+    sq_rec = None
+    if sq and n_img == 2048:
+        hit = [v for k, v in sq.get("kernels", {}).items() if pmc_key in k]
+        if hit:
+            tot = sum(v["launches"] for v in hit)
+            sq_rec = {k: sum(v[k] * v["launches"] for v in hit) / tot for k in
+                      ("mfma_busy_frac_per_simd", "wait_any_frac", "wait_inst_frac", "active_inst_frac") if all(k in v for v in hit)}
+            sq_rec["source"] = sq.get("_source", "profiles/sq_counters.json")
+    # Which roof: arithmetic intensity of the kernel's ALGORITHMIC work against the ridge point (dense MFMA peak /
+    # HBM peak = 312 FLOP/B at bf16).  The 20-channel convs sit far on the HBM side (90-180 FLOP/B), so the fraction is
+    # priced against HBM bandwidth; the MFMA-side numbers are carried along for reference.
+    ach = flops / (avg_ms * 1e-3) / 1e12
+    ai = flops / alg_bytes
+    ridge = peak * 1e12 / (HBM_PEAK_GBPS * 1e9)
+    alg_gbps = alg_bytes / (avg_ms * 1e-3) / 1e9
+    extras = {
+        "kernel": kname, "launches_timed": n_l, "avg_launch_ms": avg_ms,
+        "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
+        "arithmetic_intensity_flop_per_byte": ai, "ridge_flop_per_byte": ridge,
+        "kernel_tflops": ach, "kernel_frac_of_mfma_peak": ach / peak,
+        "hbm_capped_attainable_tflops": min(peak, ai * HBM_PEAK_GBPS / 1e3),
+        "measured_copy_gbps": copy_gbps,
+        "whole_step_model_tflops": achieved_model_tflops,
+        "whole_step_frac_of_mfma_peak": achieved_model_tflops / peak,
+        "sq_counters": sq_rec,
+        "other_timed_kernels": {k: {"launches": len(v), "avg_launch_ms": float(np.mean([d for _l, d in v]))}
+                                for k, v in fams.items() if k != fam},
+    }
+    if ai < ridge:
+        return {"bound": "hbm", "achieved": alg_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": alg_gbps / HBM_PEAK_GBPS, "traffic": traffic, **extras}
+    return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "traffic": traffic, **extras}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,17 +322,26 @@ def main():
     opt = mil_amd.FlatAdam(flat, lr=2e-4)               # reference optimizer: Adam(lr=2e-4), gbm/classify_combined.py:519
 
     # synthetic bags, generated on the device and resident before the timed region
-    n_tiles = args.bags * args.tiles
+    tile_parallel = args.infer and world > 1            # config 5: ONE bag, its tiles sharded over the ranks
+    if tile_parallel:
+        if args.bags != 1:
+            raise SystemExit("--infer with N>1 GPUs splits ONE bag over the ranks: use --bags 1 --tiles <bag size>")
+        lo, hi = rank * args.tiles // world, (rank + 1) * args.tiles // world
+        n_tiles, n_bags_local, tiles_local = hi - lo, 1, hi - lo
+    else:
+        n_tiles, n_bags_local, tiles_local = args.bags * args.tiles, args.bags, args.tiles
     gen = torch.Generator(device=dev).manual_seed(20260104 + rank)
     x_all = torch.empty((n_tiles, 3, args.size, args.size), dtype=torch.float32, device=dev)
-    for b in range(args.bags):          # bag by bag: bounded temporary memory
-        x_all[b * args.tiles:(b + 1) * args.tiles] = torch.randn(
-            (args.tiles, 3, args.size, args.size), generator=gen, device=dev).clamp_(-1.0, 1.0)
-    sizes = [args.tiles] * args.bags
-    labels = torch.tensor([(rank * args.bags + b) % 3 for b in range(args.bags)], device=dev)
+    for b in range(n_bags_local):       # bag by bag: bounded temporary memory
+        x_all[b * tiles_local:(b + 1) * tiles_local] = torch.randn(
+            (tiles_local, 3, args.size, args.size), generator=gen, device=dev).clamp_(-1.0, 1.0)
+    sizes = [tiles_local] * n_bags_local
+    labels = torch.tensor([(rank * args.bags + b) % 3 for b in range(n_bags_local)], device=dev)
 
     def infer_step():
         with torch.no_grad():
+            if tile_parallel:           # local encode -> all-gather of H over RCCL -> replicated head
+                return [net.forward_tile_parallel(x_all, torch.tensor([1], device=dev))]
             return net.forward_bags((x_all, sizes), labels)
 
     def step():
@@ -169,17 +379,22 @@ def main():
             best = max(best, 20 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
         copy_gbps = best
         del src, dst
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step()
-    # Candidate dominant kernels, all on the 64x64 maps at 20(24)->20(24) channels (layer 1, 47% of the FLOPs):
-    #   conv_block_fwd_kernel<24,2,4>   — the forward of a whole identity block (or conv_igemm_pf_kernel<24,2,3,4> per conv)
-    #   conv_bwd_fused_kernel<24,2,3>   — the fused backward of one conv (data gradient + weight gradient in one pass)
-    # Every launch of them is bracketed with HIP events on the launch stream; the one with the larger total time
-    # in the timed region is reported as `roofline`.
+        if i == 0 and world > 1 and not args.infer:
+            # self-check of the data-parallel step: after one all-reduce + Adam step every rank must hold bit-identical
+            # parameters (same summed gradient, same update), or the replicas have diverged
+            lo_, hi_ = flat.flat.clone(), flat.flat.clone()
+            dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+            if not torch.equal(lo_, hi_):
+                raise SystemExit("data-parallel self-check failed: parameters differ between ranks after one step")
+    # Every launch of the layer-1 kernel families (see roofline_record) is bracketed with HIP events on the launch
+    # stream; the one with the largest total time in the timed region is reported as `roofline`.
     timer = None
-    if not args.no_kernel_timer:
+    if not args.no_kernel_timer and not args.infer:
         timer = ops.KernelTimer(lambda label: label[:6] in (("conv", 24, 24, 3, 1, False), ("bwd_fused", 24, 24, 3, 1, False))
-                                or label[:2] == ("block_fwd", 24))
+                                or label[:2] in (("block_fwd", 24), ("block_bwd", 24)))
         ops.TIMER = timer
     fence()
     t0 = time.perf_counter()
@@ -197,89 +412,38 @@ def main():
         raise SystemExit("non-finite loss in benchmark step")
 
     if rank == 0:
-        total_tiles = n_tiles * world * args.steps
-        value = total_tiles / elapsed
+        tiles_per_step = args.tiles if tile_parallel else n_tiles * world
+        value = tiles_per_step * args.steps / elapsed
         scale = (args.size / 256.0) ** 2
-        achieved_model_tflops = value * (0.5754 if args.infer else GFLOP_PER_TILE_FWD_BWD_256) * scale / 1e3
+        achieved_model_tflops = value * (GFLOP_PER_TILE_FWD_256 if args.infer else GFLOP_PER_TILE_FWD_BWD_256) * scale / 1e3
         peak = MFMA_PEAK_BF16_TFLOPS if args.dtype == "bf16" else MFMA_PEAK_F32_TFLOPS
-        roofline = None
-        if timer is not None:
-            spans = timer.durations_ms()
-            fams = {}
-            for label, d in spans:
-                fams.setdefault(label[0], []).append((label, d))
-            if fams:
-                fam = max(fams, key=lambda k: sum(d for _l, d in fams[k]))
-                label = fams[fam][0][0]
-                n_img, ho, wo = (label[2], label[3], label[4]) if fam == "block_fwd" else (label[6], label[7], label[8])
-                avg_ms = float(np.mean([d for _l, d in fams[fam]]))
-                esz = 2 if args.dtype == "bf16" else 4
-                conv_flops = 2.0 * 9 * 20 * 20 * n_img * ho * wo          # algorithmic: 20 real channels in and out
-                px_bytes = n_img * ho * wo * 20 * esz                      # one 20-channel activation tensor
-                if fam == "block_fwd":
-                    flops, alg_bytes = 2 * conv_flops, 3 * px_bytes        # two convs; read x once, write o1 and out
-                    kname = (f"conv_block_fwd_kernel<24,2,4> (whole identity block forward: conv-lrelu-conv-add-lrelu, 20 ch, "
-                             f"{ho}x{wo} maps, {n_img} tiles/launch)")
-                elif fam == "conv":
-                    flops, alg_bytes = conv_flops, 2 * px_bytes            # read x once, write y once
-                    kname = (f"conv_igemm_pf_kernel<24,2,3,4> (3x3 s1 forward conv, 20->20 ch, {ho}x{wo} maps, "
-                             f"{n_img} tiles/launch)")
-                else:
-                    flops, alg_bytes = 2 * conv_flops, 3 * px_bytes        # dgrad + wgrad; read dz, x once, write dx once
-                    kname = (f"conv_bwd_fused_kernel<24,2,3> (fused data+weight gradient of the 3x3 s1 conv, 20->20 ch, "
-                             f"{ho}x{wo} maps, {n_img} tiles/launch)")
-                ach = flops / (avg_ms * 1e-3) / 1e12
-                traffic = None
-                try:                                                       # rocprofv3 PMC passes of this same command
-                    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
-                    key = {"conv": "conv_igemm_pf_kernel<24, 2, 3, 4", "block_fwd": "conv_block_fwd_kernel<24, 2"}.get(fam, "conv_bwd_fused_kernel<24, 2, 3")
-                    hit = [v for k, v in pmc.items() if key in k]           # all template variants of the kernel family
-                    if hit and n_img == 2048:
-                        traffic = sum(v["hbm_bytes"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit)
-                except (OSError, KeyError, ValueError):
-                    traffic = None
-                # Which roof: arithmetic intensity of the kernel's ALGORITHMIC work against the ridge point
-                # (dense MFMA peak / HBM peak = 312 FLOP/B at bf16).  The 20-channel convs sit far on the HBM side
-                # (120 FLOP/B fused backward, 90 FLOP/B forward), so the fraction is priced against HBM bandwidth;
-                # the MFMA-side numbers are carried along for reference.
-                ai = flops / alg_bytes
-                ridge = peak * 1e12 / (HBM_PEAK_GBPS * 1e9)
-                alg_gbps = alg_bytes / (avg_ms * 1e-3) / 1e9
-                extras = {
-                    "kernel": kname, "launches_timed": len(fams[fam]), "avg_launch_ms": avg_ms,
-                    "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
-                    "arithmetic_intensity_flop_per_byte": ai, "ridge_flop_per_byte": ridge,
-                    "kernel_tflops": ach, "kernel_frac_of_mfma_peak": ach / peak,
-                    "hbm_capped_attainable_tflops": min(peak, ai * HBM_PEAK_GBPS / 1e3),
-                    "measured_copy_gbps": copy_gbps,
-                    "whole_step_model_tflops": achieved_model_tflops,
-                    "whole_step_frac_of_mfma_peak": achieved_model_tflops / peak,
-                    "other_timed_kernels": {k: {"launches": len(v), "avg_launch_ms": float(np.mean([d for _l, d in v]))}
-                                            for k, v in fams.items() if k != fam},
-                }
-                if ai < ridge:
-                    roofline = {"bound": "hbm", "achieved": alg_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                "frac": alg_gbps / HBM_PEAK_GBPS, "traffic": traffic, **extras}
-                else:
-                    roofline = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                                "traffic": traffic, **extras}
-        if args.infer:
-            roofline = None
+        roofline = roofline_record(args, timer.durations_ms(), peak, copy_gbps, achieved_model_tflops) if timer else None
+        if tile_parallel:
+            par = (f"tile-parallel tp{world}: one bag's tiles sharded over the ranks, all-gather of H [N/{world},80] over RCCL, "
+                   "replicated head")
+        else:
+            par = f"bag-parallel dp{world}, one RCCL all-reduce of the flat 2.56 MB gradient bucket"
         line = {
-            "metric": ("tiles/sec fwd-only attention map, 256x256x3 bags, ResNet-26+attn" if args.infer else
-                       "tiles/sec fwd+bwd, 256x256x3 bags, ResNet-26+attn"),
+            "metric": (f"tiles/sec fwd-only attention map, {args.size}x{args.size}x3 bags, ResNet-26+attn" if args.infer else
+                       f"tiles/sec fwd+bwd, {args.size}x{args.size}x3 bags, ResNet-26+attn"),
             "value": value, "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if tile_parallel else "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.bags} bags x {args.tiles} tiles @{args.size}x{args.size}x3 per GPU, "
-                                   "ResNet-26 (20/40/60/80) + attention-MIL head, fwd+bwd full-bag path "
-                                   "(BASELINE.json configs[1])",
-                       "global_bags": args.bags * world, "tiles_per_bag": args.tiles, "tile": args.size,
-                       "parallelism": f"bag-parallel dp{world}, one RCCL all-reduce of the flat 2.56 MB gradient bucket"},
+            "config": {"workload": workload_label(args, world),
+                       "global_bags": 1 if tile_parallel else args.bags * world, "tiles_per_bag": args.tiles, "tile": args.size,
+                       "parallelism": par},
             "roofline": roofline,
         }
         if args.infer:
             line["model_tflops"] = achieved_model_tflops
+        extra = world == 1 and not args.infer and not args.no_extra_paths
+        if extra and args.dtype == "bf16":
+            line["fp32_path"] = fp32_path_record(args, w, x_all, sizes, labels, dev)
+        del x_all
+        torch.cuda.empty_cache()
+        if extra:
+            line["alt_resnet_path"] = alt_resnet_record(dev)
         if world == 1 and not args.no_cpu_baseline and not args.infer:
             line["cpu_baseline"] = cpu_baseline(args.size, w)
         print(json.dumps(line))

@@ -39,7 +39,9 @@ class BasicBlock(nn.Module):
 
 
 class _Conv:
-    """One convolution of the network: packed operands + the three kernel calls, narrow or wide path."""
+    """One convolution of the network: packed operands + the three kernel calls, narrow or wide path.  The packed
+    (MFMA fragment order) copies are built once and re-used until the weight changes: `_packed_conv` keys them on
+    the parameter's storage, its version counter and the optimizer epoch, as `encoder.ResNet.refresh_packed` does."""
 
     def __init__(self, conv, dtype):
         w = conv.weight
@@ -124,8 +126,32 @@ class ResNet(nn.Module):
         return _AltFn.apply(self, x, *self.encoder_params())
 
 
+def _weight_tag(w, dtype):
+    from .encoder import WEIGHT_EPOCH
+    return (w.data_ptr(), w._version, WEIGHT_EPOCH[0], dtype)
+
+
+def _packed_conv(net, conv, dtype):
+    """The `_Conv` of `conv`, re-packed only when its weight (or the compute dtype) changed since the last call."""
+    cache = net.__dict__.setdefault("_conv_cache", {})
+    tag = _weight_tag(conv.weight, dtype)
+    hit = cache.get(id(conv))
+    if hit is None or hit[0] != tag:
+        hit = cache[id(conv)] = (tag, _Conv(conv, dtype))
+    return hit[1]
+
+
+def _packed_stem(net, dtype):
+    cache = net.__dict__.setdefault("_conv_cache", {})
+    tag = _weight_tag(net.conv1.weight, dtype)
+    hit = cache.get("stem")
+    if hit is None or hit[0] != tag:
+        hit = cache["stem"] = (tag, ops.pack_weights(net.conv1.weight, None, L.PACK_STEM, dtype))
+    return hit[1]
+
+
 def _forward(net, x, dtype):
-    wp, bp = ops.pack_weights(net.conv1.weight, None, L.PACK_STEM, dtype)
+    wp, bp = _packed_stem(net, dtype)
     fused = ops.stem_fwd_fused(x, wp, bp, 64, slope=0.0, dtype=dtype)
     if fused is not None:
         xs, pool, widx = fused
@@ -138,8 +164,8 @@ def _forward(net, x, dtype):
     saved = {"xs": xs, "stem_hw": stem_hw, "widx": widx, "blocks": []}
     t = pool
     for blk in net.blocks():
-        c1, c2 = _Conv(blk.conv1, dtype), _Conv(blk.conv2, dtype)
-        ds = _Conv(blk.downsample[0], dtype) if blk.downsample is not None else None
+        c1, c2 = _packed_conv(net, blk.conv1, dtype), _packed_conv(net, blk.conv2, dtype)
+        ds = _packed_conv(net, blk.downsample[0], dtype) if blk.downsample is not None else None
         o1 = c1.forward(t)
         short = ds.forward(t, relu=False) if ds is not None else t
         out = c2.forward(o1, res=short)

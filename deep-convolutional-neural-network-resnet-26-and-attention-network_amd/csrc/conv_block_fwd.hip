@@ -290,7 +290,7 @@ static int launch_block_fwd(BlockFwdArgs a, hipStream_t st) {
         c.g.n_img = n; c.g.n_groups = n;
         c.x = a.x + (size_t)i0 * (img / 2); c.o1 = a.o1 + (size_t)i0 * (img / 2); c.y = a.y + (size_t)i0 * (img / 2);
         const int ntiles = n * g.tiles_y * g.tiles_x;
-        int grid = 256 * per_cu;
+        int grid = mil_num_cus() * per_cu;
         if (grid > ntiles) grid = ntiles;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, st, c, ntiles, (unsigned)(img * n));
         MIL_CHECK_LAUNCH();

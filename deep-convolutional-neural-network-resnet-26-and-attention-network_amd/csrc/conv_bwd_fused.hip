@@ -376,7 +376,7 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
         const int o3 = mil_resident_per_cu(conv_bwd_fused_kernel<CZ, NTX, KS, true, false, NW>, lds, 3, 64 * NW);
         per_cu = o1 < o2 ? o1 : o2; per_cu = per_cu < o3 ? per_cu : o3;
     }
-    int grid = 256 * per_cu;
+    int grid = mil_num_cus() * per_cu;
     if (grid > ntiles) grid = ntiles;
     const size_t slab_elems = (size_t)(MT + 1) * 16 * NTX * 16;
     const size_t bytes = slab_elems * grid * sizeof(float);

@@ -237,7 +237,7 @@ static int launch_dgrad_s2(DgradS2Args a, hipStream_t st) {
         if (a.act) c.act = a.act + (size_t)i0 * (y_img / 2);
         c.y = a.y + (size_t)i0 * (y_img / 2);
         const int ntiles = c.g.n_groups * c.g.tiles_y * c.g.tiles_x;
-        int grid = 256 * per_cu;
+        int grid = mil_num_cus() * per_cu;
         if (grid > ntiles) grid = ntiles;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, c, ntiles, (unsigned)(z_img * n), (unsigned)(y_img * n));
         MIL_CHECK_LAUNCH();

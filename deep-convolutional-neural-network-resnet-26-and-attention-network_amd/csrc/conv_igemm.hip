@@ -542,7 +542,7 @@ static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool*
         if (a.res) c.res = a.res + (size_t)i0 * (y_img / 2);
         if (a.act) c.act = a.act + (size_t)i0 * (y_img / 2);
         const int ntiles = c.g.n_groups * c.g.tiles_y * c.g.tiles_x;
-        int grid = 256 * per_cu;
+        int grid = mil_num_cus() * per_cu;
         if (grid > ntiles) grid = ntiles;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, c, ntiles, (unsigned)(x_img * n), (unsigned)(y_img * n));
         MIL_CHECK_LAUNCH();

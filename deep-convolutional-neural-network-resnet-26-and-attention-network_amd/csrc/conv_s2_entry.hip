@@ -182,7 +182,7 @@ static int launch_s2_entry(S2EntryArgs a, hipStream_t st) {
         c.y1 = a.y1 + (size_t)i0 * (y_img / 2);
         c.y2 = a.y2 + (size_t)i0 * (y_img / 2);
         const int ntiles = c.g.n_groups * c.g.tiles_y * c.g.tiles_x;
-        int grid = 256 * per_cu;
+        int grid = mil_num_cus() * per_cu;
         if (grid > ntiles) grid = ntiles;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, c, ntiles, (unsigned)(x_img * n), (unsigned)(y_img * n));
         MIL_CHECK_LAUNCH();

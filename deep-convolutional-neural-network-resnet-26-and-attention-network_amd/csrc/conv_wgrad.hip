@@ -324,7 +324,7 @@ static int plan_wgrad(ConvGeom& g, WgradPlan& pl, int* lds_z_off, bool proj = fa
     // a second round of workgroups would only double the slab traffic, which already rivals the activation traffic)
     int per_cu = (160 * 1024) / pl.lds;
     per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
-    int gx = 256 * per_cu / MSPLIT;
+    int gx = mil_num_cus() * per_cu / MSPLIT;
     if (gx > ntiles) gx = ntiles;
     if (gx < 1) gx = 1;
     pl.grid_x = gx;
@@ -694,7 +694,7 @@ static int stem_bwd_entry(const void* xs, const void* gp, const uint8_t* widx, f
     const int xb = (halo_px * PIXB + 15) & ~15, zb = 256 * PIXZ, gb = (nwin * PIXZ + 15) & ~15, ib = (nwin * 24 + 15) & ~15;
     const int lds = xb + zb + gb + ib;
     const int ntiles = g.n_groups * g.tiles_y * g.tiles_x;
-    int grid = 256 * mil_resident_per_cu(stem_bwd_fused_kernel, lds, 4) * 2;          // two rounds of the resident set
+    int grid = mil_num_cus() * mil_resident_per_cu(stem_bwd_fused_kernel, lds, 4) * 2;          // two rounds of the resident set
     if (grid > ntiles) grid = ntiles;
     const size_t slab_elems = (size_t)(MT + 1) * 16 * 32;
     const size_t bytes = slab_elems * grid * sizeof(float);

@@ -193,16 +193,32 @@ __device__ __forceinline__ bf16x8_t mil_tr_pair(const char* p0, const char* p1) 
 // partial second round would leave CUs idle while the stragglers finish.
 template <typename K>
 __host__ inline int mil_resident_per_cu(K kern, int lds, int cap, int threads = 256) {
-    // the answer depends only on (kernel, lds): remember the last one per kernel instantiation (launch-path cost)
-    static thread_local int last_lds = -1, last_n = 0;
-    static thread_local const void* last_k = nullptr;
+    // the answer depends only on (kernel, lds, threads): remember every combination asked for (launch-path cost; the
+    // function-pointer TYPE is shared by all instantiations with one signature, so the key holds the pointer itself)
+    struct Key { const void* k; int lds, threads; };
+    struct Slot { Key key; int n; };
+    static thread_local Slot slots[64];
+    static thread_local int used = 0;
     const void* kp = reinterpret_cast<const void*>(kern);
-    if (kp != last_k || lds != last_lds) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, threads, (size_t)lds) != hipSuccess || n < 1) n = 1;
-        last_k = kp; last_lds = lds; last_n = n;
+    for (int i = 0; i < used; ++i)
+        if (slots[i].key.k == kp && slots[i].key.lds == lds && slots[i].key.threads == threads)
+            return slots[i].n > cap ? cap : slots[i].n;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, threads, (size_t)lds) != hipSuccess || n < 1) n = 1;
+    if (used < 64) slots[used++] = Slot{Key{kp, lds, threads}, n};
+    return n > cap ? cap : n;
+}
+
+// Compute units of the current device (256 on MI355X), asked once per thread.
+__host__ inline int mil_num_cus() {
+    static thread_local int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+            n = 256;
+        cus = n;
     }
-    return last_n > cap ? cap : last_n;
+    return cus;
 }
 
 // How many images of `bytes_per_img` bytes fit under the 2 GiB buffer limit.

@@ -277,7 +277,7 @@ static int launch_stem_fwd(StemFwdArgs a, hipStream_t st) {
         b.widx = a.widx + (size_t)i0 * a.Ho * a.Wo * COUTP;
         b.ntiles = b.n_img * a.tiles_y * a.tiles_x;
         int grid = (b.ntiles + 7) & ~7;
-        const int cap = 256 * (NT <= 2 ? 2 : 1);
+        const int cap = mil_num_cus() * (NT <= 2 ? 2 : 1);
         if (grid > cap) grid = cap;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, st, b);
         MIL_CHECK_LAUNCH();

@@ -10,6 +10,7 @@ import torch
 from torch import nn
 
 from . import _lib as L
+from . import hooks
 from . import ops
 
 STAGE_WIDTHS = (20, 40, 60, 80)        # gbm/model.py:27-30
@@ -149,6 +150,38 @@ class ResNet(nn.Module):
     def _packed(self, key, weight, bias, mode, dtype):
         return self._pack_table[2][(key, mode)]
 
+    # ---- forward hooks on children (the reference's children are live modules: SURVEY.md §8b) ----------------
+    def block_position(self, bi):
+        """(stage index, index inside the stage, stage depth) of block `bi` of `blocks()`."""
+        for li in range(4):
+            depth = len(getattr(self, f"layer{li + 1}"))
+            if bi < depth:
+                return li, bi, depth
+            bi -= depth
+        raise IndexError(bi)
+
+    def child_hooks(self):
+        """The children that carry a forward (pre-)hook, or None: the un-hooked forward builds no views."""
+        hk = [m for m in self.modules() if m is not self and hooks.hooked(m)]
+        return hk or None
+
+    def _fire_block_hooks(self, bi, blk, stage_in, xin, o1, out):
+        """Hooks of block `bi`, of its LeakyReLU (called twice per block upstream, nnBlocks.py:180,187) and — after a
+        stage's last block — of the stage's Sequential, with NCHW fp32 views of the saved activations."""
+        cin, cout = blk.conv1.in_channels, blk.conv1.out_channels
+        if hooks.hooked(blk.relu):
+            v1 = hooks.nchw(o1, cout)
+            hooks.fire(blk.relu, v1, v1)
+            v2 = hooks.nchw(out, cout)
+            hooks.fire(blk.relu, v2, v2)
+        if hooks.hooked(blk):
+            hooks.fire(blk, hooks.nchw(xin, cin), hooks.nchw(out, cout))
+        li, j, depth = self.block_position(bi)
+        if j == depth - 1:
+            stage = getattr(self, f"layer{li + 1}")
+            if hooks.hooked(stage):
+                hooks.fire(stage, hooks.nchw(stage_in, stage[0].conv1.in_channels), hooks.nchw(out, cout))
+
     def forward(self, x):
         return _EncoderFn.apply(self, x, *self.encoder_params())
 
@@ -156,8 +189,10 @@ class ResNet(nn.Module):
 def encoder_forward(net, x, dtype):
     """Runs the kernels; returns (feats [T,80] fp32, saved-state dict for the backward)."""
     net.refresh_packed(dtype)
+    hk = net.child_hooks()              # None unless a forward hook sits on a child module (then views are built for it)
     wp, bp = net._packed("stem", net.conv1.weight, net.conv1.bias, L.PACK_STEM, dtype)
-    fused = ops.stem_fwd_fused(x, wp, bp, ops.cpad(STEM_WIDTH), dtype=dtype) if net.fuse_stem_forward else None
+    stem_hooked = hk is not None and hooks.any_hooked((net.conv1, net.relu, net.maxpool))
+    fused = ops.stem_fwd_fused(x, wp, bp, ops.cpad(STEM_WIDTH), dtype=dtype) if (net.fuse_stem_forward and not stem_hooked) else None
     if fused is not None:
         xs, pool, widx = fused
         stem_hw = tuple(xs.shape[1:3])
@@ -166,11 +201,23 @@ def encoder_forward(net, x, dtype):
         stem = ops.conv(xs, wp, bp, ops.cpad(STEM_WIDTH), ks=4, stride=1, pad=2, lrelu=True)
         pool, widx = ops.maxpool_fwd(stem)
         stem_hw = tuple(stem.shape[1:3])
+        if stem_hooked:                 # the hooked children see what the reference's would (NCHW fp32, 20 channels)
+            if hooks.hooked(net.conv1):   # pre-activation output: one extra launch, only ever paid under a hook
+                pre = ops.conv(xs, wp, bp, ops.cpad(STEM_WIDTH), ks=4, stride=1, pad=2, lrelu=False)
+                hooks.fire(net.conv1, x, hooks.nchw(pre, STEM_WIDTH))
+            stem_v = hooks.nchw(stem, STEM_WIDTH)
+            hooks.fire(net.relu, stem_v, stem_v)            # in place upstream (gbm/model.py:25): input is the output
+            hooks.fire(net.maxpool, stem_v, hooks.nchw(pool, STEM_WIDTH))
     saved = {"xs": xs, "stem_hw": stem_hw, "widx": widx, "blocks": []}      # the stem output itself is not kept
     t = pool
+    stage_in = pool
     for bi, blk in enumerate(net.blocks()):
         cout = blk.conv1.out_channels
         s = blk.stride
+        if hk is not None:
+            if net.block_position(bi)[1] == 0:
+                stage_in = t
+            hooks.refuse(blk, ["conv1", "conv2"] + (["downsample", "downsample.0"] if blk.downsample is not None else []))
         w1, b1 = net._packed(f"b{bi}.c1", blk.conv1.weight, blk.conv1.bias, L.PACK_FWD, dtype)
         w2, b2 = net._packed(f"b{bi}.c2", blk.conv2.weight, blk.conv2.bias, L.PACK_FWD, dtype)
         if s == 1 and blk.downsample is None and net.fuse_block_forward:      # whole block in one pass (24/40 channels)
@@ -178,6 +225,8 @@ def encoder_forward(net, x, dtype):
             if both is not None:
                 o1, out = both
                 saved["blocks"].append((t, o1, out))
+                if hk is not None:
+                    net._fire_block_hooks(bi, blk, stage_in, t, o1, out)
                 t = out
                 continue
         pair = None
@@ -192,9 +241,16 @@ def encoder_forward(net, x, dtype):
             short = ops.conv(t, wd, None, ops.cpad(cout), ks=1, stride=s, pad=0) if blk.downsample is not None else t
         out = ops.conv(o1, w2, b2, ops.cpad(cout), ks=3, stride=1, pad=1, res=short, lrelu=True)
         saved["blocks"].append((t, o1, out))
+        if hk is not None:
+            net._fire_block_hooks(bi, blk, stage_in, t, o1, out)
         t = out
     pooled, feats = ops.avgpool_fc_fwd(t, net.fc.weight.detach(), STAGE_WIDTHS[-1])
     saved["pooled"] = pooled
+    if hk is not None:
+        if hooks.hooked(net.avgpool):
+            hooks.fire(net.avgpool, hooks.nchw(t, STAGE_WIDTHS[-1]), pooled.view(pooled.shape[0], -1, 1, 1))
+        if hooks.hooked(net.fc):
+            hooks.fire(net.fc, pooled, feats)
     return feats, saved
 
 

@@ -62,7 +62,7 @@ class _HeadFn(torch.autograd.Function):
     """(H, 11 head parameters) -> (loss [nbags], l2 []) with grad; a1/wrois/bterm/kld/rec without."""
 
     @staticmethod
-    def forward(ctx, H, layout, labels, keep_mask, class_weights, *weights):
+    def forward(ctx, H, layout, labels, keep_mask, class_weights, internals, *weights):
         lib = L.lib()
         H = H.contiguous()
         ws = [w.detach().contiguous() for w in weights]
@@ -86,6 +86,12 @@ class _HeadFn(torch.autograd.Function):
                                  wrois.data_ptr(), bterm.data_ptr(), kld.data_ptr(), rec.data_ptr(), ntot, nbags,
                                  ops.LEAK, DROP_P, SMOOTHING, BN_EPS, L.stream_ptr()), "mil_head_fwd")
         ctx.layout, ctx.keep_mask, ctx.ws, ctx.work = layout, keep_mask, ws, work
+        if internals is not None:          # forward hooks on head children read the kernels' own intermediates
+            o = nbags * 2 * N_FEATS
+            internals["stats"] = work[:o].view(nbags, 2, N_FEATS)                      # per bag: mean, 1/sqrt(var+eps)
+            internals["t"] = work[o:o + ntot * 40].view(ntot, 40); o += ntot * 40       # tanh(attention.lin1)
+            internals["v"] = work[o:o + ntot * 40].view(ntot, 40); o += ntot * 40       # buffer.lin1 output
+            internals["araw"] = work[o:o + ntot * 3].view(ntot, 3)                      # attention output
         ctx.save_for_backward(H, bterm, rec)
         loss = rec[:, 6].clone()
         l2 = rec[0, 17].clone()
@@ -113,8 +119,8 @@ class _HeadFn(torch.autograd.Function):
         for w in ctx.ws:
             out.append(grads[o:o + w.numel()].view(w.shape))
             o += w.numel()
-        return (dH, None, None, None, None, *out)
+        return (dH, None, None, None, None, None, *out)
 
 
-def head_apply(H, layout, labels, keep_mask, class_weights, weights):
-    return _HeadFn.apply(H, layout, labels, keep_mask, class_weights, *weights)
+def head_apply(H, layout, labels, keep_mask, class_weights, weights, internals=None):
+    return _HeadFn.apply(H, layout, labels, keep_mask, class_weights, internals, *weights)

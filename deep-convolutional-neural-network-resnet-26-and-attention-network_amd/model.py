@@ -11,6 +11,7 @@ import torch
 from torch import nn
 from torch.nn import init
 
+from . import hooks
 from . import ops
 from .encoder import BasicResBlock, ResNet
 from .head import DROP_P, SMOOTHING, BagLayout, head_apply
@@ -127,6 +128,38 @@ class Attention(nn.Module):
                 self.attention.lin2.weight, self.attention.lin2.bias, self.buffer.lin1.weight, self.buffer.lin1.bias,
                 self.buffer.classifier.weight, self.buffer.classifier.bias, self.weight_mask]
 
+    # ---- forward hooks on the head's children (see hooks.py) ---------------------------------
+    _HEAD_UNMATERIALISED = ("attention.lin1", "attention.tanh", "loss")
+
+    def _hooked_head_modules(self):
+        mods = [m for top in (self.context, self.attention, self.buffer, self.loss) for m in top.modules() if hooks.hooked(m)]
+        if mods:
+            hooks.refuse(self, self._HEAD_UNMATERIALISED)
+        return mods
+
+    def _fire_head_hooks(self, H, layout, keep, bterm, internals):
+        """One call per bag, as the reference makes one forward per bag.  Every tensor handed to a hook is either what
+        the head kernels stored (batch statistics, tanh activations, buffer pre-activations, A_raw, B) or an elementwise
+        re-expression of it (the normalised / masked features, which the kernel keeps in registers only)."""
+        with torch.no_grad():
+            for b in range(layout.nbags):
+                n0, n1 = layout.offsets_host[b], layout.offsets_host[b + 1]
+                Hb = H[n0:n1]
+                mu, rstd = internals["stats"][b, 0], internals["stats"][b, 1]
+                hz = (Hb - mu) * rstd * self.context.bn.weight + self.context.bn.bias            # gbm/model.py:109
+                act = torch.where(Hb >= 0, Hb, Hb * ops.LEAK)
+                hm = act if keep is None else act * keep[n0:n1].to(act.dtype) / (1.0 - DROP_P)   # gbm/model.py:110
+                v = internals["v"][n0:n1]
+                vr = torch.where(v >= 0, v, v * ops.LEAK)
+                araw, bt = internals["araw"][n0:n1], bterm[n0:n1].view(-1, 1)
+                for mod, args, out in ((self.context.bn, Hb, hz), (self.context.relu, Hb, act), (self.context.do, act, hm),
+                                       (self.context, Hb, (hm, hz)),
+                                       (self.attention.lin2, internals["t"][n0:n1], araw), (self.attention, hz, araw),
+                                       (self.buffer.lin1, hm, v), (self.buffer.relu, v, vr), (self.buffer.classifier, vr, bt),
+                                       (self.buffer, hm, bt)):
+                    if hooks.hooked(mod):
+                        hooks.fire(mod, args, out)
+
     # ---- one bag (the reference call, gbm/model.py:189) ------------------------------------------
     def forward(self, full_input, Y=None):
         if Y is None:
@@ -181,8 +214,16 @@ class Attention(nn.Module):
         if cw is not None:
             cw = torch.as_tensor(cw, dtype=torch.float32, device=dev).contiguous()
         H = self.cnn(x_all)
-        loss, l2, a1, wrois, bterm, kld, rec = head_apply(H, layout, y, keep, cw, self.head_weights())
+        return self._finish(H, layout, y, keep, cw)
+
+    def _finish(self, H, layout, y, keep, cw):
+        """Segmented head over the features of all bags + the per-bag output dicts (gbm/model.py:198-264)."""
+        head_mods = self._hooked_head_modules()
+        internals = {} if head_mods else None
+        loss, l2, a1, wrois, bterm, kld, rec = head_apply(H, layout, y, keep, cw, self.head_weights(), internals)
         Hd = H.detach()
+        if head_mods:
+            self._fire_head_hooks(Hd, layout, keep, bterm, internals)
         outs = BagOutputs()
         outs.loss, outs.l2 = loss, l2          # [n_bags] / [] with grad: `outs.loss.sum().backward()` is one backward for all bags
         y_hat = rec[:, 16].long()              # one conversion for all bags
@@ -205,3 +246,33 @@ class Attention(nn.Module):
                 "error": r[7].view(1),
             })
         return outs
+
+
+    # ---- one LARGE bag sharded over ranks (BASELINE config 5; the reference's own multi-GPU mode) ----------------
+    def forward_tile_parallel(self, x_slice, Y=None, group=None):
+        """Inference of ONE bag whose tiles are split across the ranks of `group`: this rank encodes its slice
+        `x_slice [N_r,3,H,W]`, the features are all-gathered in rank order (ragged slices allowed) and every rank runs
+        the head on the whole bag, so each rank returns the same output dict as `forward(torch.cat(slices), Y)`.
+        This is what the reference's `nn.DataParallel(ResNet, device_ids=[0,1,2,3])` does inside one process
+        (scatter tiles -> replicas -> gather features to GPU 0, gbm/model.py:132-135), as one process per GPU over RCCL.
+        Forward only: a training step inside one sharded bag would also need the reduce-scatter of dH, which no
+        configuration of the reference asks for."""
+        from .dist import gather_features
+        if self.training:
+            raise RuntimeError("forward_tile_parallel is the inference path (attention-map extraction); call .eval() first")
+        dev = self.weight_mask.device
+        if dev.type != "cuda":
+            raise RuntimeError("Attention runs on an AMD GPU only (module parameters are not on a CUDA/HIP device)")
+        if x_slice.dim() != 4 or x_slice.shape[1] != 3:
+            raise ValueError(f"expected [N,3,H,W], got {tuple(x_slice.shape)}")
+        if Y is None:
+            Y = torch.tensor([1])
+        with torch.no_grad():
+            h_local = self.cnn(x_slice.detach().to(dev, torch.float32))
+            H = gather_features(h_local, group)
+            layout = BagLayout.cached([H.shape[0]], dev)
+            y = Y.to(dev).long().reshape(-1)[:1].contiguous()
+            cw = self.loss.weight
+            if cw is not None:
+                cw = torch.as_tensor(cw, dtype=torch.float32, device=dev).contiguous()
+            return self._finish(H, layout, y, None, cw)[0]

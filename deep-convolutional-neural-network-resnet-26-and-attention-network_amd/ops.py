@@ -164,7 +164,7 @@ def conv_bwd_fused(dz, wpack_dgrad, x, cin, cout, *, addend=None, mask=True, ks=
         dw, db = out
         _need(dw, (cout, cin, ks, ks), torch.float32, "dw")
         _need(db, (cout,), torch.float32, "db")
-    end = TIMER.bracket(("bwd_fused", cpad(cout), cpad(cin), ks, 1, False, n, h, w)) if TIMER else None
+    end = TIMER.bracket(("bwd_fused", cpad(cout), cpad(cin), ks, 1, False, n, h, w, addend is not None)) if TIMER else None
     L.check(L.lib().mil_conv_bwd_fused(dz.data_ptr(), wpack_dgrad.data_ptr(), x.data_ptr(), L.ptr(addend), dx.data_ptr(),
                                        dw.data_ptr(), db.data_ptr(), workspace.data_ptr(),
                                        workspace.numel() * workspace.element_size(), n, h, w, cout, cin, ks, pad,

@@ -67,19 +67,68 @@ class BagTrainer:
             self.pending = 0
 
 
+def _minmax_f32(values):
+    """`matplotlib.colors.Normalize()(x)` with autoscaling, restated.  matplotlib and numpy are third-party code
+    outside the reference tree (matplotlib 3.10.8 / numpy 2.2 in this image; the reference pins no versions):
+    the array keeps its own dtype (float32 for a float32 tensor); vmin / vmax are the minimum / maximum over ALL
+    elements, held as Python floats (the `vmin` setter sanitises them) and re-wrapped as float64 scalars; the result
+    is `x -= vmin; x /= (vmax - vmin)` IN PLACE, which under numpy-2 promotion evaluates each step in float64 and
+    rounds it back into the float32 array; all zeros when vmin == vmax."""
+    import numpy as np
+    a = np.array(torch.as_tensor(values).detach().cpu().numpy(), dtype=np.float32, copy=True)
+    if a.size == 0:
+        return a
+    vmin, vmax = np.float64(a.min()), np.float64(a.max())
+    if vmin == vmax:
+        a.fill(0)
+    else:
+        a[...] = (a.astype(np.float64) - vmin).astype(np.float32)
+        a[...] = (a.astype(np.float64) / (vmax - vmin)).astype(np.float32)
+    return a
+
+
+def _dla_lines(raster, column):
+    """`f'{coord[1]} {coord[0]} {value}\n'` (gbm/classify.py:212): the file lists the raster's second coordinate first;
+    a float32 element formats as the shortest repr of its value widened to a Python float."""
+    return "".join(f"{coord[1]} {coord[0]} {float(v)}\n" for coord, v in zip(raster, column))
+
+
+def write_map(meta, epoch, raster, attn, activations, output_dir="."):
+    """The reference's `.dla` overlay export, gbm/classify.py:207-225: FOUR text files per slide —
+    `prediction-AGMIL-ATTN.<name>.dla` with column 0 of the min-max-normalised attention weights (`plt.Normalize()` over
+    the whole `attn` array) and `prediction-AGMIL-ACTF{1,2,3}.<name>.dla` with columns 0..2 of `activations`, one
+    `x y value` line per tile in raster order.  `attn` is [N, >=1], `activations` [N, >=3] (for this model:
+    `out["Aterm"].t()` and `out["wROIs"].t()`); `meta["basename"]` names the slide; `epoch` is unused, as upstream.
+    `output_dir` is a module global upstream.  Returns the four paths."""
+    import os
+    name = meta["basename"]
+    attn = torch.as_tensor(attn).detach().float().cpu()
+    activations = torch.as_tensor(activations).detach().float().cpu()
+    if attn.dim() != 2 or activations.dim() != 2 or activations.shape[1] < 3:
+        raise ValueError("attn must be [N,>=1] and activations [N,>=3]")
+    if len(raster) > attn.shape[0] or len(raster) > activations.shape[0]:
+        raise IndexError("more raster coordinates than tiles")        # upstream: index error while writing
+    att = _minmax_f32(attn)
+    paths = []
+    for tag, col in (("ATTN", att[:, 0]), ("ACTF1", activations[:, 0].numpy()), ("ACTF2", activations[:, 1].numpy()),
+                     ("ACTF3", activations[:, 2].numpy())):
+        path = os.path.join(output_dir, f"prediction-AGMIL-{tag}.{name}.dla")
+        with open(path, "w+") as f:
+            f.write(_dla_lines(raster, col))
+        paths.append(path)
+    return paths
+
+
 def write_attention_map(path, raster, weights, normalise=True):
-    """`x y weight` per tile, one line each — the `.dla` overlay format of gbm/classify.py:207-225 (`raster[i]` is
-    (row, col); the file lists col first).  With `normalise` the weights are min-max scaled to [0,1] as
-    matplotlib's Normalize() does there."""
-    w = torch.as_tensor(weights, dtype=torch.float64).flatten().cpu()
+    """ONE `.dla` file in the format of gbm/classify.py:209-213 (`x y weight` per tile; `raster[i]` is (row, col), the
+    file lists col first) for a single weight vector — e.g. one of the three attention maps `out["Aterm"][k]`.  With
+    `normalise` the weights are min-max scaled as `plt.Normalize()` does there (float32 arithmetic)."""
+    w = torch.as_tensor(weights).detach().float().flatten().cpu()
     if len(raster) != w.numel():
         raise ValueError("one raster coordinate per weight expected")
-    if normalise and w.numel():
-        lo, hi = float(w.min()), float(w.max())
-        w = (w - lo) / (hi - lo) if hi > lo else torch.zeros_like(w)
+    col = _minmax_f32(w) if normalise else w.numpy()
     with open(path, "w") as f:
-        for (row, col), v in zip(raster, w.tolist()):
-            f.write(f"{col} {row} {v}\n")
+        f.write(_dla_lines(raster, col))
 
 
 def save_checkpoint(path, model, optimizer):

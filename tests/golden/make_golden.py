@@ -226,16 +226,6 @@ def run_prep_case(name, n_tiles, roi, pad, res, seed, train, store="f32"):
     print(f"{name}: {n_tiles} tiles {roi}->{res}")
 
 
-def prep_inputs(z):
-    """Regenerate the inputs of a prep_* fixture (same construction as run_prep_case)."""
-    n, roi, seed = int(z["n_tiles"]), int(z["roi"]), int(z["seed"])
-    rng = np.random.default_rng(seed)
-    rois = rng.integers(0, 256, (n, roi, roi, 3), dtype=np.uint8)
-    ramp = (np.add.outer(np.arange(roi), 2 * np.arange(roi)) % 256).astype(np.uint8)
-    rois[::2, :, :, 1] = ramp
-    return rois
-
-
 def main():
     run_prep_case("prep_s120_r32_train", 6, 120, 10, 32, 31, True)
     run_prep_case("prep_s100_r37_flat", 3, 100, 10, 37, 32, False)

@@ -126,6 +126,91 @@ def test_set_stage_and_attention_map_export(tmp_path):
         write_attention_map(str(path), [(0, 0)], torch.tensor([0.1, 0.2]))
 
 
+def test_dla_export_is_byte_exact_with_reference_statements(tmp_path, golden_dir):
+    """gbm/classify.py:207-225 writes four `.dla` files per slide (ATTN from `plt.Normalize()` in float32, ACTF1-3 raw),
+    each value printed as the repr of the float32 widened to a Python float.  The fixtures under tests/golden/dla were
+    produced by executing those statements on matplotlib itself (tests/golden/make_dla_golden.py)."""
+    import mil_amd
+    from fixture_inputs import DLA_CASES, dla_inputs
+    cases = [(name, *dla_inputs(seed, n)) for name, seed, n in DLA_CASES]
+    _, act_c, raster_c = dla_inputs(13, 4)
+    cases.append(("slideC", torch.full((4, 3), 0.25), act_c, raster_c))          # constant map: vmin == vmax -> zeros
+    for name, attn, activations, raster in cases:
+        paths = mil_amd.write_map({"basename": name}, 0, raster, attn, activations, output_dir=str(tmp_path))
+        assert [os.path.basename(p) for p in paths] == [f"prediction-AGMIL-{t}.{name}.dla" for t in ("ATTN", "ACTF1", "ACTF2", "ACTF3")]
+        for p in paths:
+            want = open(os.path.join(golden_dir, "dla", os.path.basename(p)), "rb").read()
+            assert open(p, "rb").read() == want, p
+    # the single-file helper writes the same bytes as the ATTN file when given the same column of a normalised map
+    name, attn, activations, raster = cases[0]
+    one = tmp_path / "one.dla"
+    from mil_amd.train import _minmax_f32
+    mil_amd.write_attention_map(str(one), [tuple(r) for r in raster], torch.from_numpy(_minmax_f32(attn)[:, 0]), normalise=False)
+    assert one.read_bytes() == open(os.path.join(golden_dir, "dla", f"prediction-AGMIL-ATTN.{name}.dla"), "rb").read()
+    with pytest.raises(ValueError):
+        mil_amd.write_map({"basename": "x"}, 0, raster, attn[:, 0], activations, output_dir=str(tmp_path))
+
+
+def test_init_parity_with_reference_seed(golden_dir):
+    """gbm/model.py:118-187: construction order, default-init RNG consumption and `reset_params` (name-dependent init,
+    in `named_modules()` order) must match the reference draw for draw: under `torch.manual_seed(1234)` every conv /
+    linear WEIGHT equals the reference's (tests/golden/weights.npz holds `Attention(3)` built under that seed; the
+    golden generator then overwrote only biases, the batch-norm affine and weight_mask, which reset to constants)."""
+    import mil_amd
+    w = np.load(os.path.join(golden_dir, "weights.npz"))
+    torch.manual_seed(1234)
+    net = mil_amd.Attention(3, device="cpu")
+    sd = net.state_dict()
+    overwritten = [k for k in w.keys() if (k.endswith(".bias") or k in ("context.bn.weight", "weight_mask"))]
+    assert len(overwritten) == 32
+    for k in w.keys():
+        if k in overwritten:
+            continue
+        assert np.array_equal(sd[k].numpy(), w[k]), k                 # 33 weight tensors, bit for bit
+    for k in overwritten:                                              # and the constants the reference init leaves
+        if k == "weight_mask":
+            assert torch.equal(sd[k], torch.tensor([0.25, 0.25, 0.25]))
+        elif k == "context.bn.weight":
+            assert torch.equal(sd[k], torch.ones(80))
+        else:
+            assert torch.equal(sd[k], torch.zeros_like(sd[k])), k
+    # reset_linear (gbm/model.py:183-187) re-draws every Linear with the tanh gain and zero bias
+    torch.manual_seed(7)
+    net.reset_linear()
+    torch.manual_seed(7)
+    for lin in (net.cnn.module.fc, net.attention.lin1, net.attention.lin2, net.buffer.lin1, net.buffer.classifier):   # modules() order
+        ref = torch.empty_like(lin.weight)
+        torch.nn.init.kaiming_normal_(ref, mode="fan_in", nonlinearity="tanh")
+        assert torch.equal(lin.weight.detach(), ref)
+        assert lin.bias is None or torch.equal(lin.bias.detach(), torch.zeros_like(lin.bias))
+
+
+def test_forward_hooks_are_accepted_and_unmaterialised_children_refuse():
+    """Children are real nn.Modules: hooks register on them.  Firing is covered on the GPU
+    (tests/test_gpu_hooks.py); here: the bookkeeping that needs no kernel."""
+    import mil_amd
+    from mil_amd import hooks
+    net = mil_amd.Attention(3, device="cpu")
+    enc = net.cnn.module
+    assert enc.child_hooks() is None and net._hooked_head_modules() == []
+    h1 = enc.layer1.register_forward_hook(lambda m, i, o: None)
+    h2 = net.context.register_forward_hook(lambda m, i, o: None)
+    assert enc.child_hooks() == [enc.layer1] and net._hooked_head_modules() == [net.context]
+    h1.remove(); h2.remove()
+    assert enc.child_hooks() is None
+    h3 = net.attention.lin1.register_forward_hook(lambda m, i, o: None)
+    with pytest.raises(RuntimeError, match="never"):
+        net._hooked_head_modules()
+    h3.remove()
+    h4 = enc.layer2[0].conv1.register_forward_hook(lambda m, i, o: None)
+    with pytest.raises(RuntimeError, match="never"):
+        hooks.refuse(enc.layer2[0], ["conv1", "conv2"])
+    h4.remove()
+    assert [enc.block_position(i) for i in (0, 2, 3, 11)] == [(0, 0, 3), (0, 2, 3), (1, 0, 3), (3, 2, 3)]
+    with pytest.raises(RuntimeError):
+        net.train().forward_tile_parallel(torch.zeros(4, 3, 32, 32))          # inference path only
+
+
 def test_checkpoint_roundtrip_in_reference_format(tmp_path):
     """gbm/classify_combined.py:468-474 writes {'classifier', 'optimizer'}; :521-535 reads it (full / conv-only transfer).
     The file written here must load into a plain torch.optim.Adam over the same parameters, and back."""

@@ -1,16 +1,14 @@
 """-m gpu: the device tile pre-processing (csrc/preprocess.hip through the C ABI) against outputs of Pillow itself
 (tests/golden/prep_*.npz) and against the oracle restatement — bit-exact (integer resampling, exact fp32 normalisation)."""
 import os
-import sys
 
 import numpy as np
 import pytest
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
-from make_golden import prep_inputs  # noqa: E402
-import mil_amd  # noqa: E402
-from oracle import preprocess_oracle as po  # noqa: E402
+import mil_amd
+from fixture_inputs import prep_inputs
+from oracle import preprocess_oracle as po
 
 pytestmark = pytest.mark.gpu
 CASES = ["prep_s120_r32_train", "prep_s100_r37_flat", "prep_s50_r80_train", "prep_s1200_r300_train"]

@@ -1,13 +1,11 @@
 """CPU: the pre-processing oracle against outputs of Pillow itself (tests/golden/prep_*.npz) — bit-exact."""
 import os
-import sys
 
 import numpy as np
 import pytest
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
-from make_golden import prep_inputs  # noqa: E402  (input regeneration only; nothing of the reference is imported)
-from oracle import preprocess_oracle as po  # noqa: E402
+from fixture_inputs import prep_inputs
+from oracle import preprocess_oracle as po
 
 CASES = ["prep_s120_r32_train", "prep_s100_r37_flat", "prep_s50_r80_train", "prep_s1200_r300_train"]
 

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Produces the profile evidence of one round from ONE bench.py command (run on the GPU box, from the repo root):
+#   gpurun --timeout 1100 -- 'bash tools/profile_round.sh r02'
+# 1. rocprofv3 --kernel-trace --stats          -> profiles/<round>_bench_kernel_stats.csv (+ the bench line of that run)
+# 2. --pmc FETCH_SIZE / --pmc WRITE_SIZE        (separate passes, kernel-trace only) -> profiles/pmc_traffic.json
+# 3. two SQ counter passes                      -> profiles/sq_counters.json + profiles/<round>_sq_counters.txt
+# rocprofv3 gets the program itself after `--` (python3 ...), never a wrapper.
+set -eo pipefail
+ROUND=${1:-r02}
+export TMPDIR=/tmp
+OUT=gpurun_out/prof_$ROUND
+mkdir -p $OUT profiles
+BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-extra-paths"
+
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench.err
+tail -n 1 $OUT/bench_line.json > profiles/${ROUND}_bench_line.json
+echo "bench done"
+
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths > $OUT/stats.log 2>&1
+cp "$(ls $OUT/stats/*/*kernel_stats.csv | head -n 1)" profiles/${ROUND}_bench_kernel_stats.csv
+echo "stats done"
+
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH > $OUT/fetch.log 2>&1
+echo "fetch done"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH > $OUT/write.log 2>&1
+echo "write done"
+python3 profiles/make_pmc_traffic.py $OUT/fetch $OUT/write profiles/pmc_traffic.json > $OUT/traffic.txt
+cp profiles/pmc_traffic.json profiles/${ROUND}_pmc_traffic.json
+
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d $OUT/sq1 -- $BENCH > $OUT/sq1.log 2>&1
+echo "sq1 done"
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM --output-format csv -d $OUT/sq2 -- $BENCH > $OUT/sq2.log 2>&1
+echo "sq2 done"
+python3 profiles/summarise_sq_counters.py $OUT/sq1 $OUT/sq2 profiles/sq_counters.json "$ROUND: $BENCH" > profiles/${ROUND}_sq_counters.txt
+cp profiles/sq_counters.json profiles/${ROUND}_sq_counters.json
+echo "all profiles written"
