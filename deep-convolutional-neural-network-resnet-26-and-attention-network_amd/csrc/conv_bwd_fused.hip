@@ -13,6 +13,7 @@
 // anyway for the mask) is its B operand, both read with ds_read_b64_tr_b16.  Per-workgroup partial sums
 // stay in registers across tiles and leave as one fp32 slab; a fixed-order reduction finishes them.
 #include "pf_common.cuh"
+#include <cstdlib>
 
 struct BwdFusedArgs {
     const __bf16* dz;       // [n,H,W,CZ]
@@ -24,10 +25,25 @@ struct BwdFusedArgs {
     ConvGeom g;
     int ntiles;
     int lds_w_off, lds_x_off, lds_dump_off, lds_a2_off;     // lds_a2_off: second dz-halo buffer (0 = none)
+    int lds_x2_off;         // fused16 kernel: distance to the second x-tile buffer
     int apply_mask;
     float slope;
     unsigned z_bytes, x_bytes;      // byte sizes of dz and of x/addend/dx (buffer descriptors)
+    unsigned long long* stamp;      // MIL_STAMP diagnostic build only: [grid][NW][8] phase cycle sums (else null)
 };
+
+// Diagnostic build (-DMIL_STAMP): per-wave s_memtime sums of the five phases of a tile, written behind the slab.
+// The stamps drain the LDS queue (lgkmcnt(0)) and pin the schedule: read the SHARES, never the run time.
+#ifdef MIL_STAMP
+#define MIL_ST_DECL unsigned long long st_prev = 0, st_sum[6] = {0, 0, 0, 0, 0, 0}; int st_tiles = 0; const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime();
+#define MIL_ST_T(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define MIL_ST_BEGIN() MIL_ST_T(st_prev)
+#define MIL_ST_MARK(i) { unsigned long long t_; MIL_ST_T(t_); st_sum[i] += t_ - st_prev; st_prev = t_; }
+#else
+#define MIL_ST_DECL
+#define MIL_ST_BEGIN()
+#define MIL_ST_MARK(i)
+#endif
 
 #ifndef MIL_BWD_WAVES
 #define MIL_BWD_WAVES 2
@@ -35,9 +51,13 @@ struct BwdFusedArgs {
 // NW = waves per workgroup: 4 for the 24-channel layers (two workgroups per CU), 8 for the 40/64-channel layers, whose
 // filter + tiles leave one workgroup per CU: eight waves share its LDS, every per-wave quantity halves (two row tiles of
 // data-gradient accumulators, three to five of weight-gradient ones) and each SIMD still holds two waves.
+#ifndef MIL_BWD_PIPE_MAXC
+#define MIL_BWD_PIPE_MAXC 40      // explicit one-step-ahead operand prefetch for layers up to this many channels (the 64-channel
+#endif                            // instantiation already sits at 256 VGPRs: the second operand set would spill)
 template <int CZ, int NTX, int KS, bool ADD, bool MASK, int NW = 4>
 __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES) void conv_bwd_fused_kernel(BwdFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool PIPE = CZ <= MIL_BWD_PIPE_MAXC;
     constexpr int PIXB = mil_pix_pitch(CZ, 2);            // dz halo pixel pitch
     constexpr int CG = CZ / 8;
     constexpr int CX = mil_nt_to_cp(NTX);
@@ -171,13 +191,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
     // by which time every wave has finished the previous tile's weight-gradient loop.
     const int buf_step = a.lds_a2_off;
     int buf = 0;
+    MIL_ST_DECL
     for (int tile = bid; tile < a.ntiles; tile += gridDim.x) {
+        MIL_ST_BEGIN()
         if (buf_step == 0) __syncthreads();    // single buffer: previous tile's reads of ldsA are done
         char* ldsA_t = ldsA + buf;
         buf = buf_step - buf;
         mil_commit_halo_all<NPX>(rx, ldsA_t, ht);
+        MIL_ST_MARK(0)                         // halo commit (incl. the wait for the prefetched loads)
 
         __syncthreads();                       // dz halo visible
+        MIL_ST_MARK(1)                         // barrier 1
         const bool more = tile + (int)gridDim.x < a.ntiles;
         if (more) mil_fetch_halo<CZ, NPX>(rx, rs_z, ht, g, nxt.origin(g));
         const TileOrigin o_next = nxt.origin(g);
@@ -189,6 +213,35 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
             for (int nt = 0; nt < NTX; ++nt) acc[m][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if constexpr (PIPE) {
+            // one k-step ahead: the fragment reads of step sl+1 are issued before the MFMAs of step sl, and scheduling
+            // fences keep that order (left alone, hipcc issues each read right in front of its MFMAs and waits
+            // lgkmcnt(0) per group: with two waves per SIMD the loop is then paced by LDS latency)
+            Frag8<BF16> wc[NTX], zc[MTW], wn[NTX], zn[MTW];
+#pragma unroll
+            for (int nt = 0; nt < NTX; ++nt) wc[nt] = lds_frag<BF16>(ldsW + (nt * 64 + lane) * 16);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) zc[m] = lds_frag<BF16>(ldsA_t + pixbase[m] + toff[0]);
+#pragma unroll
+            for (int sl = 0; sl < KSTEPS; ++sl) {
+                if (sl + 1 < KSTEPS) {
+#pragma unroll
+                    for (int nt = 0; nt < NTX; ++nt) wn[nt] = lds_frag<BF16>(ldsW + (((sl + 1) * NTX + nt) * 64 + lane) * 16);
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m) zn[m] = lds_frag<BF16>(ldsA_t + pixbase[m] + toff[sl + 1 < KSTEPS ? sl + 1 : sl]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < NTX; ++nt) acc[m][nt] = mma8(wc[nt], zc[m], acc[m][nt]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NTX; ++nt) wc[nt] = wn[nt];
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) zc[m] = zn[m];
+            }
+        } else {
 #pragma unroll
         for (int sl = 0; sl < KSTEPS; ++sl) {
             Frag8<BF16> wf[NTX];
@@ -202,6 +255,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
             }
         }
 
+        }
+        MIL_ST_MARK(2)                         // next-halo issue + data-gradient MFMA loop
         // x centre tile -> LDS [pixel][CX] (zeros outside the image: no contribution to dW)
 #pragma unroll
         for (int p = 0; p < NPAIR; ++p)
@@ -243,10 +298,48 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), rs_dx, off, 0, 0);
             }
         }
+        MIL_ST_MARK(3)                         // x tile write + epilogue + dx stores
         __syncthreads();                       // x centre tile visible
+        MIL_ST_MARK(4)                         // barrier 2
         if (more) fetch_xa(o_next);            // next tile's x / addend: lands while the loop below runs
 
         // ---- weight gradient: rows (tap', dz channel), cols x channel, K = the tile's 256 pixels -------
+        if constexpr (PIPE) {
+            // same, one 32-pixel k-step ahead and without branches on the wave's row-tile validity (a row tile that
+            // does not exist computes on row group 0 and is never stored); only the bias MFMA sits under a scalar branch
+            bf16x8_t xc[NTX], zc[MW], xn[NTX], zn[MW];
+            {
+                const int kb = mil_pix_base<PIXB>(g, 0, 1);
+#pragma unroll
+                for (int nt = 0; nt < NTX; ++nt) xc[nt] = mil_tr_pair(ldsX + wxl0 + nt * 32, ldsX + wxl0 + 4 * PIXX + nt * 32);
+#pragma unroll
+                for (int i = 0; i < MW; ++i) zc[i] = mil_tr_pair(ldsA_t + kb + wpl0 + wtoff[i], ldsA_t + kb + wpl1 + wtoff[i]);
+            }
+#pragma unroll
+            for (int k32 = 0; k32 < 256; k32 += 32) {
+                if (k32 + 32 < 256) {
+                    const int kb = mil_pix_base<PIXB>(g, k32 + 32, 1);
+                    const char* x0 = ldsX + (k32 + 32) * PIXX + wxl0;
+#pragma unroll
+                    for (int nt = 0; nt < NTX; ++nt) xn[nt] = mil_tr_pair(x0 + nt * 32, x0 + 4 * PIXX + nt * 32);
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) zn[i] = mil_tr_pair(ldsA_t + kb + wpl0 + wtoff[i], ldsA_t + kb + wpl1 + wtoff[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MW; ++i) {
+#pragma unroll
+                    for (int nt = 0; nt < NTX; ++nt)
+                        wacc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zc[i], xc[nt], wacc[i][nt], 0, 0, 0);
+                    if (i == bias_i) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zc[i], ones, bacc, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NTX; ++nt) xc[nt] = xn[nt];
+#pragma unroll
+                for (int i = 0; i < MW; ++i) zc[i] = zn[i];
+            }
+        } else {
 #pragma unroll 2
         for (int k32 = 0; k32 < 256; k32 += 32) {
             // pixel k = k32 + (8*gq + q4 [+4]): the halo offset is additive in the two parts (no carries between
@@ -269,7 +362,21 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
                 }
             }
         }
+        }
+        MIL_ST_MARK(5)                         // x/addend issue + weight-gradient loop
+#ifdef MIL_STAMP
+        ++st_tiles;
+#endif
     }
+#ifdef MIL_STAMP
+    if (a.stamp && lane == 0) {
+        unsigned long long* d = a.stamp + ((size_t)blockIdx.x * NW + wave) * 8;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = st_sum[i];
+        d[6] = (unsigned long long)st_tiles;
+        d[7] = __builtin_amdgcn_s_memrealtime() - st_rt0;      // 100 MHz ticks over the whole tile loop
+    }
+#endif
 
     // ---- partial sums -> slab: rows tap'*CZ + co, cols ci; bias sums in the extra row tile ---------------
     constexpr int SLAB_COLS = NTX * 16;
@@ -295,12 +402,305 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 16x16-tile form with COMPILE-TIME geometry, explicit software pipelining and no branches in the MFMA loops
+// (24-channel layers; tiles of one image, halo 18x18).  What the generic kernel above loses on these maps — measured
+// with the -DMIL_STAMP build: 2.4 k cycles in the data-gradient loop and 4.8 k in the weight-gradient loop per tile and
+// wave for 28 + 36 MFMAs (0.45 k + 0.58 k cycles of matrix pipe) — is LDS latency: hipcc issues every fragment read
+// right in front of the MFMA pair that consumes it (`s_waitcnt lgkmcnt(0)` per pair), the scalar branches on the
+// wave's row-tile validity keep it from hoisting anything, and every read pays run-time address arithmetic.  Here
+//   * tile shape and pitches are constants, so a fragment address is ONE per-lane base register + an immediate
+//     (four bases for the data gradient — the k order crosses a filter row inside k-steps 2, 4 and wraps in 6 —,
+//     four for the dz rows and one for the x tile of the weight gradient);
+//   * both loops are written one k-step ahead: the reads of step s+1 are issued, then the MFMAs of step s, with
+//     scheduling fences so the order survives (the compiler still counts the waits: builtin LDS loads);
+//   * every wave runs the same instruction stream: waves whose second row tile does not exist (rows 28..31 of 27 row
+//     groups) compute on row group 0 and never store it;
+//   * ONE barrier per tile: the x tile is prefetched and committed together with the dz halo (both double-buffered), the
+//     mask is read back from it, so between barriers a wave runs data gradient, epilogue and weight gradient at its own
+//     pace and the waves of a SIMD overlap one's MFMAs with another's epilogue instead of marching in phase;
+//   * the bias gradient needs no MFMA of its own: channel CX-1 of the x tile in LDS (a padding channel) is set to 1, so
+//     column CX-1 of the centre-tap rows of dW' is sum_q dz[q][co] (the reduction reads db from there).
+template <bool ADD, bool MASK>
+__global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CZ = 24, NTX = 2, KS = 3, NW = 8;
+    constexpr int PIXB = 48, PIXX = 48, CG = 3, CX = 24, HW = 18, ROWB = HW * PIXB;      // 864 B per halo row
+    constexpr int NTHR = 512, MTW = 2, KSTEPS = 7, RG = 27, MT = 14, MW = 2, NPX = 2;
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, gq = lane >> 4;
+    char* ldsW = smem + a.lds_w_off;
+    {
+        const int nbytes = KSTEPS * NTX * 64 * 16;
+        const char* src = reinterpret_cast<const char*>(a.w);
+        for (int i = tid * 16; i < nbytes; i += NTHR * 16)
+            *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(src + i);
+    }
+    const __amdgpu_buffer_rsrc_t rs_z = mil_rsrc(a.dz, a.z_bytes);
+    const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rs_add = mil_rsrc(a.addend, a.addend ? a.x_bytes : 0);
+    const __amdgpu_buffer_rsrc_t rs_dx = mil_rsrc(a.dx, a.x_bytes);
+    const int H = g.H, W = g.W;
+
+    // ---- halo pieces of this thread: piece id = tid + 512*i -> (halo pixel, 16-byte piece) ------------------
+    int h_pos[NPX], h_lds[NPX], h_rel[NPX];
+    const int dump_a = a.lds_w_off - 16 - a.lds_a2_off;      // 16 spare bytes behind each halo buffer
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+        const int idx = tid + NTHR * i;
+        const bool used = idx < HW * HW * CG;
+        const int px = idx / CG, j = idx - px * CG, hy = px / HW, hx = px - hy * HW;
+        h_pos[i] = used ? (hy << 10) | hx : -1;
+        h_lds[i] = used ? px * PIXB + j * 16 : dump_a;
+        h_rel[i] = (hy * W + hx) * (CZ * 2) + j * 16;
+    }
+    u32x4_t rx[NPX];
+    auto fetch_halo = [&](const TileOrigin& o) {
+        const int iy0 = o.oy0 - 1, ix0 = o.ox0 - 1;
+        const int base = ((o.img0 * H + iy0) * W + ix0) * (CZ * 2);      // may be negative; valid lanes are not
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            const int p = h_pos[i];
+            const bool ok = p >= 0 && (unsigned)(iy0 + (p >> 10)) < (unsigned)H && (unsigned)(ix0 + (p & 1023)) < (unsigned)W;
+            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_z, ok ? (unsigned)(base + h_rel[i]) : MIL_OOB, 0, 0);
+        }
+    };
+
+    // ---- data gradient: fragment address = per-lane base + immediate -----------------------------------------
+    // k index q = 4*sl + gq = (tap, 8-channel group); halo offset of q relative to the pixel's top-left tap
+    auto koff = [](int q) { int tap = q / CG, cg = q - tap * CG; if (tap >= KS * KS) { tap = 0; cg = 0; }
+                            return ((tap / KS) * HW + (tap % KS)) * PIXB + cg * 16; };
+    const int bA = (wave * MTW * HW + r) * PIXB + 16 * gq;        // pixel (row 2*wave [+m], col r), lane group part
+    int zb[KSTEPS];
+#pragma unroll
+    for (int sl = 0; sl < KSTEPS; ++sl) {
+        const int o0 = koff(4 * sl);
+        const int d1 = koff(4 * sl + 1) - o0 - 16, d2 = koff(4 * sl + 2) - o0 - 32, d3 = koff(4 * sl + 3) - o0 - 48;
+        zb[sl] = bA + (gq == 1 ? d1 : gq == 2 ? d2 : gq == 3 ? d3 : 0);      // all-zero deltas fold to bA itself
+    }
+    // ---- epilogue pair: after the permlane swap a lane holds 8 consecutive channels of pixel (2*wave + (gq&1), r)
+    const int e_ty = wave * MTW + (gq & 1);
+    const int o_rel = (e_ty * W + r) * (CX * 2) + (gq >> 1) * 16;
+    const int x_lds = (e_ty * 16 + r) * PIXX + (gq >> 1) * 16;       // own 16-byte piece(s) inside an x-tile buffer
+    const bool last_ok = (gq >> 1) == 0;                           // channels 24..31 do not exist
+    // ---- weight gradient: rows (tap', 8 dz channels) of row tiles mt = wave, wave + 8; K = the 256 centre pixels
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3;
+    int zw[MW][2];
+    {
+        const int kl0 = 8 * gq + q4, kl1 = kl0 + 4;               // pixel of this lane inside a 32-pixel k-step
+        const int wpl0 = ((kl0 >> 4) * HW + (kl0 & 15)) * PIXB, wpl1 = ((kl1 >> 4) * HW + (kl1 & 15)) * PIXB;
+#pragma unroll
+        for (int i = 0; i < MW; ++i) {
+            int rg = 2 * (wave + NW * i) + (p4 >> 1);
+            if (rg >= RG) rg = 0;                                  // a row tile that does not exist: finite data, never stored
+            const int tap = rg / CG, cg = rg - tap * CG;
+            const int wt = ((tap / KS) * HW + (tap % KS)) * PIXB + cg * 16 + (p4 & 1) * 8;
+            zw[i][0] = wpl0 + wt; zw[i][1] = wpl1 + wt;
+        }
+    }
+    const int xb = (8 * gq + q4) * PIXX + p4 * 8;                     // inside an x-tile buffer
+    f32x4_t wacc[MW][NTX];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int nt = 0; nt < NTX; ++nt) wacc[i][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    TileWalker cur, nxt;
+    const int bid = mil_xcd_block_id();
+    cur.init(g, bid, gridDim.x);
+    nxt = cur; nxt.advance();
+    if (bid < a.ntiles) fetch_halo(cur.origin(g));
+    // x (mask source + weight-gradient operand) is prefetched with the halo and committed to LDS with it, so ONE barrier
+    // per tile orders everything; the addend is only needed in the epilogue and is prefetched right after the previous one.
+    unsigned ooff = MIL_OOB, ooff_n = MIL_OOB;
+    u32x4_t rxc[NTX], radd[NTX];
+    auto fetch_x = [&](const TileOrigin& o) {
+        const int obase = ((o.img0 * H + o.oy0) * W + o.ox0) * (CX * 2);
+        const bool ok = e_ty < H - o.oy0 && r < W - o.ox0;
+        ooff_n = ok ? (unsigned)(obase + o_rel) : MIL_OOB;
+#pragma unroll
+        for (int nt = 0; nt < NTX; ++nt)
+            rxc[nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (nt == NTX - 1 && !last_ok) ? MIL_OOB : ooff_n + nt * 32, 0, 0);
+    };
+    auto fetch_add = [&]() {
+        if constexpr (ADD) {
+#pragma unroll
+            for (int nt = 0; nt < NTX; ++nt)
+                radd[nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, (nt == NTX - 1 && !last_ok) ? MIL_OOB : ooff_n + nt * 32, 0, 0);
+        }
+    };
+    if (bid < a.ntiles) { fetch_x(cur.origin(g)); fetch_add(); }
+
+    const int buf_step = a.lds_a2_off, xbuf_step = a.lds_x2_off;
+    int buf = 0, xbuf = 0;
+    MIL_ST_DECL
+    for (int tile = bid; tile < a.ntiles; tile += gridDim.x) {
+        MIL_ST_BEGIN()
+        // Two halo buffers and two x-tile buffers: a wave may commit tile t+1 while others still compute tile t (they
+        // read the other buffers); it can reach tile t+2's commit only past barrier t+1, i.e. after every wave left tile t.
+        char* ldsA_t = smem + buf;
+        char* ldsX_t = smem + a.lds_x_off + xbuf;
+        buf = buf_step - buf;
+        xbuf = xbuf_step - xbuf;
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) *reinterpret_cast<u32x4_t*>(ldsA_t + h_lds[i]) = rx[i];
+        // x centre tile -> LDS [pixel][CX] (zeros outside the image); its padding channel CX-1 := 1 (bias sums)
+#pragma unroll
+        for (int nt = 0; nt < NTX; ++nt) {
+            u32x4_t v = rxc[nt];
+            if (nt == NTX - 1) v[3] = (v[3] & 0xffffu) | 0x3f800000u;
+            char* dst = (nt == NTX - 1 && !last_ok) ? smem + a.lds_dump_off : ldsX_t + x_lds + nt * 32;
+            *reinterpret_cast<u32x4_t*>(dst) = v;
+        }
+        ooff = ooff_n;
+        MIL_ST_MARK(0)
+        __syncthreads();                       // dz halo and x tile visible: the tile's only barrier
+        MIL_ST_MARK(1)
+        const bool more = tile + (int)gridDim.x < a.ntiles;
+        if (more) { const TileOrigin o_next = nxt.origin(g); fetch_halo(o_next); fetch_x(o_next); }
+        cur = nxt; nxt.advance();
+        // own x pieces back from LDS for the LeakyReLU mask of the epilogue (their registers now hold the next tile's)
+        u32x4_t mk[NTX];
+        if constexpr (MASK) {
+#pragma unroll
+            for (int nt = 0; nt < NTX; ++nt)
+                mk[nt] = *reinterpret_cast<const u32x4_t*>((nt == NTX - 1 && !last_ok) ? smem + a.lds_dump_off : ldsX_t + x_lds + nt * 32);
+        }
+
+        // ---- data gradient D[cx][pixel], one k-step ahead ----------------------------------------------------
+        f32x4_t acc[MTW][NTX];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NTX; ++nt) acc[m][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        {
+            Frag8<BF16> wc[NTX], zc[MTW], wn[NTX], zn[MTW];
+#pragma unroll
+            for (int nt = 0; nt < NTX; ++nt) wc[nt] = lds_frag<BF16>(ldsW + (nt * 64 + lane) * 16);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) zc[m] = lds_frag<BF16>(ldsA_t + zb[0] + koff(0) + m * ROWB);
+#pragma unroll
+            for (int sl = 0; sl < KSTEPS; ++sl) {
+                if (sl + 1 < KSTEPS) {
+#pragma unroll
+                    for (int nt = 0; nt < NTX; ++nt) wn[nt] = lds_frag<BF16>(ldsW + (((sl + 1) * NTX + nt) * 64 + lane) * 16);
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m) zn[m] = lds_frag<BF16>(ldsA_t + zb[sl + 1] + koff(4 * (sl + 1)) + m * ROWB);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < NTX; ++nt) acc[m][nt] = mma8(wc[nt], zc[m], acc[m][nt]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NTX; ++nt) wc[nt] = wn[nt];
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) zc[m] = zn[m];
+            }
+        }
+        MIL_ST_MARK(2)
+
+        // ---- data-gradient epilogue from registers, 8 channels per lane ----------------------------------------
+#pragma unroll
+        for (int nt = 0; nt < NTX; ++nt) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float lo = acc[0][nt][i], hi = acc[1][nt][i];
+                if (i == 0) mil_swap16<true>(lo, hi); else mil_swap16<false>(lo, hi);
+                v[i] = lo;
+                v[4 + i] = hi;
+            }
+            if constexpr (ADD) {
+                const bf16x8_t t = __builtin_bit_cast(bf16x8_t, radd[nt]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += (float)t[i];
+            }
+            if constexpr (MASK) {
+                const bf16x8_t t = __builtin_bit_cast(bf16x8_t, mk[nt]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] *= ((float)t[i] > 0.f ? 1.f : a.slope);
+            }
+            bf16x8_t ov;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ov[i] = (__bf16)v[i];
+            const unsigned off = (nt == NTX - 1 && !last_ok) ? MIL_OOB : ooff + nt * 32;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), rs_dx, off, 0, 0);
+        }
+        MIL_ST_MARK(3)
+        if (more) fetch_add();                 // next tile's addend: its registers are free now
+        MIL_ST_MARK(4)
+
+        // ---- weight gradient, one k-step (32 pixels = two tile rows) ahead ----------------------------------------
+        {
+            bf16x8_t xc[NTX], zc[MW], xn[NTX], zn[MW];
+#pragma unroll
+            for (int nt = 0; nt < NTX; ++nt) xc[nt] = mil_tr_pair(ldsX_t + xb + nt * 32, ldsX_t + xb + nt * 32 + 4 * PIXX);
+#pragma unroll
+            for (int i = 0; i < MW; ++i) zc[i] = mil_tr_pair(ldsA_t + zw[i][0], ldsA_t + zw[i][1]);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                if (kk + 1 < 8) {
+#pragma unroll
+                    for (int nt = 0; nt < NTX; ++nt)
+                        xn[nt] = mil_tr_pair(ldsX_t + xb + (kk + 1) * 32 * PIXX + nt * 32, ldsX_t + xb + (kk + 1) * 32 * PIXX + nt * 32 + 4 * PIXX);
+#pragma unroll
+                    for (int i = 0; i < MW; ++i)
+                        zn[i] = mil_tr_pair(ldsA_t + zw[i][0] + (kk + 1) * 2 * ROWB, ldsA_t + zw[i][1] + (kk + 1) * 2 * ROWB);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MW; ++i)
+#pragma unroll
+                    for (int nt = 0; nt < NTX; ++nt)
+                        wacc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zc[i], xc[nt], wacc[i][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NTX; ++nt) xc[nt] = xn[nt];
+#pragma unroll
+                for (int i = 0; i < MW; ++i) zc[i] = zn[i];
+            }
+        }
+        MIL_ST_MARK(5)
+#ifdef MIL_STAMP
+        ++st_tiles;
+#endif
+    }
+#ifdef MIL_STAMP
+    if (a.stamp && lane == 0) {
+        unsigned long long* d = a.stamp + ((size_t)blockIdx.x * NW + wave) * 8;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = st_sum[i];
+        d[6] = (unsigned long long)st_tiles;
+        d[7] = __builtin_amdgcn_s_memrealtime() - st_rt0;      // 100 MHz ticks over the whole tile loop
+    }
+#endif
+    // ---- partial sums -> slab: rows tap'*CZ + co, cols ci (col CX-1 of the centre-tap rows = bias sums) ---------
+    constexpr int SLAB_COLS = NTX * 16;
+    constexpr size_t SLAB_ELEMS = (size_t)(MT + 1) * 16 * SLAB_COLS;
+    float* slab = a.slab + (size_t)blockIdx.x * SLAB_ELEMS;
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+        const int mt = wave + NW * i;
+        if (mt >= MT) continue;
+#pragma unroll
+        for (int nt = 0; nt < NTX; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                slab[(size_t)(mt * 16 + gq * 4 + e) * SLAB_COLS + nt * 16 + r] = wacc[i][nt][e];
+    }
+}
+
 // Fixed-order slab reduction for the fused kernel's layout: row = tap'*CZ + co (tap' = flipped tap),
 // col = ci  ->  dW[co][ci][k*k-1-tap'];  db from the extra row tile.
 __global__ __launch_bounds__(32 * MIL_RED_GROUPS) void wgrad_reduce_t_kernel(const float* __restrict__ slab, int nslab, size_t slab_elems,
                                                              int slab_cols, int n_rows, float* __restrict__ dw,
                                                              float* __restrict__ db, int cout, int cin, int ks, int czp,
-                                                             int bias_off, int accumulate) {
+                                                             int bias_off, int bias_stride, int accumulate) {
     __shared__ float part[MIL_RED_GROUPS][32];
     const int c = threadIdx.x & 31, gq = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + c;
@@ -308,7 +708,7 @@ __global__ __launch_bounds__(32 * MIL_RED_GROUPS) void wgrad_reduce_t_kernel(con
     float s = 0.f;
     const bool live = e < total;
     if (live) {
-        const size_t src = e < n_rows * slab_cols ? (size_t)e : (size_t)bias_off + (e - n_rows * slab_cols);
+        const size_t src = e < n_rows * slab_cols ? (size_t)e : (size_t)bias_off + (size_t)(e - n_rows * slab_cols) * bias_stride;
         s = mil_slab_partial(slab, slab_elems, src, gq, nslab);
     }
     part[gq][c] = s;
@@ -327,6 +727,13 @@ __global__ __launch_bounds__(32 * MIL_RED_GROUPS) void wgrad_reduce_t_kernel(con
     if (ci >= cin || co >= cout) return;
     float* q = dw + ((size_t)co * cin + ci) * (ks * ks) + (ks * ks - 1 - tapf);
     *q = accumulate ? *q + v : v;
+}
+
+// MIL_BWD16=0 falls back to the generic kernel on 16x16 tiles too (A/B runs, bit-compatible results up to the bias
+// gradient's summation path)
+static bool mil_bwd16_enabled() {
+    static const bool v = [] { const char* e = getenv("MIL_BWD16"); return !(e && e[0] == '0'); }();
+    return v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -358,11 +765,20 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
     const int w_bytes = KSTEPS * NTX * 64 * 16;
     const int x_bytes = 256 * PIXX;
     const bool dbuf = 2 * (2 * a_bytes + w_bytes + x_bytes + 16) <= 160 * 1024;      // second halo buffer if two workgroups still fit
-    const int lds = (dbuf ? 2 : 1) * a_bytes + w_bytes + x_bytes + 16;          // + dump slot for the x-tile writes
+    // 24-channel layers on 16x16 tiles of one image: the compile-time-geometry, software-pipelined, one-barrier form
+    // (two halo buffers AND two x-tile buffers: 70 KB, two workgroups per CU)
+    bool t16 = false;
+    if constexpr (CZ == 24 && NTX == 2 && KS == 3 && NW == 8)
+        t16 = mil_bwd16_enabled() && dbuf && a.g.tw_log2 == 4 && a.g.th_log2 == 4 && a.g.ti_log2 == 0 && a.g.H < 1024 && a.g.W < 1024;
+    const int lds = (dbuf ? 2 : 1) * a_bytes + w_bytes + (t16 ? 2 : 1) * x_bytes + 16;          // + dump slot for the x-tile writes
     if (lds > 160 * 1024) return MIL_ERR_UNSUPPORTED;
     const int ntiles = a.g.n_groups * a.g.tiles_y * a.g.tiles_x;
     auto kern = a.addend ? (a.apply_mask ? conv_bwd_fused_kernel<CZ, NTX, KS, true, true, NW> : conv_bwd_fused_kernel<CZ, NTX, KS, true, false, NW>)
                          : (a.apply_mask ? conv_bwd_fused_kernel<CZ, NTX, KS, false, true, NW> : conv_bwd_fused_kernel<CZ, NTX, KS, false, false, NW>);
+    if constexpr (CZ == 24 && NTX == 2 && KS == 3 && NW == 8) {
+        if (t16) kern = a.addend ? (a.apply_mask ? conv_bwd_fused16_kernel<true, true> : conv_bwd_fused16_kernel<true, false>)
+                                 : (a.apply_mask ? conv_bwd_fused16_kernel<false, true> : conv_bwd_fused16_kernel<false, false>);
+    }
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return MIL_ERR_LAUNCH;
@@ -371,20 +787,35 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
     // on the ADD/MASK variant's few registers, but take the minimum over the variants to be safe
     int per_cu = 3;
     {
-        const int o1 = mil_resident_per_cu(conv_bwd_fused_kernel<CZ, NTX, KS, true, true, NW>, lds, 3, 64 * NW);
-        const int o2 = mil_resident_per_cu(conv_bwd_fused_kernel<CZ, NTX, KS, false, true, NW>, lds, 3, 64 * NW);
-        const int o3 = mil_resident_per_cu(conv_bwd_fused_kernel<CZ, NTX, KS, true, false, NW>, lds, 3, 64 * NW);
+        int o1 = mil_resident_per_cu(conv_bwd_fused_kernel<CZ, NTX, KS, true, true, NW>, lds, 3, 64 * NW);
+        int o2 = mil_resident_per_cu(conv_bwd_fused_kernel<CZ, NTX, KS, false, true, NW>, lds, 3, 64 * NW);
+        int o3 = mil_resident_per_cu(conv_bwd_fused_kernel<CZ, NTX, KS, true, false, NW>, lds, 3, 64 * NW);
+        if constexpr (CZ == 24 && NTX == 2 && KS == 3 && NW == 8) {
+            if (t16) {
+                o1 = mil_resident_per_cu(conv_bwd_fused16_kernel<true, true>, lds, 3, 512);
+                o2 = mil_resident_per_cu(conv_bwd_fused16_kernel<false, true>, lds, 3, 512);
+                o3 = mil_resident_per_cu(conv_bwd_fused16_kernel<true, false>, lds, 3, 512);
+            }
+        }
         per_cu = o1 < o2 ? o1 : o2; per_cu = per_cu < o3 ? per_cu : o3;
     }
     int grid = mil_num_cus() * per_cu;
     if (grid > ntiles) grid = ntiles;
     const size_t slab_elems = (size_t)(MT + 1) * 16 * NTX * 16;
-    const size_t bytes = slab_elems * grid * sizeof(float);
+    size_t bytes = slab_elems * grid * sizeof(float);
+#ifdef MIL_STAMP
+    const size_t stamp_off = (bytes + 15) & ~(size_t)15;
+    bytes = stamp_off + (size_t)grid * NW * 8 * sizeof(unsigned long long);
+#endif
     if (query) { *need = bytes; return MIL_OK; }
     if (!ws || ws_bytes < bytes) return MIL_ERR_ARG;
+#ifdef MIL_STAMP
+    a.stamp = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + stamp_off);
+#endif
     const int a_tot = (dbuf ? 2 : 1) * a_bytes;
-    a.slab = (float*)ws; a.lds_w_off = a_tot; a.lds_x_off = a_tot + w_bytes; a.lds_dump_off = a_tot + w_bytes + x_bytes;
+    a.slab = (float*)ws; a.lds_w_off = a_tot; a.lds_x_off = a_tot + w_bytes; a.lds_dump_off = a_tot + w_bytes + x_bytes * (t16 ? 2 : 1);
     a.lds_a2_off = dbuf ? a_bytes : 0;
+    a.lds_x2_off = t16 ? x_bytes : 0;
     if (grid <= 0) return MIL_OK;
     const int n_rows = KS * KS * CZ;
     const int total = n_rows * NTX * 16 + CZ;
@@ -404,7 +835,8 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
         hipLaunchKernelGGL(kern, dim3(gr), dim3(64 * NW), lds, stream, c);
         MIL_CHECK_LAUNCH();
         hipLaunchKernelGGL(wgrad_reduce_t_kernel, dim3((total + 31) / 32), dim3(32 * MIL_RED_GROUPS), 0, stream, (const float*)ws, gr, slab_elems,
-                           NTX * 16, n_rows, dw, db, cout, cin, KS, CZ, MT * 16 * NTX * 16, (i0 > 0) ? 1 : accumulate);
+                           NTX * 16, n_rows, dw, db, cout, cin, KS, CZ,
+                           t16 ? (KS * KS / 2) * CZ * NTX * 16 + (CX - 1) : MT * 16 * NTX * 16, t16 ? NTX * 16 : 1, (i0 > 0) ? 1 : accumulate);
         MIL_CHECK_LAUNCH();
     }
     return MIL_OK;
