@@ -164,6 +164,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs<T> a) {
 #ifndef MIL_PF_WAVES_24
 #define MIL_PF_WAVES_24 3
 #endif
+// which instantiations get the explicit one-step-ahead operand prefetch (it costs a second operand register set)
+#ifndef MIL_PF_PIPE
+// measured: no gain on the 64/80-channel forms (56.0/52.5 -> 56.8/50.2 us per launch); the 24/40-channel forms sit at their
+// VGPR cap (3-4 waves per SIMD) and a second operand set spills -> off
+#define MIL_PF_PIPE(CINP, NT, MTW, NW) false
+#endif
 // NW = waves per workgroup: 4, or 8 for the layers whose resident filter leaves room for only ONE workgroup per CU
 // (64 channels: 72 KB of filter) — eight waves on the same LDS tiles give every SIMD a second wave to overlap with.
 template <int CINP, int NT, int KS, int MTW, int FLAGS = -1, int NW = 4>
@@ -171,6 +177,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? (CINP <= 40 ? 4 : 2) : ((MTW == 
 void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsigned y_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using T = BF16;
+    constexpr bool PIPE = MIL_PF_PIPE(CINP, NT, MTW, NW);
     constexpr int PIXB = mil_pix_pitch(CINP, 2);
     constexpr int CG = CINP / 8;
     constexpr int COUTP = mil_nt_to_cp(NT);
@@ -337,6 +344,34 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[m][nt] = bias_r[nt];
+        if constexpr (PIPE) {
+            // one k-step ahead: the fragment reads of step sl+1 are issued before the MFMAs of step sl and scheduling fences
+            // keep that order (left alone, hipcc issues every read right in front of its MFMAs behind an lgkmcnt(0))
+            Frag8<T> wc[NT], xc[MTW], wn[NT], xn[MTW];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wc[nt] = lds_frag<T>(ldsW + (nt * 64 + lane) * 16);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) xc[m] = lds_frag<T>(ldsA_t + pixbase[m] + toff[0]);
+#pragma unroll
+            for (int sl = 0; sl < KSTEPS; ++sl) {
+                if (sl + 1 < KSTEPS) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) wn[nt] = lds_frag<T>(ldsW + (((sl + 1) * NT + nt) * 64 + lane) * 16);
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m) xn[m] = lds_frag<T>(ldsA_t + pixbase[m] + toff[sl + 1 < KSTEPS ? sl + 1 : sl]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wc[nt], xc[m], acc[m][nt]);   // D[channel][pixel]
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) wc[nt] = wn[nt];
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) xc[m] = xn[m];
+            }
+        } else {
 #pragma unroll
         for (int sl = 0; sl < KSTEPS; ++sl) {
             Frag8<T> wf[NT];
@@ -348,6 +383,8 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wf[nt], xf, acc[m][nt]);   // D[channel][pixel]
             }
+        }
+
         }
 
         // register epilogue on 8 channels per lane (see "Epilogue layout" above); 4 channels per lane when unpaired

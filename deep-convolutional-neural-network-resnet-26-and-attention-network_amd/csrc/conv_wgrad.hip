@@ -453,7 +453,11 @@ struct StemBwdArgs {
 };
 
 #ifndef MIL_STEM_BWD_WAVES
-#define MIL_STEM_BWD_WAVES 3       // measured: 1209 us at 2 waves/SIMD, 1161 us at 3 (30 spilled VGPRs), 2102 us at 4
+#define MIL_STEM_BWD_WAVES 2       // measured (us per launch, 2048 tiles): no prefetch 1285 @2 waves/SIMD, 1083 @3 (30 spilled VGPRs), 2102 @4;
+                                   // one-step-ahead prefetch (MIL_STEM_BWD_PIPE) 1025 @2 (193 VGPRs, no spill), 1237 @3 (spills)
+#endif
+#ifndef MIL_STEM_BWD_PIPE
+#define MIL_STEM_BWD_PIPE 1
 #endif
 __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel(StemBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -521,17 +525,15 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
         const int tap = rg / CG, cg = rg - tap * CG;
         toff[i] = ((tap / KS) * g.hw + (tap % KS)) * PIXB + cg * 16 + (p & 1) * 8;
     }
-    const bool bias_wave = wave == 0;
-    f32x4_t acc[MW][NT], accb[NT];
+    // The bias gradient sum_p dz[p][co] needs no MFMA of its own: s2d channel 12 (a padding channel, zero in HBM) is set
+    // to 1 in the LDS halo tile, so row (tap, channel 12) of dW' is that sum for every tap; the reduction reads db from
+    // row (tap 0, channel 12).  Every wave then issues the same 64 MFMAs per tile (wave 0 used to issue 16 more).
+    const unsigned one_ch12 = (tid & 1) ? 0x3F80u : 0u;       // odd piece ids hold channels 8..15: dword 2 = channels 12, 13
+    f32x4_t acc[MW][NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        accb[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int i = 0; i < MW; ++i) acc[i][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    }
-    bf16x8_t ones;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
     const int q4 = (lane & 15) >> 2, p4 = lane & 3, gq = lane >> 4;
     const int wpl0 = mil_pix_base<PIXB>(g, 8 * gq + q4, 1), wpl1 = mil_pix_base<PIXB>(g, 8 * gq + q4 + 4, 1);
     // dz builder: thread -> (2x2 pixel block, 6-channel group) of the tile: 64 blocks x 4 groups = all 256 threads
@@ -552,6 +554,8 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
     }
     for (int tile = bid; tile < a.ntiles; tile += gridDim.x) {
         __syncthreads();                         // previous tile's MFMA loop is done with ldsX / ldsZ
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) rx[i][2] |= one_ch12;
         mil_commit_halo<NPX>(rx, ldsX, ht);
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
@@ -626,6 +630,46 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
         __syncthreads();
 
         // ---- weight gradient: rows (tap, s2d channel), cols stem channel, K = the tile's 256 pixels ---------
+        // One 32-pixel k-step ahead (MIL_STEM_BWD_PIPE): the transposed reads of step k+1 are issued before the MFMAs of
+        // step k and scheduling fences keep that order.  Left to itself hipcc reads each row tile's fragment right in
+        // front of its two MFMAs behind an lgkmcnt(0): five LDS round trips per k-step, forty per tile — the whole tile
+        // time of this kernel.  Every wave owns MW = 4 row tiles that all exist (MT = 16), so there is no validity branch.
+#if MIL_STEM_BWD_PIPE
+        {
+            static_assert(MT == 4 * MW, "every wave owns MW full row tiles");
+            bf16x8_t bc[NT], ac[MW], bn[NT], an[MW];
+            {
+                const int kb = mil_pix_base<PIXB>(g, 0, 1);
+                const char* z0 = ldsZ + (8 * gq + q4) * PIXZ + p4 * 8;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bc[nt] = mil_tr_pair(z0 + nt * 32, z0 + 4 * PIXZ + nt * 32);
+#pragma unroll
+                for (int i = 0; i < MW; ++i) ac[i] = mil_tr_pair(ldsX + kb + wpl0 + toff[i], ldsX + kb + wpl1 + toff[i]);
+            }
+#pragma unroll
+            for (int k32 = 0; k32 < 256; k32 += 32) {
+                if (k32 + 32 < 256) {
+                    const int kb = mil_pix_base<PIXB>(g, k32 + 32, 1);
+                    const char* z0 = ldsZ + (k32 + 32 + 8 * gq + q4) * PIXZ + p4 * 8;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bn[nt] = mil_tr_pair(z0 + nt * 32, z0 + 4 * PIXZ + nt * 32);
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) an[i] = mil_tr_pair(ldsX + kb + wpl0 + toff[i], ldsX + kb + wpl1 + toff[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MW; ++i)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[i], bc[nt], acc[i][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bc[nt] = bn[nt];
+#pragma unroll
+                for (int i = 0; i < MW; ++i) ac[i] = an[i];
+            }
+        }
+#else
 #pragma unroll 2
         for (int k32 = 0; k32 < 256; k32 += 32) {
             const int kb = mil_pix_base<PIXB>(g, k32, 1);
@@ -644,12 +688,8 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
                         acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[nt], acc[i][nt], 0, 0, 0);
                 }
             }
-            if (bias_wave) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    accb[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bf[nt], accb[nt], 0, 0, 0);
-            }
         }
+#endif
     }
 
     constexpr int SLAB_COLS = NT * 16;
@@ -665,13 +705,6 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 slab[(size_t)(mt * 16 + gq * 4 + e) * SLAB_COLS + nt * 16 + col] = acc[i][nt][e];
-    }
-    if (bias_wave) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                slab[(size_t)(MT * 16 + gq * 4 + e) * SLAB_COLS + nt * 16 + col] = accb[nt][e];
     }
 }
 
@@ -709,7 +742,7 @@ static int stem_bwd_entry(const void* xs, const void* gp, const uint8_t* widx, f
     const int n_rows = 16 * 16;
     const int total = (n_rows + 1) * 32;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(32 * MIL_RED_GROUPS), 0, st, (const float*)ws, grid, slab_elems, 32,
-                       n_rows, dw, db, 20, 3, 7, 16, 1, MT * 16, accumulate);
+                       n_rows, dw, db, 20, 3, 7, 16, 1, /*bias row = (tap 0, s2d channel 12), see the kernel*/ 12, accumulate);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

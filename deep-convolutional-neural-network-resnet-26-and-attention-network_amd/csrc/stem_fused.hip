@@ -14,6 +14,10 @@
 // are in flight on the same L2.
 #include "pf_common.cuh"
 
+#ifndef MIL_STEM_FWD_LOOKAHEAD
+#define MIL_STEM_FWD_LOOKAHEAD 2      // pixel fragments read this many (k-step, row tile) steps ahead of their MFMAs; 0 = compiler order
+#endif
+
 struct StemFwdArgs {
     const float* x;            // [n,3,H,W]
     const __bf16* w;           // MIL_PACK_STEM fragments [8][NT][64][8]
@@ -177,6 +181,37 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 
         for (int m = 0; m < SF_MT; ++m)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[m][nt] = bias_r[nt];
+#if MIL_STEM_FWD_LOOKAHEAD > 0
+        {
+            // The (k-step, row tile) loop flattened into one software pipeline: the pixel fragment of step j+LA is read
+            // LA steps before the two MFMAs that consume it (a ring of LA+1 fragments), the filter fragments one k-step
+            // ahead, and scheduling fences keep that order.  Left alone, hipcc reads each fragment right in front of its
+            // MFMA pair behind an lgkmcnt(0): 72 LDS round trips per tile and wave, two thirds of this kernel's time.
+            constexpr int TOT = KSTEPS * SF_MT, LA = MIL_STEM_FWD_LOOKAHEAD, R = LA + 1;
+            Frag8<BF16> ring[R], wq[2][NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wq[0][nt] = lds_frag<BF16>(ldsW + (nt * 64 + lane) * 16);
+#pragma unroll
+            for (int j = 0; j < LA; ++j)
+                ring[j % R] = lds_frag<BF16>(ldsX + pixbase[j % SF_MT] + (((j / SF_MT) >> 1) * SF_XW + 2 * ((j / SF_MT) & 1)) * SF_XPIX);
+#pragma unroll
+            for (int j = 0; j < TOT; ++j) {
+                const int sl = j / SF_MT, m = j % SF_MT;
+                if (j + LA < TOT) {
+                    const int jn = j + LA, sn = jn / SF_MT;
+                    ring[jn % R] = lds_frag<BF16>(ldsX + pixbase[jn % SF_MT] + ((sn >> 1) * SF_XW + 2 * (sn & 1)) * SF_XPIX);
+                }
+                if (m == 0 && sl + 1 < KSTEPS) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) wq[(sl + 1) & 1][nt] = lds_frag<BF16>(ldsW + (((sl + 1) * NT + nt) * 64 + lane) * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wq[sl & 1][nt], ring[j % R], acc[m][nt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#else
 #pragma unroll
         for (int sl = 0; sl < KSTEPS; ++sl) {
             Frag8<BF16> wf[NT];
@@ -189,6 +224,7 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 
                 for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wf[nt], xf, acc[m][nt]);
             }
         }
+#endif
         // Stem pixels outside the image are the pool's -inf padding: written as such, so that the pool phase below
         // needs no per-tap bounds tests (only tiles on the image border have any).
         const int sy0 = 16 * ty - 1, sx0 = 32 * tx - 1;           // image coordinates of stem-tile pixel (0,0)
