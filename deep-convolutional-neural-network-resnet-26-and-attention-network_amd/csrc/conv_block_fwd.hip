@@ -169,6 +169,11 @@ __global__ __launch_bounds__(64 * NW, (CP <= 24 ? 2 : 1) * (NW == 8 ? 2 : 1)) vo
                 for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<BF16>(ldsW1 + ((sl * NT + nt) * 64 + lane) * 16);
 #pragma unroll
                 for (int i = 0; i < MT1; ++i) {
+#ifndef MIL_BLOCK_KEEP_DUMMY
+                    // row tiles 21..23 lie entirely behind the 324 mid pixels (their results go to the dump slot): skipped
+                    // under a scalar (wave-uniform) branch — 3 of 24 row tiles of conv1's MFMA work
+                    if (i == MT1 - 1 && (wave + NW * i) * 16 >= 324) continue;
+#endif
                     const Frag8<BF16> xf = lds_frag<BF16>(ldsX + pixbase1[i] + toff1[sl]);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc[i][nt] = mma8(wf[nt], xf, acc[i][nt]);

@@ -654,10 +654,14 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < MW; ++i)
+                for (int i = 0; i < MW; ++i) {
+                    // waves 6 and 7 own only one of the 14 row tiles: their second set of MFMAs would multiply into a
+                    // tile that is never stored — skipped under a scalar (wave-uniform) branch, the reads stay (-1 %)
+                    if (i == MW - 1 && wave + NW * i >= MT) continue;
 #pragma unroll
                     for (int nt = 0; nt < NTX; ++nt)
                         wacc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zc[i], xc[nt], wacc[i][nt], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int nt = 0; nt < NTX; ++nt) xc[nt] = xn[nt];

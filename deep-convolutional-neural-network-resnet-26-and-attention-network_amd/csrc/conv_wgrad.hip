@@ -571,6 +571,7 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
         }
         cur = nxt; nxt.advance();
 
+#ifndef MIL_EXP_STEM_NO_GATHER
         // ---- dz tile = lrelu'(stem) * maxpool^T(g): gather over the 4 windows that cover a 2x2 block --------
         // A window's gradient goes to exactly one pixel (its recorded winner tap); per (window, channel) the tap and
         // the masked gradient are decoded once, then tested against the (at most 4) taps this block's pixels have in
@@ -627,9 +628,11 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
                     }
                 }
         }
+#endif
         __syncthreads();
 
         // ---- weight gradient: rows (tap, s2d channel), cols stem channel, K = the tile's 256 pixels ---------
+#ifndef MIL_EXP_STEM_NO_MFMA
         // One 32-pixel k-step ahead (MIL_STEM_BWD_PIPE): the transposed reads of step k+1 are issued before the MFMAs of
         // step k and scheduling fences keep that order.  Left to itself hipcc reads each row tile's fragment right in
         // front of its two MFMAs behind an lgkmcnt(0): five LDS round trips per k-step, forty per tile — the whole tile
@@ -690,6 +693,7 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
             }
         }
 #endif
+#endif      // MIL_EXP_STEM_NO_MFMA
     }
 
     constexpr int SLAB_COLS = NT * 16;
