@@ -237,21 +237,21 @@ def roofline_record(args, spans, peak, copy_gbps, achieved_model_tflops):
     kname = {
         "block_fwd": "conv_block_fwd_kernel<24,..> (whole identity block forward: conv-lrelu-conv-add-lrelu, 20 ch",
         "conv": "conv_igemm_pf_kernel<24,2,3,4> (3x3 s1 forward conv, 20->20 ch",
-        "bwd_fused": "conv_bwd_fused_kernel<24,2,3,..> (fused data+weight gradient of the 3x3 s1 conv, 20->20 ch",
+        "bwd_fused": "conv_bwd_fused16_kernel<ADD,MASK> (fused data+weight gradient of the 3x3 s1 conv, 16x16 tiles, 20->20 ch",
         "block_bwd": "conv_block_bwd_kernel<24,..> (backward of a whole identity block: 2x (data+weight gradient), 20 ch",
     }[fam] + f", {ho}x{wo} maps, {n_img} tiles/launch)"
-    pmc_key = {"conv": "conv_igemm_pf_kernel<24, 2, 3, 4", "block_fwd": "conv_block_fwd_kernel<24,",
-               "bwd_fused": "conv_bwd_fused_kernel<24, 2, 3", "block_bwd": "conv_block_bwd_kernel<24,"}[fam]
+    pmc_keys = {"conv": ("conv_igemm_pf_kernel<24, 2, 3, 4",), "block_fwd": ("conv_block_fwd_kernel<24,",),
+                "bwd_fused": ("conv_bwd_fused16_kernel<", "conv_bwd_fused_kernel<24, 2, 3"), "block_bwd": ("conv_block_bwd_kernel<24,",)}[fam]
     traffic = None
     pmc = _profile_json("pmc_traffic.json")                            # rocprofv3 PMC passes of this same command
     if pmc and n_img == 2048:
-        hit = [v for k, v in pmc.get("kernels", {}).items() if pmc_key in k]      # all template variants of the family
+        hit = [v for k, v in pmc.get("kernels", {}).items() if any(key in k for key in pmc_keys)]     # all template variants of the family
         if hit:
             traffic = sum(v["hbm_bytes"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit)
     sq = _profile_json("sq_counters.json")                             # SQ PMC passes of this same command
     sq_rec = None
     if sq and n_img == 2048:
-        hit = [v for k, v in sq.get("kernels", {}).items() if pmc_key in k]
+        hit = [v for k, v in sq.get("kernels", {}).items() if any(key in k for key in pmc_keys)]
         if hit:
             tot = sum(v["launches"] for v in hit)
             sq_rec = {k: sum(v[k] * v["launches"] for v in hit) / tot for k in
