@@ -13,6 +13,10 @@
 #include "pf_common.cuh"
 #include <cstdlib>
 
+#ifndef MIL_BLOCK_LOOKAHEAD
+#define MIL_BLOCK_LOOKAHEAD 2      // pixel fragments read this many (k-step, row tile) steps ahead of their MFMAs; 0 = compiler order
+#endif
+
 struct BlockFwdArgs {
     const __bf16* x;        // [n,H,W,CP]
     const __bf16* w1;       // MIL_PACK_FWD fragments [KSTEPS][NT][64][8]
@@ -162,6 +166,10 @@ __global__ __launch_bounds__(64 * NW, (CP <= 24 ? 2 : 1) * (NW == 8 ? 2 : 1)) vo
             for (int i = 0; i < MT1; ++i)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[i][nt] = b1r[nt];
+#if MIL_BLOCK_LOOKAHEAD > 0
+            mil_conv_ring<NT, MT1, KSTEPS, MIL_BLOCK_LOOKAHEAD>(acc, ldsW1, lane,
+                [&](int sl, int i) { return ldsX + pixbase1[i] + toff1[sl]; });
+#else
 #pragma unroll
             for (int sl = 0; sl < KSTEPS; ++sl) {
                 Frag8<BF16> wf[NT];
@@ -179,6 +187,7 @@ __global__ __launch_bounds__(64 * NW, (CP <= 24 ? 2 : 1) * (NW == 8 ? 2 : 1)) vo
                     for (int nt = 0; nt < NT; ++nt) acc[i][nt] = mma8(wf[nt], xf, acc[i][nt]);
                 }
             }
+#endif
             // mid pixels outside the image are conv2's zero padding (only tiles on the image border have any)
             const int my0 = o.oy0 - 1, mx0 = o.ox0 - 1;
             const bool border = my0 < 0 || mx0 < 0 || my0 + 18 > H || mx0 + 18 > W;
@@ -218,6 +227,10 @@ __global__ __launch_bounds__(64 * NW, (CP <= 24 ? 2 : 1) * (NW == 8 ? 2 : 1)) vo
         for (int m = 0; m < MT2; ++m)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[m][nt] = b2r[nt];
+#if MIL_BLOCK_LOOKAHEAD > 0
+        mil_conv_ring<NT, MT2, KSTEPS, MIL_BLOCK_LOOKAHEAD>(acc, ldsW2, lane,
+            [&](int sl, int m) { return ldsO + pixbase2[m] + toff2[sl]; });
+#else
 #pragma unroll
         for (int sl = 0; sl < KSTEPS; ++sl) {
             Frag8<BF16> wf[NT];
@@ -230,6 +243,7 @@ __global__ __launch_bounds__(64 * NW, (CP <= 24 ? 2 : 1) * (NW == 8 ? 2 : 1)) vo
                 for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wf[nt], of, acc[m][nt]);
             }
         }
+#endif
 #pragma unroll
         for (int p = 0; p < NPAIR; ++p) {
             const bool ok = (o_pos[p] >> 10) < ylim && (o_pos[p] & 1023) < xlim;

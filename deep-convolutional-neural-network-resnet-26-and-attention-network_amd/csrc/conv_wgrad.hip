@@ -42,6 +42,13 @@ __device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
 // dWp[ci][co] = sum_q x[2q][ci] * dz2[q][co] has the 3x3 conv's CENTRE-TAP rows as its A operand, so the row tiles that
 // hold those rows get a second accumulator set fed by a second dz tile — the block input is read once for both filters
 // instead of once per weight-gradient launch.  Its rows are appended to the slab behind the bias tile.
+// which instantiations take the explicit one-step-ahead operand prefetch (second operand register set): the persistent
+// bf16 forms below 64 input channels; the 64/80-channel forms sit at 232-256 VGPRs already
+#ifdef MIL_WGRAD_NO_PIPE
+#define MIL_WGRAD_PIPE(BF, PF, CINP, NW, PROJ) false
+#else
+#define MIL_WGRAD_PIPE(BF, PF, CINP, NW, PROJ) ((BF) && (PF) && (CINP) < 64)
+#endif
 template <typename T, int KS, int CINP, int NT, int MSPLIT, bool PF, int NW = 4, bool PROJ = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0)) void wgrad_kernel(WgradArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -56,6 +63,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0))
     constexpr int NTHR = 64 * NW;
     constexpr int MW = (MT_S + NW - 1) / NW;    // tiles per wave
     constexpr int PM0 = 2 * CG, PM1 = (5 * CG - 1) / 2, PMN = PROJ ? PM1 - PM0 + 1 : 0;    // row tiles holding centre-tap rows
+    constexpr bool WPIPE = MIL_WGRAD_PIPE(T::DT == MIL_DT_BF16, PF, CINP, NW, PROJ);
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     // wave id through readfirstlane: provably wave-uniform, so branches on it are scalar branches (an MFMA or a
@@ -146,6 +154,58 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0))
 #pragma unroll
             for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
             const int wpl0 = mil_pix_base<PIXB>(g, 8 * gq + q4, g.stride), wpl1 = mil_pix_base<PIXB>(g, 8 * gq + q4 + 4, g.stride);
+            if constexpr (WPIPE) {
+                // One 32-pixel k-step ahead, two k-steps per loop trip on ping-pong operand sets (tile_px is a multiple of
+                // 64): the transposed reads of step k+1 are issued before the MFMAs of step k, and the wave's row tiles are
+                // processed without validity branches (a row tile that does not exist reads row group 0 into accumulators
+                // that are never stored).  The compiler-ordered loop below waits for every fragment right in front of its
+                // MFMAs; at the one or two waves per SIMD these kernels run at, that made them LDS-latency loops.
+                bf16x8_t bA[NT], b2A[PROJ ? NT : 1], aA[MW], bB[NT], b2B[PROJ ? NT : 1], aB[MW];
+                auto load = [&](int k32, bf16x8_t (&bf)[NT], bf16x8_t (&bf2)[PROJ ? NT : 1], bf16x8_t (&af)[MW]) {
+                    const int kb = mil_pix_base<PIXB>(g, k32, g.stride);
+                    const char* z0 = ldsZ + (k32 + 8 * gq + q4) * PIXZ + p * 8;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bf[nt] = tr_pair(z0 + nt * 32, z0 + 4 * PIXZ + nt * 32);
+                    if constexpr (PROJ) {
+                        const char* y0 = ldsZ2 + (k32 + 8 * gq + q4) * PIXZ + p * 8;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) bf2[nt] = tr_pair(y0 + nt * 32, y0 + 4 * PIXZ + nt * 32);
+                    }
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) af[i] = tr_pair(ldsX + kb + wpl0 + toff[i], ldsX + kb + wpl1 + toff[i]);
+                };
+                auto mfma = [&](const bf16x8_t (&bf)[NT], const bf16x8_t (&bf2)[PROJ ? NT : 1], const bf16x8_t (&af)[MW]) {
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[nt], acc[i][nt], 0, 0, 0);
+                        if constexpr (PROJ) {
+                            if (i == proj_i) {          // wave-uniform
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt)
+                                    accp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf2[nt], accp[nt], 0, 0, 0);
+                            }
+                        }
+                    }
+                    if (bias_wave) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            accb[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bf[nt], accb[nt], 0, 0, 0);
+                    }
+                };
+                load(0, bA, b2A, aA);
+                for (int k32 = 0; k32 < a.tile_px; k32 += 64) {
+                    load(k32 + 32, bB, b2B, aB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma(bA, b2A, aA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k32 + 64 < a.tile_px) load(k32 + 64, bA, b2A, aA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma(bB, b2B, aB);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
             for (int k32 = 0; k32 < a.tile_px; k32 += 32) {
                 // halo offset of pixel k32 + lane part: additive (disjoint bit fields), k32 part is wave-uniform
                 const int kb = mil_pix_base<PIXB>(g, k32, g.stride);
@@ -183,6 +243,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0))
                     for (int nt = 0; nt < NT; ++nt)
                         accb[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bf[nt], accb[nt], 0, 0, 0);
                 }
+            }
             }
         } else {
             const int gq = lane >> 4, col = lane & 15;

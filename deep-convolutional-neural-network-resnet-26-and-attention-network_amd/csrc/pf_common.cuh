@@ -188,6 +188,35 @@ __device__ __forceinline__ bf16x8_t mil_tr_pair(const char* p0, const char* p1) 
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// The (k-step, row tile) loop of an implicit-GEMM conv as ONE flattened software pipeline (bf16): the pixel fragment of
+// step j + LA is read LA steps before the NT MFMAs that consume it (a ring of LA + 1 fragments), the filter fragments of
+// k-step sl + 1 are read at the start of k-step sl, and scheduling fences keep that order — hipcc on its own issues each
+// fragment read directly in front of its MFMAs behind an lgkmcnt(0), which makes such loops LDS-latency loops.
+// acc[m][nt] accumulates D[channel][pixel] = filter fragment (A) x pixel fragment (B); `xaddr(sl, m)` is the LDS address
+// of row tile m's fragment for k-step sl.  Everything is unrolled, so ring / buffer indices are compile-time constants.
+template <int NT, int MT, int KSTEPS, int LA, class XAddr>
+__device__ __forceinline__ void mil_conv_ring(f32x4_t (&acc)[MT][NT], const char* ldsW, int lane, XAddr xaddr) {
+    constexpr int TOT = KSTEPS * MT, R = LA + 1;
+    Frag8<BF16> ring[R], wq[2][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wq[0][nt] = lds_frag<BF16>(ldsW + (nt * 64 + lane) * 16);
+#pragma unroll
+    for (int j = 0; j < LA && j < TOT; ++j) ring[j % R] = lds_frag<BF16>(xaddr(j / MT, j % MT));
+#pragma unroll
+    for (int j = 0; j < TOT; ++j) {
+        const int sl = j / MT, m = j % MT;
+        if (j + LA < TOT) ring[(j + LA) % R] = lds_frag<BF16>(xaddr((j + LA) / MT, (j + LA) % MT));
+        if (m == 0 && sl + 1 < KSTEPS) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wq[(sl + 1) & 1][nt] = lds_frag<BF16>(ldsW + (((sl + 1) * NT + nt) * 64 + lane) * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wq[sl & 1][nt], ring[j % R], acc[m][nt]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Workgroups of `kern` (256 threads, `lds` bytes of dynamic LDS) that one CU holds at a time, from the runtime's own
 // occupancy calculation (registers AND LDS).  Persistent launches size their grid to exactly the resident set: a
 // partial second round would leave CUs idle while the stragglers finish.
