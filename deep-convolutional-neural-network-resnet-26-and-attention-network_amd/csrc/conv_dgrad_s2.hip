@@ -163,6 +163,29 @@ __global__ __launch_bounds__(256, CZ <= 40 ? 2 : 1) void conv_dgrad_s2_kernel(Dg
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[c][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#ifndef MIL_DGRAD_S2_NO_PIPE
+        {
+            // one k-step ahead (the steps of the four parity classes flattened into one sequence): the fragments of step
+            // s+1 are read before the MFMAs of step s and scheduling fences keep that order (see mil_conv_ring)
+            auto cls = [](int st) { int c = 0; while (st >= mil_s2_steps(c, CG)) { st -= mil_s2_steps(c, CG); ++c; } return c; };
+            Frag8<BF16> xq[2], wq[2][NT];
+            xq[0] = lds_frag<BF16>(ldsZ + pixbase + toff[0]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wq[0][nt] = lds_frag<BF16>(ldsW + (nt * 64 + lane) * 16);
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                if (st + 1 < NS) {
+                    xq[(st + 1) & 1] = lds_frag<BF16>(ldsZ + pixbase + toff[st + 1 < NS ? st + 1 : st]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) wq[(st + 1) & 1][nt] = lds_frag<BF16>(ldsW + (((st + 1) * NT + nt) * 64 + lane) * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[cls(st)][nt] = mma8(wq[st & 1][nt], xq[st & 1], acc[cls(st)][nt]);          // D[channel][pixel]
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#else
         {
             int s = 0;
 #pragma unroll
@@ -178,6 +201,7 @@ __global__ __launch_bounds__(256, CZ <= 40 ? 2 : 1) void conv_dgrad_s2_kernel(Dg
                 }
             }
         }
+#endif
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
 #pragma unroll

@@ -104,6 +104,11 @@ __global__ __launch_bounds__(256, CINP <= 24 ? 2 : 1) void conv_s2_entry_kernel(
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) { acc1[m][nt] = bias_r[nt]; acc2[m][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#ifndef MIL_S2_ENTRY_NO_PIPE
+        // both GEMMs as flattened software pipelines with fragments read two steps ahead (mil_conv_ring, pf_common.cuh)
+        mil_conv_ring<NT, 2, K1, 2>(acc1, ldsW, lane, [&](int sl, int m) { return ldsA + pixbase[m] + toff[sl]; });
+        mil_conv_ring<NT, 2, K2, 2>(acc2, ldsW + K1 * NT * 64 * 16, lane, [&](int sl, int m) { return ldsA + pixbase[m] + toff2[sl]; });
+#else
 #pragma unroll
         for (int sl = 0; sl < K1; ++sl) {
             Frag8<BF16> wf[NT];
@@ -128,6 +133,7 @@ __global__ __launch_bounds__(256, CINP <= 24 ? 2 : 1) void conv_s2_entry_kernel(
                 for (int nt = 0; nt < NT; ++nt) acc2[m][nt] = mma8(wf[nt], xf, acc2[m][nt]);
             }
         }
+#endif
         const int obase = ((o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (COUTP * 2);
         const bool ok = (o_pos >> 20) < g.n_img - o.img0 && ((o_pos >> 10) & 1023) < g.Ho - o.oy0 && (o_pos & 1023) < g.Wo - o.ox0;
         const unsigned ooff = ok ? (unsigned)(obase + o_rel) : MIL_OOB;
