@@ -41,6 +41,10 @@ _SIGS = {
     "mil_conv_igemm": ([_vp] * 6 + [_i] * 12 + [_f, _i, _vp], _i),
     "mil_conv_wgrad_workspace": ([_c.POINTER(_sz)] + [_i] * 12, _i),
     "mil_conv_wgrad": ([_vp, _vp, _vp, _vp, _vp, _sz] + [_i] * 13 + [_vp], _i),
+    "mil_reduce_job_bytes": ([], _i),
+    "mil_reduce_defer_begin": ([_vp, _i], _i),
+    "mil_reduce_defer_end": ([_c.POINTER(_i)], _i),
+    "mil_wgrad_reduce_all": ([_vp, _vp, _i, _vp], _i),
     "mil_conv_bwd_fused_workspace": ([_c.POINTER(_sz)] + [_i] * 8, _i),
     "mil_conv_bwd_fused": ([_vp] * 8 + [_sz] + [_i] * 9 + [_f, _i, _vp], _i),
     "mil_maxpool_fwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),

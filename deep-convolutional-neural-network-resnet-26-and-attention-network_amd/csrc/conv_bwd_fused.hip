@@ -13,6 +13,7 @@
 // anyway for the mask) is its B operand, both read with ds_read_b64_tr_b16.  Per-workgroup partial sums
 // stay in registers across tiles and leave as one fp32 slab; a fixed-order reduction finishes them.
 #include "pf_common.cuh"
+#include "reduce.cuh"
 #include <cstdlib>
 
 struct BwdFusedArgs {
@@ -699,39 +700,7 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
     }
 }
 
-// Fixed-order slab reduction for the fused kernel's layout: row = tap'*CZ + co (tap' = flipped tap),
-// col = ci  ->  dW[co][ci][k*k-1-tap'];  db from the extra row tile.
-__global__ __launch_bounds__(32 * MIL_RED_GROUPS) void wgrad_reduce_t_kernel(const float* __restrict__ slab, int nslab, size_t slab_elems,
-                                                             int slab_cols, int n_rows, float* __restrict__ dw,
-                                                             float* __restrict__ db, int cout, int cin, int ks, int czp,
-                                                             int bias_off, int bias_stride, int accumulate) {
-    __shared__ float part[MIL_RED_GROUPS][32];
-    const int c = threadIdx.x & 31, gq = threadIdx.x >> 5;
-    const int e = blockIdx.x * 32 + c;
-    const int total = n_rows * slab_cols + czp;           // weight elements, then czp bias sums
-    float s = 0.f;
-    const bool live = e < total;
-    if (live) {
-        const size_t src = e < n_rows * slab_cols ? (size_t)e : (size_t)bias_off + (size_t)(e - n_rows * slab_cols) * bias_stride;
-        s = mil_slab_partial(slab, slab_elems, src, gq, nslab);
-    }
-    part[gq][c] = s;
-    __syncthreads();
-    if (gq != 0 || !live) return;
-    float v = 0.f;
-#pragma unroll
-    for (int k = 0; k < MIL_RED_GROUPS; ++k) v += part[k][c];
-    if (e >= n_rows * slab_cols) {
-        const int co = e - n_rows * slab_cols;
-        if (co < cout && db) db[co] = accumulate ? db[co] + v : v;
-        return;
-    }
-    const int row = e / slab_cols, ci = e - row * slab_cols;
-    const int tapf = row / czp, co = row - tapf * czp;
-    if (ci >= cin || co >= cout) return;
-    float* q = dw + ((size_t)co * cin + ci) * (ks * ks) + (ks * ks - 1 - tapf);
-    *q = accumulate ? *q + v : v;
-}
+// (the slab reduction for this layout — rows tap'*CZ + co with tap' the flipped tap, cols ci — is kind 1 of reduce.cuh)
 
 // MIL_BWD16=0 falls back to the generic kernel on 16x16 tiles too (A/B runs, bit-compatible results up to the bias
 // gradient's summation path)
@@ -822,7 +791,6 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
     a.lds_x2_off = t16 ? x_bytes : 0;
     if (grid <= 0) return MIL_OK;
     const int n_rows = KS * KS * CZ;
-    const int total = n_rows * NTX * 16 + CZ;
     const BwdFusedArgs a0 = a;
     for (int i0 = 0; i0 < n_total; i0 += chunk) {
         const int n = n_total - i0 < chunk ? n_total - i0 : chunk;
@@ -838,9 +806,14 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
         int gr = grid < c.ntiles ? grid : c.ntiles;
         hipLaunchKernelGGL(kern, dim3(gr), dim3(64 * NW), lds, stream, c);
         MIL_CHECK_LAUNCH();
-        hipLaunchKernelGGL(wgrad_reduce_t_kernel, dim3((total + 31) / 32), dim3(32 * MIL_RED_GROUPS), 0, stream, (const float*)ws, gr, slab_elems,
-                           NTX * 16, n_rows, dw, db, cout, cin, KS, CZ,
-                           t16 ? (KS * KS / 2) * CZ * NTX * 16 + (CX - 1) : MT * 16 * NTX * 16, t16 ? NTX * 16 : 1, (i0 > 0) ? 1 : accumulate);
+        {
+            MilReduceJob j{};
+            j.slab = (const float*)ws; j.nslab = gr; j.slab_elems = slab_elems; j.slab_cols = NTX * 16; j.n_rows = n_rows;
+            j.dw = dw; j.db = db; j.cout = cout; j.cin = cin; j.ks = KS; j.kind = 1; j.cinp = CZ;
+            j.bias_off = t16 ? (KS * KS / 2) * CZ * NTX * 16 + (CX - 1) : MT * 16 * NTX * 16; j.bias_stride = t16 ? NTX * 16 : 1;
+            j.accumulate = (i0 > 0) ? 1 : accumulate;
+            mil_reduce_or_defer(j, stream, /*may_defer=*/chunk >= n_total);      // a split launch re-uses the slabs per chunk
+        }
         MIL_CHECK_LAUNCH();
     }
     return MIL_OK;

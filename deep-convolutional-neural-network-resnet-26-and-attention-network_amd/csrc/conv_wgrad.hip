@@ -11,6 +11,7 @@
 //   ONE fp32 slab; a second kernel sums the slabs in fixed order (deterministic, no float atomics).
 //   db comes from an all-ones A fragment on wave 0 (column sums of dz on the same MFMA stream).
 #include "pf_common.cuh"
+#include "reduce.cuh"
 
 template <typename T>
 struct WgradArgs {
@@ -305,50 +306,66 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0))
     }
 }
 
-// Sum the per-workgroup slabs in fixed order and scatter into the reference weight layout
-// [Cout][Cin][k][k] (fp32).  A 256-thread block owns 32 consecutive slab elements (coalesced 128-B reads);
-// its 8 thread groups each sum every 8th slab, then group 0 adds the 8 partials in order: the summation
-// tree is fixed, so results are bitwise reproducible.  stem_mode maps the 4x4 space-to-depth taps back
-// onto the 7x7 filter.
-__global__ __launch_bounds__(32 * MIL_RED_GROUPS) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, size_t slab_elems,
-                                                           int slab_cols, int n_rows, float* __restrict__ dw,
-                                                           float* __restrict__ db, int cout, int cin, int ks, int cinp,
-                                                           int stem_mode, int bias_row, int accumulate) {
+// The slab reductions themselves live in reduce.cuh (shared with conv_bwd_fused.hip and the batched launch).
+static thread_local MilDeferState g_defer{nullptr, 0, 0};
+MilDeferState& mil_defer_state() { return g_defer; }
+
+__global__ __launch_bounds__(32 * MIL_RED_GROUPS) void wgrad_reduce_job_kernel(MilReduceJob j) {
     __shared__ float part[MIL_RED_GROUPS][32];
-    const int c = threadIdx.x & 31, gq = threadIdx.x >> 5;
-    // rows [0, n_rows) are weight rows, row n_rows stands for the bias row
-    const int e = blockIdx.x * 32 + c;
-    const int total = (n_rows + 1) * slab_cols;
-    float s = 0.f;
-    size_t src = 0;
-    bool live = e < total;
-    if (live) {
-        const int row = e / slab_cols, col = e - row * slab_cols;
-        src = (size_t)(row == n_rows ? bias_row : row) * slab_cols + col;
-        s = mil_slab_partial(slab, slab_elems, src, gq, nslab);
+    mil_reduce_job_block(j, blockIdx.x, part);
+}
+
+// Every recorded reduction of a backward pass in ONE launch: block -> (job, block inside the job) through the jobs'
+// block0 prefix, one lane per job (at most 64 jobs per launch; the host entry point splits longer tables).
+__global__ __launch_bounds__(32 * MIL_RED_GROUPS) void wgrad_reduce_all_kernel(const MilReduceJob* __restrict__ jobs, int njobs) {
+    __shared__ float part[MIL_RED_GROUPS][32];
+    __shared__ int which;
+    const int b = blockIdx.x;
+    if (threadIdx.x < 64) {
+        bool mine = false;
+        if ((int)threadIdx.x < njobs) {
+            const int b0 = jobs[threadIdx.x].block0, nb = jobs[threadIdx.x].n_blocks;
+            mine = b >= b0 && b < b0 + nb;
+        }
+        const unsigned long long m = __ballot(mine);
+        if (threadIdx.x == 0) which = m ? __ffsll((long long)m) - 1 : -1;
     }
-    part[gq][c] = s;
     __syncthreads();
-    if (gq != 0 || !live) return;
-    float v = 0.f;
-#pragma unroll
-    for (int k = 0; k < MIL_RED_GROUPS; ++k) v += part[k][c];
-    const int row = e / slab_cols, co = e - row * slab_cols;
-    if (co >= cout) return;
-    if (row == n_rows) { if (db) db[co] = accumulate ? db[co] + v : v; return; }
-    const int tap = row / cinp, ch = row - tap * cinp;
-    if (stem_mode) {
-        if (ch >= 12) return;
-        const int ci = ch >> 2, dy = (ch >> 1) & 1, dx = ch & 1;
-        const int ky = 2 * (tap >> 2) + dy - 1, kx = 2 * (tap & 3) + dx - 1;
-        if (ky < 0 || ky >= 7 || kx < 0 || kx >= 7) return;
-        float* q = dw + (((size_t)co * 3 + ci) * 7 + ky) * 7 + kx;
-        *q = accumulate ? *q + v : v;
-    } else {
-        if (ch >= cin) return;
-        float* q = dw + ((size_t)co * cin + ch) * (ks * ks) + tap;
-        *q = accumulate ? *q + v : v;
+    const int k = which;
+    if (k < 0) return;
+    const MilReduceJob j = jobs[k];
+    mil_reduce_job_block(j, b - j.block0, part);
+}
+
+extern "C" int mil_reduce_job_bytes(void) { return (int)sizeof(MilReduceJob); }
+
+extern "C" int mil_reduce_defer_begin(void* jobs_host, int max_jobs) {
+    if (!jobs_host || max_jobs <= 0) return MIL_ERR_ARG;
+    g_defer.jobs = static_cast<MilReduceJob*>(jobs_host); g_defer.cap = max_jobs; g_defer.n = 0;
+    return MIL_OK;
+}
+
+extern "C" int mil_reduce_defer_end(int* njobs) {
+    if (njobs) *njobs = g_defer.n;
+    g_defer.jobs = nullptr; g_defer.cap = 0; g_defer.n = 0;
+    return MIL_OK;
+}
+
+// jobs_dev: device copy of the first `njobs` records of a table filled between defer_begin / defer_end.
+extern "C" int mil_wgrad_reduce_all(const void* jobs_dev, const void* jobs_host, int njobs, void* stream) {
+    if (njobs < 0 || (njobs > 0 && (!jobs_dev || !jobs_host))) return MIL_ERR_ARG;
+    const MilReduceJob* hj = static_cast<const MilReduceJob*>(jobs_host);
+    const MilReduceJob* dj = static_cast<const MilReduceJob*>(jobs_dev);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    for (int k0 = 0; k0 < njobs; k0 += 64) {               // 64 jobs per launch (one lane per job in the lookup)
+        const int n = njobs - k0 < 64 ? njobs - k0 : 64;
+        const int first = hj[k0].block0, last = hj[k0 + n - 1].block0 + hj[k0 + n - 1].n_blocks;
+        if (last <= first) continue;
+        if (k0 != 0) return MIL_ERR_UNSUPPORTED;           // block0 prefixes are relative to job 0: tables are <= 64 jobs
+        hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3(last - first), dim3(32 * MIL_RED_GROUPS), 0, st, dj + k0, n);
+        MIL_CHECK_LAUNCH();
     }
+    return MIL_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -427,16 +444,20 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     hipLaunchKernelGGL(kern, dim3(pl.grid_x, MSPLIT), dim3(nthr), pl.lds, stream, a);
     MIL_CHECK_LAUNCH();
     const int n_rows = KS * KS * CINP;
-    const int total = (n_rows + 1) * pl.slab_cols;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(32 * MIL_RED_GROUPS), 0, stream, (const float*)ws, pl.grid_x,
-                       pl.slab_elems, pl.slab_cols, n_rows, dw, db, cout, cin, KS, CINP, stem_mode, pl.mt * 16, accumulate);
-    MIL_CHECK_LAUNCH();
-    if constexpr (PROJ) {            // the projection's rows sit behind the bias tile: rows = input channel, one tap
-        const int total1 = (CINP + 1) * pl.slab_cols;                // + the (unused, db == null) bias row slot
-        const float* seg = (const float*)ws + (size_t)(pl.mt + 1) * 16 * pl.slab_cols;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total1 + 31) / 32), dim3(32 * MIL_RED_GROUPS), 0, stream, seg, pl.grid_x,
-                           pl.slab_elems, pl.slab_cols, CINP, dw1, (float*)nullptr, cout, cin, 1, CINP, 0, 0, accumulate);
+    {
+        MilReduceJob j{};
+        j.slab = (const float*)ws; j.nslab = pl.grid_x; j.slab_elems = pl.slab_elems; j.slab_cols = pl.slab_cols; j.n_rows = n_rows;
+        j.dw = dw; j.db = db; j.cout = cout; j.cin = cin; j.ks = KS; j.kind = 0; j.cinp = CINP; j.stem_mode = stem_mode;
+        j.bias_row = pl.mt * 16; j.accumulate = accumulate;
+        mil_reduce_or_defer(j, stream);
         MIL_CHECK_LAUNCH();
+        if constexpr (PROJ) {        // the projection's rows sit behind the bias tile: rows = input channel, one tap
+            MilReduceJob j1 = j;
+            j1.slab = (const float*)ws + (size_t)(pl.mt + 1) * 16 * pl.slab_cols;
+            j1.n_rows = CINP; j1.dw = dw1; j1.db = nullptr; j1.ks = 1; j1.stem_mode = 0; j1.bias_row = 0;
+            mil_reduce_or_defer(j1, stream);
+            MIL_CHECK_LAUNCH();
+        }
     }
     return MIL_OK;
 }
@@ -804,11 +825,15 @@ static int stem_bwd_entry(const void* xs, const void* gp, const uint8_t* widx, f
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(stem_bwd_fused_kernel, dim3(grid), dim3(256), lds, st, a);
     MIL_CHECK_LAUNCH();
-    const int n_rows = 16 * 16;
-    const int total = (n_rows + 1) * 32;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(32 * MIL_RED_GROUPS), 0, st, (const float*)ws, grid, slab_elems, 32,
-                       n_rows, dw, db, 20, 3, 7, 16, 1, /*bias row = (tap 0, s2d channel 12), see the kernel*/ 12, accumulate);
-    MIL_CHECK_LAUNCH();
+    {
+        MilReduceJob j{};
+        j.slab = (const float*)ws; j.nslab = grid; j.slab_elems = slab_elems; j.slab_cols = 32; j.n_rows = 16 * 16;
+        j.dw = dw; j.db = db; j.cout = 20; j.cin = 3; j.ks = 7; j.kind = 0; j.cinp = 16; j.stem_mode = 1;
+        j.bias_row = 12;             // (tap 0, s2d channel 12): the ones channel, see the kernel
+        j.accumulate = accumulate;
+        mil_reduce_or_defer(j, st);
+        MIL_CHECK_LAUNCH();
+    }
     return MIL_OK;
 }
 

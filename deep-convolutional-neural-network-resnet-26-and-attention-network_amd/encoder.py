@@ -6,6 +6,8 @@ state-dict keys — but `forward` never calls a torch conv: it sequences the C-A
 include/mil_hip.h (NHWC, channel-padded, fp32 or bf16 operands) and a custom autograd Function
 provides the backward (dgrad / wgrad / pooling backward) from saved NHWC activations.
 """
+import contextlib
+
 import torch
 from torch import nn
 
@@ -65,6 +67,10 @@ class ResNet(nn.Module):
         self.fuse_stem_forward = True
         self.fuse_stage_entry = True
         self.fuse_block_forward = True
+        # the 28 slab reductions of a backward pass recorded and run as ONE launch (ops.ReduceBatch) instead of one ~10 us
+        # launch behind every weight-gradient kernel
+        self.batch_reductions = True
+        self._reduce_batch = None
         self._pack_table = None
         self._pack_version = None
         self._side = None
@@ -273,16 +279,23 @@ def encoder_backward(net, saved, dfeats, dtype):
     rr = [0]
 
     direct = net.direct_grad and all(p.grad is not None and p.grad.is_contiguous() for p in net.encoder_params())
+    batch = None
+    if net.batch_reductions and not use_side:
+        if net._reduce_batch is None or net._reduce_batch.device != dfeats.device:
+            net._reduce_batch = ops.ReduceBatch(dfeats.device)
+        batch = net._reduce_batch
 
     def gout(*params):
         """Destination gradient tensors (the parameters' own .grad) when accumulating in place, else None."""
         return tuple(None if p is None else p.grad for p in params) if direct else None
 
-    def wgrad(xin, dzz, cin, cout, **kw):
+    def wgrad(xin, dzz, cin, cout, key=None, **kw):
         n, h, w, _ = xin.shape
         _, ho, wo, _ = dzz.shape
         need = ops.wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, kw["ks"], kw["stride"], kw["pad"],
                                          kw.get("stem", False), xin.dtype)
+        if batch is not None:                # deferred reduction: a slab buffer of its own, alive until the batched launch
+            return ops.conv_wgrad(xin, dzz, cin, cout, workspace=batch.workspace(("w", key), need), **kw)
         if not use_side:
             if ws[-1] is None or ws[-1].numel() * 4 < need:
                 ws[-1] = torch.empty((need + 3) // 4, dtype=torch.float32, device=xin.device)
@@ -301,76 +314,85 @@ def encoder_backward(net, saved, dfeats, dtype):
 
     fws = None
 
-    def fused_bwd(dzz, wd, xin, cin, cout, addend, mask, out):
+    def fused_bwd(dzz, wd, xin, cin, cout, addend, mask, out, key=None):
         nonlocal fws
         n, h, w, _ = dzz.shape
         need = ops.bwd_fused_workspace_bytes(n, h, w, cout, cin, 3, 1, dzz.dtype)
         if need is None:
             return None
+        if batch is not None:
+            return ops.conv_bwd_fused(dzz, wd, xin, cin, cout, addend=addend, mask=mask, workspace=batch.workspace(("f", key), need), out=out)
         if fws is None or fws.numel() * 4 < need:
             fws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dzz.device)
         return ops.conv_bwd_fused(dzz, wd, xin, cin, cout, addend=addend, mask=mask, workspace=fws, out=out)
 
-    for bi in range(len(blocks) - 1, -1, -1):
-        blk = blocks[bi]
-        xin, o1, _out = saved["blocks"][bi]
-        cin, cout, s = blk.conv1.in_channels, blk.conv1.out_channels, blk.stride
-        w2d, _ = net._packed(f"b{bi}.c2", blk.conv2.weight, None, L.PACK_DGRAD, dtype)
-        fused = fused_bwd(dz, w2d, o1, cout, cout, None, True, gout(blk.conv2.weight, blk.conv2.bias)) if net.fuse_backward else None
-        if fused is not None:                       # one pass: dz1 and dW2/db2
-            dz1, grads[f"b{bi}.c2"] = fused[0], (fused[1], fused[2])
-        else:
-            grads[f"b{bi}.c2"] = wgrad(o1, dz, cout, cout, ks=3, stride=1, pad=1, out=gout(blk.conv2.weight, blk.conv2.bias))
-            dz1 = ops.conv(dz, w2d, None, ops.cpad(cout), ks=3, stride=1, pad=1, act=o1)
-        w1d, _ = net._packed(f"b{bi}.c1", blk.conv1.weight, None, L.PACK_DGRAD, dtype)
-        mask = xin if bi > 0 else None          # block 0 reads the max-pool output (no activation in between)
-        if s == 1 and blk.downsample is None and net.fuse_backward:
-            fused = fused_bwd(dz1, w1d, xin, cin, cout, dz, mask is not None, gout(blk.conv1.weight, blk.conv1.bias))
-            if fused is not None:                   # one pass: previous block's dz and dW1/db1
-                dz, grads[f"b{bi}.c1"] = fused[0], (fused[1], fused[2])
-                continue
-        pair = None
-        if s == 2 and blk.downsample is not None and net.fuse_backward and not use_side:
-            # both weight gradients of the stage-entry convs from one pass over the block input
-            o = gout(blk.conv1.weight, blk.conv1.bias, blk.downsample[0].weight)
-            pair = ops.conv_wgrad_pair(xin, dz1, dz, cin, cout, workspace=ws[-1], out=o)
-        if pair is not None:
-            ws[-1] = pair[3]
-            grads[f"b{bi}.c1"], grads[f"b{bi}.ds"] = (pair[0], pair[1]), (pair[2], None)
-        else:
-            grads[f"b{bi}.c1"] = wgrad(xin, dz1, cin, cout, ks=3, stride=s, pad=1, out=gout(blk.conv1.weight, blk.conv1.bias))
-        if blk.downsample is not None:
-            if pair is None:
-                grads[f"b{bi}.ds"] = wgrad(xin, dz, cin, cout, ks=1, stride=s, pad=0, want_bias=False,
-                                           out=gout(blk.downsample[0].weight, None))
-            if s == 2 and net.fuse_backward:     # both transposed convs + the mask in one pass over the compact dz maps
-                ws2, _ = net._packed(f"b{bi}.c1", blk.conv1.weight, blk.downsample[0].weight, L.PACK_DGRAD_S2, dtype)
-                fused = ops.conv_dgrad_s2(dz1, dz, ws2, ops.cpad(cin), xin.shape[1:3], act=mask)
-                if fused is not None:
-                    dz = fused
-                    continue
-            wdd, _ = net._packed(f"b{bi}.ds", blk.downsample[0].weight, None, L.PACK_DGRAD, dtype)
-            if s == 2:
-                addend = ops.conv(dz, wdd, None, ops.cpad(cin), ks=1, stride=1, pad=0, zero_insert=True,
-                                  out_hw=xin.shape[1:3])
+    # weight-gradient producers record their slab reductions; leaving the block runs them all in one launch
+    with (batch if batch is not None else contextlib.nullcontext()):
+        for bi in range(len(blocks) - 1, -1, -1):
+            blk = blocks[bi]
+            xin, o1, _out = saved["blocks"][bi]
+            cin, cout, s = blk.conv1.in_channels, blk.conv1.out_channels, blk.stride
+            w2d, _ = net._packed(f"b{bi}.c2", blk.conv2.weight, None, L.PACK_DGRAD, dtype)
+            fused = fused_bwd(dz, w2d, o1, cout, cout, None, True, gout(blk.conv2.weight, blk.conv2.bias), key=(bi, 2)) if net.fuse_backward else None
+            if fused is not None:                       # one pass: dz1 and dW2/db2
+                dz1, grads[f"b{bi}.c2"] = fused[0], (fused[1], fused[2])
             else:
-                addend = ops.conv(dz, wdd, None, ops.cpad(cin), ks=1, stride=1, pad=0)
+                grads[f"b{bi}.c2"] = wgrad(o1, dz, cout, cout, key=(bi, 2), ks=3, stride=1, pad=1, out=gout(blk.conv2.weight, blk.conv2.bias))
+                dz1 = ops.conv(dz, w2d, None, ops.cpad(cout), ks=3, stride=1, pad=1, act=o1)
+            w1d, _ = net._packed(f"b{bi}.c1", blk.conv1.weight, None, L.PACK_DGRAD, dtype)
+            mask = xin if bi > 0 else None          # block 0 reads the max-pool output (no activation in between)
+            if s == 1 and blk.downsample is None and net.fuse_backward:
+                fused = fused_bwd(dz1, w1d, xin, cin, cout, dz, mask is not None, gout(blk.conv1.weight, blk.conv1.bias), key=(bi, 1))
+                if fused is not None:                   # one pass: previous block's dz and dW1/db1
+                    dz, grads[f"b{bi}.c1"] = fused[0], (fused[1], fused[2])
+                    continue
+            pair = None
+            if s == 2 and blk.downsample is not None and net.fuse_backward and not use_side:
+                # both weight gradients of the stage-entry convs from one pass over the block input
+                o = gout(blk.conv1.weight, blk.conv1.bias, blk.downsample[0].weight)
+                pws = batch.ws.get(("p", bi)) if batch is not None else ws[-1]
+                pair = ops.conv_wgrad_pair(xin, dz1, dz, cin, cout, workspace=pws, out=o)
+            if pair is not None:
+                if batch is not None:
+                    batch.ws[("p", bi)] = pair[3]           # kept until the batched reduction has run
+                else:
+                    ws[-1] = pair[3]
+                grads[f"b{bi}.c1"], grads[f"b{bi}.ds"] = (pair[0], pair[1]), (pair[2], None)
+            else:
+                grads[f"b{bi}.c1"] = wgrad(xin, dz1, cin, cout, key=(bi, 1), ks=3, stride=s, pad=1, out=gout(blk.conv1.weight, blk.conv1.bias))
+            if blk.downsample is not None:
+                if pair is None:
+                    grads[f"b{bi}.ds"] = wgrad(xin, dz, cin, cout, key=(bi, 0), ks=1, stride=s, pad=0, want_bias=False,
+                                               out=gout(blk.downsample[0].weight, None))
+                if s == 2 and net.fuse_backward:     # both transposed convs + the mask in one pass over the compact dz maps
+                    ws2, _ = net._packed(f"b{bi}.c1", blk.conv1.weight, blk.downsample[0].weight, L.PACK_DGRAD_S2, dtype)
+                    fused = ops.conv_dgrad_s2(dz1, dz, ws2, ops.cpad(cin), xin.shape[1:3], act=mask)
+                    if fused is not None:
+                        dz = fused
+                        continue
+                wdd, _ = net._packed(f"b{bi}.ds", blk.downsample[0].weight, None, L.PACK_DGRAD, dtype)
+                if s == 2:
+                    addend = ops.conv(dz, wdd, None, ops.cpad(cin), ks=1, stride=1, pad=0, zero_insert=True,
+                                      out_hw=xin.shape[1:3])
+                else:
+                    addend = ops.conv(dz, wdd, None, ops.cpad(cin), ks=1, stride=1, pad=0)
+            else:
+                addend = dz
+            if s == 2:
+                dz = ops.conv(dz1, w1d, None, ops.cpad(cin), ks=3, stride=1, pad=1, zero_insert=True,
+                              out_hw=xin.shape[1:3], res=addend, act=mask)
+            else:
+                dz = ops.conv(dz1, w1d, None, ops.cpad(cin), ks=3, stride=1, pad=1, res=addend, act=mask)
+        fused_stem = None
+        if net.fuse_backward:               # pool backward + lrelu backward + stem wgrad in one pass (bf16 path)
+            fused_stem = ops.stem_bwd_fused(saved["xs"], dz, saved["widx"], out=gout(net.conv1.weight, net.conv1.bias),
+                                            ws_alloc=(lambda nb: batch.workspace(("s", 0), nb)) if batch is not None else None)
+        if fused_stem is not None:
+            grads["stem"] = fused_stem
         else:
-            addend = dz
-        if s == 2:
-            dz = ops.conv(dz1, w1d, None, ops.cpad(cin), ks=3, stride=1, pad=1, zero_insert=True,
-                          out_hw=xin.shape[1:3], res=addend, act=mask)
-        else:
-            dz = ops.conv(dz1, w1d, None, ops.cpad(cin), ks=3, stride=1, pad=1, res=addend, act=mask)
-    fused_stem = None
-    if net.fuse_backward:               # pool backward + lrelu backward + stem wgrad in one pass (bf16 path)
-        fused_stem = ops.stem_bwd_fused(saved["xs"], dz, saved["widx"], out=gout(net.conv1.weight, net.conv1.bias))
-    if fused_stem is not None:
-        grads["stem"] = fused_stem
-    else:
-        dstem = ops.maxpool_bwd(dz, saved["widx"], saved["stem_hw"])
-        grads["stem"] = wgrad(saved["xs"], dstem, 3, STEM_WIDTH, ks=4, stride=1, pad=2, stem=True,
-                              out=gout(net.conv1.weight, net.conv1.bias))
+            dstem = ops.maxpool_bwd(dz, saved["widx"], saved["stem_hw"])
+            grads["stem"] = wgrad(saved["xs"], dstem, 3, STEM_WIDTH, key=("stem", 0), ks=4, stride=1, pad=2, stem=True,
+                                  out=gout(net.conv1.weight, net.conv1.bias))
 
     if use_side:
         for side in sides:

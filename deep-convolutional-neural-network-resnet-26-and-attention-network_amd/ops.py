@@ -35,6 +35,45 @@ class KernelTimer:
 TIMER = None   # set to a KernelTimer by bench.py
 
 
+class ReduceBatch:
+    """Deferred slab reductions (mil_reduce_defer_begin / _end / mil_wgrad_reduce_all): inside `with batch:` every
+    weight-gradient producer records its reduction instead of launching it; leaving the block runs them all in ONE
+    launch.  The producers' workspaces must stay untouched until then: `workspace(key, nbytes)` hands out one persistent
+    buffer per call site."""
+    MAX_JOBS = 64
+
+    def __init__(self, device):
+        self.device = device
+        self.rec = L.lib().mil_reduce_job_bytes()
+        self.host = (ctypes.c_char * (self.rec * self.MAX_JOBS))()
+        self.dev = torch.empty(self.rec * self.MAX_JOBS, dtype=torch.uint8, device=device)
+        self.uploaded = None                 # bytes of the table the device copy holds
+        self.ws = {}
+
+    def workspace(self, key, nbytes):
+        t = self.ws.get(key)
+        if t is None or t.numel() * 4 < nbytes:
+            t = self.ws[key] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
+        return t
+
+    def __enter__(self):
+        L.check(L.lib().mil_reduce_defer_begin(ctypes.addressof(self.host), self.MAX_JOBS), "mil_reduce_defer_begin")
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        n = ctypes.c_int(0)
+        L.check(L.lib().mil_reduce_defer_end(ctypes.byref(n)), "mil_reduce_defer_end")
+        if exc_type is not None or n.value == 0:
+            return False
+        raw = bytes(self.host[: self.rec * n.value])
+        if raw != self.uploaded:             # pointers and shapes repeat step after step: the table is uploaded once
+            self.dev[: len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            self.uploaded = raw
+        L.check(L.lib().mil_wgrad_reduce_all(self.dev.data_ptr(), ctypes.addressof(self.host), n.value, L.stream_ptr()),
+                "mil_wgrad_reduce_all")
+        return False
+
+
 def cpad(c):
     return (c + 7) // 8 * 8
 
@@ -331,7 +370,7 @@ def stem_fwd_fused(x, wpack, bias_pad, cout_p, *, slope=LEAK, dtype=torch.bfloat
     return xs, pool, widx
 
 
-def stem_bwd_fused(xs, g_pool, widx, *, workspace=None, out=None, slope=LEAK):
+def stem_bwd_fused(xs, g_pool, widx, *, workspace=None, out=None, slope=LEAK, ws_alloc=None):
     """(dW [20,3,7,7], db [20]) of the stem from the pooled-output gradient in one pass (see mil_stem_bwd_fused),
     or None when the shape/dtype has no fused kernel."""
     n, h2, w2, c = xs.shape
@@ -344,6 +383,8 @@ def stem_bwd_fused(xs, g_pool, widx, *, workspace=None, out=None, slope=LEAK):
     _need(xs, (n, h2, w2, 16), xs.dtype, "xs")
     _need(g_pool, (n, hp, wp, 24), xs.dtype, "g_pool")
     _need(widx, (n, hp, wp, 24), torch.uint8, "widx")
+    if ws_alloc is not None:                 # deferred reductions: the slab buffer must outlive this call
+        workspace = ws_alloc(need.value)
     if workspace is None or workspace.numel() * workspace.element_size() < need.value:
         workspace = torch.empty((need.value + 3) // 4, dtype=torch.float32, device=xs.device)
     if out is None:

@@ -83,6 +83,21 @@ int mil_conv_wgrad(const void* x, const void* dz, float* dw, float* db, void* wo
                    int n_img, int H, int W, int cin, int Ho, int Wo, int cout, int ks, int stride, int pad,
                    int stem_mode, int accumulate, int dtype, void* stream);
 
+/* ---- batched slab reductions -------------------------------------------------------------------------
+ * Every weight-gradient producer below (mil_conv_wgrad, mil_conv_wgrad_pair, mil_conv_bwd_fused, mil_stem_bwd_fused) ends in
+ * a fixed-order reduction of per-workgroup partial sums ("slabs" in its workspace) into dW/db: 28 launches of ~10 us in one
+ * backward pass of the encoder (autograd of nnBlocks.py:169-171 / gbm/model.py:24).  Between mil_reduce_defer_begin and
+ * mil_reduce_defer_end the producers called on THIS thread record that reduction as a job in the caller's host table
+ * (max_jobs records of mil_reduce_job_bytes() bytes) instead of launching it; mil_wgrad_reduce_all then runs every recorded
+ * job in ONE launch (same summation trees: bit-identical to the per-call reductions).  Contract: each producer's workspace
+ * must stay untouched until mil_wgrad_reduce_all has run on the same stream; `jobs_dev` is a device copy of the table,
+ * `jobs_host` the table itself; at most 64 jobs per table.  This is the library's only state: thread-local, and empty
+ * outside a begin/end pair. */
+int mil_reduce_job_bytes(void);
+int mil_reduce_defer_begin(void* jobs_host, int max_jobs);
+int mil_reduce_defer_end(int* njobs);
+int mil_wgrad_reduce_all(const void* jobs_dev, const void* jobs_host, int njobs, void* stream);
+
 /* ---- fused backward of a 3x3 stride-1 conv (bf16 path, narrow layers) --------------------------
  * One pass over dz and x yields BOTH autograd results of nn.Conv2d (nnBlocks.py:169-171):
  *     dx = (conv^T(dz, W) + addend?) * (apply_mask ? lrelu'(x) : 1)      and      dW, db

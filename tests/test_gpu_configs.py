@@ -338,3 +338,33 @@ def test_fused_backward_sequencing_vs_unfused_bf16(golden_dir, monkeypatch):
     print("fused vs un-fused backward: worst max-relative gradient difference", worst, "worst cosine", wcos)
     assert worst[0] < 5e-2, worst
     assert wcos[0] > 0.999, wcos
+
+
+def test_batched_slab_reductions_are_bit_identical(golden_dir, monkeypatch):
+    """The 28 weight-gradient slab reductions of a backward pass run as ONE launch (mil_reduce_defer_begin / _end /
+    mil_wgrad_reduce_all) instead of one launch behind every producer: same summation trees, so every gradient must be
+    BIT-identical to the per-call reductions — bf16 (fused kernels) and fp32 (plain dgrad / wgrad), persistent and
+    generic launch sizes, accumulating into the flat bucket and through autograd's own accumulation."""
+    import mil_amd
+    x, sizes, labels = _bags_128()
+    for dtype, pf in ((torch.bfloat16, "1"), (torch.float32, "1000000000"), (torch.bfloat16, "1000000000")):
+        monkeypatch.setenv("MIL_PF_MIN_TILES", pf)
+        grads = []
+        for batched in (False, True):
+            net = _model(golden_dir, dtype)
+            net.cnn.module.batch_reductions = batched
+            flat = mil_amd.FlatParams(net)
+            for _ in range(2):                               # second pass accumulates on top of the first
+                net.forward_bags((x[:48], [20, 28]), labels[:2]).loss.sum().backward()
+            torch.cuda.synchronize()
+            grads.append(flat.flat_grad.clone())
+            assert (net.cnn.module._reduce_batch is not None) == batched
+        assert torch.equal(grads[0], grads[1]) and float(grads[0].abs().max()) > 0, dtype
+    net = _model(golden_dir, torch.bfloat16)                 # autograd path (fresh dW tensors every call)
+    out = net(x[:16], labels[:1])
+    out["loss"].backward()
+    ref = _model(golden_dir, torch.bfloat16)
+    ref.cnn.module.batch_reductions = False
+    ref(x[:16], labels[:1])["loss"].backward()
+    for (k, p), q in zip(net.named_parameters(), ref.parameters()):
+        assert torch.equal(p.grad, q.grad), k
