@@ -181,7 +181,8 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 
         for (int m = 0; m < SF_MT; ++m)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[m][nt] = bias_r[nt];
-#if MIL_STEM_FWD_LOOKAHEAD > 0
+#ifdef MIL_EXP_STEMF_NO_CONV
+#elif MIL_STEM_FWD_LOOKAHEAD > 0
         {
             // The (k-step, row tile) loop flattened into one software pipeline: the pixel fragment of step j+LA is read
             // LA steps before the two MFMAs that consume it (a ring of LA+1 fragments), the filter fragments one k-step
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 
         }
         __syncthreads();
         // ---- 3x3 s2 max-pool of the stem tile: first maximum in (ky,kx) scan order wins ---------------------
+#ifndef MIL_EXP_STEMF_NO_POOL
         {
             const int obase = ((img * Ho + 8 * ty) * Wo + 16 * tx) * COUTP;
             const int ylim = Ho - 8 * ty, xlim = Wo - 16 * tx;
@@ -284,6 +286,7 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 
                 __builtin_amdgcn_raw_buffer_store_b32(rec, rs_i, ok ? eoff : MIL_OOB, 0, 0);
             }
         }
+#endif
     }
 }
 
