@@ -161,6 +161,160 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(WideArgs<T> a, int lds_w
     }
 }
 
+// Pipelined bf16 form of the kernel above for stride-1 launches without zero insertion (all 3x3 s1 forward convs and
+// data gradients of the wide layers: 36 of the 42 wide_conv launches of an alt_resnet [3,3,3,3] step):
+//   * the NEXT chunk's halo slice and filter slice are requested into registers before the current chunk's MFMA loop
+//     and written to LDS after it (issue-early / write-late), so their L2/HBM latency hides under 72 MFMAs per wave
+//     instead of stalling every chunk at a synchronous load -> barrier -> compute -> barrier sequence;
+//   * a workgroup owns one tile for all chunks, so every piece's address and predicate is computed ONCE (buffer
+//     descriptor, out-of-range offset as the predicate): a chunk adds 64 bytes;
+//   * the (tap, row tile) loop is one flattened software pipeline: pixel fragments read two steps ahead through a ring,
+//     filter fragments one tap ahead, scheduling fences keep the order (hipcc's own order waits for every fragment
+//     right in front of its MFMAs);
+//   * KS is a template parameter: tap offsets are loop-invariant registers, the tap loop is unrolled.
+template <int KS>
+__global__ __launch_bounds__(256, 2) void wide_conv_pf_kernel(WideArgs<BF16> a, int lds_w_off, unsigned x_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using T = BF16;
+    constexpr int PIXB = mil_pix_pitch(WIDE_CK, 2);
+    constexpr int NTAP = KS * KS;
+    constexpr int NPH = 4;                                   // halo pieces per thread: <= 256 pixels x 4 pieces of 16 B
+    constexpr int NPW = NTAP;                                // filter pieces per thread: NTAP * 4 * 64 fragments of 16 B / 256
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;              // wave grid: 2 (pixels) x 2 (channels)
+    const int r = lane & 15, gq = lane >> 4;
+    const int cb = blockIdx.y;
+    const TileOrigin o = mil_tile_origin(g, blockIdx.x);
+    char* ldsA = smem;
+    char* ldsW = smem + lds_w_off;
+    const int nchunks = a.cin / WIDE_CK;
+    const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, x_bytes);
+
+    // halo pieces of this thread: fixed for the whole workgroup (one tile), a chunk only shifts the channel offset
+    unsigned h_off[NPH];
+    int h_lds[NPH];
+    {
+        const int npix = (g.hh * g.hw) << g.ti_log2;
+        const int iy0 = o.oy0 - g.pad, ix0 = o.ox0 - g.pad;
+#pragma unroll
+        for (int i = 0; i < NPH; ++i) {
+            const int idx = tid + 256 * i;
+            const int hp = idx >> 2, j = idx & 3;
+            const int ti = hp / (g.hh * g.hw), rem = hp - ti * (g.hh * g.hw);
+            const int hy = rem / g.hw, hx = rem - hy * g.hw;
+            const int img = o.img0 + ti, iy = iy0 + hy, ix = ix0 + hx;
+            const bool used = hp < npix;
+            const bool ok = used && img < g.n_img && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+            h_off[i] = ok ? (unsigned)((((img * g.H + iy) * g.W + ix) * a.cin) * 2 + j * 16) : MIL_OOB;
+            h_lds[i] = used ? hp * PIXB + j * 16 : lds_w_off - 16;        // unused slots: 16 spare bytes behind the halo tile
+        }
+    }
+    int pixbase[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) pixbase[m] = mil_pix_base<PIXB>(g, (wm * 4 + m) * 16 + r, 1) + gq * 16;
+    int toff[NTAP];
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap) toff[tap] = ((tap / KS) * g.hw + (tap % KS)) * PIXB;
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const size_t chunk_bytes = (size_t)NTAP * WIDE_NT * 64 * 16;
+    const char* wbase = reinterpret_cast<const char*>(a.w) + (size_t)cb * nchunks * chunk_bytes + (size_t)tid * 16;
+    u32x4_t rh[NPH], rw[NPW];
+    auto fetch = [&](int ch) {
+#pragma unroll
+        for (int i = 0; i < NPH; ++i)
+            rh[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, h_off[i] == MIL_OOB ? MIL_OOB : h_off[i] + (unsigned)(ch * WIDE_CK * 2), 0, 0);
+        const char* src = wbase + (size_t)ch * chunk_bytes;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) rw[i] = *reinterpret_cast<const u32x4_t*>(src + i * 256 * 16);
+    };
+    fetch(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();                       // the previous chunk's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < NPH; ++i) *reinterpret_cast<u32x4_t*>(ldsA + h_lds[i]) = rh[i];
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) *reinterpret_cast<u32x4_t*>(ldsW + (tid + 256 * i) * 16) = rw[i];
+        __syncthreads();
+        if (ch + 1 < nchunks) fetch(ch + 1);   // lands while the loop below runs
+        {
+            constexpr int TOT = NTAP * 4, LA = TOT > 2 ? 2 : 1, R = LA + 1;
+            Frag8<T> ring[R], bq[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bq[0][j] = lds_frag<T>(ldsW + ((wn * 2 + j) * 64 + lane) * 16);
+#pragma unroll
+            for (int q = 0; q < LA; ++q) ring[q % R] = lds_frag<T>(ldsA + pixbase[q % 4] + toff[q / 4]);
+#pragma unroll
+            for (int q = 0; q < TOT; ++q) {
+                const int tap = q / 4, m = q % 4;
+                if (q + LA < TOT) ring[(q + LA) % R] = lds_frag<T>(ldsA + pixbase[(q + LA) % 4] + toff[(q + LA) / 4]);
+                if (m == 0 && tap + 1 < NTAP) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bq[(tap + 1) & 1][j] = lds_frag<T>(ldsW + (((tap + 1) * WIDE_NT + wn * 2 + j) * 64 + lane) * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[m][j] = mma8(ring[q % R], bq[tap & 1][j], acc[m][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();
+    float* epi = reinterpret_cast<float*>(smem);             // [128 px][64 ch] fp32
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                epi[((wm * 4 + m) * 16 + gq * 4 + i) * WIDE_NB + (wn * 2 + j) * 16 + r] = acc[m][j][i];
+    __syncthreads();
+    const int tw_mask = (1 << g.tw_log2) - 1, th_mask = (1 << g.th_log2) - 1;
+    for (int idx = tid; idx < 128 * (WIDE_NB / 8); idx += 256) {
+        const int tp = idx >> 3, c8 = idx & 7;
+        const int ox = o.ox0 + (tp & tw_mask);
+        const int oy = o.oy0 + ((tp >> g.tw_log2) & th_mask);
+        const int img = o.img0 + (tp >> (g.tw_log2 + g.th_log2));
+        if (img >= g.n_img || oy >= g.Ho || ox >= g.Wo) continue;
+        float v[8];
+        {
+            const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(epi + tp * WIDE_NB + c8 * 8);
+            const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(epi + tp * WIDE_NB + c8 * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+        }
+        const int c = cb * WIDE_NB + c8 * 8;
+        if (a.bias) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += a.bias[c + j];
+        }
+        const size_t off = (((size_t)img * g.Ho + oy) * g.Wo + ox) * a.cout + c;
+        if (a.res) {
+            float rv[8];
+            load8<T>(a.res + off, rv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += rv[j];
+        }
+        if (a.apply_relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = lrelu(v[j], a.slope);
+        }
+        if (a.act) {
+            float av[8];
+            load8<T>(a.act + off, av);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= lrelu_grad(av[j], a.slope);
+        }
+        store8<T>(a.y + off, v);
+    }
+}
+
 // fp32 master [Cout][Cin][k][k] -> [co_block][ci_chunk][tap][4][64][8] (mode 0 forward, 1 dgrad; see conv_igemm)
 template <typename T>
 __global__ void wide_pack_kernel(const float* __restrict__ w, typename T::elem* __restrict__ out, int cout, int cin, int ks,
@@ -204,6 +358,12 @@ extern "C" int mil_wide_pack_weights(const float* w, void* wpack, int cout, int 
     return MIL_OK;
 }
 
+#include <cstdlib>
+static bool mil_wide_pf_enabled() {          // MIL_WIDE_PF=0: the plain kernel everywhere (A/B runs)
+    static const bool v = [] { const char* e = getenv("MIL_WIDE_PF"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
 template <typename T>
 static int launch_wide(WideArgs<T> a, hipStream_t st) {
     constexpr int ESZ = T::ESZ;
@@ -220,11 +380,27 @@ static int launch_wide(WideArgs<T> a, hipStream_t st) {
     int lds = a_bytes + w_bytes;
     if (lds < 128 * WIDE_NB * 4) lds = 128 * WIDE_NB * 4;
     if (lds > 160 * 1024) return MIL_ERR_UNSUPPORTED;
+    const int tiles = a.g.n_groups * a.g.tiles_y * a.g.tiles_x;
+    if (tiles <= 0) return MIL_OK;
+    if constexpr (T::DT == MIL_DT_BF16) {
+        // stride-1 bf16 launches whose halo fits the register prefetch: the pipelined form
+        const int halo_px = (a.g.hh * a.g.hw) << a.g.ti_log2;
+        const size_t xb = (size_t)a.g.n_img * a.g.H * a.g.W * a.cin * 2;
+        if (mil_wide_pf_enabled() && a.g.stride == 1 && !a.g.zins && halo_px <= 256 && xb < ((size_t)1 << 31) && (a.g.ks == 3 || a.g.ks == 1)) {
+            const int a_pf = a_bytes + 16;                    // + dump slot for the unused halo piece slots
+            int lds_pf = a_pf + w_bytes;
+            if (lds_pf < 128 * WIDE_NB * 4) lds_pf = 128 * WIDE_NB * 4;
+            auto kpf = a.g.ks == 3 ? wide_conv_pf_kernel<3> : wide_conv_pf_kernel<1>;
+            if (lds_pf > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kpf), hipFuncAttributeMaxDynamicSharedMemorySize, lds_pf) != hipSuccess)
+                return MIL_ERR_LAUNCH;
+            hipLaunchKernelGGL(kpf, dim3(tiles, a.cout / WIDE_NB), dim3(256), lds_pf, st, a, a_pf, (unsigned)xb);
+            MIL_CHECK_LAUNCH();
+            return MIL_OK;
+        }
+    }
     auto kern = wide_conv_kernel<T>;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MIL_ERR_LAUNCH;
-    const int tiles = a.g.n_groups * a.g.tiles_y * a.g.tiles_x;
-    if (tiles <= 0) return MIL_OK;
     hipLaunchKernelGGL(kern, dim3(tiles, a.cout / WIDE_NB), dim3(256), lds, st, a, a_bytes);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
