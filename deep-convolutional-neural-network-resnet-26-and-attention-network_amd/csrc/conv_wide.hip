@@ -557,6 +557,133 @@ __global__ __launch_bounds__(256) void wide_wgrad_kernel(WideWgradArgs<T> a) {
     }
 }
 
+// Pipelined bf16 form of the kernel above (stride 1, halo <= 256 pixels): the NEXT tile's halo slice and dz tile are
+// requested into registers before the current tile's MFMA loop and written to LDS after it; piece -> (halo position, LDS
+// offset, relative address) tables are built once per workgroup (buffer descriptors, out-of-range offset as the
+// predicate); the four 32-pixel k-steps of a tile run one step ahead on ping-pong operand sets without validity branches
+// (a row tile that does not exist reads row group 0 into accumulators that are never stored).
+template <int KS>
+__global__ __launch_bounds__(256, 2) void wide_wgrad_pf_kernel(WideWgradArgs<BF16> a, unsigned x_bytes, unsigned z_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PIXB = mil_pix_pitch(WIDE_CK, 2);
+    constexpr int PIXZ = mil_pix_pitch(WIDE_NB, 2);
+    constexpr int CG = WIDE_CK / 8;
+    constexpr int RG = KS * KS * CG, MT = RG / 2, MW = (MT + 3) / 4;
+    constexpr int NPH = 4, NPZ = 4;                          // 16-byte pieces per thread: halo slice (<= 256 px x 4), dz tile (128 px x 8)
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchunks = a.cin / WIDE_CK;
+    const int cb = blockIdx.y / nchunks, ch = blockIdx.y - cb * nchunks;
+    char* ldsX = smem;
+    char* ldsZ = smem + a.lds_z_off;
+    const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, x_bytes);
+    const __amdgpu_buffer_rsrc_t rs_z = mil_rsrc(a.dz, z_bytes);
+    int h_pos[NPH], h_lds[NPH], h_rel[NPH], z_pos[NPZ], z_lds[NPZ], z_rel[NPZ];
+    {
+        const int npix = (g.hh * g.hw) << g.ti_log2;
+        const int tw_mask = (1 << g.tw_log2) - 1, th_mask = (1 << g.th_log2) - 1;
+#pragma unroll
+        for (int i = 0; i < NPH; ++i) {
+            const int idx = tid + 256 * i, hp = idx >> 2, j = idx & 3;
+            const int ti = hp / (g.hh * g.hw), rem = hp - ti * (g.hh * g.hw), hy = rem / g.hw, hx = rem - hy * g.hw;
+            const bool used = hp < npix;
+            h_pos[i] = used ? (ti << 20) | (hy << 10) | hx : -1;
+            h_lds[i] = used ? hp * PIXB + j * 16 : a.lds_z_off - 16;          // 16 spare bytes behind the halo tile
+            h_rel[i] = ((ti * g.H + hy) * g.W + hx) * (a.cin * 2) + j * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < NPZ; ++i) {
+            const int idx = tid + 256 * i, tp = idx >> 3, j = idx & 7;
+            const int tx = tp & tw_mask, ty = (tp >> g.tw_log2) & th_mask, ti = tp >> (g.tw_log2 + g.th_log2);
+            z_pos[i] = (ti << 20) | (ty << 10) | tx;
+            z_lds[i] = tp * PIXZ + j * 16;
+            z_rel[i] = ((ti * g.Ho + ty) * g.Wo + tx) * (a.cout * 2) + j * 16;
+        }
+    }
+    u32x4_t rh[NPH], rz[NPZ];
+    auto fetch = [&](int tile) {
+        const TileOrigin o = mil_tile_origin(g, tile);
+        const int iy0 = o.oy0 - g.pad, ix0 = o.ox0 - g.pad, ilim = g.n_img - o.img0;
+        const int xbase = ((o.img0 * g.H + iy0) * g.W + ix0) * (a.cin * 2) + ch * (WIDE_CK * 2);      // may be negative; valid lanes are not
+        const int zbase = ((o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (a.cout * 2) + cb * (WIDE_NB * 2);
+#pragma unroll
+        for (int i = 0; i < NPH; ++i) {
+            const int p = h_pos[i];
+            const bool ok = p >= 0 && (p >> 20) < ilim && (unsigned)(iy0 + ((p >> 10) & 1023)) < (unsigned)g.H &&
+                            (unsigned)(ix0 + (p & 1023)) < (unsigned)g.W;
+            rh[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (unsigned)(xbase + h_rel[i]) : MIL_OOB, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NPZ; ++i) {
+            const int p = z_pos[i];
+            const bool ok = (p >> 20) < ilim && o.oy0 + ((p >> 10) & 1023) < g.Ho && o.ox0 + (p & 1023) < g.Wo;
+            rz[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_z, ok ? (unsigned)(zbase + z_rel[i]) : MIL_OOB, 0, 0);
+        }
+    };
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3, gq = lane >> 4;
+    int toff[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+        int rg = 2 * (wave + 4 * i) + (p4 >> 1);
+        if (rg >= RG) rg = 0;
+        const int tap = rg / CG, cg = rg - tap * CG;
+        toff[i] = ((tap / KS) * g.hw + (tap % KS)) * PIXB + cg * 16 + (p4 & 1) * 8;
+    }
+    const int wpl0 = mil_pix_base<PIXB>(g, 8 * gq + q4, 1), wpl1 = mil_pix_base<PIXB>(g, 8 * gq + q4 + 4, 1);
+    const int zl0 = (8 * gq + q4) * PIXZ + p4 * 8;
+    f32x4_t acc[MW][WIDE_NT];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int nt = 0; nt < WIDE_NT; ++nt) acc[i][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if ((int)blockIdx.x < a.ntiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        __syncthreads();                       // the previous tile's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < NPH; ++i) *reinterpret_cast<u32x4_t*>(ldsX + h_lds[i]) = rh[i];
+#pragma unroll
+        for (int i = 0; i < NPZ; ++i) *reinterpret_cast<u32x4_t*>(ldsZ + z_lds[i]) = rz[i];
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
+        bf16x8_t bq[2][WIDE_NT], aq[2][MW];
+        auto load = [&](int k32, bf16x8_t (&bf)[WIDE_NT], bf16x8_t (&af)[MW]) {
+            const int kb = mil_pix_base<PIXB>(g, k32, 1);
+            const char* z0 = ldsZ + k32 * PIXZ + zl0;
+#pragma unroll
+            for (int nt = 0; nt < WIDE_NT; ++nt) bf[nt] = mil_tr_pair(z0 + nt * 32, z0 + 4 * PIXZ + nt * 32);
+#pragma unroll
+            for (int i = 0; i < MW; ++i) af[i] = mil_tr_pair(ldsX + kb + wpl0 + toff[i], ldsX + kb + wpl1 + toff[i]);
+        };
+        load(0, bq[0], aq[0]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k + 1 < 4) load((k + 1) * 32, bq[(k + 1) & 1], aq[(k + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MW; ++i)
+#pragma unroll
+                for (int nt = 0; nt < WIDE_NT; ++nt)
+                    acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[k & 1][i], bq[k & 1][nt], acc[i][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    constexpr size_t SLAB = (size_t)MT * 16 * WIDE_NB;
+    float* slab = a.slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SLAB;
+    const int col = lane & 15;
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+        const int mt = wave + 4 * i;
+        if (mt >= MT) continue;
+#pragma unroll
+        for (int nt = 0; nt < WIDE_NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                slab[(size_t)(mt * 16 + gq * 4 + e) * WIDE_NB + nt * 16 + col] = acc[i][nt][e];
+    }
+}
+
 // dW[cb*64+col][ch*32+ci][tap] (+)= sum over the pair's slabs (fixed order); slab row = tap*32 + ci
 __global__ void wide_wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int npairs, int nchunks, int ks,
                                          float* __restrict__ dw, int cout, int cin, int accumulate) {
@@ -598,12 +725,29 @@ static int run_wide_wgrad(const void* x, const void* dz, float* dw, void* ws, si
     WideWgradArgs<T> a{};
     a.x = (const typename T::elem*)x; a.dz = (const typename T::elem*)dz; a.slab = (float*)ws; a.g = g;
     a.cin = cin; a.cout = cout; a.ntiles = ntiles; a.lds_z_off = xb;
-    auto kern = wide_wgrad_kernel<T, KS>;
-    const int lds = xb + zb;
-    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-        return MIL_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(gx, npairs), dim3(256), lds, st, a);
-    MIL_CHECK_LAUNCH();
+    bool done = false;
+    if constexpr (T::DT == MIL_DT_BF16) {
+        const size_t xbytes = (size_t)g.n_img * g.H * g.W * cin * 2, zbytes = (size_t)g.n_img * g.Ho * g.Wo * cout * 2;
+        if (mil_wide_pf_enabled() && g.stride == 1 && ((g.hh * g.hw) << g.ti_log2) <= 256 && g.hh < 1024 && g.hw < 1024 &&
+            xbytes < ((size_t)1 << 31) && zbytes < ((size_t)1 << 31)) {
+            a.lds_z_off = xb + 16;                              // + dump slot for the unused halo piece slots
+            auto kpf = wide_wgrad_pf_kernel<KS>;
+            const int lds = xb + 16 + zb;
+            if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kpf), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+                return MIL_ERR_LAUNCH;
+            hipLaunchKernelGGL(kpf, dim3(gx, npairs), dim3(256), lds, st, a, (unsigned)xbytes, (unsigned)zbytes);
+            MIL_CHECK_LAUNCH();
+            done = true;
+        }
+    }
+    if (!done) {
+        auto kern = wide_wgrad_kernel<T, KS>;
+        const int lds = xb + zb;
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return MIL_ERR_LAUNCH;
+        hipLaunchKernelGGL(kern, dim3(gx, npairs), dim3(256), lds, st, a);
+        MIL_CHECK_LAUNCH();
+    }
     const size_t total = (size_t)KS * KS * WIDE_CK * WIDE_NB * npairs;
     hipLaunchKernelGGL(wide_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)ws, gx, npairs,
                        cin / WIDE_CK, KS, dw, cout, cin, accumulate);
