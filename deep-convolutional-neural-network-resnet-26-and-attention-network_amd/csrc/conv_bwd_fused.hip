@@ -423,12 +423,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
 //     pace and the waves of a SIMD overlap one's MFMAs with another's epilogue instead of marching in phase;
 //   * the bias gradient needs no MFMA of its own: channel CX-1 of the x tile in LDS (a padding channel) is set to 1, so
 //     column CX-1 of the centre-tap rows of dW' is sum_q dz[q][co] (the reduction reads db from there).
+#ifndef MIL_BWD16_K20
+#define MIL_BWD16_K20 1
+#endif
 template <bool ADD, bool MASK>
 __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CZ = 24, NTX = 2, KS = 3, NW = 8;
     constexpr int PIXB = 48, PIXX = 48, CG = 3, CX = 24, HW = 18, ROWB = HW * PIXB;      // 864 B per halo row
-    constexpr int NTHR = 512, MTW = 2, KSTEPS = 7, RG = 27, MT = 14, MW = 2, NPX = 2;
+    constexpr bool K20 = MIL_BWD16_K20 != 0;                  // 24 k-groups / 45 four-channel row pieces (geom.cuh) instead of 27 / 54
+    constexpr int KSTEPS_STD = 7;
+    constexpr int NTHR = 512, MTW = 2, KSTEPS = K20 ? MIL_K20_STEPS : KSTEPS_STD, RG = 27, MT = K20 ? 12 : 14, MW = 2, NPX = 2;
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -436,9 +441,11 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
     char* ldsW = smem + a.lds_w_off;
     {
         const int nbytes = KSTEPS * NTX * 64 * 16;
-        const char* src = reinterpret_cast<const char*>(a.w);
+        const char* src = reinterpret_cast<const char*>(a.w) + (K20 ? KSTEPS_STD * NTX * 64 * 16 : 0);      // K20 k-steps sit behind the standard ones
         for (int i = tid * 16; i < nbytes; i += NTHR * 16)
             *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(src + i);
+        // the last halo record's "next pixel" slot is never written by a commit: finite once and for all (zero weights read it)
+        if (K20 && tid < 2) *reinterpret_cast<u32x2_t*>(smem + tid * a.lds_a2_off + 16 + (HW * HW - 1) * PIXB + 40) = u32x2_t{0u, 0u};
     }
     const __amdgpu_buffer_rsrc_t rs_z = mil_rsrc(a.dz, a.z_bytes);
     const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, a.x_bytes);
@@ -447,14 +454,19 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
     const int H = g.H, W = g.W;
 
     // ---- halo pieces of this thread: piece id = tid + 512*i -> (halo pixel, 16-byte piece) ------------------
+    // K20: a pixel's third piece (channels 16-19 + padding) is committed as two 8-byte halves: channels 16-19 into its own
+    // record and AGAIN into the previous pixel's "next pixel" slot (bit 20 of h_pos marks these pieces)
+    // (at its record offset - 40; pixel 0's lands in the spare bytes)
     int h_pos[NPX], h_lds[NPX], h_rel[NPX];
-    const int dump_a = a.lds_w_off - 16 - a.lds_a2_off;      // 16 spare bytes behind each halo buffer
+    constexpr int HALO0 = K20 ? 16 : 0;                      // the 16 spare bytes of a halo buffer sit in FRONT of the K20 tile
+    const int dump_a = K20 ? -16 : a.lds_w_off - 16 - a.lds_a2_off;
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
         const int idx = tid + NTHR * i;
         const bool used = idx < HW * HW * CG;
         const int px = idx / CG, j = idx - px * CG, hy = px / HW, hx = px - hy * HW;
-        h_pos[i] = used ? (hy << 10) | hx : -1;
+        const bool third = K20 && used && j == CG - 1;
+        h_pos[i] = used ? (third ? 1 << 20 : 0) | (hy << 10) | hx : (int)0x80000000u;      // unused: negative, bit 20 clear (its dump write stays in the spare bytes)
         h_lds[i] = used ? px * PIXB + j * 16 : dump_a;
         h_rel[i] = (hy * W + hx) * (CZ * 2) + j * 16;
     }
@@ -464,15 +476,25 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
         const int base = ((o.img0 * H + iy0) * W + ix0) * (CZ * 2);      // may be negative; valid lanes are not
 #pragma unroll
         for (int i = 0; i < NPX; ++i) {
-            const int p = h_pos[i];
-            const bool ok = p >= 0 && (unsigned)(iy0 + (p >> 10)) < (unsigned)H && (unsigned)(ix0 + (p & 1023)) < (unsigned)W;
-            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_z, ok ? (unsigned)(base + h_rel[i]) : MIL_OOB, 0, 0);
+            int p = h_pos[i];
+            if constexpr (K20) asm volatile("" : "+v"(p));      // keeps what is derived from p from being hoisted into loop-long registers
+            const bool ok = (p >= 0) & ((unsigned)(iy0 + ((p >> 10) & 1023)) < (unsigned)H) & ((unsigned)(ix0 + (p & 1023)) < (unsigned)W);
+            if constexpr (K20) {      // two 8-byte halves; a third piece loads channels 16-19 into both (its copy for the previous record)
+                const unsigned off = ok ? (unsigned)(base + h_rel[i]) : MIL_OOB;
+                const u32x2_t lo = __builtin_amdgcn_raw_buffer_load_b64(rs_z, off, 0, 0);
+                const u32x2_t hi = __builtin_amdgcn_raw_buffer_load_b64(rs_z, off + (((p >> 20) & 1) ? 0u : 8u), 0, 0);
+                rx[i] = u32x4_t{lo[0], lo[1], hi[0], hi[1]};
+            } else {
+                rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_z, ok ? (unsigned)(base + h_rel[i]) : MIL_OOB, 0, 0);
+            }
         }
     };
 
     // ---- data gradient: fragment address = per-lane base + immediate -----------------------------------------
-    // k index q = 4*sl + gq = (tap, 8-channel group); halo offset of q relative to the pixel's top-left tap
-    auto koff = [](int q) { int tap = q / CG, cg = q - tap * CG; if (tap >= KS * KS) { tap = 0; cg = 0; }
+    // k index q = 4*sl + gq = (tap, 8-channel group) [K20: k-group q of geom.cuh]; halo offset of q relative to the
+    // pixel's top-left tap
+    auto koff = [](int q) { if constexpr (K20) return mil_k20_off(q, ROWB, PIXB);
+                            int tap = q / CG, cg = q - tap * CG; if (tap >= KS * KS) { tap = 0; cg = 0; }
                             return ((tap / KS) * HW + (tap % KS)) * PIXB + cg * 16; };
     const int bA = (wave * MTW * HW + r) * PIXB + 16 * gq;        // pixel (row 2*wave [+m], col r), lane group part
     int zb[KSTEPS];
@@ -495,10 +517,18 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
         const int wpl0 = ((kl0 >> 4) * HW + (kl0 & 15)) * PIXB, wpl1 = ((kl1 >> 4) * HW + (kl1 & 15)) * PIXB;
 #pragma unroll
         for (int i = 0; i < MW; ++i) {
-            int rg = 2 * (wave + NW * i) + (p4 >> 1);
-            if (rg >= RG) rg = 0;                                  // a row tile that does not exist: finite data, never stored
-            const int tap = rg / CG, cg = rg - tap * CG;
-            const int wt = ((tap / KS) * HW + (tap % KS)) * PIXB + cg * 16 + (p4 & 1) * 8;
+            int wt;
+            if constexpr (K20) {                                   // row piece P = (tap', four dz channels): rows tap'*20 + co
+                int P = 4 * (wave + NW * i) + p4;
+                if (P >= KS * KS * 5) P = 0;                       // rows that do not exist: finite data, never reduced
+                const int tap = P / 5, c4 = P - tap * 5;
+                wt = ((tap / KS) * HW + (tap % KS)) * PIXB + c4 * 8;
+            } else {
+                int rg = 2 * (wave + NW * i) + (p4 >> 1);
+                if (rg >= RG) rg = 0;                              // a row tile that does not exist: finite data, never stored
+                const int tap = rg / CG, cg = rg - tap * CG;
+                wt = ((tap / KS) * HW + (tap % KS)) * PIXB + cg * 16 + (p4 & 1) * 8;
+            }
             zw[i][0] = wpl0 + wt; zw[i][1] = wpl1 + wt;
         }
     }
@@ -542,12 +572,22 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
         MIL_ST_BEGIN()
         // Two halo buffers and two x-tile buffers: a wave may commit tile t+1 while others still compute tile t (they
         // read the other buffers); it can reach tile t+2's commit only past barrier t+1, i.e. after every wave left tile t.
-        char* ldsA_t = smem + buf;
+        char* ldsA_t = smem + buf + HALO0;
         char* ldsX_t = smem + a.lds_x_off + xbuf;
         buf = buf_step - buf;
         xbuf = xbuf_step - xbuf;
 #pragma unroll
-        for (int i = 0; i < NPX; ++i) *reinterpret_cast<u32x4_t*>(ldsA_t + h_lds[i]) = rx[i];
+        for (int i = 0; i < NPX; ++i) {
+            if constexpr (K20) {
+                int p = h_pos[i];
+                asm volatile("" : "+v"(p));
+                const bool third = (p >> 20) & 1;
+                *reinterpret_cast<u32x2_t*>(ldsA_t + h_lds[i]) = u32x2_t{rx[i][0], rx[i][1]};
+                *reinterpret_cast<u32x2_t*>(ldsA_t + h_lds[i] + (third ? -40 : 8)) = u32x2_t{rx[i][2], rx[i][3]};
+            } else {
+                *reinterpret_cast<u32x4_t*>(ldsA_t + h_lds[i]) = rx[i];
+            }
+        }
         // x centre tile -> LDS [pixel][CX] (zeros outside the image); its padding channel CX-1 := 1 (bias sums)
 #pragma unroll
         for (int nt = 0; nt < NTX; ++nt) {
@@ -686,7 +726,7 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
 #endif
     // ---- partial sums -> slab: rows tap'*CZ + co, cols ci (col CX-1 of the centre-tap rows = bias sums) ---------
     constexpr int SLAB_COLS = NTX * 16;
-    constexpr size_t SLAB_ELEMS = (size_t)(MT + 1) * 16 * SLAB_COLS;
+    constexpr size_t SLAB_ELEMS = (size_t)(14 + 1) * 16 * SLAB_COLS;      // the launcher's slab pitch (generic kernel's row count)
     float* slab = a.slab + (size_t)blockIdx.x * SLAB_ELEMS;
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
@@ -742,7 +782,8 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
     // (two halo buffers AND two x-tile buffers: 70 KB, two workgroups per CU)
     bool t16 = false;
     if constexpr (CZ == 24 && NTX == 2 && KS == 3 && NW == 8)
-        t16 = mil_bwd16_enabled() && dbuf && a.g.tw_log2 == 4 && a.g.th_log2 == 4 && a.g.ti_log2 == 0 && a.g.H < 1024 && a.g.W < 1024;
+        t16 = mil_bwd16_enabled() && dbuf && a.g.tw_log2 == 4 && a.g.th_log2 == 4 && a.g.ti_log2 == 0 && a.g.H < 1024 && a.g.W < 1024 &&
+              (!MIL_BWD16_K20 || cout == 20);      // the K20 order (and the packed filter's second section) exists for 20 dz channels
     const int lds = (dbuf ? 2 : 1) * a_bytes + w_bytes + (t16 ? 2 : 1) * x_bytes + 16;          // + dump slot for the x-tile writes
     if (lds > 160 * 1024) return MIL_ERR_UNSUPPORTED;
     const int ntiles = a.g.n_groups * a.g.tiles_y * a.g.tiles_x;
@@ -811,6 +852,9 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
             j.slab = (const float*)ws; j.nslab = gr; j.slab_elems = slab_elems; j.slab_cols = NTX * 16; j.n_rows = n_rows;
             j.dw = dw; j.db = db; j.cout = cout; j.cin = cin; j.ks = KS; j.kind = 1; j.cinp = CZ;
             j.bias_off = t16 ? (KS * KS / 2) * CZ * NTX * 16 + (CX - 1) : MT * 16 * NTX * 16; j.bias_stride = t16 ? NTX * 16 : 1;
+            if (t16 && MIL_BWD16_K20) {          // rows tap'*20 + co (four-channel row pieces)
+                j.cinp = 20; j.n_rows = KS * KS * 20; j.bias_off = (KS * KS / 2) * 20 * NTX * 16 + (CX - 1);
+            }
             j.accumulate = (i0 > 0) ? 1 : accumulate;
             mil_reduce_or_defer(j, stream, /*may_defer=*/chunk >= n_total);      // a split launch re-uses the slabs per chunk
         }

@@ -546,7 +546,9 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
     constexpr int CINP = 16, NT = 2, KS = 4, COUTP = 24;
     constexpr int PIXB = mil_pix_pitch(CINP, 2);
     constexpr int PIXZ = mil_pix_pitch(COUTP, 2);           // 48: dz tile and pooled-gradient tile
-    constexpr int CG = CINP / 8, RG = KS * KS * CG, MT = (RG + 1) / 2, MW = (MT + 3) / 4;
+    // GEMM rows = (tap, s2d channel) in four-channel pieces (one ds_read_b64_tr_b16 each): 16 taps x 3 real pieces = 48 pieces
+    // = 12 row tiles; the padding piece (channels 12-15) of a pixel record is never read
+    constexpr int NPC = 3, MT = KS * KS * NPC / 4, MW = (MT + 3) / 4;
     constexpr int NPX = mil_halo_np(CINP, 2);
     constexpr int NPW = 2;                                  // pooled-window pieces per thread (<= 144 windows x 3)
     const ConvGeom& g = a.g;
@@ -594,23 +596,20 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
         }
     };
 
-    // per-lane tr-read offsets of this wave's row tiles (rows = (tap, 8 s2d channels))
+    // per-lane tr-read offsets of this wave's row tiles: row piece P = 4*mt + (lane&3) = (tap, four s2d channels)
     int toff[MW];
     bool mvalid[MW];
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
         const int mt = wave + 4 * i;
         mvalid[i] = mt < MT;
-        const int p = lane & 3;
-        int rg = 2 * mt + (p >> 1);
-        if (rg >= RG) rg = 0;
-        const int tap = rg / CG, cg = rg - tap * CG;
-        toff[i] = ((tap / KS) * g.hw + (tap % KS)) * PIXB + cg * 16 + (p & 1) * 8;
+        const int P = mvalid[i] ? 4 * mt + (lane & 3) : 0;
+        const int tap = P / NPC, c3 = P - tap * NPC;
+        toff[i] = ((tap / KS) * g.hw + (tap % KS)) * PIXB + c3 * 8;
     }
-    // The bias gradient sum_p dz[p][co] needs no MFMA of its own: s2d channel 12 (a padding channel, zero in HBM) is set
-    // to 1 in the LDS halo tile, so row (tap, channel 12) of dW' is that sum for every tap; the reduction reads db from
-    // row (tap 0, channel 12).  Every wave then issues the same 64 MFMAs per tile (wave 0 used to issue 16 more).
-    const unsigned one_ch12 = (tid & 1) ? 0x3F80u : 0u;       // odd piece ids hold channels 8..15: dword 2 = channels 12, 13
+    // The bias gradient sum_p dz[p][co] needs no MFMA: the thread that builds (2x2 pixel block, 6 channels) of the dz tile
+    // keeps the running sums of what it wrote (6 registers), reduced over the workgroup in a fixed order at the end.
+    float bsum[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x4_t acc[MW][NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -636,8 +635,6 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
     }
     for (int tile = bid; tile < a.ntiles; tile += gridDim.x) {
         __syncthreads();                         // previous tile's MFMA loop is done with ldsX / ldsZ
-#pragma unroll
-        for (int i = 0; i < NPX; ++i) rx[i][2] |= one_ch12;
         mil_commit_halo<NPX>(rx, ldsX, ht);
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
@@ -707,6 +704,7 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
                         bf16x2_t pr;
                         pr[0] = (__bf16)gsum[dy][dx][2 * k]; pr[1] = (__bf16)gsum[dy][dx][2 * k + 1];
                         dst[k] = __builtin_bit_cast(unsigned, pr);
+                        bsum[2 * k] += (float)pr[0]; bsum[2 * k + 1] += (float)pr[1];      // the rounded values, as the MFMA loop sees them
                     }
                 }
         }
@@ -718,7 +716,7 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
         // One 32-pixel k-step ahead (MIL_STEM_BWD_PIPE): the transposed reads of step k+1 are issued before the MFMAs of
         // step k and scheduling fences keep that order.  Left to itself hipcc reads each row tile's fragment right in
         // front of its two MFMAs behind an lgkmcnt(0): five LDS round trips per k-step, forty per tile — the whole tile
-        // time of this kernel.  Every wave owns MW = 4 row tiles that all exist (MT = 16), so there is no validity branch.
+        // time of this kernel.  Every wave owns MW = 3 row tiles that all exist (MT = 12), so there is no validity branch.
 #if MIL_STEM_BWD_PIPE
         {
             static_assert(MT == 4 * MW, "every wave owns MW full row tiles");
@@ -792,6 +790,17 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
             for (int e = 0; e < 4; ++e)
                 slab[(size_t)(mt * 16 + gq * 4 + e) * SLAB_COLS + nt * 16 + col] = acc[i][nt][e];
     }
+    // bias sums -> slab row MT*16: 64 pixel-block threads per channel, added in thread order
+    __syncthreads();                             // the last tile's MFMA loop is done with the LDS tiles
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) red[(tid >> 2) * 24 + bc6 * 6 + j] = bsum[j];
+    __syncthreads();
+    if (tid < 24) {
+        float v = 0.f;
+        for (int b = 0; b < 64; ++b) v += red[b * 24 + tid];
+        slab[(size_t)MT * 16 * SLAB_COLS + tid] = v;
+    }
 }
 
 static int stem_bwd_entry(const void* xs, const void* gp, const uint8_t* widx, float* dw, float* db, void* ws,
@@ -800,7 +809,7 @@ static int stem_bwd_entry(const void* xs, const void* gp, const uint8_t* widx, f
     if (dtype != MIL_DT_BF16) return MIL_ERR_UNSUPPORTED;
     if (n <= 0 || H2 <= 0 || W2 <= 0) return MIL_ERR_ARG;
     constexpr int PIXB = mil_pix_pitch(16, 2), PIXZ = mil_pix_pitch(24, 2);
-    constexpr int MT = 16;
+    constexpr int MT = 12;                                  // 16 taps x 3 four-channel row pieces / 4 (see the kernel)
     StemBwdArgs a{};
     ConvGeom& g = a.g;
     g.n_img = n; g.H = H2; g.W = W2; g.Ho = H2; g.Wo = W2; g.ks = 4; g.stride = 1; g.pad = 2; g.zins = 0;
@@ -827,9 +836,9 @@ static int stem_bwd_entry(const void* xs, const void* gp, const uint8_t* widx, f
     MIL_CHECK_LAUNCH();
     {
         MilReduceJob j{};
-        j.slab = (const float*)ws; j.nslab = grid; j.slab_elems = slab_elems; j.slab_cols = 32; j.n_rows = 16 * 16;
-        j.dw = dw; j.db = db; j.cout = 20; j.cin = 3; j.ks = 7; j.kind = 0; j.cinp = 16; j.stem_mode = 1;
-        j.bias_row = 12;             // (tap 0, s2d channel 12): the ones channel, see the kernel
+        j.slab = (const float*)ws; j.nslab = grid; j.slab_elems = slab_elems; j.slab_cols = 32; j.n_rows = 16 * 12;
+        j.dw = dw; j.db = db; j.cout = 20; j.cin = 3; j.ks = 7; j.kind = 0; j.cinp = 12; j.stem_mode = 1;      // rows tap*12 + s2d channel
+        j.bias_row = MT * 16;        // the row behind the weight rows: the kernel's VALU bias sums
         j.accumulate = accumulate;
         mil_reduce_or_defer(j, st);
         MIL_CHECK_LAUNCH();

@@ -261,6 +261,36 @@ __host__ __device__ inline float mil_s2_pack_value(const float* w1, const float*
     return w1[((size_t)kin * cin + nout) * 9 + (2 - gr.ky) * 3 + (2 - gr.kx)];
 }
 
+// ---- K-packed order of a 3x3 filter over 20 channels ("K20") ----------------------------------------------------
+// 9 taps x 20 channels are 45 four-channel pieces.  The standard order spends 27 eight-channel k-groups on them (7
+// k-steps: the third group of every tap is half padding).  Here the half groups of two horizontally neighbouring taps
+// share a k-group:
+//   q = 0..17 : tap q/2, channels 8*(q&1) .. +7
+//   q = 18..20: filter row ty = q-18: elements 0-3 = tap (ty,0) channels 16-19, elements 4-7 = tap (ty,1) channels 16-19
+//   q = 21..23: filter row ty = q-21: elements 0-3 = tap (ty,2) channels 16-19, elements 4-7 = zero weights
+// 24 k-groups = 6 k-steps (-14 % MFMAs and fragment reads).  The kernels that use it keep the LDS pixel record as
+// [ch 0-15][ch 16-19][ch 16-19 of the NEXT pixel of the tile row] (the 48-byte pitch of a 24-channel record), so every
+// k-group is still ONE aligned 16-byte read at (tap offset) + {0, 16, 32}.
+#define MIL_K20_STEPS 6
+struct K20Elem { int tap, ch; };              // tap < 0: a zero weight
+__host__ __device__ inline K20Elem mil_k20_elem(int q, int e) {
+    if (q < 18) return K20Elem{q >> 1, 8 * (q & 1) + e};
+    if (q < 21) return K20Elem{(q - 18) * 3 + (e >> 2), 16 + (e & 3)};
+    if (q < 24 && e < 4) return K20Elem{(q - 21) * 3 + 2, 16 + e};
+    return K20Elem{-1, 0};
+}
+// LDS byte offset of k-group q's 16 bytes relative to the record of the pixel under the filter's top-left tap
+__host__ __device__ constexpr int mil_k20_off(int q, int row_pitch, int pix_pitch) {
+    return q < 18 ? ((q >> 1) / 3) * row_pitch + ((q >> 1) % 3) * pix_pitch + (q & 1) * 16
+         : q < 21 ? (q - 18) * row_pitch + 32
+         : q < 24 ? (q - 21) * row_pitch + 2 * pix_pitch + 32 : 0;
+}
+// packed buffers of these filters carry the K20 k-steps behind the standard ones (mode 0: forward, K side = cin; mode 1:
+// data gradient, K side = cout)
+__host__ __device__ constexpr bool mil_pack_has_k20(int mode, int cout, int cin, int ks) {
+    return ks == 3 && ((mode == 0 && cin == 20) || (mode == 1 && cout == 20));
+}
+
 // Fixed-order sum over slabs for the weight-gradient reductions: thread group gq of MIL_RED_GROUPS sums slabs gq,
 // gq+G, gq+2G, ... (8 independent loads in flight per thread, added in index order), group 0 then adds the G partial
 // sums in order.  The tree depends only on (nslab, G): bitwise reproducible run to run.

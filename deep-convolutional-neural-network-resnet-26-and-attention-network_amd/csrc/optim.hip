@@ -2,7 +2,7 @@
 // gradient buckets (one launch for all 640,967 parameters; reference: torch.optim.Adam(lr=2e-4) at
 // gbm/classify_combined.py:519, stepped every few bags at :450-454) and a single-launch re-pack of every
 // convolution filter into MFMA fragment order after the weights changed.
-#include "geom.cuh"
+#include "pack.cuh"
 
 // torch.optim.Adam semantics (no amsgrad, L2 weight decay folded into the gradient):
 //   g += wd*p;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;
@@ -38,53 +38,12 @@ extern "C" int mil_adam_step(float* params, const float* grads, float* exp_avg, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// One launch packs every filter listed in a device-resident job table (see pack_weights_kernel in
-// pointwise.hip for the three index maps).  blockIdx.y = job.
-struct PackJob {
-    const float* w;
-    const float* bias;
-    void* out;
-    float* bias_pad;
-    int cout, cin, ks, mode;
-    int CG, NT, nsteps, dtype;
-};
-
+// One launch packs every filter listed in a device-resident job table (index maps and job record: pack.cuh).
+// blockIdx.y = job.
 __global__ void pack_all_kernel(const PackJob* __restrict__ jobs) {
     const PackJob j = jobs[blockIdx.y];
     const int total = j.nsteps * j.NT * 64 * 8;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        if (idx < j.NT * 16 && j.bias_pad && j.mode != MIL_PACK_DGRAD_S2) {
-            const int n_out = (j.mode == 1) ? j.cin : j.cout;
-            j.bias_pad[idx] = (j.bias && idx < n_out) ? j.bias[idx] : 0.f;
-        }
-        const int e = idx & 7, lane = (idx >> 3) & 63;
-        const int t = idx >> 9;
-        const int nt = t % j.NT, s = t / j.NT;
-        if (j.mode == MIL_PACK_DGRAD_S2) {      // `bias` carries the projection's weight for this mode
-            const float v = mil_s2_pack_value(j.w, j.bias, s, lane, e, nt, j.cout, j.cin, j.CG);
-            if (j.dtype == MIL_DT_BF16) reinterpret_cast<__bf16*>(j.out)[idx] = (__bf16)v;
-            else reinterpret_cast<float*>(j.out)[idx] = v;
-            continue;
-        }
-        const int q = 4 * s + (lane >> 4);
-        const int tap = q / j.CG, cg = q - tap * j.CG;
-        const int kin = cg * 8 + e, nout = nt * 16 + (lane & 15);
-        const int kk = j.ks * j.ks;
-        float val = 0.f;
-        if (j.mode == 0) {
-            if (tap < kk && kin < j.cin && nout < j.cout) val = j.w[((size_t)nout * j.cin + kin) * kk + tap];
-        } else if (j.mode == 1) {
-            if (tap < kk && kin < j.cout && nout < j.cin) val = j.w[((size_t)kin * j.cin + nout) * kk + (kk - 1 - tap)];
-        } else {
-            if (tap < 16 && kin < 12 && nout < j.cout) {
-                const int c = kin >> 2, dy = (kin >> 1) & 1, dx = kin & 1;
-                const int ky = 2 * (tap >> 2) + dy - 1, kx = 2 * (tap & 3) + dx - 1;
-                if (ky >= 0 && ky < 7 && kx >= 0 && kx < 7) val = j.w[(((size_t)nout * 3 + c) * 7 + ky) * 7 + kx];
-            }
-        }
-        if (j.dtype == MIL_DT_BF16) reinterpret_cast<__bf16*>(j.out)[idx] = (__bf16)val;
-        else reinterpret_cast<float*>(j.out)[idx] = val;
-    }
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) mil_pack_job_elem(j, idx);
 }
 
 // Fills one host-side job record (the caller copies the table to the device once).
@@ -94,15 +53,10 @@ extern "C" int mil_pack_job_fill(void* job_host, const float* w, const float* bi
                                  int cin, int ks, int mode, int dtype) {
     if (!job_host || !w || !out || mode < 0 || mode > 3) return MIL_ERR_ARG;
     PackJob* j = reinterpret_cast<PackJob*>(job_host);
-    int cin_exec, cout_exec, ks_exec;
-    if (mode == 2) { cin_exec = 16; cout_exec = mil_cpad(cout); ks_exec = 4; }
-    else if (mode == 1) { cin_exec = mil_cpad(cout); cout_exec = mil_cpad(cin); ks_exec = ks; }
-    else { cin_exec = mil_cpad(cin); cout_exec = mil_cpad(cout); ks_exec = ks; }
+    *j = PackJob{};
     j->w = w; j->bias = bias; j->out = out; j->bias_pad = bias_pad;
-    j->cout = cout; j->cin = cin; j->ks = ks; j->mode = mode;
-    j->CG = cin_exec / 8; j->NT = (cout_exec + 15) / 16;
-    j->nsteps = (ks_exec * ks_exec * j->CG + 3) / 4; j->dtype = dtype;
-    if (mode == MIL_PACK_DGRAD_S2) { j->CG = mil_cpad(cout) / 8; j->NT = (mil_cpad(cin) + 15) / 16; j->nsteps = mil_s2_nsteps(j->CG); }
+    j->cout = cout; j->cin = cin; j->ks = ks; j->mode = mode; j->dtype = dtype;
+    mil_pack_job_dims(j);
     return MIL_OK;
 }
 

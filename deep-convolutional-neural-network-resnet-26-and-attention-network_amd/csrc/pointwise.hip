@@ -3,6 +3,7 @@
 // + bias-free linear (fwd + bwd).  Reference ops: gbm/model.py:24-26 (stem conv/LeakyReLU/MaxPool2d),
 // gbm/model.py:31-32,58-60 (AdaptiveAvgPool2d + fc).
 #include "geom.cuh"
+#include "pack.cuh"
 
 // ---------------------------------------------------------------------------------------------
 // fp32 NCHW [n,3,H,W]  ->  NHWC space-to-depth [n, ceil(H/2), ceil(W/2), 16]; channel = c*4 + dy*2 + dx
@@ -48,82 +49,32 @@ extern "C" int mil_stem_s2d(const float* x_nchw, void* out, int n, int H, int W,
 }
 
 // ---------------------------------------------------------------------------------------------
-// fp32 master weights [Cout][Cin][k][k] -> MFMA B-fragment order [kstep][ntile][lane][8].
-//   k-group q = 4*kstep + (lane>>4) = tap*CG + cg; element j is input channel cg*8+j; column = lane&15.
-//   mode 0 (forward):  B[(tap,ci)][co] = W[co][ci][ky][kx]
-//   mode 1 (dgrad):    B[(tap,co)][ci] = W[co][ci][k-1-ky][k-1-kx]   (transposed + flipped)
-//   mode 2 (stem):     7x7 stride-2 filter re-indexed as a 4x4 filter over the 12 space-to-depth channels
-#define MIL_PACK_FWD 0
-#define MIL_PACK_DGRAD 1
-#define MIL_PACK_STEM 2
-
-template <typename T>
-__global__ void pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ bias,
-                                    typename T::elem* __restrict__ out, float* __restrict__ bias_pad, int cout, int cin,
-                                    int ks, int mode, int CG, int NT, int nsteps) {
-    const int total = nsteps * NT * 64 * 8;
+// fp32 master weights [Cout][Cin][k][k] -> MFMA fragment order: index maps and job record in pack.cuh.
+__global__ void pack_weights_kernel(PackJob j) {
+    const int total = j.nsteps * j.NT * 64 * 8;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < NT * 16 && bias_pad && mode != MIL_PACK_DGRAD_S2) {
-        const int n_out = (mode == MIL_PACK_DGRAD) ? cin : cout;
-        bias_pad[idx] = (bias && idx < n_out) ? bias[idx] : 0.f;
-    }
-    if (idx >= total) return;
-    const int j = idx & 7, lane = (idx >> 3) & 63;
-    const int t = idx >> 9;
-    const int nt = t % NT, s = t / NT;
-    if (mode == MIL_PACK_DGRAD_S2) {            // `bias` carries the projection's weight for this mode
-        out[idx] = (typename T::elem)mil_s2_pack_value(w, bias, s, lane, j, nt, cout, cin, CG);
-        return;
-    }
-    const int q = 4 * s + (lane >> 4);
-    const int tap = q / CG, cg = q - tap * CG;
-    const int kin = cg * 8 + j, nout = nt * 16 + (lane & 15);
-    float val = 0.f;
-    if (mode == MIL_PACK_FWD) {
-        if (tap < ks * ks && kin < cin && nout < cout) val = w[((size_t)nout * cin + kin) * ks * ks + tap];
-    } else if (mode == MIL_PACK_DGRAD) {
-        if (tap < ks * ks && kin < cout && nout < cin) val = w[((size_t)kin * cin + nout) * ks * ks + (ks * ks - 1 - tap)];
-    } else {
-        if (tap < 16 && kin < 12 && nout < cout) {
-            const int c = kin >> 2, dy = (kin >> 1) & 1, dx = kin & 1;
-            const int ky = 2 * (tap >> 2) + dy - 1, kx = 2 * (tap & 3) + dx - 1;
-            if (ky >= 0 && ky < 7 && kx >= 0 && kx < 7) val = w[(((size_t)nout * 3 + c) * 7 + ky) * 7 + kx];
-        }
-    }
-    out[idx] = (typename T::elem)val;
-}
-
-static void pack_dims(int cout, int cin, int ks, int mode, int* CG, int* NT, int* nsteps) {
-    int cin_exec, cout_exec, ks_exec;
-    if (mode == MIL_PACK_STEM) { cin_exec = 16; cout_exec = mil_cpad(cout); ks_exec = 4; }
-    else if (mode == MIL_PACK_DGRAD) { cin_exec = mil_cpad(cout); cout_exec = mil_cpad(cin); ks_exec = ks; }
-    else { cin_exec = mil_cpad(cin); cout_exec = mil_cpad(cout); ks_exec = ks; }
-    *CG = cin_exec / 8;
-    *NT = (cout_exec + 15) / 16;
-    *nsteps = (ks_exec * ks_exec * (*CG) + 3) / 4;
-    if (mode == MIL_PACK_DGRAD_S2) { *CG = mil_cpad(cout) / 8; *NT = (mil_cpad(cin) + 15) / 16; *nsteps = mil_s2_nsteps(*CG); }
+    if (idx < total) mil_pack_job_elem(j, idx);
 }
 
 extern "C" int mil_packed_weight_elems(size_t* elems, int cout, int cin, int ks, int mode) {
     if (!elems || cout <= 0 || cin <= 0) return MIL_ERR_ARG;
-    int CG, NT, nsteps;
-    pack_dims(cout, cin, ks, mode, &CG, &NT, &nsteps);
-    *elems = (size_t)nsteps * NT * 64 * 8;
+    PackJob j{};
+    j.cout = cout; j.cin = cin; j.ks = ks; j.mode = mode;
+    mil_pack_job_dims(&j);
+    *elems = (size_t)j.nsteps * j.NT * 64 * 8;
     return MIL_OK;
 }
 
 extern "C" int mil_pack_conv_weights(const float* w, const float* bias, void* wpack, float* bias_pad, int cout, int cin,
                                      int ks, int mode, int dtype, void* stream) {
     if (!w || !wpack || cout <= 0 || cin <= 0 || mode < 0 || mode > 3 || (mode == 3 && ks != 3)) return MIL_ERR_ARG;
-    int CG, NT, nsteps;
-    pack_dims(cout, cin, ks, mode, &CG, &NT, &nsteps);
-    const int total = nsteps * NT * 64 * 8;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MIL_DT_BF16)
-        hipLaunchKernelGGL(pack_weights_kernel<BF16>, dim3((total + 255) / 256), dim3(256), 0, st, w, bias, (__bf16*)wpack, bias_pad, cout, cin, ks, mode, CG, NT, nsteps);
-    else if (dtype == MIL_DT_F32)
-        hipLaunchKernelGGL(pack_weights_kernel<F32>, dim3((total + 255) / 256), dim3(256), 0, st, w, bias, (float*)wpack, bias_pad, cout, cin, ks, mode, CG, NT, nsteps);
-    else return MIL_ERR_ARG;
+    if (dtype != MIL_DT_BF16 && dtype != MIL_DT_F32) return MIL_ERR_ARG;
+    PackJob j{};
+    j.w = w; j.bias = bias; j.out = wpack; j.bias_pad = bias_pad;
+    j.cout = cout; j.cin = cin; j.ks = ks; j.mode = mode; j.dtype = dtype;
+    mil_pack_job_dims(&j);
+    const int total = j.nsteps * j.NT * 64 * 8;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), j);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

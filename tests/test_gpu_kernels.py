@@ -185,6 +185,7 @@ def test_avgpool_fc(ops, dtype, shape):
 
 
 @pytest.mark.parametrize("shape", [(3, 16, 16, 20), (2, 19, 23, 20), (5, 8, 8, 20), (2, 64, 64, 20),
+                                   (36, 64, 64, 20),                    # 576 tiles > the resident workgroups: both LDS tile buffers in use
                                    (3, 32, 32, 40), (2, 19, 23, 40), (9, 8, 8, 40),            # 8-wave workgroups
                                    (3, 16, 16, 60), (2, 21, 18, 60), (2, 32, 32, 60)])
 @pytest.mark.parametrize("with_addend,mask", [(True, True), (False, True), (True, False)])

@@ -34,3 +34,5 @@ echo "sq2 done"
 python3 profiles/summarise_sq_counters.py $OUT/sq1 $OUT/sq2 profiles/sq_counters.json "$ROUND: $BENCH" > profiles/${ROUND}_sq_counters.txt
 cp profiles/sq_counters.json profiles/${ROUND}_sq_counters.json
 echo "all profiles written"
+mkdir -p gpurun_out/profiles_out
+cp profiles/${ROUND}_* profiles/pmc_traffic.json profiles/sq_counters.json gpurun_out/profiles_out/
