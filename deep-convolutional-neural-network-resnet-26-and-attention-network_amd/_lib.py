@@ -60,6 +60,8 @@ _SIGS = {
     "mil_stem_fwd_fused": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp], _i),
     "mil_stem_bwd_fused_workspace": ([_c.POINTER(_sz), _i, _i, _i, _i], _i),
     "mil_stem_bwd_fused": ([_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _f, _i, _i, _vp], _i),
+    "mil_stem_bwd_fused_nchw_workspace": ([_c.POINTER(_sz), _i, _i, _i, _i], _i),
+    "mil_stem_bwd_fused_nchw": ([_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _f, _i, _i, _vp], _i),
     "mil_avgpool_fc_fwd": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "mil_avgpool_fc_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
     "mil_wide_packed_elems": ([_c.POINTER(_sz), _i, _i, _i, _i], _i),

@@ -522,7 +522,11 @@ static int wgrad_entry(const void* x, const void* dz, float* dw, float* db, void
 // the (TH/2+1)x(TW/2+1) pooling windows that cover the tile (deterministic gather, one thread per 2x2 pixel
 // block as in maxpool_bwd_kernel).  The 4x-larger d(stem output) tensor is never written or read.
 struct StemBwdArgs {
-    const __bf16* xs;        // [n,H2,W2,16] space-to-depth input
+    const __bf16* xs;        // [n,H2,W2,16] space-to-depth input (FROM_X = false)
+    const float* x;          // [n,3,H,W] the fp32 tiles themselves (FROM_X = true: the s2d tile is rebuilt in LDS, no copy kept)
+    int H, W;                // input dims (FROM_X)
+    unsigned x_bytes;
+    int lds_dump_off;
     const __bf16* gp;        // [n,Hp,Wp,24] gradient of the pooled output
     const uint8_t* widx;     // [n,Hp,Wp,24] winner tap (bits 0-3) + "winner <= 0" (bit 4)
     float* slab;
@@ -541,6 +545,7 @@ struct StemBwdArgs {
 #ifndef MIL_STEM_BWD_PIPE
 #define MIL_STEM_BWD_PIPE 1
 #endif
+template <bool FROM_X>
 __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel(StemBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CINP = 16, NT = 2, KS = 4, COUTP = 24;
@@ -550,6 +555,7 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
     // = 12 row tiles; the padding piece (channels 12-15) of a pixel record is never read
     constexpr int NPC = 3, MT = KS * KS * NPC / 4, MW = (MT + 3) / 4;
     constexpr int NPX = mil_halo_np(CINP, 2);
+    constexpr int NL = 3;                                   // FROM_X load items per thread (<= 400 halo px: <= 210 pairs x 3 colours)
     constexpr int NPW = 2;                                  // pooled-window pieces per thread (<= 144 windows x 3)
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -562,11 +568,59 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
     const int WH = TH / 2 + 1, WW = TW / 2 + 1;             // pooling windows per image of the tile
     const int nwin = (WH * WW) << g.ti_log2;
 
-    const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.xs, a.xs_bytes);
+    const __amdgpu_buffer_rsrc_t rs_x = FROM_X ? mil_rsrc(a.x, a.x_bytes) : mil_rsrc(a.xs, a.xs_bytes);
     const __amdgpu_buffer_rsrc_t rs_g = mil_rsrc(a.gp, a.gp_bytes);
     const __amdgpu_buffer_rsrc_t rs_i = mil_rsrc(a.widx, a.wi_bytes);
     HaloTables<NPX> ht;
-    mil_build_halo_tables<CINP, NPX>(ht, g, tid);
+    if constexpr (!FROM_X) mil_build_halo_tables<CINP, NPX>(ht, g, tid);
+    // FROM_X: load item = (image of the tile, halo row, PAIR of s2d pixels, colour) = input rows 2r, 2r+1 x 4 columns of one
+    // colour plane (two 16-byte loads) -> s2d channels 4c..4c+3 of two neighbouring pixels (as stem_fwd_fused_kernel)
+    //   l_pos = ti<<20 | hy<<10 | pair (-1: unused);  l_lds = LDS offset of the first pixel's piece | "second pixel is
+    //   outside the halo tile" << 20;  l_rel = byte offset of the first load relative to the tile's first load
+    int l_pos[NL], l_lds[NL], l_rel[NL];
+    if constexpr (FROM_X) {
+        const int npair = (g.hw + 1) >> 1, rows = g.hh << g.ti_log2;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = tid + 256 * i;
+            l_pos[i] = -1; l_lds[i] = a.lds_dump_off | (1 << 20); l_rel[i] = 0;
+            if (idx < rows * npair * 3) {
+                const int pair = idx % npair, t = idx / npair;
+                const int c = t % 3, row = t / 3;
+                const int ti = row / g.hh, hy = row - ti * g.hh;
+                l_pos[i] = (ti << 20) | (hy << 10) | pair;
+                l_lds[i] = ((row * g.hw + 2 * pair) * PIXB + c * 8) | ((2 * pair + 1 >= g.hw) ? 1 << 20 : 0);
+                l_rel[i] = (((ti * 3 + c) * a.H + 2 * hy) * a.W + 4 * pair) * 4;
+            }
+        }
+    }
+    u32x4_t lr0[NL], lr1[NL];
+    auto fetch_x = [&](const TileOrigin& o) {
+        const int y0 = o.oy0 - g.pad, c0 = 2 * (o.ox0 - g.pad);          // first s2d row / first input column of the halo tile
+        const int base = (((o.img0 * 3) * a.H + 2 * y0) * a.W + c0) * 4;       // may be negative; valid lanes are not
+        const int ilim = g.n_img - o.img0;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int p = l_pos[i];
+            const bool ok = (p >= 0) & ((p >> 20) < ilim) & ((unsigned)(y0 + ((p >> 10) & 1023)) < (unsigned)g.H) &
+                            ((unsigned)(c0 + 4 * (p & 1023)) < (unsigned)a.W);
+            const unsigned off = ok ? (unsigned)(base + l_rel[i]) : MIL_OOB;
+            lr0[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+            lr1[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off + (unsigned)(a.W * 4), 0, 0);
+        }
+    };
+    auto commit_x = [&]() {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const f32x4_t v0 = __builtin_bit_cast(f32x4_t, lr0[i]), v1 = __builtin_bit_cast(f32x4_t, lr1[i]);
+            bf16x4_t pa, pb;
+            pa[0] = (__bf16)v0[0]; pa[1] = (__bf16)v0[1]; pa[2] = (__bf16)v1[0]; pa[3] = (__bf16)v1[1];
+            pb[0] = (__bf16)v0[2]; pb[1] = (__bf16)v0[3]; pb[2] = (__bf16)v1[2]; pb[3] = (__bf16)v1[3];
+            const int d0 = l_lds[i] & 0xFFFFF;
+            *reinterpret_cast<bf16x4_t*>(ldsX + d0) = pa;
+            *reinterpret_cast<bf16x4_t*>(ldsX + ((l_lds[i] >> 20) ? a.lds_dump_off : d0 + PIXB)) = pb;
+        }
+    };
     // pooled-window pieces: item = window*3 + j; gradient piece = 16 B (8 channels), winner piece = 8 B
     int w_pos[NPW], w_rel[NPW], w_lds[NPW];
 #pragma unroll
@@ -630,12 +684,12 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
     u32x4_t rx[NPX], rgp[NPW];
     u32x2_t rwi[NPW];
     if (bid < a.ntiles) {
-        mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, cur.origin(g));
+        if constexpr (FROM_X) fetch_x(cur.origin(g)); else mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, cur.origin(g));
         fetch_win(rgp, rwi, cur.origin(g));
     }
     for (int tile = bid; tile < a.ntiles; tile += gridDim.x) {
         __syncthreads();                         // previous tile's MFMA loop is done with ldsX / ldsZ
-        mil_commit_halo<NPX>(rx, ldsX, ht);
+        if constexpr (FROM_X) commit_x(); else mil_commit_halo<NPX>(rx, ldsX, ht);
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             if (w_pos[i] >= 0) {
@@ -645,7 +699,7 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
         }
         __syncthreads();
         if (tile + (int)gridDim.x < a.ntiles) {
-            mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, nxt.origin(g));
+            if constexpr (FROM_X) fetch_x(nxt.origin(g)); else mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, nxt.origin(g));
             fetch_win(rgp, rwi, nxt.origin(g));
         }
         cur = nxt; nxt.advance();
@@ -803,11 +857,15 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
     }
 }
 
-static int stem_bwd_entry(const void* xs, const void* gp, const uint8_t* widx, float* dw, float* db, void* ws,
-                          size_t ws_bytes, int n, int H2, int W2, float slope, int accumulate, int dtype, bool query,
+// xs != null: the bf16 space-to-depth copy [n,H2,W2,16] is the conv input; else x = the fp32 tiles [n,3,H,W] (H = 2*H2,
+// W = 2*W2, W % 4 == 0) and the kernel rebuilds its s2d tiles itself.  Inputs beyond the 2 GiB reach of a buffer
+// descriptor are walked in image chunks, later chunks accumulating into dW/db.
+static int stem_bwd_entry(const void* xs, const float* x, const void* gp, const uint8_t* widx, float* dw, float* db, void* ws,
+                          size_t ws_bytes, int n, int H2, int W2, float slope, int accumulate, int dtype, bool from_x, bool query,
                           size_t* need, void* stream) {
     if (dtype != MIL_DT_BF16) return MIL_ERR_UNSUPPORTED;
     if (n <= 0 || H2 <= 0 || W2 <= 0) return MIL_ERR_ARG;
+    if (from_x && (W2 & 1)) return MIL_ERR_UNSUPPORTED;      // 16-byte input pieces: W % 4 == 0
     constexpr int PIXB = mil_pix_pitch(16, 2), PIXZ = mil_pix_pitch(24, 2);
     constexpr int MT = 12;                                  // 16 taps x 3 four-channel row pieces / 4 (see the kernel)
     StemBwdArgs a{};
@@ -815,32 +873,48 @@ static int stem_bwd_entry(const void* xs, const void* gp, const uint8_t* widx, f
     g.n_img = n; g.H = H2; g.W = W2; g.Ho = H2; g.Wo = W2; g.ks = 4; g.stride = 1; g.pad = 2; g.zins = 0;
     mil_geom_tiles(g, 8);
     a.Hp = (H2 - 1) / 2 + 1; a.Wp = (W2 - 1) / 2 + 1;
+    a.H = 2 * H2; a.W = 2 * W2;
     const int halo_px = (g.hh * g.hw) << g.ti_log2;
     const int nwin = (((1 << g.th_log2) / 2 + 1) * ((1 << g.tw_log2) / 2 + 1)) << g.ti_log2;
-    const size_t xs_b = (size_t)n * H2 * W2 * 32, gp_b = (size_t)n * a.Hp * a.Wp * 48;
-    if (halo_px > 400 || nwin * 3 > 512 || xs_b >= ((size_t)1 << 31) || gp_b >= ((size_t)1 << 31)) return MIL_ERR_UNSUPPORTED;
+    if (halo_px > 400 || nwin * 3 > 512 || g.hh >= 1024 || g.hw >= 1024) return MIL_ERR_UNSUPPORTED;
+    if (from_x && ((g.hh << g.ti_log2) * ((g.hw + 1) >> 1) * 3 > 3 * 256)) return MIL_ERR_UNSUPPORTED;
+    // images per launch: every tensor of a launch must stay under 2 GiB; whole tiles of images per chunk
+    const size_t in_img = from_x ? (size_t)12 * a.H * a.W : (size_t)H2 * W2 * 32, gp_img = (size_t)a.Hp * a.Wp * 48;
+    int chunk = mil_imgs_under_2g(in_img > gp_img ? in_img : gp_img);
+    if (chunk >= (1 << g.ti_log2)) chunk &= ~((1 << g.ti_log2) - 1); else return MIL_ERR_UNSUPPORTED;
+    if (chunk > n) chunk = n;
     const int xb = (halo_px * PIXB + 15) & ~15, zb = 256 * PIXZ, gb = (nwin * PIXZ + 15) & ~15, ib = (nwin * 24 + 15) & ~15;
-    const int lds = xb + zb + gb + ib;
-    const int ntiles = g.n_groups * g.tiles_y * g.tiles_x;
-    int grid = mil_num_cus() * mil_resident_per_cu(stem_bwd_fused_kernel, lds, 4) * 2;          // two rounds of the resident set
-    if (grid > ntiles) grid = ntiles;
+    const int lds = xb + zb + gb + ib + 16;                 // + dump slot (FROM_X: second pixel of a pair behind an odd-width halo)
+    const int groups = (chunk + (1 << g.ti_log2) - 1) >> g.ti_log2;
+    const int ntiles_max = groups * g.tiles_y * g.tiles_x;
+    auto kern = from_x ? stem_bwd_fused_kernel<true> : stem_bwd_fused_kernel<false>;
+    int grid = mil_num_cus() * mil_resident_per_cu(kern, lds, 4) * 2;          // two rounds of the resident set
+    if (grid > ntiles_max) grid = ntiles_max;
     const size_t slab_elems = (size_t)(MT + 1) * 16 * 32;
     const size_t bytes = slab_elems * grid * sizeof(float);
     if (query) { *need = bytes; return MIL_OK; }
     if (!ws || ws_bytes < bytes) return MIL_ERR_ARG;
-    a.xs = (const __bf16*)xs; a.gp = (const __bf16*)gp; a.widx = widx; a.slab = (float*)ws;
-    a.ntiles = ntiles; a.lds_z_off = xb; a.lds_g_off = xb + zb; a.lds_i_off = xb + zb + gb;
-    a.xs_bytes = (unsigned)xs_b; a.gp_bytes = (unsigned)gp_b; a.wi_bytes = (unsigned)(gp_b / 2); a.slope = slope;
+    a.slab = (float*)ws;
+    a.lds_z_off = xb; a.lds_g_off = xb + zb; a.lds_i_off = xb + zb + gb; a.lds_dump_off = xb + zb + gb + ib; a.slope = slope;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(stem_bwd_fused_kernel, dim3(grid), dim3(256), lds, st, a);
-    MIL_CHECK_LAUNCH();
-    {
+    for (int i0 = 0; i0 < n; i0 += chunk) {
+        const int nc = n - i0 < chunk ? n - i0 : chunk;
+        StemBwdArgs c = a;
+        c.g.n_img = nc; c.g.n_groups = (nc + (1 << g.ti_log2) - 1) >> g.ti_log2;
+        c.ntiles = c.g.n_groups * g.tiles_y * g.tiles_x;
+        if (from_x) { c.x = x + (size_t)i0 * 3 * a.H * a.W; c.x_bytes = (unsigned)((size_t)nc * 12 * a.H * a.W); }
+        else { c.xs = (const __bf16*)xs + (size_t)i0 * H2 * W2 * 16; c.xs_bytes = (unsigned)((size_t)nc * H2 * W2 * 32); }
+        c.gp = (const __bf16*)gp + (size_t)i0 * a.Hp * a.Wp * 24; c.gp_bytes = (unsigned)((size_t)nc * gp_img);
+        c.widx = widx + (size_t)i0 * a.Hp * a.Wp * 24; c.wi_bytes = c.gp_bytes / 2;
+        const int gr = grid < c.ntiles ? grid : c.ntiles;
+        hipLaunchKernelGGL(kern, dim3(gr), dim3(256), lds, st, c);
+        MIL_CHECK_LAUNCH();
         MilReduceJob j{};
-        j.slab = (const float*)ws; j.nslab = grid; j.slab_elems = slab_elems; j.slab_cols = 32; j.n_rows = 16 * 12;
+        j.slab = (const float*)ws; j.nslab = gr; j.slab_elems = slab_elems; j.slab_cols = 32; j.n_rows = 16 * 12;
         j.dw = dw; j.db = db; j.cout = 20; j.cin = 3; j.ks = 7; j.kind = 0; j.cinp = 12; j.stem_mode = 1;      // rows tap*12 + s2d channel
         j.bias_row = MT * 16;        // the row behind the weight rows: the kernel's VALU bias sums
-        j.accumulate = accumulate;
-        mil_reduce_or_defer(j, st);
+        j.accumulate = (i0 > 0) ? 1 : accumulate;
+        mil_reduce_or_defer(j, st, /*may_defer=*/chunk >= n);      // a split launch re-uses the slabs per chunk
         MIL_CHECK_LAUNCH();
     }
     return MIL_OK;
@@ -848,7 +922,7 @@ static int stem_bwd_entry(const void* xs, const void* gp, const uint8_t* widx, f
 
 extern "C" int mil_stem_bwd_fused_workspace(size_t* bytes, int n, int H2, int W2, int dtype) {
     if (!bytes) return MIL_ERR_ARG;
-    return stem_bwd_entry(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n, H2, W2, 0.1f, 0, dtype, true, bytes, nullptr);
+    return stem_bwd_entry(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n, H2, W2, 0.1f, 0, dtype, false, true, bytes, nullptr);
 }
 
 extern "C" int mil_stem_bwd_fused(const void* xs, const void* g_pool, const uint8_t* widx, float* dw, float* db,
@@ -856,7 +930,23 @@ extern "C" int mil_stem_bwd_fused(const void* xs, const void* g_pool, const uint
                                   int accumulate, int dtype, void* stream) {
     if (!xs || !g_pool || !widx || !dw || !db) return MIL_ERR_ARG;
     size_t need = 0;
-    return stem_bwd_entry(xs, g_pool, widx, dw, db, workspace, workspace_bytes, n, H2, W2, slope, accumulate, dtype, false,
+    return stem_bwd_entry(xs, nullptr, g_pool, widx, dw, db, workspace, workspace_bytes, n, H2, W2, slope, accumulate, dtype, false, false,
+                          &need, stream);
+}
+
+extern "C" int mil_stem_bwd_fused_nchw_workspace(size_t* bytes, int n, int H, int W, int dtype) {
+    if (!bytes) return MIL_ERR_ARG;
+    if (H <= 0 || W <= 0 || (H & 1) || (W & 3)) return MIL_ERR_UNSUPPORTED;
+    return stem_bwd_entry(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, n, H / 2, W / 2, 0.1f, 0, dtype, true, true, bytes, nullptr);
+}
+
+extern "C" int mil_stem_bwd_fused_nchw(const float* x, const void* g_pool, const uint8_t* widx, float* dw, float* db,
+                                       void* workspace, size_t workspace_bytes, int n, int H, int W, float slope,
+                                       int accumulate, int dtype, void* stream) {
+    if (!x || !g_pool || !widx || !dw || !db) return MIL_ERR_ARG;
+    if (H <= 0 || W <= 0 || (H & 1) || (W & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return MIL_ERR_UNSUPPORTED;
+    size_t need = 0;
+    return stem_bwd_entry(nullptr, x, g_pool, widx, dw, db, workspace, workspace_bytes, n, H / 2, W / 2, slope, accumulate, dtype, true, false,
                           &need, stream);
 }
 

@@ -163,8 +163,8 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 
         }
         __syncthreads();
         if (tile + G8 < t_end) fetch(tile + G8);
-        // ---- the tile's own 16x32 s2d pixels go to the xs tensor ------------------------------------
-        {
+        // ---- the tile's own 16x32 s2d pixels go to the xs tensor (when the caller keeps one) ------------
+        if (a.xs) {
             const int xbase = ((img * H2 + 16 * ty) * W2 + 32 * tx) * 32;
             const int ylim = H2 - 16 * ty, xlim = W2 - 32 * tx;
 #pragma unroll
@@ -311,7 +311,7 @@ static int launch_stem_fwd(StemFwdArgs a, hipStream_t st) {
         StemFwdArgs b = a;
         b.n_img = n_total - i0 < chunk ? n_total - i0 : chunk;
         b.x = a.x + (size_t)i0 * 3 * a.H * a.W;
-        b.xs = a.xs + (size_t)i0 * a.H2 * a.W2 * 16;
+        b.xs = a.xs ? a.xs + (size_t)i0 * a.H2 * a.W2 * 16 : nullptr;
         b.pool = a.pool + (size_t)i0 * a.Ho * a.Wo * COUTP;
         b.widx = a.widx + (size_t)i0 * a.Ho * a.Wo * COUTP;
         b.ntiles = b.n_img * a.tiles_y * a.tiles_x;
@@ -326,9 +326,11 @@ static int launch_stem_fwd(StemFwdArgs a, hipStream_t st) {
 
 // xs = s2d(x); pool, widx = maxpool(lrelu(conv7x7s2(x) + bias)).  bf16 only; needs H even, W a multiple of 4 and a
 // 16-byte aligned x (otherwise MIL_ERR_UNSUPPORTED: the caller runs mil_stem_s2d / mil_conv_igemm / mil_maxpool_fwd).
+// xs may be null: no space-to-depth copy is kept (1.07 GB less written at 2048 tiles of 256x256) and the backward
+// rebuilds its s2d tiles from x itself (mil_stem_bwd_fused_nchw).
 extern "C" int mil_stem_fwd_fused(const float* x_nchw, const void* wpack, const float* bias_pad, void* xs, void* pool,
                                   uint8_t* widx, int n_img, int H, int W, int cout_p, float slope, int dtype, void* stream) {
-    if (!x_nchw || !wpack || !xs || !pool || !widx || n_img < 0 || H <= 0 || W <= 0) return MIL_ERR_ARG;
+    if (!x_nchw || !wpack || !pool || !widx || n_img < 0 || H <= 0 || W <= 0) return MIL_ERR_ARG;
     if (dtype != MIL_DT_BF16 || (H & 1) || (W & 3) || (reinterpret_cast<uintptr_t>(x_nchw) & 15) || slope < 0.f || slope >= 1.f)
         return MIL_ERR_UNSUPPORTED;
     if (cout_p != 24 && cout_p != 64) return MIL_ERR_UNSUPPORTED;

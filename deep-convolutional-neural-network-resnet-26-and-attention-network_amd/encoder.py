@@ -65,6 +65,7 @@ class ResNet(nn.Module):
         self.n_side_streams = 1
         self.fuse_backward = True
         self.fuse_stem_forward = True
+        self.keep_s2d = False               # True: the fused stem forward also writes the bf16 space-to-depth copy of the input
         self.fuse_stage_entry = True
         self.fuse_block_forward = True
         # the 28 slab reductions of a backward pass recorded and run as ONE launch (ops.ReduceBatch) instead of one ~10 us
@@ -198,10 +199,12 @@ def encoder_forward(net, x, dtype):
     hk = net.child_hooks()              # None unless a forward hook sits on a child module (then views are built for it)
     wp, bp = net._packed("stem", net.conv1.weight, net.conv1.bias, L.PACK_STEM, dtype)
     stem_hooked = hk is not None and hooks.any_hooked((net.conv1, net.relu, net.maxpool))
-    fused = ops.stem_fwd_fused(x, wp, bp, ops.cpad(STEM_WIDTH), dtype=dtype) if (net.fuse_stem_forward and not stem_hooked) else None
+    # no space-to-depth copy is kept (keep_s2d False): the fused stem backward rebuilds its tiles from x itself
+    fused = ops.stem_fwd_fused(x, wp, bp, ops.cpad(STEM_WIDTH), dtype=dtype,
+                               keep_s2d=net.keep_s2d or not net.fuse_backward) if (net.fuse_stem_forward and not stem_hooked) else None
     if fused is not None:
         xs, pool, widx = fused
-        stem_hw = tuple(xs.shape[1:3])
+        stem_hw = (x.shape[2] // 2, x.shape[3] // 2)
     else:
         xs = ops.stem_s2d(x, dtype)
         stem = ops.conv(xs, wp, bp, ops.cpad(STEM_WIDTH), ks=4, stride=1, pad=2, lrelu=True)
@@ -214,7 +217,7 @@ def encoder_forward(net, x, dtype):
             stem_v = hooks.nchw(stem, STEM_WIDTH)
             hooks.fire(net.relu, stem_v, stem_v)            # in place upstream (gbm/model.py:25): input is the output
             hooks.fire(net.maxpool, stem_v, hooks.nchw(pool, STEM_WIDTH))
-    saved = {"xs": xs, "stem_hw": stem_hw, "widx": widx, "blocks": []}      # the stem output itself is not kept
+    saved = {"xs": xs, "x": x if xs is None else None, "stem_hw": stem_hw, "widx": widx, "blocks": []}      # the stem output itself is not kept
     t = pool
     stage_in = pool
     for bi, blk in enumerate(net.blocks()):
@@ -385,12 +388,19 @@ def encoder_backward(net, saved, dfeats, dtype):
                 dz = ops.conv(dz1, w1d, None, ops.cpad(cin), ks=3, stride=1, pad=1, res=addend, act=mask)
         fused_stem = None
         if net.fuse_backward:               # pool backward + lrelu backward + stem wgrad in one pass (bf16 path)
-            fused_stem = ops.stem_bwd_fused(saved["xs"], dz, saved["widx"], out=gout(net.conv1.weight, net.conv1.bias),
-                                            ws_alloc=(lambda nb: batch.workspace(("s", 0), nb)) if batch is not None else None)
+            stem_ws = (lambda nb: batch.workspace(("s", 0), nb)) if batch is not None else None
+            if saved["xs"] is None:
+                fused_stem = ops.stem_bwd_fused_nchw(saved["x"], dz, saved["widx"], out=gout(net.conv1.weight, net.conv1.bias),
+                                                     ws_alloc=stem_ws)
+            else:
+                fused_stem = ops.stem_bwd_fused(saved["xs"], dz, saved["widx"], out=gout(net.conv1.weight, net.conv1.bias),
+                                                ws_alloc=stem_ws)
         if fused_stem is not None:
             grads["stem"] = fused_stem
         else:
             dstem = ops.maxpool_bwd(dz, saved["widx"], saved["stem_hw"])
+            if saved["xs"] is None:
+                saved["xs"] = ops.stem_s2d(saved["x"], dz.dtype)
             grads["stem"] = wgrad(saved["xs"], dstem, 3, STEM_WIDTH, key=("stem", 0), ks=4, stride=1, pad=2, stem=True,
                                   out=gout(net.conv1.weight, net.conv1.bias))
 

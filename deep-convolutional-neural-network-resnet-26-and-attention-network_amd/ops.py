@@ -345,9 +345,10 @@ def conv_dgrad_s2(dz1, dz2, wpack, cx_p, out_hw, *, act=None, slope=LEAK):
     return y
 
 
-def stem_fwd_fused(x, wpack, bias_pad, cout_p, *, slope=LEAK, dtype=torch.bfloat16):
+def stem_fwd_fused(x, wpack, bias_pad, cout_p, *, slope=LEAK, dtype=torch.bfloat16, keep_s2d=True):
     """(xs, pool, widx) of the whole stem in one pass over the fp32 NCHW tiles (see mil_stem_fwd_fused), or None when
-    the shape/dtype has no fused kernel (the caller then runs stem_s2d / conv / maxpool_fwd)."""
+    the shape/dtype has no fused kernel (the caller then runs stem_s2d / conv / maxpool_fwd).  keep_s2d=False: no
+    space-to-depth copy is written (xs is None); the backward then reads x itself (stem_bwd_fused_nchw)."""
     if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or not x.is_cuda:
         raise ValueError(f"expected a CUDA fp32 [N,3,H,W] tile stack, got {tuple(x.shape)} {x.dtype} on {x.device}")
     x = x.contiguous()
@@ -356,11 +357,11 @@ def stem_fwd_fused(x, wpack, bias_pad, cout_p, *, slope=LEAK, dtype=torch.bfloat
         return None
     h2, w2 = h // 2, w // 2
     hp, wp = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
-    xs = torch.empty((n, h2, w2, 16), dtype=dtype, device=x.device)
+    xs = torch.empty((n, h2, w2, 16), dtype=dtype, device=x.device) if keep_s2d else None
     pool = torch.empty((n, hp, wp, cout_p), dtype=dtype, device=x.device)
     widx = torch.empty((n, hp, wp, cout_p), dtype=torch.uint8, device=x.device)
     end = TIMER.bracket(("stem_fwd", cout_p, n, h, w)) if TIMER else None
-    rc = L.lib().mil_stem_fwd_fused(x.data_ptr(), wpack.data_ptr(), L.ptr(bias_pad), xs.data_ptr(), pool.data_ptr(),
+    rc = L.lib().mil_stem_fwd_fused(x.data_ptr(), wpack.data_ptr(), L.ptr(bias_pad), L.ptr(xs), pool.data_ptr(),
                                     widx.data_ptr(), n, h, w, cout_p, slope, L.dt_code(dtype), L.stream_ptr())
     if rc == 2:
         return None
@@ -398,6 +399,44 @@ def stem_bwd_fused(xs, g_pool, widx, *, workspace=None, out=None, slope=LEAK, ws
                                        workspace.data_ptr(), workspace.numel() * workspace.element_size(), n, h2, w2,
                                        slope, 0 if out is None else 1, L.dt_code(xs.dtype), L.stream_ptr()),
             "mil_stem_bwd_fused")
+    return dw, db
+
+
+def stem_bwd_fused_nchw(x, g_pool, widx, *, workspace=None, out=None, slope=LEAK, ws_alloc=None):
+    """stem_bwd_fused without a kept space-to-depth copy: reads the fp32 tiles x [n,3,H,W] (see mil_stem_bwd_fused_nchw);
+    None when the shape/dtype/alignment has no such kernel."""
+    if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous():
+        return None
+    n, _, h, w = x.shape
+    need = ctypes.c_size_t(0)
+    rc = L.lib().mil_stem_bwd_fused_nchw_workspace(ctypes.byref(need), n, h, w, L.dt_code(g_pool.dtype))
+    if rc == 2 or x.data_ptr() % 16:
+        return None
+    L.check(rc, "mil_stem_bwd_fused_nchw_workspace")
+    h2, w2 = h // 2, w // 2
+    hp, wp = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
+    _need(g_pool, (n, hp, wp, 24), g_pool.dtype, "g_pool")
+    _need(widx, (n, hp, wp, 24), torch.uint8, "widx")
+    if ws_alloc is not None:                 # deferred reductions: the slab buffer must outlive this call
+        workspace = ws_alloc(need.value)
+    if workspace is None or workspace.numel() * workspace.element_size() < need.value:
+        workspace = torch.empty((need.value + 3) // 4, dtype=torch.float32, device=x.device)
+    if out is None:
+        dw = torch.empty((20, 3, 7, 7), dtype=torch.float32, device=x.device)
+        db = torch.empty(20, dtype=torch.float32, device=x.device)
+    else:
+        dw, db = out
+        _need(dw, (20, 3, 7, 7), torch.float32, "dw")
+        _need(db, (20,), torch.float32, "db")
+    end = TIMER.bracket(("stem_bwd", n, h, w)) if TIMER else None
+    rc = L.lib().mil_stem_bwd_fused_nchw(x.data_ptr(), g_pool.data_ptr(), widx.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                         workspace.data_ptr(), workspace.numel() * workspace.element_size(), n, h, w,
+                                         slope, 0 if out is None else 1, L.dt_code(g_pool.dtype), L.stream_ptr())
+    if rc == 2:
+        return None
+    L.check(rc, "mil_stem_bwd_fused_nchw")
+    if end is not None:
+        end.record()
     return dw, db
 
 

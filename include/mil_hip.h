@@ -167,7 +167,8 @@ int mil_conv_dgrad_s2(const void* dz1, const void* dz2, const void* wpack, const
 
 /* Fused forward of the whole stem (bf16 path): space-to-depth + Conv2d(3,C,7,2,3) + bias + LeakyReLU +
  * MaxPool2d(3,2,1) in one pass over the fp32 NCHW tiles (gbm/model.py:24-26,51-53; alt_resnet.py:81-84,128-131
- * with slope 0).  Writes xs [n,H/2,W/2,16] (kept for the stem weight gradient), pool [n,Hp,Wp,cout_p] and the
+ * with slope 0).  Writes xs [n,H/2,W/2,16] (kept for the stem weight gradient; NULL = keep none, the backward is
+ * then mil_stem_bwd_fused_nchw), pool [n,Hp,Wp,cout_p] and the
  * winner records widx; bit-identical to mil_stem_s2d -> mil_conv_igemm(ks=4) -> mil_maxpool_fwd, whose
  * intermediate tensors are never materialised.  cout_p 24 or 64; H even, W % 4 == 0, x 16-byte aligned,
  * otherwise MIL_ERR_UNSUPPORTED (the caller then uses the three calls). */
@@ -182,6 +183,14 @@ int mil_stem_bwd_fused_workspace(size_t* bytes, int n, int H2, int W2, int dtype
 int mil_stem_bwd_fused(const void* xs, const void* g_pool, const uint8_t* widx, float* dw, float* db, void* workspace,
                        size_t workspace_bytes, int n, int H2, int W2, float slope, int accumulate, int dtype,
                        void* stream);
+/* Same backward when no space-to-depth copy was kept (mil_stem_fwd_fused with xs = NULL): reads the fp32 tiles
+ * x [n,3,H,W] themselves and rebuilds the bf16 s2d tile in LDS (H even, W % 4 == 0, x 16-byte aligned, else
+ * MIL_ERR_UNSUPPORTED).  The stem then moves 1.07 GB less in the forward and 0.5 GB more in the (compute-bound)
+ * backward per 2048 tiles of 256x256. */
+int mil_stem_bwd_fused_nchw_workspace(size_t* bytes, int n, int H, int W, int dtype);
+int mil_stem_bwd_fused_nchw(const float* x_nchw, const void* g_pool, const uint8_t* widx, float* dw, float* db,
+                            void* workspace, size_t workspace_bytes, int n, int H, int W, float slope, int accumulate,
+                            int dtype, void* stream);
 
 /* AdaptiveAvgPool2d((1,1)) + flatten + Linear(80,L,bias=False) (gbm/model.py:31-32,58-60).
  * x [n,hw,cp] -> pooled [n,c] fp32 (kept for backward), feats [n,nf] fp32 = pooled @ wfc^T (+ bias when given:

@@ -37,7 +37,9 @@ def test_host_side_queries_need_no_gpu():
     lib = mil_amd.lib()
     n = ctypes.c_size_t(0)
     assert lib.mil_packed_weight_elems(ctypes.byref(n), 20, 20, 3, 0) == 0
-    assert n.value == 7 * 2 * 64 * 8                   # 27 channel groups -> 7 k-steps, 2 column tiles
+    assert n.value == (7 + 6) * 2 * 64 * 8             # 27 channel groups -> 7 k-steps, 2 column tiles; + the K-packed order's 6
+    assert lib.mil_packed_weight_elems(ctypes.byref(n), 40, 40, 3, 0) == 0
+    assert n.value == 12 * 3 * 64 * 8                  # 45 channel groups -> 12 k-steps, 3 column tiles (no second order)
     assert lib.mil_packed_weight_elems(ctypes.byref(n), 20, 3, 7, 2) == 0
     assert n.value == 8 * 2 * 64 * 8                   # stem as 4x4 over 16 s2d channels
     assert lib.mil_conv_wgrad_workspace(ctypes.byref(n), 8, 64, 64, 20, 64, 64, 20, 3, 1, 1, 0, 1) == 0

@@ -251,6 +251,14 @@ def test_stem_backward_fused_equals_pool_bwd_plus_wgrad(ops, shape):
     dw2, db2 = ops.conv_wgrad(xs, dstem, 3, 20, ks=4, stride=1, pad=2, stem=True)
     assert rel_err(dw.cpu(), dw2.cpu()) < 1e-5 and rel_err(db.cpu(), db2.cpu()) < 1e-5
     assert rel_err(dw.cpu(), wt.grad) < 2e-2 and rel_err(db.cpu(), b.grad) < 2e-2     # vs autograd (bf16 stem rounding)
+    # the variant that rebuilds the s2d tiles from the fp32 input (no copy kept): the same LDS tiles, the same sums
+    if (2 * w) % 4 == 0:
+        out3 = ops.stem_bwd_fused_nchw(x.cuda(), to_nhwc(gp, dtype), widx)
+        assert out3 is not None
+        assert torch.equal(out3[0], dw) and torch.equal(out3[1], db)
+    acc_w, acc_b = dw.clone(), db.clone()
+    ops.stem_bwd_fused(xs, to_nhwc(gp, dtype), widx, out=(acc_w, acc_b))
+    assert torch.allclose(acc_w, 2 * dw, rtol=1e-6, atol=0) and torch.allclose(acc_b, 2 * db, rtol=1e-6, atol=0)
 
 
 WIDE_CASES = [
@@ -336,6 +344,9 @@ def test_stem_forward_fused_is_bit_identical_to_the_three_kernels(ops, case):
     # and against torch directly (bf16 operands, fp32 accumulate)
     ref = F.max_pool2d(F.leaky_relu(F.conv2d(round_to(x.cpu(), dt), round_to(wt.cpu(), dt), b.cpu(), stride=2, padding=3), slope), 3, 2, 1)
     assert rel_err(from_nhwc(pool1, cout), ref) < TOL[dt]
+    # without the space-to-depth copy (what the encoder runs): same pooled map and winner records
+    xs2, pool2, widx2 = ops.stem_fwd_fused(x, wp, bp, cp, slope=slope, dtype=dt, keep_s2d=False)
+    assert xs2 is None and torch.equal(pool1.view(torch.int16), pool2.view(torch.int16)) and torch.equal(widx1, widx2)
 
 
 def test_stem_forward_fused_declines_unsupported_shapes(ops):
