@@ -245,8 +245,7 @@ static int launch_dgrad_s2(DgradS2Args a, hipStream_t st) {
     auto kern = conv_dgrad_s2_kernel<CZ, NT>;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MIL_ERR_LAUNCH;
-    int per_cu = (160 * 1024) / lds;
-    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    const int per_cu = mil_resident_per_cu(kern, lds, 4);      // by registers AND LDS (see conv_s2_entry.hip)
     const size_t z_img = (size_t)a.g.H * a.g.W * CZ * 2, y_img = (size_t)a.g.Ho * a.g.Wo * CXP * 2;
     int chunk = mil_imgs_under_2g(z_img > y_img ? z_img : y_img);
     if (chunk >= 16) chunk &= ~15;

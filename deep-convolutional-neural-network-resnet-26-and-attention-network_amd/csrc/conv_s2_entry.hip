@@ -19,14 +19,16 @@ struct S2EntryArgs {
     float slope;
 };
 
-template <int CINP, int NT>
+// MTW = 16-pixel row tiles per wave: 2 (128-pixel output tiles) or 1 (64-pixel tiles, for the 64 -> 80 channel entry whose
+// halo tile and filters would not fit in LDS otherwise)
+template <int CINP, int NT, int MTW = 2>
 __global__ __launch_bounds__(256, CINP <= 24 ? 2 : 1) void conv_s2_entry_kernel(S2EntryArgs a, int ntiles, unsigned x_bytes, unsigned y_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PIXB = mil_pix_pitch(CINP, 2);
     constexpr int CG = CINP / 8;
     constexpr int COUTP = mil_nt_to_cp(NT);
     constexpr int K1 = (9 * CG + 3) / 4, K2 = (CG + 3) / 4;
-    constexpr int NPX = (648 * CG + 255) / 256;                 // halos of 128-px tiles at stride 2: 17x33, 2 x 17x17, 8 x 9x9
+    constexpr int NPX = (324 * MTW * CG + 255) / 256;           // halos of 128-px tiles at stride 2: 17x33, 2 x 17x17, 8 x 9x9 (64-px: 17x17, 4 x 9x9)
     constexpr bool LAST_PARTIAL = (COUTP % 16) != 0;
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -62,19 +64,20 @@ __global__ __launch_bounds__(256, CINP <= 24 ? 2 : 1) void conv_s2_entry_kernel(
         const int q = 4 * sl + gq;
         toff2[sl] = (g.hw + 1) * PIXB + (q < CG ? q : 0) * 16;     // centre tap of the 3x3 window = the 1x1/s2 sample
     }
-    int pixbase[2];
+    int pixbase[MTW];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int tp = (wave * 2 + m) * 16 + r;
+    for (int m = 0; m < MTW; ++m) {
+        const int tp = (wave * MTW + m) * 16 + r;
         const int tx = tp & (TW - 1), ty = (tp >> g.tw_log2) & (TH - 1), ti = tp >> (g.tw_log2 + g.th_log2);
         pixbase[m] = ((ti * g.hh + ty * 2) * g.hw + tx * 2) * PIXB;
     }
     // after the swap between row tiles 0 and 1 a lane holds channels 16*nt + 8*(gq>>1) .. +8 of pixel ((gq&1), r)
+    // (MTW = 1: no partner row tile; a lane stores its own 4 channels 16*nt + 4*gq .. of pixel r)
     int o_rel, o_pos;
     {
-        const int tp = (wave * 2 + (gq & 1)) * 16 + r;
+        const int tp = MTW == 2 ? (wave * 2 + (gq & 1)) * 16 + r : wave * 16 + r;
         const int tx = tp & (TW - 1), ty = (tp >> g.tw_log2) & (TH - 1), ti = tp >> (g.tw_log2 + g.th_log2);
-        o_rel = ((ti * g.Ho + ty) * g.Wo + tx) * (COUTP * 2) + (gq >> 1) * 16;
+        o_rel = ((ti * g.Ho + ty) * g.Wo + tx) * (COUTP * 2) + (MTW == 2 ? (gq >> 1) * 16 : gq * 8);
         o_pos = (ti << 20) | (ty << 10) | tx;
     }
     const bool last_ok = !LAST_PARTIAL || (gq >> 1) == 0;
@@ -99,15 +102,15 @@ __global__ __launch_bounds__(256, CINP <= 24 ? 2 : 1) void conv_s2_entry_kernel(
         if (tile + G < ntiles) mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, nxt.origin(g));
         cur = nxt; nxt.advance();
 
-        f32x4_t acc1[2][NT], acc2[2][NT];
+        f32x4_t acc1[MTW][NT], acc2[MTW][NT];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MTW; ++m)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) { acc1[m][nt] = bias_r[nt]; acc2[m][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 #ifndef MIL_S2_ENTRY_NO_PIPE
         // both GEMMs as flattened software pipelines with fragments read two steps ahead (mil_conv_ring, pf_common.cuh)
-        mil_conv_ring<NT, 2, K1, 2>(acc1, ldsW, lane, [&](int sl, int m) { return ldsA + pixbase[m] + toff[sl]; });
-        mil_conv_ring<NT, 2, K2, 2>(acc2, ldsW + K1 * NT * 64 * 16, lane, [&](int sl, int m) { return ldsA + pixbase[m] + toff2[sl]; });
+        mil_conv_ring<NT, MTW, K1, 2>(acc1, ldsW, lane, [&](int sl, int m) { return ldsA + pixbase[m] + toff[sl]; });
+        mil_conv_ring<NT, MTW, K2, 2>(acc2, ldsW + K1 * NT * 64 * 16, lane, [&](int sl, int m) { return ldsA + pixbase[m] + toff2[sl]; });
 #else
 #pragma unroll
         for (int sl = 0; sl < K1; ++sl) {
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256, CINP <= 24 ? 2 : 1) void conv_s2_entry_kernel(
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<BF16>(ldsW + ((sl * NT + nt) * 64 + lane) * 16);
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
+            for (int m = 0; m < MTW; ++m) {
                 const Frag8<BF16> xf = lds_frag<BF16>(ldsA + pixbase[m] + toff[sl]);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc1[m][nt] = mma8(wf[nt], xf, acc1[m][nt]);
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(256, CINP <= 24 ? 2 : 1) void conv_s2_entry_kernel(
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<BF16>(ldsW + (((K1 + sl) * NT + nt) * 64 + lane) * 16);
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
+            for (int m = 0; m < MTW; ++m) {
                 const Frag8<BF16> xf = lds_frag<BF16>(ldsA + pixbase[m] + toff2[sl]);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc2[m][nt] = mma8(wf[nt], xf, acc2[m][nt]);
@@ -137,6 +140,17 @@ __global__ __launch_bounds__(256, CINP <= 24 ? 2 : 1) void conv_s2_entry_kernel(
         const int obase = ((o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (COUTP * 2);
         const bool ok = (o_pos >> 20) < g.n_img - o.img0 && ((o_pos >> 10) & 1023) < g.Ho - o.oy0 && (o_pos & 1023) < g.Wo - o.ox0;
         const unsigned ooff = ok ? (unsigned)(obase + o_rel) : MIL_OOB;
+        if constexpr (MTW == 1) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bf16x4_t ov, ou;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const float v = acc1[0][nt][i]; ov[i] = (__bf16)fmaxf(v, v * a.slope); ou[i] = (__bf16)acc2[0][nt][i]; }
+                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && gq >= 2) ? MIL_OOB : ooff + nt * 32;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, ov), rs_y1, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, ou), rs_y2, off, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             float v[8], u[8];
@@ -156,25 +170,27 @@ __global__ __launch_bounds__(256, CINP <= 24 ? 2 : 1) void conv_s2_entry_kernel(
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), rs_y1, off, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ou), rs_y2, off, 0, 0);
         }
+        }
     }
 }
 
-template <int CINP, int NT>
+template <int CINP, int NT, int MTW = 2>
 static int launch_s2_entry(S2EntryArgs a, hipStream_t st) {
     constexpr int CG = CINP / 8, PIXB = mil_pix_pitch(CINP, 2), COUTP = mil_nt_to_cp(NT);
     constexpr int K1 = (9 * CG + 3) / 4, K2 = (CG + 3) / 4;
-    mil_geom_tiles(a.g, 7);
+    mil_geom_tiles(a.g, MTW == 2 ? 7 : 6);
     const int halo_px = (a.g.hh * a.g.hw) << a.g.ti_log2;
-    if (halo_px > 648 || a.g.hh >= 1024 || a.g.hw >= 1024) return MIL_ERR_UNSUPPORTED;
+    if (halo_px > 324 * MTW || a.g.hh >= 1024 || a.g.hw >= 1024) return MIL_ERR_UNSUPPORTED;
     const int a_bytes = (halo_px * PIXB + 15) & ~15;
     const int lds = a_bytes + (K1 + K2) * NT * 64 * 16;
     if (lds > 160 * 1024) return MIL_ERR_UNSUPPORTED;
     a.lds_w_off = a_bytes;
-    auto kern = conv_s2_entry_kernel<CINP, NT>;
+    auto kern = conv_s2_entry_kernel<CINP, NT, MTW>;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MIL_ERR_LAUNCH;
-    int per_cu = (160 * 1024) / lds;
-    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    // the resident set by registers AND LDS: a grid sized by LDS alone (3 per CU at 178 VGPRs) ran its last third of
+    // workgroups as a second round behind the 2 per CU that fit (217 us against 148 us of traffic at copy rate)
+    const int per_cu = mil_resident_per_cu(kern, lds, 4);
     const size_t x_img = (size_t)a.g.H * a.g.W * CINP * 2, y_img = (size_t)a.g.Ho * a.g.Wo * COUTP * 2;
     int chunk = mil_imgs_under_2g(x_img > y_img ? x_img : y_img);
     if (chunk >= 16) chunk &= ~15;
@@ -197,7 +213,7 @@ static int launch_s2_entry(S2EntryArgs a, hipStream_t st) {
 }
 
 // y1 = lrelu(conv3x3_s2(x) + bias), y2 = conv1x1_s2(x); x [n,H,W,cin_p], y1/y2 [n,(H-1)/2+1,(W-1)/2+1,cout_p].
-// bf16, (cin_p,cout_p) in {(24,40),(40,64)}; otherwise MIL_ERR_UNSUPPORTED (caller: two mil_conv_igemm calls).
+// bf16, (cin_p,cout_p) in {(24,40),(40,64),(64,80)}; otherwise MIL_ERR_UNSUPPORTED (caller: two mil_conv_igemm calls).
 extern "C" int mil_conv_s2_entry(const void* x, const void* wpack3, const float* bias_pad, const void* wpack1, void* y1, void* y2,
                                  int n_img, int H, int W, int cin_p, int cout_p, float slope, int dtype, void* stream) {
     if (!x || !wpack3 || !wpack1 || !y1 || !y2 || n_img < 0 || H <= 0 || W <= 0) return MIL_ERR_ARG;
@@ -211,5 +227,6 @@ extern "C" int mil_conv_s2_entry(const void* x, const void* wpack3, const float*
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (cin_p == 24 && cout_p == 40) return launch_s2_entry<24, 3>(a, st);
     if (cin_p == 40 && cout_p == 64) return launch_s2_entry<40, 4>(a, st);
+    if (cin_p == 64 && cout_p == 80) return launch_s2_entry<64, 5, 1>(a, st);
     return MIL_ERR_UNSUPPORTED;
 }

@@ -397,15 +397,7 @@ static int plan_wgrad(ConvGeom& g, WgradPlan& pl, int* lds_z_off, bool proj = fa
         const int pmn = proj ? (5 * CGc - 1) / 2 - 2 * CGc + 1 : 0;
         pl.slab_elems = (size_t)(MT + 1 + pmn) * 16 * NT * 16;
     }
-    const int ntiles = g.n_groups * g.tiles_y * g.tiles_x;
-    // one fp32 slab per workgroup: no more workgroups than can be resident (the 64/80-channel slabs are 150-235 KB —
-    // a second round of workgroups would only double the slab traffic, which already rivals the activation traffic)
-    int per_cu = (160 * 1024) / pl.lds;
-    per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
-    int gx = mil_num_cus() * per_cu / MSPLIT;
-    if (gx > ntiles) gx = ntiles;
-    if (gx < 1) gx = 1;
-    pl.grid_x = gx;
+    pl.grid_x = 0;                                           // set by run_wgrad once the kernel (and its residency) is known
     return MIL_OK;
 }
 
@@ -417,9 +409,6 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     int lds_z_off = 0;
     int rc = plan_wgrad<T, KS, CINP, NT, MSPLIT>(g, pl, &lds_z_off, PROJ);
     if (rc != MIL_OK) return rc;
-    const size_t bytes = pl.slab_elems * pl.grid_x * sizeof(float);
-    if (query) { *need = bytes; return MIL_OK; }
-    if (ws_bytes < bytes || !ws) return MIL_ERR_ARG;
     WgradArgs<T> a{};
     a.x = (const typename T::elem*)x; a.dz = (const typename T::elem*)dz; a.slab = (float*)ws; a.g = g;
     a.ntiles = g.n_groups * g.tiles_y * g.tiles_x; a.tile_px = 1 << pl.tile_px_log2; a.lds_z_off = lds_z_off;
@@ -441,6 +430,18 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds) != hipSuccess)
             return MIL_ERR_LAUNCH;
     }
+    {   // one fp32 slab per workgroup: no more workgroups than are resident at once, by registers AND LDS (the 64/80-channel
+        // slabs are 150-235 KB — a second round of workgroups would only double the slab traffic, which already rivals
+        // the activation traffic — and a partial second round leaves CUs idle behind the stragglers)
+        const int per_cu = mil_resident_per_cu(kern, pl.lds, 2, nthr);
+        int gx = mil_num_cus() * per_cu / MSPLIT;
+        if (gx > a.ntiles) gx = a.ntiles;
+        if (gx < 1) gx = 1;
+        pl.grid_x = gx;
+    }
+    const size_t bytes = pl.slab_elems * pl.grid_x * sizeof(float);
+    if (query) { *need = bytes; return MIL_OK; }
+    if (ws_bytes < bytes || !ws) return MIL_ERR_ARG;
     hipLaunchKernelGGL(kern, dim3(pl.grid_x, MSPLIT), dim3(nthr), pl.lds, stream, a);
     MIL_CHECK_LAUNCH();
     const int n_rows = KS * KS * CINP;

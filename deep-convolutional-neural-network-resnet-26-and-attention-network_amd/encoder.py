@@ -7,6 +7,7 @@ include/mil_hip.h (NHWC, channel-padded, fp32 or bf16 operands) and a custom aut
 provides the backward (dgrad / wgrad / pooling backward) from saved NHWC activations.
 """
 import contextlib
+import os
 
 import torch
 from torch import nn
@@ -65,7 +66,7 @@ class ResNet(nn.Module):
         self.n_side_streams = 1
         self.fuse_backward = True
         self.fuse_stem_forward = True
-        self.keep_s2d = False               # True: the fused stem forward also writes the bf16 space-to-depth copy of the input
+        self.keep_s2d = os.environ.get("MIL_KEEP_S2D", "0") == "1"      # True: the fused stem forward also writes the bf16 space-to-depth copy of the input
         self.fuse_stage_entry = True
         self.fuse_block_forward = True
         # the 28 slab reductions of a backward pass recorded and run as ONE launch (ops.ReduceBatch) instead of one ~10 us

@@ -139,7 +139,7 @@ int mil_conv_block_fwd(const void* x, const void* wpack1, const float* bias1, co
 
 /* Forward of a stage-entry block's two stride-2 convs in one pass over the block input (bf16 path):
  *   y1 = lrelu(conv3x3_s2(x) + bias)   (nnBlocks.py:176-177)      y2 = conv1x1_s2(x)   (gbm/model.py:38-40)
- * wpack3 / wpack1: MIL_PACK_FWD fragments of the two filters.  (cin_p,cout_p) in {(24,40),(40,64)}; otherwise
+ * wpack3 / wpack1: MIL_PACK_FWD fragments of the two filters.  (cin_p,cout_p) in {(24,40),(40,64),(64,80)}; otherwise
  * MIL_ERR_UNSUPPORTED (caller: two mil_conv_igemm calls). */
 int mil_conv_s2_entry(const void* x, const void* wpack3, const float* bias_pad, const void* wpack1, void* y1, void* y2,
                       int n_img, int H, int W, int cin_p, int cout_p, float slope, int dtype, void* stream);

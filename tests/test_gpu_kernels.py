@@ -411,6 +411,9 @@ S2_ENTRY_CASES = [
     (40, 60, 5, 8, 8),
     (40, 60, 3, 32, 32),
     (40, 60, 9, 6, 6),
+    (60, 80, 5, 16, 16),        # 64-pixel output tiles (one row tile per wave)
+    (60, 80, 3, 13, 19),
+    (60, 80, 7, 4, 4),
 ]
 
 
