@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: the HIP runtime torch loade
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmil_hip.so")
 
-MIL_DT_F32, MIL_DT_BF16 = 0, 1
+MIL_DT_F32, MIL_DT_BF16, MIL_DT_BF16_DGRAD = 0, 1, 2
 PACK_FWD, PACK_DGRAD, PACK_STEM, PACK_DGRAD_S2 = 0, 1, 2, 3
 _ERR = {1: "invalid argument", 2: "unsupported shape / channel configuration", 3: "kernel launch failed"}
 
@@ -120,7 +120,13 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def dt_code(dtype):
+def dt_code(dtype, dense_grads=False):
+    """MIL_DT_* code of a compute dtype; dense_grads selects MIL_DT_BF16_DGRAD (gradient tensors of the 20-channel layer
+    at 20 channels per pixel instead of 24; see include/mil_hip.h)."""
+    if dense_grads:
+        if dtype != torch.bfloat16:
+            raise ValueError("the dense gradient layout exists for bfloat16 only")
+        return MIL_DT_BF16_DGRAD
     if dtype == torch.float32:
         return MIL_DT_F32
     if dtype == torch.bfloat16:

@@ -17,6 +17,10 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
 #define MIL_DT_F32 0
 #define MIL_DT_BF16 1
+// bf16 with the GRADIENT tensors of a 20-channel layer (dz / addend / dx, the pooled-output gradient of the stem) stored
+// dense, 20 channels = 40 bytes per pixel, instead of padded to 24; activations keep the padded layout.  Accepted by the
+// kernels that form that gradient chain: mil_conv_dgrad_s2 (its output), mil_conv_bwd_fused, mil_stem_bwd_fused(_nchw).
+#define MIL_DT_BF16_DGRAD 2
 
 // Channel padding used by every NHWC activation tensor (multiple of 8 elements = one 16-B bf16 piece).
 __host__ __device__ constexpr int mil_cpad(int c) { return (c + 7) / 8 * 8; }

@@ -30,6 +30,8 @@ struct BwdFusedArgs {
     int apply_mask;
     float slope;
     unsigned z_bytes, x_bytes;      // byte sizes of dz and of x/addend/dx (buffer descriptors)
+    unsigned g_bytes;               // fused16 kernel: byte size of addend / dx (z_bytes there is dz at the gradient stride)
+    int gpx;                        // fused16 kernel: bytes per pixel of dz / addend / dx: 48 (padded) or 40 (MIL_DT_BF16_DGRAD)
     unsigned long long* stamp;      // MIL_STAMP diagnostic build only: [grid][NW][8] phase cycle sums (else null)
 };
 
@@ -406,23 +408,28 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
 
 // ---------------------------------------------------------------------------------------------
 // 16x16-tile form with COMPILE-TIME geometry, explicit software pipelining and no branches in the MFMA loops
-// (24-channel layers; tiles of one image, halo 18x18).  What the generic kernel above loses on these maps — measured
+// (20-channel layers; tiles of one image, halo 18x18).  What the generic kernel above loses on these maps — measured
 // with the -DMIL_STAMP build: 2.4 k cycles in the data-gradient loop and 4.8 k in the weight-gradient loop per tile and
 // wave for 28 + 36 MFMAs (0.45 k + 0.58 k cycles of matrix pipe) — is LDS latency: hipcc issues every fragment read
 // right in front of the MFMA pair that consumes it (`s_waitcnt lgkmcnt(0)` per pair), the scalar branches on the
 // wave's row-tile validity keep it from hoisting anything, and every read pays run-time address arithmetic.  Here
-//   * tile shape and pitches are constants, so a fragment address is ONE per-lane base register + an immediate
-//     (four bases for the data gradient — the k order crosses a filter row inside k-steps 2, 4 and wraps in 6 —,
-//     four for the dz rows and one for the x tile of the weight gradient);
+//   * tile shape and pitches are constants, so a fragment address is ONE per-lane base register + an immediate;
 //   * both loops are written one k-step ahead: the reads of step s+1 are issued, then the MFMAs of step s, with
 //     scheduling fences so the order survives (the compiler still counts the waits: builtin LDS loads);
-//   * every wave runs the same instruction stream: waves whose second row tile does not exist (rows 28..31 of 27 row
-//     groups) compute on row group 0 and never store it;
+//   * the K order is the packed one of geom.cuh ("K20"): 24 k-groups in 6 k-steps for the data gradient, 45
+//     four-channel row pieces in 12 row tiles for the weight gradient (standard order: 7 k-steps, 14 row tiles); the LDS
+//     record of a dz pixel is [ch 0-15][ch 16-19][ch 16-19 of the next pixel];
+//   * every wave runs the same instruction stream: waves whose second row tile does not exist compute on row piece 0
+//     and never store it;
 //   * ONE barrier per tile: the x tile is prefetched and committed together with the dz halo (both double-buffered), the
 //     mask is read back from it, so between barriers a wave runs data gradient, epilogue and weight gradient at its own
 //     pace and the waves of a SIMD overlap one's MFMAs with another's epilogue instead of marching in phase;
 //   * the bias gradient needs no MFMA of its own: channel CX-1 of the x tile in LDS (a padding channel) is set to 1, so
-//     column CX-1 of the centre-tap rows of dW' is sum_q dz[q][co] (the reduction reads db from there).
+//     column CX-1 of the centre-tap rows of dW' is sum_q dz[q][co] (the reduction reads db from there);
+//   * GRADIENT tensors (dz, addend, dx) are read and written in 8-byte pieces of four channels, five per pixel, at a
+//     RUN-TIME pixel stride a.gpx: 48 bytes (the padded 24-channel layout every activation has) or 40 (dense: the
+//     gradient chain of the 20-channel layer is produced and consumed only by kernels that know this layout —
+//     MIL_DT_BF16_DGRAD —, 17 % fewer bytes on three of the four tensor passes).
 #ifndef MIL_BWD16_K20
 #define MIL_BWD16_K20 1
 #endif
@@ -430,10 +437,11 @@ template <bool ADD, bool MASK>
 __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CZ = 24, NTX = 2, KS = 3, NW = 8;
-    constexpr int PIXB = 48, PIXX = 48, CG = 3, CX = 24, HW = 18, ROWB = HW * PIXB;      // 864 B per halo row
-    constexpr bool K20 = MIL_BWD16_K20 != 0;                  // 24 k-groups / 45 four-channel row pieces (geom.cuh) instead of 27 / 54
+    constexpr int PIXB = 48, PIXX = 48, CX = 24, HW = 18, ROWB = HW * PIXB;      // 864 B per halo row
     constexpr int KSTEPS_STD = 7;
-    constexpr int NTHR = 512, MTW = 2, KSTEPS = K20 ? MIL_K20_STEPS : KSTEPS_STD, RG = 27, MT = K20 ? 12 : 14, MW = 2, NPX = 2;
+    constexpr int NTHR = 512, MTW = 2, KSTEPS = MIL_K20_STEPS, MT = 12, MW = 2;
+    constexpr int NPX = 4;                                   // 8-byte halo pieces per thread: 3 slots of pieces 0-3, 1 slot of piece 4
+    constexpr int HALO0 = 16;                                // 16 spare bytes in FRONT of a halo tile (dump slot / pixel 0's back-copy)
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -441,61 +449,50 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
     char* ldsW = smem + a.lds_w_off;
     {
         const int nbytes = KSTEPS * NTX * 64 * 16;
-        const char* src = reinterpret_cast<const char*>(a.w) + (K20 ? KSTEPS_STD * NTX * 64 * 16 : 0);      // K20 k-steps sit behind the standard ones
+        const char* src = reinterpret_cast<const char*>(a.w) + KSTEPS_STD * NTX * 64 * 16;      // the K20 k-steps sit behind the standard ones
         for (int i = tid * 16; i < nbytes; i += NTHR * 16)
             *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(src + i);
         // the last halo record's "next pixel" slot is never written by a commit: finite once and for all (zero weights read it)
-        if (K20 && tid < 2) *reinterpret_cast<u32x2_t*>(smem + tid * a.lds_a2_off + 16 + (HW * HW - 1) * PIXB + 40) = u32x2_t{0u, 0u};
+        if (tid < 2) *reinterpret_cast<u32x2_t*>(smem + tid * a.lds_a2_off + HALO0 + (HW * HW - 1) * PIXB + 40) = u32x2_t{0u, 0u};
     }
     const __amdgpu_buffer_rsrc_t rs_z = mil_rsrc(a.dz, a.z_bytes);
     const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, a.x_bytes);
-    const __amdgpu_buffer_rsrc_t rs_add = mil_rsrc(a.addend, a.addend ? a.x_bytes : 0);
-    const __amdgpu_buffer_rsrc_t rs_dx = mil_rsrc(a.dx, a.x_bytes);
-    const int H = g.H, W = g.W;
+    const __amdgpu_buffer_rsrc_t rs_add = mil_rsrc(a.addend, a.addend ? a.g_bytes : 0);
+    const __amdgpu_buffer_rsrc_t rs_dx = mil_rsrc(a.dx, a.g_bytes);
+    const int H = g.H, W = g.W, GPX = a.gpx;                  // GPX: bytes per pixel of dz / addend / dx (48 or 40)
 
-    // ---- halo pieces of this thread: piece id = tid + 512*i -> (halo pixel, 16-byte piece) ------------------
-    // K20: a pixel's third piece (channels 16-19 + padding) is committed as two 8-byte halves: channels 16-19 into its own
-    // record and AGAIN into the previous pixel's "next pixel" slot (bit 20 of h_pos marks these pieces)
-    // (at its record offset - 40; pixel 0's lands in the spare bytes)
-    int h_pos[NPX], h_lds[NPX], h_rel[NPX];
-    constexpr int HALO0 = K20 ? 16 : 0;                      // the 16 spare bytes of a halo buffer sit in FRONT of the K20 tile
-    const int dump_a = K20 ? -16 : a.lds_w_off - 16 - a.lds_a2_off;
+    // ---- halo pieces of this thread (8 bytes = four channels; the padding piece of the 48-byte layout is never read) ----
+    // slots 0-2: piece id = tid + 512*s -> (pixel id>>2, piece id&3): LDS offset = h_lds0 + s*128*PIXB (an immediate)
+    // slot 3   : pixel tid (< 324), piece 4 (channels 16-19): committed to its own record AND to the previous pixel's
+    //            "next pixel" slot (record offset - 40; pixel 0's lands in the spare bytes)
+    // h_pos = hy<<10 | hx, negative when the slot is unused (its writes go to the spare bytes)
+    int h_pos[NPX];
+    const int h_j8 = (tid & 3) * 8;
+    const int h_lds0 = (tid >> 2) * PIXB + h_j8;
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
-        const int idx = tid + NTHR * i;
-        const bool used = idx < HW * HW * CG;
-        const int px = idx / CG, j = idx - px * CG, hy = px / HW, hx = px - hy * HW;
-        const bool third = K20 && used && j == CG - 1;
-        h_pos[i] = used ? (third ? 1 << 20 : 0) | (hy << 10) | hx : (int)0x80000000u;      // unused: negative, bit 20 clear (its dump write stays in the spare bytes)
-        h_lds[i] = used ? px * PIXB + j * 16 : dump_a;
-        h_rel[i] = (hy * W + hx) * (CZ * 2) + j * 16;
+        const int px = i < 3 ? (tid >> 2) + 128 * i : tid;
+        const int hy = px / HW, hx = px - hy * HW;
+        h_pos[i] = px < HW * HW ? (hy << 10) | hx : (int)0x80000000u;
     }
-    u32x4_t rx[NPX];
+    u32x2_t rx[NPX];
     auto fetch_halo = [&](const TileOrigin& o) {
         const int iy0 = o.oy0 - 1, ix0 = o.ox0 - 1;
-        const int base = ((o.img0 * H + iy0) * W + ix0) * (CZ * 2);      // may be negative; valid lanes are not
+        const int base = ((o.img0 * H + iy0) * W + ix0) * GPX;      // may be negative; valid lanes are not
 #pragma unroll
         for (int i = 0; i < NPX; ++i) {
             int p = h_pos[i];
-            if constexpr (K20) asm volatile("" : "+v"(p));      // keeps what is derived from p from being hoisted into loop-long registers
-            const bool ok = (p >= 0) & ((unsigned)(iy0 + ((p >> 10) & 1023)) < (unsigned)H) & ((unsigned)(ix0 + (p & 1023)) < (unsigned)W);
-            if constexpr (K20) {      // two 8-byte halves; a third piece loads channels 16-19 into both (its copy for the previous record)
-                const unsigned off = ok ? (unsigned)(base + h_rel[i]) : MIL_OOB;
-                const u32x2_t lo = __builtin_amdgcn_raw_buffer_load_b64(rs_z, off, 0, 0);
-                const u32x2_t hi = __builtin_amdgcn_raw_buffer_load_b64(rs_z, off + (((p >> 20) & 1) ? 0u : 8u), 0, 0);
-                rx[i] = u32x4_t{lo[0], lo[1], hi[0], hi[1]};
-            } else {
-                rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_z, ok ? (unsigned)(base + h_rel[i]) : MIL_OOB, 0, 0);
-            }
+            asm volatile("" : "+v"(p));       // keeps what is derived from p from being hoisted into loop-long registers
+            const int hy = (p >> 10) & 1023, hx = p & 1023;
+            const bool ok = (p >= 0) & ((unsigned)(iy0 + hy) < (unsigned)H) & ((unsigned)(ix0 + hx) < (unsigned)W);
+            const int rel = (hy * W + hx) * GPX + (i < 3 ? h_j8 : 32);
+            rx[i] = __builtin_amdgcn_raw_buffer_load_b64(rs_z, ok ? (unsigned)(base + rel) : MIL_OOB, 0, 0);
         }
     };
 
     // ---- data gradient: fragment address = per-lane base + immediate -----------------------------------------
-    // k index q = 4*sl + gq = (tap, 8-channel group) [K20: k-group q of geom.cuh]; halo offset of q relative to the
-    // pixel's top-left tap
-    auto koff = [](int q) { if constexpr (K20) return mil_k20_off(q, ROWB, PIXB);
-                            int tap = q / CG, cg = q - tap * CG; if (tap >= KS * KS) { tap = 0; cg = 0; }
-                            return ((tap / KS) * HW + (tap % KS)) * PIXB + cg * 16; };
+    // k-group q = 4*sl + gq of geom.cuh's K20 order; halo offset of q relative to the pixel's top-left tap
+    auto koff = [](int q) { return mil_k20_off(q, ROWB, PIXB); };
     const int bA = (wave * MTW * HW + r) * PIXB + 16 * gq;        // pixel (row 2*wave [+m], col r), lane group part
     int zb[KSTEPS];
 #pragma unroll
@@ -506,10 +503,10 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
     }
     // ---- epilogue pair: after the permlane swap a lane holds 8 consecutive channels of pixel (2*wave + (gq&1), r)
     const int e_ty = wave * MTW + (gq & 1);
-    const int o_rel = (e_ty * W + r) * (CX * 2) + (gq >> 1) * 16;
-    const int x_lds = (e_ty * 16 + r) * PIXX + (gq >> 1) * 16;       // own 16-byte piece(s) inside an x-tile buffer
+    const int c_off = (gq >> 1) * 16;                              // byte offset of the lane's channels inside a pixel (x and gradients)
+    const int x_lds = (e_ty * 16 + r) * PIXX + c_off;             // own 16-byte piece(s) inside an x-tile buffer
     const bool last_ok = (gq >> 1) == 0;                           // channels 24..31 do not exist
-    // ---- weight gradient: rows (tap', 8 dz channels) of row tiles mt = wave, wave + 8; K = the 256 centre pixels
+    // ---- weight gradient: row pieces (tap', four dz channels) of row tiles mt = wave, wave + 8; K = the 256 centre pixels
     const int q4 = (lane & 15) >> 2, p4 = lane & 3;
     int zw[MW][2];
     {
@@ -517,18 +514,10 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
         const int wpl0 = ((kl0 >> 4) * HW + (kl0 & 15)) * PIXB, wpl1 = ((kl1 >> 4) * HW + (kl1 & 15)) * PIXB;
 #pragma unroll
         for (int i = 0; i < MW; ++i) {
-            int wt;
-            if constexpr (K20) {                                   // row piece P = (tap', four dz channels): rows tap'*20 + co
-                int P = 4 * (wave + NW * i) + p4;
-                if (P >= KS * KS * 5) P = 0;                       // rows that do not exist: finite data, never reduced
-                const int tap = P / 5, c4 = P - tap * 5;
-                wt = ((tap / KS) * HW + (tap % KS)) * PIXB + c4 * 8;
-            } else {
-                int rg = 2 * (wave + NW * i) + (p4 >> 1);
-                if (rg >= RG) rg = 0;                              // a row tile that does not exist: finite data, never stored
-                const int tap = rg / CG, cg = rg - tap * CG;
-                wt = ((tap / KS) * HW + (tap % KS)) * PIXB + cg * 16 + (p4 & 1) * 8;
-            }
+            int P = 4 * (wave + NW * i) + p4;                      // rows tap'*20 + co
+            if (P >= KS * KS * 5) P = 0;                           // rows that do not exist: finite data, never reduced
+            const int tap = P / 5, c4 = P - tap * 5;
+            const int wt = ((tap / KS) * HW + (tap % KS)) * PIXB + c4 * 8;
             zw[i][0] = wpl0 + wt; zw[i][1] = wpl1 + wt;
         }
     }
@@ -546,21 +535,22 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
     if (bid < a.ntiles) fetch_halo(cur.origin(g));
     // x (mask source + weight-gradient operand) is prefetched with the halo and committed to LDS with it, so ONE barrier
     // per tile orders everything; the addend is only needed in the epilogue and is prefetched right after the previous one.
-    unsigned ooff = MIL_OOB, ooff_n = MIL_OOB;
-    u32x4_t rxc[NTX], radd[NTX];
+    unsigned goff = MIL_OOB, goff_n = MIL_OOB;                 // byte offset of the lane's channels in addend / dx (this / next tile)
+    // a lane's second piece holds channels 16-19 only (20-23 are padding): 8 bytes everywhere
+    u32x4_t rxc0, radd0;
+    u32x2_t rxc1, radd1;
     auto fetch_x = [&](const TileOrigin& o) {
-        const int obase = ((o.img0 * H + o.oy0) * W + o.ox0) * (CX * 2);
+        const int opix = (o.img0 * H + o.oy0 + e_ty) * W + o.ox0 + r;
         const bool ok = e_ty < H - o.oy0 && r < W - o.ox0;
-        ooff_n = ok ? (unsigned)(obase + o_rel) : MIL_OOB;
-#pragma unroll
-        for (int nt = 0; nt < NTX; ++nt)
-            rxc[nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (nt == NTX - 1 && !last_ok) ? MIL_OOB : ooff_n + nt * 32, 0, 0);
+        const unsigned xoff = ok ? (unsigned)(opix * (CX * 2) + c_off) : MIL_OOB;
+        goff_n = ok ? (unsigned)(opix * GPX + c_off) : MIL_OOB;
+        rxc0 = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff, 0, 0);
+        rxc1 = __builtin_amdgcn_raw_buffer_load_b64(rs_x, last_ok ? xoff + 32 : MIL_OOB, 0, 0);
     };
     auto fetch_add = [&]() {
         if constexpr (ADD) {
-#pragma unroll
-            for (int nt = 0; nt < NTX; ++nt)
-                radd[nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, (nt == NTX - 1 && !last_ok) ? MIL_OOB : ooff_n + nt * 32, 0, 0);
+            radd0 = __builtin_amdgcn_raw_buffer_load_b128(rs_add, goff_n, 0, 0);
+            radd1 = __builtin_amdgcn_raw_buffer_load_b64(rs_add, last_ok ? goff_n + 32 : MIL_OOB, 0, 0);
         }
     };
     if (bid < a.ntiles) { fetch_x(cur.origin(g)); fetch_add(); }
@@ -576,27 +566,20 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
         char* ldsX_t = smem + a.lds_x_off + xbuf;
         buf = buf_step - buf;
         xbuf = xbuf_step - xbuf;
-#pragma unroll
-        for (int i = 0; i < NPX; ++i) {
-            if constexpr (K20) {
-                int p = h_pos[i];
-                asm volatile("" : "+v"(p));
-                const bool third = (p >> 20) & 1;
-                *reinterpret_cast<u32x2_t*>(ldsA_t + h_lds[i]) = u32x2_t{rx[i][0], rx[i][1]};
-                *reinterpret_cast<u32x2_t*>(ldsA_t + h_lds[i] + (third ? -40 : 8)) = u32x2_t{rx[i][2], rx[i][3]};
-            } else {
-                *reinterpret_cast<u32x4_t*>(ldsA_t + h_lds[i]) = rx[i];
-            }
+        {
+            int p2 = h_pos[2], p3 = h_pos[3];
+            asm volatile("" : "+v"(p2), "+v"(p3));
+            *reinterpret_cast<u32x2_t*>(ldsA_t + h_lds0) = rx[0];
+            *reinterpret_cast<u32x2_t*>(ldsA_t + h_lds0 + 128 * PIXB) = rx[1];
+            *reinterpret_cast<u32x2_t*>(ldsA_t + (p2 >= 0 ? h_lds0 + 256 * PIXB : -16)) = rx[2];
+            const int l3 = p3 >= 0 ? tid * PIXB + 32 : -16;       // an unused slot writes the spare bytes twice
+            *reinterpret_cast<u32x2_t*>(ldsA_t + l3) = rx[3];
+            *reinterpret_cast<u32x2_t*>(ldsA_t + (p3 >= 0 ? l3 - 40 : -8)) = rx[3];
         }
         // x centre tile -> LDS [pixel][CX] (zeros outside the image); its padding channel CX-1 := 1 (bias sums)
-#pragma unroll
-        for (int nt = 0; nt < NTX; ++nt) {
-            u32x4_t v = rxc[nt];
-            if (nt == NTX - 1) v[3] = (v[3] & 0xffffu) | 0x3f800000u;
-            char* dst = (nt == NTX - 1 && !last_ok) ? smem + a.lds_dump_off : ldsX_t + x_lds + nt * 32;
-            *reinterpret_cast<u32x4_t*>(dst) = v;
-        }
-        ooff = ooff_n;
+        *reinterpret_cast<u32x4_t*>(ldsX_t + x_lds) = rxc0;
+        *reinterpret_cast<u32x4_t*>(last_ok ? ldsX_t + x_lds + 32 : smem + a.lds_dump_off) = u32x4_t{rxc1[0], rxc1[1], 0u, 0x3f800000u};
+        goff = goff_n;
         MIL_ST_MARK(0)
         __syncthreads();                       // dz halo and x tile visible: the tile's only barrier
         MIL_ST_MARK(1)
@@ -604,11 +587,11 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
         if (more) { const TileOrigin o_next = nxt.origin(g); fetch_halo(o_next); fetch_x(o_next); }
         cur = nxt; nxt.advance();
         // own x pieces back from LDS for the LeakyReLU mask of the epilogue (their registers now hold the next tile's)
-        u32x4_t mk[NTX];
+        u32x4_t mk0;
+        u32x2_t mk1;
         if constexpr (MASK) {
-#pragma unroll
-            for (int nt = 0; nt < NTX; ++nt)
-                mk[nt] = *reinterpret_cast<const u32x4_t*>((nt == NTX - 1 && !last_ok) ? smem + a.lds_dump_off : ldsX_t + x_lds + nt * 32);
+            mk0 = *reinterpret_cast<const u32x4_t*>(ldsX_t + x_lds);
+            mk1 = *reinterpret_cast<const u32x2_t*>(last_ok ? ldsX_t + x_lds + 32 : smem + a.lds_dump_off);
         }
 
         // ---- data gradient D[cx][pixel], one k-step ahead ----------------------------------------------------
@@ -645,32 +628,57 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
         }
         MIL_ST_MARK(2)
 
-        // ---- data-gradient epilogue from registers, 8 channels per lane ----------------------------------------
-#pragma unroll
-        for (int nt = 0; nt < NTX; ++nt) {
+        // ---- data-gradient epilogue from registers: channels 0-15 as 8 per lane, channels 16-19 as 4 per lane --------
+        {
             float v[8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float lo = acc[0][nt][i], hi = acc[1][nt][i];
+                float lo = acc[0][0][i], hi = acc[1][0][i];
                 if (i == 0) mil_swap16<true>(lo, hi); else mil_swap16<false>(lo, hi);
                 v[i] = lo;
                 v[4 + i] = hi;
             }
             if constexpr (ADD) {
-                const bf16x8_t t = __builtin_bit_cast(bf16x8_t, radd[nt]);
+                const bf16x8_t t = __builtin_bit_cast(bf16x8_t, radd0);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] += (float)t[i];
             }
             if constexpr (MASK) {
-                const bf16x8_t t = __builtin_bit_cast(bf16x8_t, mk[nt]);
+                const bf16x8_t t = __builtin_bit_cast(bf16x8_t, mk0);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] *= ((float)t[i] > 0.f ? 1.f : a.slope);
             }
             bf16x8_t ov;
 #pragma unroll
             for (int i = 0; i < 8; ++i) ov[i] = (__bf16)v[i];
-            const unsigned off = (nt == NTX - 1 && !last_ok) ? MIL_OOB : ooff + nt * 32;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), rs_dx, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), rs_dx, goff, 0, 0);
+        }
+        {
+            // second column tile: only the lanes that end up with channels 16-19 (gq>>1 == 0) store; channels 20-23 are padding
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float lo = acc[0][1][i], hi = acc[1][1][i];
+                if (i == 0) mil_swap16<true>(lo, hi); else mil_swap16<false>(lo, hi);
+                v[i] = lo;
+            }
+            if constexpr (ADD) {
+                const bf16x4_t t = __builtin_bit_cast(bf16x4_t, radd1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] += (float)t[i];
+            }
+            if constexpr (MASK) {
+                const bf16x4_t t = __builtin_bit_cast(bf16x4_t, mk1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] *= ((float)t[i] > 0.f ? 1.f : a.slope);
+            }
+            bf16x4_t ov;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ov[i] = (__bf16)v[i];
+            const u32x2_t ou = __builtin_bit_cast(u32x2_t, ov);
+            const unsigned off = last_ok ? goff + 32 : MIL_OOB;
+            if (GPX == 48) __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{ou[0], ou[1], 0u, 0u}, rs_dx, off, 0, 0);      // + the zero padding channels
+            else __builtin_amdgcn_raw_buffer_store_b64(ou, rs_dx, off, 0, 0);
         }
         MIL_ST_MARK(3)
         if (more) fetch_add();                 // next tile's addend: its registers are free now
@@ -696,8 +704,8 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < MW; ++i) {
-                    // waves 6 and 7 own only one of the 14 row tiles: their second set of MFMAs would multiply into a
-                    // tile that is never stored — skipped under a scalar (wave-uniform) branch, the reads stay (-1 %)
+                    // waves 4..7 own only one of the 12 row tiles: their second set of MFMAs would multiply into a
+                    // tile that is never stored — skipped under a scalar (wave-uniform) branch, the reads stay
                     if (i == MW - 1 && wave + NW * i >= MT) continue;
 #pragma unroll
                     for (int nt = 0; nt < NTX; ++nt)
@@ -724,7 +732,7 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
         d[7] = __builtin_amdgcn_s_memrealtime() - st_rt0;      // 100 MHz ticks over the whole tile loop
     }
 #endif
-    // ---- partial sums -> slab: rows tap'*CZ + co, cols ci (col CX-1 of the centre-tap rows = bias sums) ---------
+    // ---- partial sums -> slab: rows tap'*20 + co, cols ci (col CX-1 of the centre-tap rows = bias sums) ---------
     constexpr int SLAB_COLS = NTX * 16;
     constexpr size_t SLAB_ELEMS = (size_t)(14 + 1) * 16 * SLAB_COLS;      // the launcher's slab pitch (generic kernel's row count)
     float* slab = a.slab + (size_t)blockIdx.x * SLAB_ELEMS;
@@ -752,7 +760,7 @@ static bool mil_bwd16_enabled() {
 // ---------------------------------------------------------------------------------------------
 template <int CZ, int NTX, int KS, int NW = 4>
 static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t ws_bytes, int cout, int cin, int accumulate, bool query,
-                         size_t* need, hipStream_t stream) {
+                         size_t* need, hipStream_t stream, bool dense_grads = false) {
     constexpr int PIXB = mil_pix_pitch(CZ, 2);
     constexpr int CX = mil_nt_to_cp(NTX);
     constexpr int PIXX = mil_pix_pitch(CX, 2);
@@ -783,7 +791,8 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
     bool t16 = false;
     if constexpr (CZ == 24 && NTX == 2 && KS == 3 && NW == 8)
         t16 = mil_bwd16_enabled() && dbuf && a.g.tw_log2 == 4 && a.g.th_log2 == 4 && a.g.ti_log2 == 0 && a.g.H < 1024 && a.g.W < 1024 &&
-              (!MIL_BWD16_K20 || cout == 20);      // the K20 order (and the packed filter's second section) exists for 20 dz channels
+              cout == 20;      // the K20 order (and the packed filter's second section) exists for 20 dz channels
+    if (dense_grads && !t16) return MIL_ERR_UNSUPPORTED;      // only the 16x16-tile kernel reads the dense gradient layout
     const int lds = (dbuf ? 2 : 1) * a_bytes + w_bytes + (t16 ? 2 : 1) * x_bytes + 16;          // + dump slot for the x-tile writes
     if (lds > 160 * 1024) return MIL_ERR_UNSUPPORTED;
     const int ntiles = a.g.n_groups * a.g.tiles_y * a.g.tiles_x;
@@ -839,11 +848,14 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
         c.g.n_img = n;
         c.g.n_groups = (n + (1 << c.g.ti_log2) - 1) >> c.g.ti_log2;
         c.ntiles = c.g.n_groups * c.g.tiles_y * c.g.tiles_x;
-        const size_t zo = (size_t)i0 * a.g.H * a.g.W * CZ, xo = (size_t)i0 * a.g.H * a.g.W * CX;
-        c.dz = a0.dz + zo; c.x = a0.x + xo; c.dx = a0.dx + xo;
-        if (a0.addend) c.addend = a0.addend + xo;
-        c.z_bytes = (unsigned)((size_t)n * a.g.H * a.g.W * CZ * 2);
+        const int gz = dense_grads ? 20 : CZ, gx = dense_grads ? 20 : CX;      // channels per pixel of the gradient tensors
+        const size_t zo = (size_t)i0 * a.g.H * a.g.W * gz, xo = (size_t)i0 * a.g.H * a.g.W * CX, go = (size_t)i0 * a.g.H * a.g.W * gx;
+        c.dz = a0.dz + zo; c.x = a0.x + xo; c.dx = a0.dx + go;
+        if (a0.addend) c.addend = a0.addend + go;
+        c.z_bytes = (unsigned)((size_t)n * a.g.H * a.g.W * gz * 2);
         c.x_bytes = (unsigned)((size_t)n * a.g.H * a.g.W * CX * 2);
+        c.g_bytes = (unsigned)((size_t)n * a.g.H * a.g.W * gx * 2);
+        c.gpx = gz * 2;
         int gr = grid < c.ntiles ? grid : c.ntiles;
         hipLaunchKernelGGL(kern, dim3(gr), dim3(64 * NW), lds, stream, c);
         MIL_CHECK_LAUNCH();
@@ -852,7 +864,7 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
             j.slab = (const float*)ws; j.nslab = gr; j.slab_elems = slab_elems; j.slab_cols = NTX * 16; j.n_rows = n_rows;
             j.dw = dw; j.db = db; j.cout = cout; j.cin = cin; j.ks = KS; j.kind = 1; j.cinp = CZ;
             j.bias_off = t16 ? (KS * KS / 2) * CZ * NTX * 16 + (CX - 1) : MT * 16 * NTX * 16; j.bias_stride = t16 ? NTX * 16 : 1;
-            if (t16 && MIL_BWD16_K20) {          // rows tap'*20 + co (four-channel row pieces)
+            if (t16) {                           // rows tap'*20 + co (four-channel row pieces)
                 j.cinp = 20; j.n_rows = KS * KS * 20; j.bias_off = (KS * KS / 2) * 20 * NTX * 16 + (CX - 1);
             }
             j.accumulate = (i0 > 0) ? 1 : accumulate;
@@ -866,7 +878,8 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
 static int bwd_fused_entry(const void* dz, const void* wpack, const void* x, const void* addend, void* dx, float* dw,
                            float* db, void* ws, size_t ws_bytes, int n_img, int H, int W, int cout, int cin, int ks,
                            int pad, int apply_mask, int accumulate, float slope, int dtype, bool query, size_t* need, void* stream) {
-    if (dtype != MIL_DT_BF16 || ks != 3 || pad != 1) return MIL_ERR_UNSUPPORTED;
+    const bool dense_grads = dtype == MIL_DT_BF16_DGRAD;
+    if ((dtype != MIL_DT_BF16 && !dense_grads) || ks != 3 || pad != 1) return MIL_ERR_UNSUPPORTED;
     if (n_img <= 0 || H <= 0 || W <= 0) return MIL_ERR_ARG;
     if (slope <= 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
     BwdFusedArgs a{};
@@ -878,7 +891,8 @@ static int bwd_fused_entry(const void* dz, const void* wpack, const void* x, con
 #ifndef MIL_BWD24_WAVES
 #define MIL_BWD24_WAVES 8       // measured in the model: 397/428/401 us per launch with 4 waves per workgroup (two per SIMD), 356/397/371 us with 8 (four per SIMD, 122-128 VGPRs)
 #endif
-    if (czp == 24 && cxp == 24) return run_bwd_fused<24, 2, 3, MIL_BWD24_WAVES>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st);
+    if (czp == 24 && cxp == 24) return run_bwd_fused<24, 2, 3, MIL_BWD24_WAVES>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st, dense_grads);
+    if (dense_grads) return MIL_ERR_UNSUPPORTED;
     if (czp == 40 && cxp == 40) return run_bwd_fused<40, 3, 3, 8>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st);
     if (czp == 64 && cxp == 64) return run_bwd_fused<64, 4, 3, 8>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st);
     return MIL_ERR_UNSUPPORTED;

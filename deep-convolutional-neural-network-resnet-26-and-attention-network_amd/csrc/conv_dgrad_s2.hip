@@ -21,6 +21,8 @@ struct DgradS2Args {
     int ch, cw;             // compact halo extent per image: TH/2+1, TW/2+1
     int lds_z2_off, lds_w_off;
     float slope;
+    int ypx;                // bytes per pixel of y: CXP*2, or 40 when a 20-channel output is written dense (MIL_DT_BF16_DGRAD)
+    unsigned act_bytes;
 };
 
 template <int CZ, int NT>
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256, CZ <= 40 ? 2 : 1) void conv_dgrad_s2_kernel(Dg
     }
     const __amdgpu_buffer_rsrc_t rs_z1 = mil_rsrc(a.dz1, z_bytes);
     const __amdgpu_buffer_rsrc_t rs_z2 = mil_rsrc(a.dz2, a.dz2 ? z_bytes : 0);
-    const __amdgpu_buffer_rsrc_t rs_act = mil_rsrc(a.act, a.act ? y_bytes : 0);
+    const __amdgpu_buffer_rsrc_t rs_act = mil_rsrc(a.act, a.act ? a.act_bytes : 0);
     const __amdgpu_buffer_rsrc_t rs_y = mil_rsrc(a.y, y_bytes);
     const int CH = a.ch, CW = a.cw, h = g.H, w = g.W, H = g.Ho, W = g.Wo;
     const int TW = 1 << g.tw_log2, TH = 1 << g.th_log2;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256, CZ <= 40 ? 2 : 1) void conv_dgrad_s2_kernel(Dg
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int oy = 2 * ci + p, ox = 2 * cj + (gq & 1);
-        o_rel[p] = ((cti * H + oy) * W + ox) * (CXP * 2) + (gq >> 1) * 16;
+        o_rel[p] = (cti * H + oy) * W + ox;                      // in pixels: act is read at CXP*2 bytes per pixel, y written at a.ypx
         o_pos[p] = (cti << 20) | (oy << 10) | ox;
     }
     const bool last_ok = !LAST_PARTIAL || (gq >> 1) == 0;
@@ -112,15 +114,17 @@ __global__ __launch_bounds__(256, CZ <= 40 ? 2 : 1) void conv_dgrad_s2_kernel(Dg
         }
     };
     auto fetch_epi = [&](const TileOrigin& o, unsigned (&ooff)[2], u32x4_t (&ract)[2][NT]) {
-        const int obase = ((o.img0 * H + o.oy0) * W + o.ox0) * (CXP * 2);
+        const int obase = (o.img0 * H + o.oy0) * W + o.ox0;
         const int ylim = H - o.oy0, xlim = W - o.ox0, ilim = g.n_img - o.img0;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const bool ok = (o_pos[p] >> 20) < ilim && ((o_pos[p] >> 10) & 1023) < ylim && (o_pos[p] & 1023) < xlim;
-            ooff[p] = ok ? (unsigned)(obase + o_rel[p]) : MIL_OOB;
+            const int opix = obase + o_rel[p];
+            ooff[p] = ok ? (unsigned)(opix * a.ypx + (gq >> 1) * 16) : MIL_OOB;
+            const unsigned aoff = ok ? (unsigned)(opix * (CXP * 2) + (gq >> 1) * 16) : MIL_OOB;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 32;
+                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : aoff + nt * 32;
                 if (a.act) ract[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, off, 0, 0);
             }
         }
@@ -223,7 +227,9 @@ __global__ __launch_bounds__(256, CZ <= 40 ? 2 : 1) void conv_dgrad_s2_kernel(Dg
 #pragma unroll
                 for (int i = 0; i < 8; ++i) ov[i] = (__bf16)v[i];
                 const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 32;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), rs_y, off, 0, 0);
+                const u32x4_t ou = __builtin_bit_cast(u32x4_t, ov);
+                if (LAST_PARTIAL && nt == NT - 1 && a.ypx != CXP * 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{ou[0], ou[1]}, rs_y, off, 0, 0);      // dense: channels 16-19 only
+                else __builtin_amdgcn_raw_buffer_store_b128(ou, rs_y, off, 0, 0);
             }
         }
     }
@@ -246,8 +252,8 @@ static int launch_dgrad_s2(DgradS2Args a, hipStream_t st) {
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MIL_ERR_LAUNCH;
     const int per_cu = mil_resident_per_cu(kern, lds, 4);      // by registers AND LDS (see conv_s2_entry.hip)
-    const size_t z_img = (size_t)a.g.H * a.g.W * CZ * 2, y_img = (size_t)a.g.Ho * a.g.Wo * CXP * 2;
-    int chunk = mil_imgs_under_2g(z_img > y_img ? z_img : y_img);
+    const size_t z_img = (size_t)a.g.H * a.g.W * CZ * 2, act_img = (size_t)a.g.Ho * a.g.Wo * CXP * 2, y_img = (size_t)a.g.Ho * a.g.Wo * a.ypx;
+    int chunk = mil_imgs_under_2g(z_img > act_img ? z_img : act_img);
     if (chunk >= 16) chunk &= ~15;
     const int n_total = a.g.n_img;
     for (int i0 = 0; i0 < n_total; i0 += chunk) {
@@ -257,7 +263,8 @@ static int launch_dgrad_s2(DgradS2Args a, hipStream_t st) {
         c.g.n_groups = (n + (1 << c.g.ti_log2) - 1) >> c.g.ti_log2;
         c.dz1 = a.dz1 + (size_t)i0 * (z_img / 2);
         if (a.dz2) c.dz2 = a.dz2 + (size_t)i0 * (z_img / 2);
-        if (a.act) c.act = a.act + (size_t)i0 * (y_img / 2);
+        if (a.act) c.act = a.act + (size_t)i0 * (act_img / 2);
+        c.act_bytes = (unsigned)(act_img * n);
         c.y = a.y + (size_t)i0 * (y_img / 2);
         const int ntiles = c.g.n_groups * c.g.tiles_y * c.g.tiles_x;
         int grid = mil_num_cus() * per_cu;
@@ -270,17 +277,23 @@ static int launch_dgrad_s2(DgradS2Args a, hipStream_t st) {
 
 // y[n,H,W,cx_p] = lrelu'(act) * ( conv3x3_s2^T(dz1) + conv1x1_s2^T(dz2) ), with wpack from
 // mil_pack_conv_weights(mode MIL_PACK_DGRAD_S2: w = the 3x3 weight, bias argument = the 1x1 projection weight or null).
-// dz1/dz2 [n,h,w,cz_p] with h = (H-1)/2+1, w = (W-1)/2+1.  bf16, (cz_p,cx_p) in {(40,24),(64,40),(80,64)}.
+// dz1/dz2 [n,h,w,cz_p] with h = (H-1)/2+1, w = (W-1)/2+1.  bf16, (cz_p,cx_p) in {(40,24),(64,40),(80,64)}; with
+// MIL_DT_BF16_DGRAD and (40,24) y is [n,H,W,20] (dense gradient layout of the 20-channel layer; act stays padded).
 extern "C" int mil_conv_dgrad_s2(const void* dz1, const void* dz2, const void* wpack, const void* act, void* y, int n_img,
                                  int h, int w, int cz_p, int H, int W, int cx_p, float slope, int dtype, void* stream) {
     if (!dz1 || !wpack || !y || n_img < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return MIL_ERR_ARG;
-    if (dtype != MIL_DT_BF16 || h != (H - 1) / 2 + 1 || w != (W - 1) / 2 + 1 || slope < 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
+    if ((dtype != MIL_DT_BF16 && dtype != MIL_DT_BF16_DGRAD) || h != (H - 1) / 2 + 1 || w != (W - 1) / 2 + 1 || slope < 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
     if (n_img == 0) return MIL_OK;
     DgradS2Args a{};
     a.dz1 = (const __bf16*)dz1; a.dz2 = (const __bf16*)dz2; a.w = (const __bf16*)wpack; a.act = (const __bf16*)act; a.y = (__bf16*)y;
     a.g.n_img = n_img; a.g.H = h; a.g.W = w; a.g.Ho = H; a.g.Wo = W; a.g.ks = 3; a.g.stride = 1; a.g.pad = 1; a.g.zins = 1;
     a.slope = slope;
+    a.ypx = cx_p * 2;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIL_DT_BF16_DGRAD) {            // y [n,H,W,20] dense: the 40 -> 20 channel entry only
+        if (cz_p != 40 || cx_p != 24) return MIL_ERR_UNSUPPORTED;
+        a.ypx = 40;
+    }
     if (cz_p == 40 && cx_p == 24) return launch_dgrad_s2<40, 2>(a, st);
     if (cz_p == 64 && cx_p == 40) return launch_dgrad_s2<64, 3>(a, st);
     if (cz_p == 80 && cx_p == 64) return launch_dgrad_s2<80, 4>(a, st);

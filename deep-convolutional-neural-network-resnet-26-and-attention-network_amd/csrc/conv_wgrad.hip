@@ -528,7 +528,8 @@ struct StemBwdArgs {
     int H, W;                // input dims (FROM_X)
     unsigned x_bytes;
     int lds_dump_off;
-    const __bf16* gp;        // [n,Hp,Wp,24] gradient of the pooled output
+    const __bf16* gp;        // [n,Hp,Wp,24] gradient of the pooled output ([n,Hp,Wp,20] when gpx == 40: MIL_DT_BF16_DGRAD)
+    int gpx;                 // bytes per pixel of gp: 48 or 40
     const uint8_t* widx;     // [n,Hp,Wp,24] winner tap (bits 0-3) + "winner <= 0" (bit 4)
     float* slab;
     ConvGeom g;              // geometry of the stem conv as executed (ks 4, stride 1, pad 2, Ho=H2, Wo=W2)
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
         }
     };
     // pooled-window pieces: item = window*3 + j; gradient piece = 16 B (8 channels), winner piece = 8 B
-    int w_pos[NPW], w_rel[NPW], w_lds[NPW];
+    int w_pos[NPW], w_rel[NPW], w_lds[NPW];                  // w_rel = pooled pixel (relative) * 4 + piece
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
         const int idx = tid + 256 * i;
@@ -633,21 +634,24 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
             const int ti = win / (WH * WW), rem = win - ti * (WH * WW);
             const int wy = rem / WW, wx = rem - wy * WW;
             w_pos[i] = (ti << 20) | (wy << 10) | wx;
-            w_rel[i] = ((ti * a.Hp + wy) * a.Wp + wx) * COUTP + j * 8;      // in channels (= bytes of widx, x2 for g)
+            w_rel[i] = (((ti * a.Hp + wy) * a.Wp + wx) << 2) | j;
             w_lds[i] = win * COUTP + j * 8;
         }
     }
     auto fetch_win = [&](u32x4_t (&rg)[NPW], u32x2_t (&ri)[NPW], const TileOrigin& o) {
         const int py0 = o.oy0 >> 1, px0 = o.ox0 >> 1;
-        const int base = ((o.img0 * a.Hp + py0) * a.Wp + px0) * COUTP;
+        const int base = (o.img0 * a.Hp + py0) * a.Wp + px0;
         const int ylim = a.Hp - py0, xlim = a.Wp - px0, ilim = g.n_img - o.img0;
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             const int p = w_pos[i];
             const bool ok = p >= 0 && (p >> 20) < ilim && ((p >> 10) & 1023) < ylim && (p & 1023) < xlim;
-            const unsigned off = ok ? (unsigned)(base + w_rel[i]) : MIL_OOB;
-            rg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, ok ? off * 2u : MIL_OOB, 0, 0);
-            ri[i] = __builtin_amdgcn_raw_buffer_load_b64(rs_i, off, 0, 0);
+            const int pix = base + (w_rel[i] >> 2), j = w_rel[i] & 3;
+            const unsigned goff = ok ? (unsigned)(pix * a.gpx + j * 16) : MIL_OOB;
+            const u32x2_t lo = __builtin_amdgcn_raw_buffer_load_b64(rs_g, goff, 0, 0);
+            const u32x2_t hi = __builtin_amdgcn_raw_buffer_load_b64(rs_g, (a.gpx != 48 && j == 2) ? MIL_OOB : goff + 8, 0, 0);      // dense: channels 20-23 do not exist
+            rg[i] = u32x4_t{lo[0], lo[1], hi[0], hi[1]};
+            ri[i] = __builtin_amdgcn_raw_buffer_load_b64(rs_i, ok ? (unsigned)(pix * COUTP + j * 8) : MIL_OOB, 0, 0);
         }
     };
 
@@ -864,7 +868,8 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
 static int stem_bwd_entry(const void* xs, const float* x, const void* gp, const uint8_t* widx, float* dw, float* db, void* ws,
                           size_t ws_bytes, int n, int H2, int W2, float slope, int accumulate, int dtype, bool from_x, bool query,
                           size_t* need, void* stream) {
-    if (dtype != MIL_DT_BF16) return MIL_ERR_UNSUPPORTED;
+    if (dtype != MIL_DT_BF16 && dtype != MIL_DT_BF16_DGRAD) return MIL_ERR_UNSUPPORTED;
+    const int gpx = dtype == MIL_DT_BF16_DGRAD ? 40 : 48;   // g_pool [n,Hp,Wp,20] dense or [n,Hp,Wp,24]
     if (n <= 0 || H2 <= 0 || W2 <= 0) return MIL_ERR_ARG;
     if (from_x && (W2 & 1)) return MIL_ERR_UNSUPPORTED;      // 16-byte input pieces: W % 4 == 0
     constexpr int PIXB = mil_pix_pitch(16, 2), PIXZ = mil_pix_pitch(24, 2);
@@ -880,7 +885,8 @@ static int stem_bwd_entry(const void* xs, const float* x, const void* gp, const 
     if (halo_px > 400 || nwin * 3 > 512 || g.hh >= 1024 || g.hw >= 1024) return MIL_ERR_UNSUPPORTED;
     if (from_x && ((g.hh << g.ti_log2) * ((g.hw + 1) >> 1) * 3 > 3 * 256)) return MIL_ERR_UNSUPPORTED;
     // images per launch: every tensor of a launch must stay under 2 GiB; whole tiles of images per chunk
-    const size_t in_img = from_x ? (size_t)12 * a.H * a.W : (size_t)H2 * W2 * 32, gp_img = (size_t)a.Hp * a.Wp * 48;
+    const size_t in_img = from_x ? (size_t)12 * a.H * a.W : (size_t)H2 * W2 * 32, gp_img = (size_t)a.Hp * a.Wp * gpx;
+    a.gpx = gpx;
     int chunk = mil_imgs_under_2g(in_img > gp_img ? in_img : gp_img);
     if (chunk >= (1 << g.ti_log2)) chunk &= ~((1 << g.ti_log2) - 1); else return MIL_ERR_UNSUPPORTED;
     if (chunk > n) chunk = n;
@@ -905,8 +911,8 @@ static int stem_bwd_entry(const void* xs, const float* x, const void* gp, const 
         c.ntiles = c.g.n_groups * g.tiles_y * g.tiles_x;
         if (from_x) { c.x = x + (size_t)i0 * 3 * a.H * a.W; c.x_bytes = (unsigned)((size_t)nc * 12 * a.H * a.W); }
         else { c.xs = (const __bf16*)xs + (size_t)i0 * H2 * W2 * 16; c.xs_bytes = (unsigned)((size_t)nc * H2 * W2 * 32); }
-        c.gp = (const __bf16*)gp + (size_t)i0 * a.Hp * a.Wp * 24; c.gp_bytes = (unsigned)((size_t)nc * gp_img);
-        c.widx = widx + (size_t)i0 * a.Hp * a.Wp * 24; c.wi_bytes = c.gp_bytes / 2;
+        c.gp = (const __bf16*)gp + (size_t)i0 * a.Hp * a.Wp * (gpx / 2); c.gp_bytes = (unsigned)((size_t)nc * gp_img);
+        c.widx = widx + (size_t)i0 * a.Hp * a.Wp * 24; c.wi_bytes = (unsigned)((size_t)nc * a.Hp * a.Wp * 24);
         const int gr = grid < c.ntiles ? grid : c.ntiles;
         hipLaunchKernelGGL(kern, dim3(gr), dim3(256), lds, st, c);
         MIL_CHECK_LAUNCH();

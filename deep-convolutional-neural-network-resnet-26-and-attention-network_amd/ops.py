@@ -173,10 +173,10 @@ def conv_wgrad(x, dz, cin, cout, *, ks, stride, pad, stem=False, want_bias=True,
     return dw, db
 
 
-def bwd_fused_workspace_bytes(n, h, w, cout, cin, ks, pad, dtype):
-    """Slab bytes the fused backward needs, or None when this shape has no fused kernel."""
+def bwd_fused_workspace_bytes(n, h, w, cout, cin, ks, pad, dtype, dense=False):
+    """Slab bytes the fused backward needs, or None when this shape (and gradient layout) has no fused kernel."""
     need = ctypes.c_size_t(0)
-    rc = L.lib().mil_conv_bwd_fused_workspace(ctypes.byref(need), n, h, w, cout, cin, ks, pad, L.dt_code(dtype))
+    rc = L.lib().mil_conv_bwd_fused_workspace(ctypes.byref(need), n, h, w, cout, cin, ks, pad, L.dt_code(dtype, dense))
     if rc == 2:
         return None
     L.check(rc, "mil_conv_bwd_fused_workspace")
@@ -185,17 +185,20 @@ def bwd_fused_workspace_bytes(n, h, w, cout, cin, ks, pad, dtype):
 
 def conv_bwd_fused(dz, wpack_dgrad, x, cin, cout, *, addend=None, mask=True, ks=3, pad=1, workspace=None, slope=LEAK,
                    out=None):
-    """(dx, dW, db) of a 3x3 stride-1 conv in one pass, or None if unsupported — see mil_conv_bwd_fused."""
-    n, h, w, _ = dz.shape
-    need = bwd_fused_workspace_bytes(n, h, w, cout, cin, ks, pad, dz.dtype)
+    """(dx, dW, db) of a 3x3 stride-1 conv in one pass, or None if unsupported — see mil_conv_bwd_fused.  A dz with exactly
+    `cout` (unpadded) channels selects the dense gradient layout (MIL_DT_BF16_DGRAD): addend and dx are then [n,h,w,cin]
+    too, x keeps its padded channels."""
+    n, h, w, cz = dz.shape
+    dense = cz == cout and cpad(cout) != cout
+    need = bwd_fused_workspace_bytes(n, h, w, cout, cin, ks, pad, dz.dtype, dense)
     if need is None:
         return None
-    _need(dz, (n, h, w, cpad(cout)), dz.dtype, "dz")
+    _need(dz, (n, h, w, cout if dense else cpad(cout)), dz.dtype, "dz")
     _need(x, (n, h, w, cpad(cin)), dz.dtype, "x")
-    _need(addend, (n, h, w, cpad(cin)), dz.dtype, "addend")
+    _need(addend, (n, h, w, cin if dense else cpad(cin)), dz.dtype, "addend")
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=dz.device)
-    dx = torch.empty_like(x)
+    dx = torch.empty((n, h, w, cin), dtype=dz.dtype, device=dz.device) if dense else torch.empty_like(x)
     if out is None:
         dw = torch.empty((cout, cin, ks, ks), dtype=torch.float32, device=dz.device)
         db = torch.empty(cout, dtype=torch.float32, device=dz.device)
@@ -207,7 +210,7 @@ def conv_bwd_fused(dz, wpack_dgrad, x, cin, cout, *, addend=None, mask=True, ks=
     L.check(L.lib().mil_conv_bwd_fused(dz.data_ptr(), wpack_dgrad.data_ptr(), x.data_ptr(), L.ptr(addend), dx.data_ptr(),
                                        dw.data_ptr(), db.data_ptr(), workspace.data_ptr(),
                                        workspace.numel() * workspace.element_size(), n, h, w, cout, cin, ks, pad,
-                                       1 if mask else 0, 0 if out is None else 1, slope, L.dt_code(dz.dtype), L.stream_ptr()),
+                                       1 if mask else 0, 0 if out is None else 1, slope, L.dt_code(dz.dtype, dense), L.stream_ptr()),
             "mil_conv_bwd_fused")
     if end is not None:
         end.record()
@@ -323,20 +326,22 @@ def conv_wgrad_pair(x, dz1, dz2, cin, cout, *, workspace=None, out=None):
     return dw3, db3, dw1, workspace
 
 
-def conv_dgrad_s2(dz1, dz2, wpack, cx_p, out_hw, *, act=None, slope=LEAK):
+def conv_dgrad_s2(dz1, dz2, wpack, cx_p, out_hw, *, act=None, slope=LEAK, dense_cx=None):
     """lrelu'(act) * (conv3x3_s2^T(dz1) + conv1x1_s2^T(dz2)) in one pass (see mil_conv_dgrad_s2), or None when the
-    shape/dtype has no such kernel."""
+    shape/dtype has no such kernel.  dense_cx = the unpadded channel count: the result is [n,H,W,dense_cx] (dense gradient
+    layout, MIL_DT_BF16_DGRAD); act keeps its padded channels."""
     n, h, w, cz_p = dz1.shape
     hh, ww = out_hw
     if dz1.dtype != torch.bfloat16:
         return None
+    dense = dense_cx is not None
     _need(dz1, dz1.shape, dz1.dtype, "dz1")
     _need(dz2, dz1.shape, dz1.dtype, "dz2")
-    y = torch.empty((n, hh, ww, cx_p), dtype=dz1.dtype, device=dz1.device)
-    _need(act, y.shape, dz1.dtype, "act")
+    y = torch.empty((n, hh, ww, dense_cx if dense else cx_p), dtype=dz1.dtype, device=dz1.device)
+    _need(act, (n, hh, ww, cx_p), dz1.dtype, "act")
     end = TIMER.bracket(("dgrad_s2", cz_p, cx_p, n, hh, ww)) if TIMER else None
     rc = L.lib().mil_conv_dgrad_s2(dz1.data_ptr(), L.ptr(dz2), wpack.data_ptr(), L.ptr(act), y.data_ptr(), n, h, w, cz_p,
-                                   hh, ww, cx_p, slope, L.dt_code(dz1.dtype), L.stream_ptr())
+                                   hh, ww, cx_p, slope, L.dt_code(dz1.dtype, dense), L.stream_ptr())
     if rc == 2:
         return None
     L.check(rc, "mil_conv_dgrad_s2")
@@ -375,14 +380,15 @@ def stem_bwd_fused(xs, g_pool, widx, *, workspace=None, out=None, slope=LEAK, ws
     """(dW [20,3,7,7], db [20]) of the stem from the pooled-output gradient in one pass (see mil_stem_bwd_fused),
     or None when the shape/dtype has no fused kernel."""
     n, h2, w2, c = xs.shape
+    dense = g_pool.shape[-1] == 20            # dense gradient layout (MIL_DT_BF16_DGRAD)
     need = ctypes.c_size_t(0)
-    rc = L.lib().mil_stem_bwd_fused_workspace(ctypes.byref(need), n, h2, w2, L.dt_code(xs.dtype))
+    rc = L.lib().mil_stem_bwd_fused_workspace(ctypes.byref(need), n, h2, w2, L.dt_code(xs.dtype, dense))
     if rc == 2:
         return None
     L.check(rc, "mil_stem_bwd_fused_workspace")
     hp, wp = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
     _need(xs, (n, h2, w2, 16), xs.dtype, "xs")
-    _need(g_pool, (n, hp, wp, 24), xs.dtype, "g_pool")
+    _need(g_pool, (n, hp, wp, 20 if dense else 24), xs.dtype, "g_pool")
     _need(widx, (n, hp, wp, 24), torch.uint8, "widx")
     if ws_alloc is not None:                 # deferred reductions: the slab buffer must outlive this call
         workspace = ws_alloc(need.value)
@@ -397,7 +403,7 @@ def stem_bwd_fused(xs, g_pool, widx, *, workspace=None, out=None, slope=LEAK, ws
         _need(db, (20,), torch.float32, "db")
     L.check(L.lib().mil_stem_bwd_fused(xs.data_ptr(), g_pool.data_ptr(), widx.data_ptr(), dw.data_ptr(), db.data_ptr(),
                                        workspace.data_ptr(), workspace.numel() * workspace.element_size(), n, h2, w2,
-                                       slope, 0 if out is None else 1, L.dt_code(xs.dtype), L.stream_ptr()),
+                                       slope, 0 if out is None else 1, L.dt_code(xs.dtype, dense), L.stream_ptr()),
             "mil_stem_bwd_fused")
     return dw, db
 
@@ -408,14 +414,15 @@ def stem_bwd_fused_nchw(x, g_pool, widx, *, workspace=None, out=None, slope=LEAK
     if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous():
         return None
     n, _, h, w = x.shape
+    dense = g_pool.shape[-1] == 20            # dense gradient layout (MIL_DT_BF16_DGRAD)
     need = ctypes.c_size_t(0)
-    rc = L.lib().mil_stem_bwd_fused_nchw_workspace(ctypes.byref(need), n, h, w, L.dt_code(g_pool.dtype))
+    rc = L.lib().mil_stem_bwd_fused_nchw_workspace(ctypes.byref(need), n, h, w, L.dt_code(g_pool.dtype, dense))
     if rc == 2 or x.data_ptr() % 16:
         return None
     L.check(rc, "mil_stem_bwd_fused_nchw_workspace")
     h2, w2 = h // 2, w // 2
     hp, wp = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
-    _need(g_pool, (n, hp, wp, 24), g_pool.dtype, "g_pool")
+    _need(g_pool, (n, hp, wp, 20 if dense else 24), g_pool.dtype, "g_pool")
     _need(widx, (n, hp, wp, 24), torch.uint8, "widx")
     if ws_alloc is not None:                 # deferred reductions: the slab buffer must outlive this call
         workspace = ws_alloc(need.value)
@@ -431,13 +438,26 @@ def stem_bwd_fused_nchw(x, g_pool, widx, *, workspace=None, out=None, slope=LEAK
     end = TIMER.bracket(("stem_bwd", n, h, w)) if TIMER else None
     rc = L.lib().mil_stem_bwd_fused_nchw(x.data_ptr(), g_pool.data_ptr(), widx.data_ptr(), dw.data_ptr(), db.data_ptr(),
                                          workspace.data_ptr(), workspace.numel() * workspace.element_size(), n, h, w,
-                                         slope, 0 if out is None else 1, L.dt_code(g_pool.dtype), L.stream_ptr())
+                                         slope, 0 if out is None else 1, L.dt_code(g_pool.dtype, dense), L.stream_ptr())
     if rc == 2:
         return None
     L.check(rc, "mil_stem_bwd_fused_nchw")
     if end is not None:
         end.record()
     return dw, db
+
+
+def stem_bwd_dense_ok(src, dtype):
+    """True when the fused stem backward for this saved input (the fp32 tiles [n,3,H,W] or the s2d copy [n,H2,W2,16])
+    exists with the dense pooled-gradient layout."""
+    need = ctypes.c_size_t(0)
+    if src.dim() == 4 and src.shape[1] == 3 and src.dtype == torch.float32:
+        n, _, h, w = src.shape
+        if not src.is_contiguous() or src.data_ptr() % 16:
+            return False
+        return L.lib().mil_stem_bwd_fused_nchw_workspace(ctypes.byref(need), n, h, w, L.dt_code(dtype, True)) == 0
+    n, h2, w2, _ = src.shape
+    return L.lib().mil_stem_bwd_fused_workspace(ctypes.byref(need), n, h2, w2, L.dt_code(dtype, True)) == 0
 
 
 def avgpool_fc_fwd(x, wfc, c, bias=None):
