@@ -311,14 +311,14 @@ static thread_local MilDeferState g_defer{nullptr, 0, 0};
 MilDeferState& mil_defer_state() { return g_defer; }
 
 __global__ __launch_bounds__(32 * MIL_RED_GROUPS) void wgrad_reduce_job_kernel(MilReduceJob j) {
-    __shared__ float part[MIL_RED_GROUPS][32];
+    __shared__ f32x4_t part[MIL_RED_GROUPS][32];
     mil_reduce_job_block(j, blockIdx.x, part);
 }
 
 // Every recorded reduction of a backward pass in ONE launch: block -> (job, block inside the job) through the jobs'
 // block0 prefix, one lane per job (at most 64 jobs per launch; the host entry point splits longer tables).
 __global__ __launch_bounds__(32 * MIL_RED_GROUPS) void wgrad_reduce_all_kernel(const MilReduceJob* __restrict__ jobs, int njobs) {
-    __shared__ float part[MIL_RED_GROUPS][32];
+    __shared__ f32x4_t part[MIL_RED_GROUPS][32];
     __shared__ int which;
     const int b = blockIdx.x;
     if (threadIdx.x < 64) {
