@@ -23,38 +23,52 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 __device__ __forceinline__ float softplusf_(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
-    // 256-thread block reduction, result broadcast to every thread
+    // block reduction (<= 16 waves), wave sums added in wave order, result broadcast to every thread
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) red[wave] = v;
     __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    float s = red[0];
+    for (int k = 1; k < (int)(blockDim.x >> 6); ++k) s += red[k];
+    return s;
 }
 
 // K1: per-bag column statistics.  stats[b] = { mu[80], rstd[80] }, kld[b] = 0.5*mean(H^2)
-__global__ __launch_bounds__(256) void head_colstats_kernel(const float* __restrict__ H, const int* __restrict__ off,
-                                                            float* __restrict__ stats, float* __restrict__ kld, float eps) {
-    __shared__ float part[3][HL];
+// One workgroup per bag; HP row partials per column (thread = (column, partial p), rows p, p+HP, ...), added in p order:
+// the tree depends only on the bag's length.  (Three partials on 256 threads took 33 us for 256-instance bags — one serial
+// chain of 85 loads per thread — and 0.4 ms for a 4096-instance bag.)
+#define HP 12
+__global__ __launch_bounds__(1024) void head_colstats_kernel(const float* __restrict__ H, const int* __restrict__ off,
+                                                             float* __restrict__ stats, float* __restrict__ kld, float eps) {
+    __shared__ float part[HP][HL];
     __shared__ float mu_s[HL];
-    __shared__ float red[4];
+    __shared__ float red[16];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n0 = off[b], n1 = off[b + 1], N = n1 - n0;
     const int i = tid % HL, p = tid / HL;
     float s = 0.f, sq = 0.f;
-    if (p < 3) for (int n = n0 + p; n < n1; n += 3) { const float v = H[(size_t)n * HL + i]; s += v; sq += v * v; }
-    if (p < 3) part[p][i] = s;
-    const float sq_tot = block_sum(p < 3 ? sq : 0.f, red);
-    __syncthreads();
-    if (tid < HL) mu_s[tid] = (part[0][tid] + part[1][tid] + part[2][tid]) / (float)N;
-    __syncthreads();
-    float v2 = 0.f;
-    if (p < 3) { const float m = mu_s[i]; for (int n = n0 + p; n < n1; n += 3) { const float d = H[(size_t)n * HL + i] - m; v2 += d * d; } }
-    __syncthreads();
-    if (p < 3) part[p][i] = v2;
+    if (p < HP) for (int n = n0 + p; n < n1; n += HP) { const float v = H[(size_t)n * HL + i]; s += v; sq += v * v; }
+    if (p < HP) part[p][i] = s;
+    const float sq_tot = block_sum(p < HP ? sq : 0.f, red);
     __syncthreads();
     if (tid < HL) {
-        const float var = (part[0][tid] + part[1][tid] + part[2][tid]) / (float)N;
+        float t = part[0][tid];
+#pragma unroll
+        for (int k = 1; k < HP; ++k) t += part[k][tid];
+        mu_s[tid] = t / (float)N;
+    }
+    __syncthreads();
+    float v2 = 0.f;
+    if (p < HP) { const float m = mu_s[i]; for (int n = n0 + p; n < n1; n += HP) { const float d = H[(size_t)n * HL + i] - m; v2 += d * d; } }
+    __syncthreads();
+    if (p < HP) part[p][i] = v2;
+    __syncthreads();
+    if (tid < HL) {
+        float t = part[0][tid];
+#pragma unroll
+        for (int k = 1; k < HP; ++k) t += part[k][tid];
+        const float var = t / (float)N;
         stats[(size_t)b * 2 * HL + tid] = mu_s[tid];
         stats[(size_t)b * 2 * HL + HL + tid] = 1.f / sqrtf(var + eps);
     }
@@ -63,62 +77,92 @@ __global__ __launch_bounds__(256) void head_colstats_kernel(const float* __restr
 
 // K2: per-instance forward of both MLPs.  Saves t=tanh(u) [n,40], v (buffer pre-activation) [n,40],
 // A_raw [n,3], B [n].
-__global__ __launch_bounds__(128) void head_inst_fwd_kernel(const float* __restrict__ H, const int* __restrict__ inst_bag,
+// One WAVE per slice of HSL instances, lane j < 40 = hidden unit j of both MLPs with its two weight rows (160 values) in
+// registers; an instance's normalised / dropped-out feature rows are staged in the wave's LDS strip and read back as
+// broadcasts.  Every dot product runs in the same order as the one-thread-per-instance form it replaces (which spent 44 us
+// on 16 workgroups: 6.4 k serial FMAs per thread, each with its weight read from LDS): same bits, ~256 waves.
+#ifndef HSL
+#define HSL 8
+#endif
+__global__ __launch_bounds__(256) void head_inst_fwd_kernel(const float* __restrict__ H, const int* __restrict__ inst_bag,
                                                             const float* __restrict__ stats, const uint8_t* __restrict__ keep,
                                                             HeadWeights w, float* __restrict__ t_out, float* __restrict__ v_out,
                                                             float* __restrict__ araw, float* __restrict__ bterm, int ntot,
                                                             float slope, float keep_scale) {
-    __shared__ float w1[HD * HL], wl[HD * HL];
-    __shared__ float b1[HD], bl[HD], w2[HK * HD], wc[HD], gam[HL], bet[HL];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < HD * HL; i += 128) { w1[i] = w.a_w1[i]; wl[i] = w.b_w1[i]; }
-    for (int i = tid; i < HK * HD; i += 128) w2[i] = w.a_w2[i];
-    if (tid < HD) { b1[tid] = w.a_b1[tid]; bl[tid] = w.b_b1[tid]; wc[tid] = w.b_wc[tid]; }
-    if (tid < HL) { gam[tid] = w.bn_w[tid]; bet[tid] = w.bn_b[tid]; }
-    __syncthreads();
-    const int n = blockIdx.x * 128 + tid;
-    if (n >= ntot) return;
-    const int b = inst_bag[n];
-    const float* st = stats + (size_t)b * 2 * HL;
-    float h[HL], z[HL];
+    __shared__ __attribute__((aligned(16))) float strip[4][2 * HL + 2 * HD];      // per wave: z[80] m[80] t[40] lv[40]
+    __shared__ float w2[HK * HD], wc[HD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < HK * HD; i += 256) w2[i] = w.a_w2[i];
+    if (tid < HD) wc[tid] = w.b_wc[tid];
+    const int j = lane < HD ? lane : 0;
+    float w1r[HL], wlr[HL];
 #pragma unroll
     for (int i = 0; i < HL; i += 4) {
-        const f32x4_t q = *reinterpret_cast<const f32x4_t*>(H + (size_t)n * HL + i);
+        const f32x4_t q1 = *reinterpret_cast<const f32x4_t*>(w.a_w1 + j * HL + i);
+        const f32x4_t q2 = *reinterpret_cast<const f32x4_t*>(w.b_w1 + j * HL + i);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) h[i + j] = q[j];
+        for (int e = 0; e < 4; ++e) { w1r[i + e] = q1[e]; wlr[i + e] = q2[e]; }
     }
+    const float b1 = w.a_b1[j], bl = w.b_b1[j];
+    // feature columns of this lane: i0 = lane, i1 = 64 + lane (lane < 16)
+    const int i1 = lane < HL - 64 ? 64 + lane : 0;
+    const float g0 = w.bn_w[lane], be0 = w.bn_b[lane], g1 = w.bn_w[i1], be1 = w.bn_b[i1];
+    float* z = strip[wave];
+    float* m = z + HL;
+    float* ts = m + HL;
+    float* lv = ts + HD;
+    __syncthreads();
+    const int base = (blockIdx.x * 4 + wave) * HSL;
+    for (int sl = 0; sl < HSL; ++sl) {
+        const int n = base + sl;
+        const bool live = n < ntot;
+        if (live) {
+            const float* st = stats + (size_t)inst_bag[n] * 2 * HL;
+            const float h0 = H[(size_t)n * HL + lane];
+            z[lane] = g0 * ((h0 - st[lane]) * st[HL + lane]) + be0;
+            float m0 = lrelu(h0, slope);
+            if (keep) m0 = keep[(size_t)n * HL + lane] ? m0 * keep_scale : 0.f;
+            m[lane] = m0;
+            if (lane < HL - 64) {
+                const float h1 = H[(size_t)n * HL + i1];
+                z[i1] = g1 * ((h1 - st[i1]) * st[HL + i1]) + be1;
+                float m1 = lrelu(h1, slope);
+                if (keep) m1 = keep[(size_t)n * HL + i1] ? m1 * keep_scale : 0.f;
+                m[i1] = m1;
+            }
+        }
+        __syncthreads();
+        if (live && lane < HD) {
+            float u = b1, v = bl;
 #pragma unroll
-    for (int i = 0; i < HL; ++i) z[i] = gam[i] * ((h[i] - st[i]) * st[HL + i]) + bet[i];
-    float a[HK];
+            for (int i = 0; i < HL; i += 4) {
+                const f32x4_t zq = *reinterpret_cast<const f32x4_t*>(z + i);
 #pragma unroll
-    for (int k = 0; k < HK; ++k) a[k] = w.a_b2[k];
-    for (int j = 0; j < HD; ++j) {
-        float u = b1[j];
+                for (int e = 0; e < 4; ++e) u += w1r[i + e] * zq[e];
+            }
 #pragma unroll
-        for (int i = 0; i < HL; ++i) u += w1[j * HL + i] * z[i];
-        const float t = tanhf(u);
-        t_out[(size_t)n * HD + j] = t;
+            for (int i = 0; i < HL; i += 4) {
+                const f32x4_t mq = *reinterpret_cast<const f32x4_t*>(m + i);
 #pragma unroll
-        for (int k = 0; k < HK; ++k) a[k] += w2[k * HD + j] * t;
+                for (int e = 0; e < 4; ++e) v += wlr[i + e] * mq[e];
+            }
+            const float t = tanhf(u);
+            t_out[(size_t)n * HD + lane] = t;
+            v_out[(size_t)n * HD + lane] = v;
+            ts[lane] = t;
+            lv[lane] = lrelu(v, slope);
+        }
+        __syncthreads();
+        if (live && lane < HK) {                  // A_raw[k] = b2[k] + sum_j w2[k][j] t[j], in j order
+            float a = w.a_b2[lane];
+            for (int jj = 0; jj < HD; ++jj) a += w2[lane * HD + jj] * ts[jj];
+            araw[(size_t)n * HK + lane] = a;
+        } else if (live && lane == HK) {          // B = bc + sum_j wc[j] lrelu(v[j]), in j order
+            float bsum = w.b_bc[0];
+            for (int jj = 0; jj < HD; ++jj) bsum += wc[jj] * lv[jj];
+            bterm[n] = bsum;
+        }
     }
-#pragma unroll
-    for (int k = 0; k < HK; ++k) araw[(size_t)n * HK + k] = a[k];
-    // buffer branch: Hm = dropout(lrelu(H))
-#pragma unroll
-    for (int i = 0; i < HL; ++i) {
-        float m = lrelu(h[i], slope);
-        if (keep) m = keep[(size_t)n * HL + i] ? m * keep_scale : 0.f;
-        z[i] = m;
-    }
-    float bsum = w.b_bc[0];
-    for (int j = 0; j < HD; ++j) {
-        float v = bl[j];
-#pragma unroll
-        for (int i = 0; i < HL; ++i) v += wl[j * HL + i] * z[i];
-        v_out[(size_t)n * HD + j] = v;
-        bsum += wc[j] * lrelu(v, slope);
-    }
-    bterm[n] = bsum;
 }
 
 // Per-bag scalar record written by K3 and read back by the host wrapper / backward kernels.
@@ -131,7 +175,7 @@ __global__ __launch_bounds__(256) void head_bag_fwd_kernel(const float* __restri
                                                            const float* __restrict__ cw, HeadWeights w, float smoothing,
                                                            float* __restrict__ a1, float* __restrict__ wrois,
                                                            float* __restrict__ rec) {
-    __shared__ float red[4];
+    __shared__ float red[16];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n0 = off[b], n1 = off[b + 1], N = n1 - n0;
     float s0[HK], s1[HK];
@@ -208,7 +252,11 @@ __global__ __launch_bounds__(256) void head_bag_fwd_kernel(const float* __restri
 
 // K4: per-instance backward.  Writes dA_raw-derived quantities for the weight-gradient pass and the
 // buffer-branch part of dH; the BN-branch part is finished by K6.
-__global__ __launch_bounds__(128) void head_inst_bwd_kernel(const float* __restrict__ H, const int* __restrict__ inst_bag,
+// One wave per slice of HSL instances, as K2.  Phase A: lane j < 40 = hidden unit (du[j], dv[j]; the few per-instance
+// scalars are computed by every lane).  Phase B: lane = feature column i (and 64 + i for i < 16) with that column of both
+// weight matrices in registers; du / dv come back from the wave's LDS strip as broadcasts.  Same summation orders as the
+// one-thread-per-instance form (62 us on 16 workgroups).
+__global__ __launch_bounds__(256) void head_inst_bwd_kernel(const float* __restrict__ H, const int* __restrict__ inst_bag,
                                                             const uint8_t* __restrict__ keep, HeadWeights w,
                                                             const float* __restrict__ t_in, const float* __restrict__ v_in,
                                                             const float* __restrict__ araw, const float* __restrict__ bterm,
@@ -217,58 +265,90 @@ __global__ __launch_bounds__(128) void head_inst_bwd_kernel(const float* __restr
                                                             float* __restrict__ da_out, float* __restrict__ dwm_out,
                                                             float* __restrict__ db_out, float* __restrict__ dhz_out,
                                                             float* __restrict__ dH, int ntot, float slope, float keep_scale) {
-    __shared__ float w1[HD * HL], wl[HD * HL];
-    __shared__ float w2[HK * HD], wc[HD];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < HD * HL; i += 128) { w1[i] = w.a_w1[i]; wl[i] = w.b_w1[i]; }
-    for (int i = tid; i < HK * HD; i += 128) w2[i] = w.a_w2[i];
-    if (tid < HD) wc[tid] = w.b_wc[tid];
-    __syncthreads();
-    const int n = blockIdx.x * 128 + tid;
-    if (n >= ntot) return;
-    const int b = inst_bag[n];
-    const float* r = rec + (size_t)b * HREC;
-    const float g = gloss[b];
-    const float bv = bterm[n];
-    float da[HK], dB = 0.f;
+    __shared__ __attribute__((aligned(16))) float strip[4][2 * HD];      // per wave: du[40] dv[40]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane < HD ? lane : 0;
+    const float w2j[HK] = {w.a_w2[j], w.a_w2[HD + j], w.a_w2[2 * HD + j]};
+    const float wcj = w.b_wc[j];
+    const int i1 = lane < HL - 64 ? 64 + lane : 0;
+    float c10[HD], cl0[HD], c11[HD], cl1[HD];        // columns lane and 64+lane of W1 and Wl
 #pragma unroll
-    for (int k = 0; k < HK; ++k) {
-        const float wk = w.wmask[k];
-        const float s0 = sigmoidf_(-10.f * wk), s1 = sigmoidf_(10.f * wk);
-        const float a = araw[(size_t)n * HK + k];
-        const float sp = softplusf_(a);
-        const float dM = g * r[13 + k];
-        const float D = r[10 + k];
-        const float a1 = (s0 * sp + s1) / D;
-        dB += dM * a1;
-        const float dam = dM * (bv - r[k]) / D;                 // d loss / d A_mask[n,k]
-        dwm_out[(size_t)n * HK + k] = dam * (sp * (-10.f * s0 * (1.f - s0)) + 10.f * s1 * (1.f - s1));
-        da[k] = dam * s0 * (a > 20.f ? 1.f : sigmoidf_(a));     // softplus'
-        da_out[(size_t)n * HK + k] = da[k];
+    for (int jj = 0; jj < HD; ++jj) {
+        c10[jj] = w.a_w1[jj * HL + lane]; cl0[jj] = w.b_w1[jj * HL + lane];
+        c11[jj] = w.a_w1[jj * HL + i1]; cl1[jj] = w.b_w1[jj * HL + i1];
     }
-    db_out[n] = dB;
-    float du[HD], dv[HD];
+    float s0k[HK], s1k[HK];
 #pragma unroll
-    for (int j = 0; j < HD; ++j) {
-        const float t = t_in[(size_t)n * HD + j];
-        float s = 0.f;
+    for (int k = 0; k < HK; ++k) { const float wk = w.wmask[k]; s0k[k] = sigmoidf_(-10.f * wk); s1k[k] = sigmoidf_(10.f * wk); }
+    float* dus = strip[wave];
+    float* dvs = dus + HD;
+    const int base = (blockIdx.x * 4 + wave) * HSL;
+    for (int sl = 0; sl < HSL; ++sl) {
+        const int n = base + sl;
+        const bool live = n < ntot;
+        if (live) {
+            const int b = inst_bag[n];
+            const float* r = rec + (size_t)b * HREC;
+            const float g = gloss[b];
+            const float bv = bterm[n];
+            float da[HK], dB = 0.f;
 #pragma unroll
-        for (int k = 0; k < HK; ++k) s += da[k] * w2[k * HD + j];
-        du[j] = s * (1.f - t * t);
-        du_out[(size_t)n * HD + j] = du[j];
-        const float v = v_in[(size_t)n * HD + j];
-        dv[j] = dB * wc[j] * lrelu_grad(v, slope);
-        dv_out[(size_t)n * HD + j] = dv[j];
-    }
-    for (int i = 0; i < HL; ++i) {
-        float s1 = 0.f, s2 = 0.f;
+            for (int k = 0; k < HK; ++k) {
+                const float s0 = s0k[k], s1 = s1k[k];
+                const float a = araw[(size_t)n * HK + k];
+                const float sp = softplusf_(a);
+                const float dM = g * r[13 + k];
+                const float D = r[10 + k];
+                const float a1 = (s0 * sp + s1) / D;
+                dB += dM * a1;
+                const float dam = dM * (bv - r[k]) / D;                 // d loss / d A_mask[n,k]
+                if (lane == k) dwm_out[(size_t)n * HK + k] = dam * (sp * (-10.f * s0 * (1.f - s0)) + 10.f * s1 * (1.f - s1));
+                da[k] = dam * s0 * (a > 20.f ? 1.f : sigmoidf_(a));     // softplus'
+                if (lane == k) da_out[(size_t)n * HK + k] = da[k];
+            }
+            if (lane == HK) db_out[n] = dB;
+            if (lane < HD) {
+                const float t = t_in[(size_t)n * HD + lane];
+                float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < HD; ++j) { s1 += du[j] * w1[j * HL + i]; s2 += dv[j] * wl[j * HL + i]; }
-        dhz_out[(size_t)n * HL + i] = s1;
-        const float h = H[(size_t)n * HL + i];
-        float m = s2 * lrelu_grad(h, slope);
-        if (keep) m = keep[(size_t)n * HL + i] ? m * keep_scale : 0.f;
-        dH[(size_t)n * HL + i] = m;
+                for (int k = 0; k < HK; ++k) s += da[k] * w2j[k];
+                const float du = s * (1.f - t * t);
+                du_out[(size_t)n * HD + lane] = du;
+                const float v = v_in[(size_t)n * HD + lane];
+                const float dv = dB * wcj * lrelu_grad(v, slope);
+                dv_out[(size_t)n * HD + lane] = dv;
+                dus[lane] = du; dvs[lane] = dv;
+            }
+        }
+        __syncthreads();
+        if (live) {
+            float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < HD; jj += 4) {
+                const f32x4_t uq = *reinterpret_cast<const f32x4_t*>(dus + jj);
+                const f32x4_t vq = *reinterpret_cast<const f32x4_t*>(dvs + jj);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a0 += uq[e] * c10[jj + e]; b0 += vq[e] * cl0[jj + e];
+                    a1 += uq[e] * c11[jj + e]; b1 += vq[e] * cl1[jj + e];
+                }
+            }
+            {
+                dhz_out[(size_t)n * HL + lane] = a0;
+                const float h = H[(size_t)n * HL + lane];
+                float mm = b0 * lrelu_grad(h, slope);
+                if (keep) mm = keep[(size_t)n * HL + lane] ? mm * keep_scale : 0.f;
+                dH[(size_t)n * HL + lane] = mm;
+            }
+            if (lane < HL - 64) {
+                dhz_out[(size_t)n * HL + i1] = a1;
+                const float h = H[(size_t)n * HL + i1];
+                float mm = b1 * lrelu_grad(h, slope);
+                if (keep) mm = keep[(size_t)n * HL + i1] ? mm * keep_scale : 0.f;
+                dH[(size_t)n * HL + i1] = mm;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -388,7 +468,7 @@ __global__ __launch_bounds__(256) void head_wgrad_reduce_kernel(const float* __r
 
 // l2 = 0.5*(||Wl||_F + ||Wc||_F) contributes gl2 * 0.5 * W/||W|| to the two buffer weights.
 __global__ __launch_bounds__(256) void head_l2_grad_kernel(HeadWeights w, const float* __restrict__ gl2, float* __restrict__ grads) {
-    __shared__ float red[4];
+    __shared__ float red[16];
     const int tid = threadIdx.x;
     float q1 = 0.f, q2 = 0.f;
     for (int i = tid; i < HD * HL; i += 256) { const float v = w.b_w1[i]; q1 += v * v; }
@@ -401,29 +481,32 @@ __global__ __launch_bounds__(256) void head_l2_grad_kernel(HeadWeights w, const 
 }
 
 // K6: finish dH with the batch-norm branch:  dH += rstd/N * (N*dx - sum(dx) - xhat*sum(dx*xhat)), dx = dHz*gamma
-__global__ __launch_bounds__(256) void head_bn_bwd_kernel(const float* __restrict__ H, const int* __restrict__ off,
-                                                          const float* __restrict__ stats, HeadWeights w,
-                                                          const float* __restrict__ dhz, float* __restrict__ dH) {
-    __shared__ float p1[3][HL], p2[3][HL];
+// (HP row partials per column, as K1)
+__global__ __launch_bounds__(1024) void head_bn_bwd_kernel(const float* __restrict__ H, const int* __restrict__ off,
+                                                           const float* __restrict__ stats, HeadWeights w,
+                                                           const float* __restrict__ dhz, float* __restrict__ dH) {
+    __shared__ float p1[HP][HL], p2[HP][HL];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n0 = off[b], n1 = off[b + 1], N = n1 - n0;
     const int i = tid % HL, p = tid / HL;
     const float* st = stats + (size_t)b * 2 * HL;
     float s1 = 0.f, s2 = 0.f;
-    if (p < 3) {
+    if (p < HP) {
         const float gm = w.bn_w[i], mu = st[i], rs = st[HL + i];
-        for (int n = n0 + p; n < n1; n += 3) {
+        for (int n = n0 + p; n < n1; n += HP) {
             const float dx = dhz[(size_t)n * HL + i] * gm;
             s1 += dx; s2 += dx * ((H[(size_t)n * HL + i] - mu) * rs);
         }
         p1[p][i] = s1; p2[p][i] = s2;
     }
     __syncthreads();
-    if (p < 3) {
+    if (p < HP) {
         const float gm = w.bn_w[i], mu = st[i], rs = st[HL + i];
-        const float t1 = p1[0][i] + p1[1][i] + p1[2][i], t2 = p2[0][i] + p2[1][i] + p2[2][i];
+        float t1 = p1[0][i], t2 = p2[0][i];
+#pragma unroll
+        for (int k = 1; k < HP; ++k) { t1 += p1[k][i]; t2 += p2[k][i]; }
         const float invn = 1.f / (float)N;
-        for (int n = n0 + p; n < n1; n += 3) {
+        for (int n = n0 + p; n < n1; n += HP) {
             const float xh = (H[(size_t)n * HL + i] - mu) * rs;
             const float dx = dhz[(size_t)n * HL + i] * gm;
             dH[(size_t)n * HL + i] += rs * (dx - invn * t1 - invn * xh * t2);
@@ -472,9 +555,9 @@ extern "C" int mil_head_fwd(const float* H, const int* bag_offsets, const int* i
     const HeadWeights w = make_weights(weights);
     HeadWs ws = carve(workspace, ntot, nbags);
     const float ks = 1.f / (1.f - drop_p);
-    hipLaunchKernelGGL(head_colstats_kernel, dim3(nbags), dim3(256), 0, st, H, bag_offsets, ws.stats, kld, bn_eps);
+    hipLaunchKernelGGL(head_colstats_kernel, dim3(nbags), dim3(1024), 0, st, H, bag_offsets, ws.stats, kld, bn_eps);
     MIL_CHECK_LAUNCH();
-    hipLaunchKernelGGL(head_inst_fwd_kernel, dim3((ntot + 127) / 128), dim3(128), 0, st, H, inst_bag, ws.stats, keep_mask, w,
+    hipLaunchKernelGGL(head_inst_fwd_kernel, dim3((ntot + 4 * HSL - 1) / (4 * HSL)), dim3(256), 0, st, H, inst_bag, ws.stats, keep_mask, w,
                        ws.t, ws.v, ws.araw, bterm, ntot, slope, ks);
     MIL_CHECK_LAUNCH();
     hipLaunchKernelGGL(head_bag_fwd_kernel, dim3(nbags), dim3(256), 0, st, ws.araw, bterm, bag_offsets, labels, class_weights, w,
@@ -495,7 +578,7 @@ extern "C" int mil_head_bwd(const float* H, const int* bag_offsets, const int* i
     const HeadWeights w = make_weights(weights);
     HeadWs ws = carve(workspace, ntot, nbags);
     const float ks = 1.f / (1.f - drop_p);
-    hipLaunchKernelGGL(head_inst_bwd_kernel, dim3((ntot + 127) / 128), dim3(128), 0, st, H, inst_bag, keep_mask, w, ws.t, ws.v,
+    hipLaunchKernelGGL(head_inst_bwd_kernel, dim3((ntot + 4 * HSL - 1) / (4 * HSL)), dim3(256), 0, st, H, inst_bag, keep_mask, w, ws.t, ws.v,
                        ws.araw, bterm, rec, grad_loss, ws.du, ws.dv, ws.da, ws.dwm, ws.db, ws.dhz, dH, ntot, slope, ks);
     MIL_CHECK_LAUNCH();
     {
@@ -517,7 +600,7 @@ extern "C" int mil_head_bwd(const float* H, const int* bag_offsets, const int* i
         hipLaunchKernelGGL(head_l2_grad_kernel, dim3(1), dim3(256), 0, st, w, grad_l2, grads);
         MIL_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(head_bn_bwd_kernel, dim3(nbags), dim3(256), 0, st, H, bag_offsets, ws.stats, w, ws.dhz, dH);
+    hipLaunchKernelGGL(head_bn_bwd_kernel, dim3(nbags), dim3(1024), 0, st, H, bag_offsets, ws.stats, w, ws.dhz, dH);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }

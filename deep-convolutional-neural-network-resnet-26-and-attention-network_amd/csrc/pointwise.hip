@@ -234,22 +234,43 @@ extern "C" int mil_maxpool_bwd(const void* gy, const uint8_t* widx, void* gx, in
 // One workgroup per tile (blockDim = max(C, NF) rounded up to a wave, <= 512); pooled means are kept (fp32)
 // for the backward pass.  gbm/model.py:31-32,58-60 (C = 80, no bias); alt_resnet.py:92-93,139-143 (C = 512, bias).
 #define POOL_MAXC 512
+// The tile's pixels are staged in LDS as floats in chunks (all threads load 16-byte pieces), then one thread per channel
+// adds its column IN PIXEL ORDER — the order of the one-thread-per-channel form this replaces (2-byte loads, 0.8 TB/s): same
+// bits (the 2-instance bags of the live driver make the head's batch norm ill-conditioned enough for another summation
+// order to show in the gradients) — and the C x NF matrix-vector product follows from LDS.
 template <typename T>
 __global__ void avgpool_fc_fwd_kernel(const typename T::elem* __restrict__ x, const float* __restrict__ wfc,
                                       const float* __restrict__ bias, float* __restrict__ pooled,
                                       float* __restrict__ feats, int hw, int CP, int C, int NF) {
+    __shared__ float stage[4096];                            // [pixels of a chunk][CP]
     __shared__ float sp[POOL_MAXC];
-    const int t = blockIdx.x, c = threadIdx.x;
-    float s = 0.f;
-    if (c < C) {
-        const typename T::elem* p = x + (size_t)t * hw * CP + c;
-        for (int i = 0; i < hw; ++i) s += (float)p[(size_t)i * CP];
-        s /= (float)hw;
-        pooled[(size_t)t * C + c] = s;
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int NG = CP >> 3, PCH = 4096 / CP;
+    float s0 = 0.f, s1 = 0.f;                                // channels tid and tid + blockDim (CP <= 2 * blockDim)
+    for (int i0 = 0; i0 < hw; i0 += PCH) {
+        const int npx = hw - i0 < PCH ? hw - i0 : PCH;
+        for (int idx = tid; idx < npx * NG; idx += blockDim.x) {
+            const int i = idx / NG, cg = idx - i * NG;
+            float v[8];
+            load8<T>(x + ((size_t)t * hw + i0 + i) * CP + cg * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) stage[i * CP + cg * 8 + j] = v[j];
+        }
+        __syncthreads();
+        if (tid < C) for (int i = 0; i < npx; ++i) s0 += stage[i * CP + tid];
+        if (tid + (int)blockDim.x < C) for (int i = 0; i < npx; ++i) s1 += stage[i * CP + tid + blockDim.x];
+        __syncthreads();
     }
-    sp[c] = s;
+    for (int c = tid; c < POOL_MAXC; c += blockDim.x) {
+        float s = 0.f;
+        if (c < C) {
+            s = (c == tid ? s0 : s1) / (float)hw;
+            pooled[(size_t)t * C + c] = s;
+        }
+        sp[c] = s;
+    }
     __syncthreads();
-    if (c < NF) {
+    for (int c = tid; c < NF; c += blockDim.x) {
         float acc = bias ? bias[c] : 0.f;
         for (int i = 0; i < C; ++i) acc += sp[i] * wfc[(size_t)c * C + i];
         feats[(size_t)t * NF + c] = acc;
@@ -257,25 +278,38 @@ __global__ void avgpool_fc_fwd_kernel(const typename T::elem* __restrict__ x, co
 }
 
 // dz[t][p][c] = lrelu'(act[t][p][c]) * (sum_o dfeats[t][o] * Wfc[o][c]) / hw      (padded channels -> 0)
+// g[c] first (one thread per channel), then the map in 8-channel pieces.
 template <typename T>
 __global__ void avgpool_fc_bwd_kernel(const float* __restrict__ dfeats, const float* __restrict__ wfc,
                                       const typename T::elem* __restrict__ act, typename T::elem* __restrict__ dz, int hw,
                                       int CP, int C, int NF, float slope) {
-    __shared__ float sd[POOL_MAXC];
-    const int t = blockIdx.x, c = threadIdx.x;
-    sd[c] = (c < NF) ? dfeats[(size_t)t * NF + c] : 0.f;
+    __shared__ float sd[POOL_MAXC], sg[POOL_MAXC];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < POOL_MAXC; c += blockDim.x) sd[c] = (c < NF) ? dfeats[(size_t)t * NF + c] : 0.f;
     __syncthreads();
-    if (c >= CP) return;
-    float g = 0.f;
-    if (c < C) {
-        for (int o = 0; o < NF; ++o) g += sd[o] * wfc[(size_t)o * C + c];
-        g /= (float)hw;
+    for (int c = tid; c < CP; c += blockDim.x) {
+        float g = 0.f;
+        if (c < C) {
+            for (int o = 0; o < NF; ++o) g += sd[o] * wfc[(size_t)o * C + c];
+            g /= (float)hw;
+        }
+        sg[c] = g;
     }
-    for (int i = 0; i < hw; ++i) {
-        const size_t off = ((size_t)t * hw + i) * CP + c;
-        float v = g;
-        if (act) v *= lrelu_grad((float)act[off], slope);
-        dz[off] = (typename T::elem)v;
+    __syncthreads();
+    const int NG = CP >> 3;
+    for (int idx = tid; idx < hw * NG; idx += blockDim.x) {
+        const int i = idx / NG, cg = idx - i * NG;
+        const size_t off = ((size_t)t * hw + i) * CP + cg * 8;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = sg[cg * 8 + j];
+        if (act) {
+            float a[8];
+            load8<T>(act + off, a);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= lrelu_grad(a[j], slope);
+        }
+        store8<T>(dz + off, v);
     }
 }
 
@@ -372,15 +406,16 @@ extern "C" int mil_fc_wgrad(const float* dfeats, const float* pooled, float* dwf
     return MIL_OK;
 }
 
+// 256 threads (512 for more than 256 channels): (pixel group, 8-channel group) items; needs cp % 8 == 0
 static int pool_block(int c, int nf, int cp) {
     int m = c > nf ? c : nf;
     if (cp > m) m = cp;
-    return (m + 63) / 64 * 64;
+    return m > 256 ? 512 : 256;
 }
 
 extern "C" int mil_avgpool_fc_fwd(const void* x, const float* wfc, const float* bias, float* pooled, float* feats, int n,
                                   int hw, int cp, int c, int nf, int dtype, void* stream) {
-    if (!x || !wfc || !pooled || !feats || c > POOL_MAXC || nf > POOL_MAXC || cp > POOL_MAXC || hw <= 0) return MIL_ERR_ARG;
+    if (!x || !wfc || !pooled || !feats || c > POOL_MAXC || nf > POOL_MAXC || cp > POOL_MAXC || (cp & 7) || hw <= 0) return MIL_ERR_ARG;
     if (n == 0) return MIL_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int bd = pool_block(c, nf, cp);
@@ -395,7 +430,7 @@ extern "C" int mil_avgpool_fc_bwd(const float* dfeats, const float* wfc, const f
                                   float* dwfc, float* dbias, int n, int hw, int cp, int c, int nf, int accumulate, float slope,
                                   int dtype, void* stream) {
     // dwfc == null: data path only (the parameter gradients then come from mil_fc_wgrad)
-    if (!dfeats || !wfc || !pooled || !dz || c > POOL_MAXC || nf > POOL_MAXC || cp > POOL_MAXC || hw <= 0) return MIL_ERR_ARG;
+    if (!dfeats || !wfc || !pooled || !dz || c > POOL_MAXC || nf > POOL_MAXC || cp > POOL_MAXC || (cp & 7) || hw <= 0) return MIL_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int bd = pool_block(c, nf, cp);
     if (n > 0) {
