@@ -15,6 +15,10 @@ BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench.err
 tail -n 1 $OUT/bench_line.json > profiles/${ROUND}_bench_line.json
 echo "bench done"
+# the other single-GPU configurations of BASELINE.json (512x512 tiles; one 4096-tile bag, forward only)
+python3 bench.py --size 512 --tiles 128 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_cfg3_512.json
+python3 bench.py --infer --bags 1 --tiles 4096 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_cfg5_infer4096.json
+echo "cfg3 / cfg5 lines done"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths > $OUT/stats.log 2>&1
 cp "$(ls $OUT/stats/*/*kernel_stats.csv | head -n 1)" profiles/${ROUND}_bench_kernel_stats.csv
