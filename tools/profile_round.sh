@@ -12,14 +12,6 @@ OUT=gpurun_out/prof_$ROUND
 mkdir -p $OUT profiles
 BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-extra-paths"
 
-python3 bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench.err
-tail -n 1 $OUT/bench_line.json > profiles/${ROUND}_bench_line.json
-echo "bench done"
-# the other single-GPU configurations of BASELINE.json (512x512 tiles; one 4096-tile bag, forward only)
-python3 bench.py --size 512 --tiles 128 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_cfg3_512.json
-python3 bench.py --infer --bags 1 --tiles 4096 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_cfg5_infer4096.json
-echo "cfg3 / cfg5 lines done"
-
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths > $OUT/stats.log 2>&1
 cp "$(ls $OUT/stats/*/*kernel_stats.csv | head -n 1)" profiles/${ROUND}_bench_kernel_stats.csv
 echo "stats done"
@@ -37,6 +29,15 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACT
 echo "sq2 done"
 python3 profiles/summarise_sq_counters.py $OUT/sq1 $OUT/sq2 profiles/sq_counters.json "$ROUND: $BENCH" > profiles/${ROUND}_sq_counters.txt
 cp profiles/sq_counters.json profiles/${ROUND}_sq_counters.json
+# the bench lines last: their roofline.traffic / sq_counters fields read the PMC summaries written just above
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench.err
+tail -n 1 $OUT/bench_line.json > profiles/${ROUND}_bench_line.json
+echo "bench done"
+# the other single-GPU configurations of BASELINE.json (512x512 tiles; one 4096-tile bag, forward only)
+python3 bench.py --size 512 --tiles 128 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_cfg3_512.json
+python3 bench.py --infer --bags 1 --tiles 4096 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_cfg5_infer4096.json
+echo "cfg3 / cfg5 lines done"
+
 echo "all profiles written"
 mkdir -p gpurun_out/profiles_out
 cp profiles/${ROUND}_* profiles/pmc_traffic.json profiles/sq_counters.json gpurun_out/profiles_out/
