@@ -340,6 +340,43 @@ def test_fused_backward_sequencing_vs_unfused_bf16(golden_dir, monkeypatch):
     assert wcos[0] > 0.999, wcos
 
 
+def test_dense_gradient_layout_and_dropped_s2d_copy_change_no_bit(golden_dir, monkeypatch):
+    """Two byte-saving choices of the bf16 encoder are pure layout: (a) the gradient tensors of the 20-channel stage at 20
+    channels per pixel (MIL_DT_BF16_DGRAD) instead of the padded 24, (b) no space-to-depth copy of the input kept — the
+    fused stem backward rebuilds its tiles from the fp32 input.  Every gradient must be BIT-identical with either choice
+    switched off, at the benchmark's tile size (64x64 first-stage maps) and at 128x128 tiles (32x32 maps), and the dense
+    chain must really have run (a [T,H,W,20] tensor reaches the fused stem backward)."""
+    from mil_amd import ops
+    monkeypatch.setenv("MIL_PF_MIN_TILES", "1")
+    gen = torch.Generator().manual_seed(77)
+    for size, sizes in ((256, [20, 12]), (128, [24, 40])):
+        x = torch.randn(sum(sizes), 3, size, size, generator=gen).clamp_(-1, 1).cuda()
+        labels = torch.tensor([2, 0])
+        grads, seen = {}, {}
+        real = ops.stem_bwd_fused_nchw
+
+        def spy(xx, g_pool, *a, **k):
+            seen["c"] = g_pool.shape[-1]
+            return real(xx, g_pool, *a, **k)
+        monkeypatch.setattr(ops, "stem_bwd_fused_nchw", spy)
+        for dense, keep in ((True, False), (False, False), (True, True)):
+            net = _model(golden_dir, torch.bfloat16)
+            net.cnn.module.dense_grads = dense
+            net.cnn.module.keep_s2d = keep
+            seen.clear()
+            net.forward_bags((x, sizes), labels).loss.sum().backward()
+            torch.cuda.synchronize()
+            grads[(dense, keep)] = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+            if not keep:
+                assert seen.get("c") == (20 if dense else 24), (size, dense, seen)
+        monkeypatch.setattr(ops, "stem_bwd_fused_nchw", real)
+        ref = grads[(True, False)]
+        for key in ((False, False), (True, True)):
+            for k, g in grads[key].items():
+                assert torch.equal(g, ref[k]), (size, key, k)
+        assert all(float(g.abs().max()) > 0 for k, g in ref.items() if "conv" in k)
+
+
 def test_batched_slab_reductions_are_bit_identical(golden_dir, monkeypatch):
     """The 28 weight-gradient slab reductions of a backward pass run as ONE launch (mil_reduce_defer_begin / _end /
     mil_wgrad_reduce_all) instead of one launch behind every producer: same summation trees, so every gradient must be
