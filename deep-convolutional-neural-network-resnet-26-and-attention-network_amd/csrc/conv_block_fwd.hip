@@ -54,14 +54,8 @@ __global__ __launch_bounds__(64 * NW, (CP <= 24 ? 2 : 1) * (NW == 8 ? 2 : 1)) vo
     char* ldsO = smem + a.lds_o_off;
     char* ldsW1 = smem + a.lds_w_off;
     char* ldsW2 = ldsW1 + KSTEPS * NT * 64 * 16;
-    {
-        const char* s1 = reinterpret_cast<const char*>(a.w1);
-        const char* s2 = reinterpret_cast<const char*>(a.w2);
-        for (int i = tid * 16; i < KSTEPS * NT * 64 * 16; i += NTHR * 16) {
-            *reinterpret_cast<uint4*>(ldsW1 + i) = *reinterpret_cast<const uint4*>(s1 + i);
-            *reinterpret_cast<uint4*>(ldsW2 + i) = *reinterpret_cast<const uint4*>(s2 + i);
-        }
-    }
+    mil_stage_filter(ldsW1, a.w1, KSTEPS * NT * 64 * 16, tid, NTHR);
+    mil_stage_filter(ldsW2, a.w2, KSTEPS * NT * 64 * 16, tid, NTHR);
     const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, bytes);
     const __amdgpu_buffer_rsrc_t rs_o = mil_rsrc(a.o1, bytes);
     const __amdgpu_buffer_rsrc_t rs_y = mil_rsrc(a.y, bytes);

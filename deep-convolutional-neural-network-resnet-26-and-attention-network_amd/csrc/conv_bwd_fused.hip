@@ -83,12 +83,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
     char* ldsW = smem + a.lds_w_off;
     char* ldsX = smem + a.lds_x_off;
 
-    {
-        const int nbytes = KSTEPS * NTX * 64 * 16;
-        const char* src = reinterpret_cast<const char*>(a.w);
-        for (int i = tid * 16; i < nbytes; i += NTHR * 16)
-            *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(src + i);
-    }
+    mil_stage_filter(ldsW, a.w, KSTEPS * NTX * 64 * 16, tid, NTHR);
     const int TW = 1 << g.tw_log2, TH = 1 << g.th_log2;
 
     const __amdgpu_buffer_rsrc_t rs_z = mil_rsrc(a.dz, a.z_bytes);
@@ -448,10 +443,8 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
     const int r = lane & 15, gq = lane >> 4;
     char* ldsW = smem + a.lds_w_off;
     {
-        const int nbytes = KSTEPS * NTX * 64 * 16;
-        const char* src = reinterpret_cast<const char*>(a.w) + KSTEPS_STD * NTX * 64 * 16;      // the K20 k-steps sit behind the standard ones
-        for (int i = tid * 16; i < nbytes; i += NTHR * 16)
-            *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(src + i);
+        // the K20 k-steps sit behind the standard ones
+        mil_stage_filter(ldsW, reinterpret_cast<const char*>(a.w) + KSTEPS_STD * NTX * 64 * 16, KSTEPS * NTX * 64 * 16, tid, NTHR);
         // the last halo record's "next pixel" slot is never written by a commit: finite once and for all (zero weights read it)
         if (tid < 2) *reinterpret_cast<u32x2_t*>(smem + tid * a.lds_a2_off + HALO0 + (HW * HW - 1) * PIXB + 40) = u32x2_t{0u, 0u};
     }

@@ -40,11 +40,7 @@ __global__ __launch_bounds__(256, CZ <= 40 ? 2 : 1) void conv_dgrad_s2_kernel(Dg
     const int r = lane & 15, gq = lane >> 4;
     char* ldsZ = smem;
     char* ldsW = smem + a.lds_w_off;
-    {
-        const char* src = reinterpret_cast<const char*>(a.w);
-        for (int i = tid * 16; i < NS * NT * 64 * 16; i += 256 * 16)
-            *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(src + i);
-    }
+    mil_stage_filter(ldsW, a.w, NS * NT * 64 * 16, tid, 256);
     const __amdgpu_buffer_rsrc_t rs_z1 = mil_rsrc(a.dz1, z_bytes);
     const __amdgpu_buffer_rsrc_t rs_z2 = mil_rsrc(a.dz2, a.dz2 ? z_bytes : 0);
     const __amdgpu_buffer_rsrc_t rs_act = mil_rsrc(a.act, a.act ? a.act_bytes : 0);

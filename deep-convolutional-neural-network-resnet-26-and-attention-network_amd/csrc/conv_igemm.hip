@@ -67,12 +67,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs<T> a) {
     for (int s0 = 0; s0 < a.nsteps; s0 += a.kc) {
         __syncthreads();
         const int cs = min(a.kc, a.nsteps - s0);
-        {
-            const int nbytes = cs * NT * 64 * FRAGB;
-            const char* src = reinterpret_cast<const char*>(a.w) + (size_t)s0 * NT * 64 * FRAGB;
-            for (int i = tid * 16; i < nbytes; i += 256 * 16)
-                *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(src + i);
-        }
+        mil_stage_filter(ldsW, reinterpret_cast<const char*>(a.w) + (size_t)s0 * NT * 64 * FRAGB, cs * NT * 64 * FRAGB, tid, 256);
         __syncthreads();
         for (int sl = 0; sl < cs; ++sl) {
             const int q = 4 * (s0 + sl) + gq;
@@ -195,12 +190,7 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
     const bool has_act = FLAGS < 0 ? (a.act != nullptr) : (FLAGS & 2) != 0;
     const bool do_lrelu = FLAGS < 0 ? (a.apply_lrelu != 0) : (FLAGS & 4) != 0;
 
-    {
-        const int nbytes = KSTEPS * NT * 64 * 16;
-        const char* src = reinterpret_cast<const char*>(a.w);
-        for (int i = tid * 16; i < nbytes; i += NTHR * 16)
-            *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(src + i);
-    }
+    mil_stage_filter(ldsW, a.w, KSTEPS * NT * 64 * 16, tid, NTHR);
     const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, x_bytes);
     const __amdgpu_buffer_rsrc_t rs_res = mil_rsrc(a.res, a.res ? y_bytes : 0);
     const __amdgpu_buffer_rsrc_t rs_act = mil_rsrc(a.act, a.act ? y_bytes : 0);
@@ -289,7 +279,10 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
 #endif
     // measured twice: a second tile of halo loads in flight is 8% slower on the 24-channel layers and no faster on the
     // 40-channel ones (108 -> 107 us plain, 142 -> 230 us with both epilogue operands: the second register set spills)
-    constexpr int DEPTH = (CINP == 40 && NW == 4) ? MIL_PF_DEPTH40 : 1;
+#ifndef MIL_PF_DEPTH80
+#define MIL_PF_DEPTH80 1
+#endif
+    constexpr int DEPTH = (CINP == 40 && NW == 4) ? MIL_PF_DEPTH40 : (CINP == 80 ? MIL_PF_DEPTH80 : 1);
     const int G = gridDim.x;
     TileWalker nx2 = nxt;
     nx2.advance();

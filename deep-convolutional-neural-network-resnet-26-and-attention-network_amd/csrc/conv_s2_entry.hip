@@ -36,14 +36,8 @@ __global__ __launch_bounds__(256, CINP <= 24 ? 2 : 1) void conv_s2_entry_kernel(
     const int r = lane & 15, gq = lane >> 4;
     char* ldsA = smem;
     char* ldsW = smem + a.lds_w_off;
-    {
-        const char* s1 = reinterpret_cast<const char*>(a.w1);
-        for (int i = tid * 16; i < K1 * NT * 64 * 16; i += 256 * 16)
-            *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(s1 + i);
-        const char* s2 = reinterpret_cast<const char*>(a.wp);
-        for (int i = tid * 16; i < K2 * NT * 64 * 16; i += 256 * 16)
-            *reinterpret_cast<uint4*>(ldsW + K1 * NT * 64 * 16 + i) = *reinterpret_cast<const uint4*>(s2 + i);
-    }
+    mil_stage_filter(ldsW, a.w1, K1 * NT * 64 * 16, tid, 256);
+    mil_stage_filter(ldsW + K1 * NT * 64 * 16, a.wp, K2 * NT * 64 * 16, tid, 256);
     const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, x_bytes);
     const __amdgpu_buffer_rsrc_t rs_y1 = mil_rsrc(a.y1, y_bytes);
     const __amdgpu_buffer_rsrc_t rs_y2 = mil_rsrc(a.y2, y_bytes);

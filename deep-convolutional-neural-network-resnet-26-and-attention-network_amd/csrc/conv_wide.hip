@@ -91,10 +91,7 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(WideArgs<T> a, int lds_w
         __syncthreads();
         wide_load_halo<T>(ldsA, a.x, g, o, tid, a.cin, ch * WIDE_CK);
         {
-            const char* src = reinterpret_cast<const char*>(a.w + ((size_t)cb * nchunks + ch) * chunk_elems);
-            const int nbytes = (int)(chunk_elems * ESZ);
-            for (int i = tid * 16; i < nbytes; i += 256 * 16)
-                *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(src + i);
+            mil_stage_filter(ldsW, a.w + ((size_t)cb * nchunks + ch) * chunk_elems, (int)(chunk_elems * ESZ), tid, 256);
         }
         __syncthreads();
         for (int tap = 0; tap < ntaps; ++tap) {

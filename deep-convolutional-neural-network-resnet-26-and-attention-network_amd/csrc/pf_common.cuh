@@ -19,6 +19,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mil_rsrc(const void* p, unsign
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
+// Stage `nbytes` (a multiple of 16) of packed filter from global memory into LDS with all `nthr` threads of the workgroup,
+// EIGHT 16-byte loads in flight per thread.  The plain copy loop compiles to `global_load; s_waitcnt vmcnt(0); ds_write`
+// per iteration: one L2 round trip per 16 bytes and thread — 14 serial round trips (≈10 us) for the 115 KB filter of an
+// 80-channel layer on 512 threads, 25 for the 100 KB of the 64->80 stage entry on 256: a third of those launches.
+__device__ __forceinline__ void mil_stage_filter(char* lds, const void* src, int nbytes, int tid, int nthr) {
+    const __amdgpu_buffer_rsrc_t rs = mil_rsrc(src, (unsigned)nbytes);
+    const int step = nthr * 16;
+    for (int i0 = tid * 16; i0 < nbytes; i0 += 8 * step) {
+        u32x4_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(i0 + k * step), 0, 0);      // beyond nbytes: zeros, not stored
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (i0 + k * step < nbytes) *reinterpret_cast<u32x4_t*>(lds + i0 + k * step) = v[k];
+    }
+}
+
 // Walks tile ids t0, t0+G, t0+2G, ... as (image group, tile row, tile col) with carries instead of
 // divisions; every member is wave-uniform (lives in SGPRs).
 struct TileWalker {

@@ -68,9 +68,7 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     {
-        const char* src = reinterpret_cast<const char*>(a.w);
-        for (int i = tid * 16; i < KSTEPS * NT * 64 * 16; i += NTHR * 16)
-            *reinterpret_cast<uint4*>(ldsW + i) = *reinterpret_cast<const uint4*>(src + i);
+        mil_stage_filter(ldsW, a.w, KSTEPS * NT * 64 * 16, tid, NTHR);
         for (int i = tid * 16; i < SF_XBYTES; i += NTHR * 16)          // channels 12..15 of every s2d pixel stay zero
             *reinterpret_cast<uint4*>(ldsX + i) = make_uint4(0, 0, 0, 0);
     }
