@@ -652,6 +652,10 @@ static int dispatch_conv(const ConvArgs<T>& a, int cin_p, int cout_p, hipStream_
     return MIL_ERR_UNSUPPORTED;
 }
 
+// pixel-resident kernel for the 80-channel 8x8 maps (conv_res80.hip); MIL_ERR_UNSUPPORTED for every other shape
+int mil_res80_conv(const void* x, const void* wpack, const float* bias_pad, const void* res, const void* act, void* y, int n_img,
+                   int H, int W, int apply_lrelu, float slope, hipStream_t st);
+
 extern "C" int mil_conv_igemm(const void* x, const void* wpack, const float* bias_pad, const void* res,
                               const void* act, void* y, int n_img, int H, int W, int cin_p, int Ho, int Wo,
                               int cout_p, int ks, int stride, int pad, int zero_insert, int apply_lrelu,
@@ -664,6 +668,10 @@ extern "C" int mil_conv_igemm(const void* x, const void* wpack, const float* bia
     const int nsteps = (ks * ks * (cin_p / 8) + 3) / 4;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MIL_DT_BF16) {
+        if (cin_p == 80 && cout_p == 80 && ks == 3 && stride == 1 && pad == 1 && !zero_insert && H == 8 && W == 8 && Ho == 8 && Wo == 8) {
+            const int rc = mil_res80_conv(x, wpack, bias_pad, res, act, y, n_img, H, W, apply_lrelu, slope, st);
+            if (rc != MIL_ERR_UNSUPPORTED) return rc;
+        }
         ConvArgs<BF16> a{};
         a.x = (const __bf16*)x; a.w = (const __bf16*)wpack; a.bias = bias_pad; a.res = (const __bf16*)res;
         a.act = (const __bf16*)act; a.y = (__bf16*)y; a.g = g; a.nsteps = nsteps; a.apply_lrelu = apply_lrelu; a.slope = slope;

@@ -235,6 +235,8 @@ def encoder_forward(net, x, dtype):
         w2, b2 = net._packed(f"b{bi}.c2", blk.conv2.weight, blk.conv2.bias, L.PACK_FWD, dtype)
         if s == 1 and blk.downsample is None and net.fuse_block_forward:      # whole block in one pass (24/40 channels)
             both = ops.conv_block_fwd(t, w1, b1, w2, b2)
+            if both is None:                             # 80 channels on 8x8 maps: both convs on the LDS-resident images
+                both = ops.conv_pair80(t, w1, b1, w2, b2, lreluA=True, resB=t, lreluB=True)
             if both is not None:
                 o1, out = both
                 saved["blocks"].append((t, o1, out))
@@ -353,6 +355,16 @@ def encoder_backward(net, saved, dfeats, dtype):
                 raise RuntimeError("dense gradient layout without the fused backward")
             else:
                 grads[f"b{bi}.c2"] = wgrad(o1, dz, cout, cout, key=(bi, 2), ks=3, stride=1, pad=1, out=gout(blk.conv2.weight, blk.conv2.bias))
+                if s == 1 and blk.downsample is None and net.fuse_backward:
+                    # 80 channels on 8x8 maps: the block's two transposed convs on the LDS-resident images, one launch:
+                    # dz1 = lrelu'(o1) * conv2^T(dz),  dz(prev) = lrelu'(x) * (conv1^T(dz1) + dz)
+                    w1d_, _ = net._packed(f"b{bi}.c1", blk.conv1.weight, None, L.PACK_DGRAD, dtype)
+                    chain = ops.conv_pair80(dz, w2d, None, w1d_, None, actA=o1, resB=dz, actB=xin if bi > 0 else None)
+                    if chain is not None:
+                        dz1, dz_prev = chain
+                        grads[f"b{bi}.c1"] = wgrad(xin, dz1, cin, cout, key=(bi, 1), ks=3, stride=1, pad=1, out=gout(blk.conv1.weight, blk.conv1.bias))
+                        dz = dz_prev
+                        continue
                 dz1 = ops.conv(dz, w2d, None, ops.cpad(cout), ks=3, stride=1, pad=1, act=o1)
             w1d, _ = net._packed(f"b{bi}.c1", blk.conv1.weight, None, L.PACK_DGRAD, dtype)
             mask = xin if bi > 0 else None          # block 0 reads the max-pool output (no activation in between)

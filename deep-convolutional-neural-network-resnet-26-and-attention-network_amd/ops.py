@@ -266,6 +266,28 @@ def conv_block_fwd(x, wpack1, bias1, wpack2, bias2, *, slope=LEAK):
     return o1, y
 
 
+def conv_pair80(x, wA, biasA, wB, biasB, *, resA=None, actA=None, lreluA=False, resB=None, actB=None, lreluB=False, slope=LEAK):
+    """(outA, outB) = two 3x3 stride-1 convs back to back on the 80-channel 8x8 maps in one launch (see mil_conv_pair80),
+    or None when the shape/dtype has no such kernel."""
+    n, h, w, cp = x.shape
+    if x.dtype != torch.bfloat16 or cp != 80 or h != 8 or w != 8:
+        return None
+    _need(x, x.shape, x.dtype, "x")
+    for name, t in (("resA", resA), ("actA", actA), ("resB", resB), ("actB", actB)):
+        _need(t, x.shape, x.dtype, name)
+    outA, outB = torch.empty_like(x), torch.empty_like(x)
+    end = TIMER.bracket(("pair80", cp, n, h, w)) if TIMER else None
+    rc = L.lib().mil_conv_pair80(x.data_ptr(), wA.data_ptr(), L.ptr(biasA), L.ptr(resA), L.ptr(actA), 1 if lreluA else 0,
+                                 outA.data_ptr(), wB.data_ptr(), L.ptr(biasB), L.ptr(resB), L.ptr(actB), 1 if lreluB else 0,
+                                 outB.data_ptr(), n, h, w, cp, slope, L.dt_code(x.dtype), L.stream_ptr())
+    if rc == 2:
+        return None
+    L.check(rc, "mil_conv_pair80")
+    if end is not None:
+        end.record()
+    return outA, outB
+
+
 def conv_s2_entry(x, wpack3, bias_pad, wpack1, cout_p, *, slope=LEAK):
     """(lrelu(conv3x3_s2(x)+b), conv1x1_s2(x)) in one pass over x (see mil_conv_s2_entry), or None when the shape/dtype
     has no such kernel."""
