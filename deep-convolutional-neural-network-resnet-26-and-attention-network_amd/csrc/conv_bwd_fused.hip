@@ -428,6 +428,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
 #ifndef MIL_BWD16_K20
 #define MIL_BWD16_K20 1
 #endif
+#ifndef MIL_BWD16_PRIO
+#define MIL_BWD16_PRIO 0      // measured: no difference either way (366-385 us with and without on the same box)
+#endif
 template <bool ADD, bool MASK>
 __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -550,6 +553,11 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
 
     const int buf_step = a.lds_a2_off, xbuf_step = a.lds_x2_off;
     int buf = 0, xbuf = 0;
+#if MIL_BWD16_PRIO
+    // the second-dispatched half of an 8-wave workgroup loses issue arbitration to the older half (priority, then age) and
+    // sets the pace at every barrier (finding 3 of DESIGN.md): one static priority raise for it, no per-phase flips
+    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     MIL_ST_DECL
     for (int tile = bid; tile < a.ntiles; tile += gridDim.x) {
         MIL_ST_BEGIN()
