@@ -652,9 +652,9 @@ static int dispatch_conv(const ConvArgs<T>& a, int cin_p, int cout_p, hipStream_
     return MIL_ERR_UNSUPPORTED;
 }
 
-// pixel-resident kernel for the 80-channel 8x8 maps (conv_res80.hip); MIL_ERR_UNSUPPORTED for every other shape
-int mil_res80_conv(const void* x, const void* wpack, const float* bias_pad, const void* res, const void* act, void* y, int n_img,
-                   int H, int W, int apply_lrelu, float slope, hipStream_t st);
+// pixel-resident kernels for the small maps of the last two stages (conv_resident.hip); MIL_ERR_UNSUPPORTED for every other shape
+int mil_resident_conv(const void* x, const void* wpack, const float* bias_pad, const void* res, const void* act, void* y, int n_img,
+                      int H, int W, int cp, int apply_lrelu, float slope, hipStream_t st);
 
 extern "C" int mil_conv_igemm(const void* x, const void* wpack, const float* bias_pad, const void* res,
                               const void* act, void* y, int n_img, int H, int W, int cin_p, int Ho, int Wo,
@@ -668,8 +668,8 @@ extern "C" int mil_conv_igemm(const void* x, const void* wpack, const float* bia
     const int nsteps = (ks * ks * (cin_p / 8) + 3) / 4;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MIL_DT_BF16) {
-        if (cin_p == 80 && cout_p == 80 && ks == 3 && stride == 1 && pad == 1 && !zero_insert && H == 8 && W == 8 && Ho == 8 && Wo == 8) {
-            const int rc = mil_res80_conv(x, wpack, bias_pad, res, act, y, n_img, H, W, apply_lrelu, slope, st);
+        if (cin_p == cout_p && ks == 3 && stride == 1 && pad == 1 && !zero_insert && Ho == H && Wo == W) {
+            const int rc = mil_resident_conv(x, wpack, bias_pad, res, act, y, n_img, H, W, cin_p, apply_lrelu, slope, st);
             if (rc != MIL_ERR_UNSUPPORTED) return rc;
         }
         ConvArgs<BF16> a{};

@@ -1,0 +1,283 @@
+// 3x3 stride-1 convolutions of the two LAST stages on their small maps, PIXEL-RESIDENT:
+//   80 channels on 8x8 maps   (layer 4 at 256x256 tiles): EIGHT whole images per workgroup (8 x 10x10 records = 138 KB)
+//   64 channels on 16x16 maps (layer 3 at 256x256 tiles): THREE whole images per workgroup (3 x 18x18 records = 137 KB)
+// A workgroup keeps whole images (with their zero border) in LDS and streams the 72-115 KB filter past them — every wave
+// reads its filter fragments straight from global memory (L1/L2: the packed layout IS fragment order, 1 KB per wave
+// load, two k-steps ahead in registers, the fragment index in the scalar offset of the buffer load) — the opposite of
+// conv_igemm_pf_kernel, which keeps the filter resident in LDS and streams 128/256-pixel tiles.  On these maps the
+// activations are the small operand (21 / 67 MB per tensor) and the filter-resident form pays for it: on the 80-channel
+// maps one 16-pixel row tile per wave means every MFMA reads its own filter fragment from LDS (0.9 MB of LDS reads per
+// tile), four tiles per workgroup, two barriers each — 29.5 us per launch for 13 us of traffic.  Here a wave owns four
+// (six) row tiles, so a filter fragment feeds four (six) MFMAs, the pixels are loaded in one linear, fully coalesced
+// copy per group of images, and one conv needs NO barrier between that copy and its stores.  80 channels: one conv
+// 29.5 -> 19-21 us per launch.  (Staging the filter through an LDS double buffer instead costs a barrier per two
+// k-steps and measured 22.5-25 us.)
+//
+// Whole images also mean no halo exchange between workgroups, so TWO convolutions can run back to back on the resident
+// tile: conv A's output (after its epilogue) overwrites the tile's interior and is conv B's input.  That is a whole
+// identity-shortcut block forward (nnBlocks.py:175-189: o1 = lrelu(convA(x)+b), y = lrelu(convB(o1)+b+x); the residual
+// x is re-read from global memory, L2-hot) and a whole block's data-gradient chain (dmid = lrelu'(o1) * convB^T(dz),
+// dx = lrelu'(x) * (convA^T(dmid) + dz)) in ONE launch each instead of two (80 channels: 30 / 34 us against 2 x 29.5).
+//
+// Epilogue of either conv: out = mask( lrelu?( acc + bias? + res? ) ), mask(v) = v * (act > 0 ? 1 : slope) if act — the
+// contract of mil_conv_igemm, same MFMA order as the generic kernels (bit-identical outputs).  bf16 only; every other
+// shape takes the generic kernels.
+#include "pf_common.cuh"
+#include <cstdlib>
+
+struct ResConv {
+    const __bf16* w;        // packed fragments [KSTEPS][NT][64][8] (MIL_PACK_FWD or MIL_PACK_DGRAD)
+    const float* bias;      // [C] or null
+    const __bf16* res;      // [n,S,S,C] or null
+    const __bf16* act;      // [n,S,S,C] or null
+    __bf16* out;            // [n,S,S,C]
+    int lrelu;
+};
+struct ResArgs {
+    const __bf16* x;        // [n,S,S,C]
+    ResConv A, B;           // B unused when the kernel runs one conv
+    int n_img, ngroups;
+    unsigned bytes;         // n*S*S*C*2
+    float slope;
+};
+
+#ifndef MIL_RES_BDEPTH
+#define MIL_RES_BDEPTH 2        // k-steps of filter fragments in flight per wave
+#endif
+
+template <int C, int S, int IMGS>
+struct ResGeom {
+    static constexpr int CG = C / 8, NT = C / 16;
+    static constexpr int PIX = mil_pix_pitch(C, 2);           // LDS record of a pixel (odd 16-byte-slot pitch)
+    static constexpr int HS = S + 2;
+    static constexpr int IMG = HS * HS * PIX;
+    static constexpr int TILE = IMGS * IMG;
+    static constexpr int KSTEPS = (9 * CG + 3) / 4;
+    static constexpr int TPI = S * S / 16;                    // 16-pixel row tiles per image
+    static constexpr int MW = IMGS * TPI / 8;                 // row tiles per wave
+    static constexpr int NPIECE = IMGS * S * S * CG;          // 16-byte pieces of a group of images
+    static constexpr int NP = NPIECE / 512;
+    // a wave's row tiles are exactly one image's (80 channels: 4 and 4): no wave ever reads another wave's records, so the
+    // two convs of a pair need no workgroup barrier between them
+    static constexpr bool WAVE_IS_IMAGE = (TPI == MW);
+    static_assert(NPIECE % 512 == 0 && (IMGS * TPI) % 8 == 0 && MW % 2 == 0 && C % 16 == 0, "shape");
+    static_assert(TILE <= 160 * 1024, "LDS");
+};
+
+template <int C, int S, int IMGS, bool TWO>
+__global__ __launch_bounds__(512, 2) void conv_resident_kernel(ResArgs a) {
+    using G = ResGeom<C, S, IMGS>;
+    constexpr int CG = G::CG, NT = G::NT, PIX = G::PIX, HS = G::HS, IMG = G::IMG, KSTEPS = G::KSTEPS, TPI = G::TPI, MW = G::MW, NP = G::NP;
+    extern __shared__ __attribute__((aligned(16))) char tile[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, gq = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, a.bytes);
+
+    // ---- zero border records, once: the commits and the first conv's epilogue only ever write interiors ----------------
+    {
+        constexpr int NB = 4 * S + 4, PPR = PIX / 16;
+        for (int idx = tid; idx < IMGS * NB * PPR; idx += 512) {
+            const int bp = idx / PPR, j = idx - bp * PPR;
+            const int im = bp / NB, b = bp - im * NB;
+            int hy, hx;
+            if (b < HS) { hy = 0; hx = b; }
+            else if (b < 2 * HS) { hy = HS - 1; hx = b - HS; }
+            else { hy = 1 + ((b - 2 * HS) >> 1); hx = ((b - 2 * HS) & 1) * (HS - 1); }
+            *reinterpret_cast<u32x4_t*>(tile + im * IMG + (hy * HS + hx) * PIX + j * 16) = u32x4_t{0u, 0u, 0u, 0u};
+        }
+    }
+    // this wave's row tiles t = wave*MW + m: image t / TPI, pixels (t % TPI)*16 + r of it; top-left tap record of lane r
+    int pixbase[MW];
+#pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        const int t = wave * MW + m, im = t / TPI, p = (t % TPI) * 16 + r;
+        pixbase[m] = im * IMG + ((p / S) * HS + (p % S)) * PIX;
+    }
+    // epilogue: after the permlane swap between row tiles 2p and 2p+1 a lane holds channels 16*nt + 8*(gq>>1) .. +7 of
+    // pixel r of row tile 2p + (gq&1)
+    const int c_off = (gq >> 1) * 16;
+
+    for (int grp = blockIdx.x; grp < a.ngroups; grp += gridDim.x) {
+        const int img0 = grp * IMGS;
+        if (grp != (int)blockIdx.x) __syncthreads();       // the previous group's last fragment reads are done
+        // ---- the group's images: one linear copy of contiguous bytes (NP pieces per thread) ---------------------------
+        {
+            u32x4_t v[NP];
+            const unsigned g0 = (unsigned)img0 * (unsigned)(S * S * C * 2);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, g0 + (unsigned)(tid + 512 * i) * 16u, 0, 0);   // beyond n_img: zeros
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int idx = tid + 512 * i, pl = idx / CG, j = idx - pl * CG;
+                const int im = pl / (S * S), p = pl - im * (S * S);
+                *reinterpret_cast<u32x4_t*>(tile + im * IMG + (((p / S) + 1) * HS + (p % S) + 1) * PIX + j * 16) = v[i];
+            }
+        }
+
+        auto run_conv = [&](const ResConv& cv, bool to_lds, bool first) {
+            const __amdgpu_buffer_rsrc_t rs_w = mil_rsrc(cv.w, KSTEPS * NT * 1024);
+            const __amdgpu_buffer_rsrc_t rs_res = mil_rsrc(cv.res, cv.res ? a.bytes : 0);
+            const __amdgpu_buffer_rsrc_t rs_act = mil_rsrc(cv.act, cv.act ? a.bytes : 0);
+            const __amdgpu_buffer_rsrc_t rs_out = mil_rsrc(cv.out, a.bytes);
+            f32x4_t acc[MW][NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4_t b;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[i] = cv.bias ? cv.bias[nt * 16 + gq * 4 + i] : 0.f;
+#pragma unroll
+                for (int m = 0; m < MW; ++m) acc[m][nt] = b;
+            }
+            constexpr int BD = MIL_RES_BDEPTH;
+            Frag8<BF16> bq[BD + 1][NT], aq[2][MW];
+            auto fetch_b = [&](int ks) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    bq[ks % (BD + 1)][nt].v = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(lane * 16), (ks * NT + nt) * 1024, 0));      // fragment index in the scalar offset
+            };
+            // k-group q = 4*ks + gq = (tap, 8-channel group) -> byte offset of its 16 bytes from the top-left tap's record,
+            // by arithmetic (a table of per-lane offsets would be hoisted over both convs and spill); a q beyond the ninth tap
+            // (zero weights) reads the top-left record — always written, always finite (0 x NaN is NaN)
+            auto off_ks = [&](int ks) {
+                const int q = 4 * ks + gq;
+                const int tap = q / CG, cg = q - tap * CG;
+                const int ty = (tap * 11) >> 5, tx = tap - ty * 3;            // tap / 3 for tap < 10
+                return q < 9 * CG ? (ty * HS + tx) * PIX + cg * 16 : 0;
+            };
+            auto fetch_a = [&](int ks) {
+                const int off = off_ks(ks);
+#pragma unroll
+                for (int m = 0; m < MW; ++m) aq[ks & 1][m] = lds_frag<BF16>(tile + pixbase[m] + off);
+            };
+#pragma unroll
+            for (int ks = 0; ks < BD; ++ks) fetch_b(ks);
+            if (first || !G::WAVE_IS_IMAGE) __syncthreads();         // the pixel tile (or the first conv's output) is visible to every wave
+            fetch_a(0);
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                if (ks + BD < KSTEPS) fetch_b(ks + BD);
+                if (ks + 1 < KSTEPS) fetch_a(ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MW; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(bq[ks % (BD + 1)][nt], aq[ks & 1][m], acc[m][nt]);      // D[channel][pixel]
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (to_lds && !G::WAVE_IS_IMAGE) __syncthreads();         // every wave is past its last read of the tile this epilogue overwrites
+            // ---- epilogue, 8 channels per lane ------------------------------------------------------------------------
+#pragma unroll
+            for (int p = 0; p < MW / 2; ++p) {
+                const int t = wave * MW + 2 * p + (gq & 1), im = t / TPI, px = (t % TPI) * 16 + r;
+                const bool img_ok = img0 + im < a.n_img;
+                const unsigned goff = img_ok ? (unsigned)(((img0 + im) * (S * S) + px) * (C * 2) + c_off) : MIL_OOB;
+                u32x4_t rr[NT], ra[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (cv.res) rr[nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, goff + nt * 32, 0, 0);
+                    if (cv.act) ra[nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, goff + nt * 32, 0, 0);
+                }
+                const int loff = im * IMG + (((px / S) + 1) * HS + (px % S) + 1) * PIX + c_off;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float lo = acc[2 * p][nt][i], hi = acc[2 * p + 1][nt][i];
+                        if (i == 0) mil_swap16<true>(lo, hi); else mil_swap16<false>(lo, hi);
+                        v[i] = lo;
+                        v[4 + i] = hi;
+                    }
+                    if (cv.res) {
+                        const bf16x8_t tt = __builtin_bit_cast(bf16x8_t, rr[nt]);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] += (float)tt[i];
+                    }
+                    if (cv.lrelu) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], v[i] * a.slope);      // 0 < slope < 1
+                    }
+                    if (cv.act) {
+                        const bf16x8_t tt = __builtin_bit_cast(bf16x8_t, ra[nt]);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] *= ((float)tt[i] > 0.f ? 1.f : a.slope);
+                    }
+                    bf16x8_t ov;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) ov[i] = (__bf16)v[i];
+                    const u32x4_t ou = __builtin_bit_cast(u32x4_t, ov);
+                    __builtin_amdgcn_raw_buffer_store_b128(ou, rs_out, goff + nt * 32, 0, 0);
+                    if (to_lds) *reinterpret_cast<u32x4_t*>(tile + loff + nt * 32) = img_ok ? ou : u32x4_t{0u, 0u, 0u, 0u};      // the next conv's input
+                }
+            }
+        };
+        run_conv(a.A, TWO, true);
+        // keep the second conv's prologue (its bias values, its first filter fragments) out of the first conv's registers
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (TWO) run_conv(a.B, false, false);
+    }
+}
+
+static bool mil_resident_enabled() {
+    static const bool v = [] { const char* e = getenv("MIL_RESIDENT"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
+template <int C, int S, int IMGS>
+static int launch_resident(ResArgs a, bool two, hipStream_t st) {
+    using G = ResGeom<C, S, IMGS>;
+    auto kern = two ? conv_resident_kernel<C, S, IMGS, true> : conv_resident_kernel<C, S, IMGS, false>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::TILE) != hipSuccess)
+        return MIL_ERR_LAUNCH;
+    a.ngroups = (a.n_img + IMGS - 1) / IMGS;
+    // one workgroup per CU is resident (137-138 KB of LDS): groups beyond that are walked by the same workgroups
+    int grid = mil_num_cus();
+    if (grid > a.ngroups) grid = a.ngroups;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G::TILE, st, a);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+// which (channels, map) pairs have a pixel-resident kernel
+static int resident_dispatch(ResArgs a, int cp, int H, int W, bool two, hipStream_t st) {
+    if ((size_t)a.n_img * H * W * cp * 2 >= ((size_t)1 << 31)) return MIL_ERR_UNSUPPORTED;
+    a.bytes = (unsigned)((size_t)a.n_img * H * W * cp * 2);
+    if (cp == 80 && H == 8 && W == 8) return launch_resident<80, 8, 8>(a, two, st);
+    if (cp == 64 && H == 16 && W == 16) return launch_resident<64, 16, 3>(a, two, st);
+    return MIL_ERR_UNSUPPORTED;
+}
+
+// One conv: the contract of mil_conv_igemm for (C -> C, 3x3, stride 1, pad 1, bf16) on the shapes above.  Returns
+// MIL_ERR_UNSUPPORTED for any other shape (or MIL_RESIDENT=0): the caller runs the generic kernels.
+int mil_resident_conv(const void* x, const void* wpack, const float* bias_pad, const void* res, const void* act, void* y, int n_img,
+                      int H, int W, int cp, int apply_lrelu, float slope, hipStream_t st) {
+    if (!mil_resident_enabled() || n_img <= 0 || slope < 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
+    // one conv at a time only where it wins: 80 channels (19-22 us against 29.5); on the 64-channel 16x16 maps the filter-resident
+    // kernel is as fast (51-58 us against 53-62: three images per workgroup are 2.7 rounds of copy-then-compute without a
+    // prefetch) and only the two-conv form pays (91 us against 2 x 52)
+    if (cp != 80) return MIL_ERR_UNSUPPORTED;
+    ResArgs a{};
+    a.x = (const __bf16*)x; a.n_img = n_img; a.slope = slope;
+    a.A.w = (const __bf16*)wpack; a.A.bias = bias_pad; a.A.res = (const __bf16*)res; a.A.act = (const __bf16*)act;
+    a.A.out = (__bf16*)y; a.A.lrelu = apply_lrelu;
+    return resident_dispatch(a, cp, H, W, false, st);
+}
+
+// Two convs back to back on the resident tile (see the header): outA = epilogueA(convA(x)), outB = epilogueB(convB(outA)).
+extern "C" int mil_conv_pair(const void* x, const void* wpackA, const float* biasA, const void* resA, const void* actA,
+                             int lreluA, void* outA, const void* wpackB, const float* biasB, const void* resB,
+                             const void* actB, int lreluB, void* outB, int n_img, int H, int W, int cp, float slope,
+                             int dtype, void* stream) {
+    if (!x || !wpackA || !wpackB || !outA || !outB || n_img < 0) return MIL_ERR_ARG;
+    if (dtype != MIL_DT_BF16 || slope < 0.f || slope >= 1.f || !mil_resident_enabled()) return MIL_ERR_UNSUPPORTED;
+    if (n_img == 0) return MIL_OK;
+    ResArgs a{};
+    a.x = (const __bf16*)x; a.n_img = n_img; a.slope = slope;
+    a.A.w = (const __bf16*)wpackA; a.A.bias = biasA; a.A.res = (const __bf16*)resA; a.A.act = (const __bf16*)actA;
+    a.A.out = (__bf16*)outA; a.A.lrelu = lreluA;
+    a.B.w = (const __bf16*)wpackB; a.B.bias = biasB; a.B.res = (const __bf16*)resB; a.B.act = (const __bf16*)actB;
+    a.B.out = (__bf16*)outB; a.B.lrelu = lreluB;
+    return resident_dispatch(a, cp, H, W, true, reinterpret_cast<hipStream_t>(stream));
+}

@@ -236,7 +236,7 @@ def encoder_forward(net, x, dtype):
         if s == 1 and blk.downsample is None and net.fuse_block_forward:      # whole block in one pass (24/40 channels)
             both = ops.conv_block_fwd(t, w1, b1, w2, b2)
             if both is None:                             # 80 channels on 8x8 maps: both convs on the LDS-resident images
-                both = ops.conv_pair80(t, w1, b1, w2, b2, lreluA=True, resB=t, lreluB=True)
+                both = ops.conv_pair(t, w1, b1, w2, b2, lreluA=True, resB=t, lreluB=True)
             if both is not None:
                 o1, out = both
                 saved["blocks"].append((t, o1, out))
@@ -359,7 +359,7 @@ def encoder_backward(net, saved, dfeats, dtype):
                     # 80 channels on 8x8 maps: the block's two transposed convs on the LDS-resident images, one launch:
                     # dz1 = lrelu'(o1) * conv2^T(dz),  dz(prev) = lrelu'(x) * (conv1^T(dz1) + dz)
                     w1d_, _ = net._packed(f"b{bi}.c1", blk.conv1.weight, None, L.PACK_DGRAD, dtype)
-                    chain = ops.conv_pair80(dz, w2d, None, w1d_, None, actA=o1, resB=dz, actB=xin if bi > 0 else None)
+                    chain = ops.conv_pair(dz, w2d, None, w1d_, None, actA=o1, resB=dz, actB=xin if bi > 0 else None)
                     if chain is not None:
                         dz1, dz_prev = chain
                         grads[f"b{bi}.c1"] = wgrad(xin, dz1, cin, cout, key=(bi, 1), ks=3, stride=1, pad=1, out=gout(blk.conv1.weight, blk.conv1.bias))

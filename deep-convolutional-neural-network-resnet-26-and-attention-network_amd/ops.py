@@ -266,23 +266,26 @@ def conv_block_fwd(x, wpack1, bias1, wpack2, bias2, *, slope=LEAK):
     return o1, y
 
 
-def conv_pair80(x, wA, biasA, wB, biasB, *, resA=None, actA=None, lreluA=False, resB=None, actB=None, lreluB=False, slope=LEAK):
-    """(outA, outB) = two 3x3 stride-1 convs back to back on the 80-channel 8x8 maps in one launch (see mil_conv_pair80),
-    or None when the shape/dtype has no such kernel."""
+RESIDENT_SHAPES = ((80, 8, 8), (64, 16, 16))     # (padded channels, H, W) with a pixel-resident kernel
+
+
+def conv_pair(x, wA, biasA, wB, biasB, *, resA=None, actA=None, lreluA=False, resB=None, actB=None, lreluB=False, slope=LEAK):
+    """(outA, outB) = two 3x3 stride-1 convs back to back on LDS-resident whole images in one launch (see mil_conv_pair:
+    80 channels on 8x8 maps, 64 channels on 16x16 maps), or None when the shape/dtype has no such kernel."""
     n, h, w, cp = x.shape
-    if x.dtype != torch.bfloat16 or cp != 80 or h != 8 or w != 8:
+    if x.dtype != torch.bfloat16 or (cp, h, w) not in RESIDENT_SHAPES:
         return None
     _need(x, x.shape, x.dtype, "x")
     for name, t in (("resA", resA), ("actA", actA), ("resB", resB), ("actB", actB)):
         _need(t, x.shape, x.dtype, name)
     outA, outB = torch.empty_like(x), torch.empty_like(x)
-    end = TIMER.bracket(("pair80", cp, n, h, w)) if TIMER else None
-    rc = L.lib().mil_conv_pair80(x.data_ptr(), wA.data_ptr(), L.ptr(biasA), L.ptr(resA), L.ptr(actA), 1 if lreluA else 0,
-                                 outA.data_ptr(), wB.data_ptr(), L.ptr(biasB), L.ptr(resB), L.ptr(actB), 1 if lreluB else 0,
-                                 outB.data_ptr(), n, h, w, cp, slope, L.dt_code(x.dtype), L.stream_ptr())
+    end = TIMER.bracket(("pair", cp, n, h, w)) if TIMER else None
+    rc = L.lib().mil_conv_pair(x.data_ptr(), wA.data_ptr(), L.ptr(biasA), L.ptr(resA), L.ptr(actA), 1 if lreluA else 0,
+                               outA.data_ptr(), wB.data_ptr(), L.ptr(biasB), L.ptr(resB), L.ptr(actB), 1 if lreluB else 0,
+                               outB.data_ptr(), n, h, w, cp, slope, L.dt_code(x.dtype), L.stream_ptr())
     if rc == 2:
         return None
-    L.check(rc, "mil_conv_pair80")
+    L.check(rc, "mil_conv_pair")
     if end is not None:
         end.record()
     return outA, outB

@@ -141,17 +141,18 @@ int mil_tile_preprocess(const uint8_t* rois, const int32_t* params, const int32_
  * downsample=None): o1 = lrelu(conv3x3(x)+b1) — written because the backward needs it — and
  * y = lrelu(conv3x3(o1)+b2+x).  x is read once (operand and residual), the mid activation feeds conv2 from LDS.
  * cp in {24, 40}, H and W >= 16; otherwise MIL_ERR_UNSUPPORTED (caller: two mil_conv_igemm calls). */
-/* Two 3x3 stride-1 convs back to back on the 80-channel 8x8 maps (layer 4 at 256x256 tiles), one launch: a workgroup
- * keeps eight whole images in LDS (no halo exchange between workgroups on whole images) and streams both filters:
+/* Two 3x3 stride-1 convs back to back on the small maps of the last two stages — 80 channels on 8x8 maps, 64 channels on
+ * 16x16 maps (layers 4 and 3 at 256x256 tiles) —, one launch: a workgroup keeps whole images in LDS (no halo exchange
+ * between workgroups on whole images) and streams both filters:
  *     outA = epiA( convA(x) ),   outB = epiB( convB(outA) ),   epi(v) = mask( lrelu?( v + bias? + res? ) )
  * i.e. mil_conv_igemm's epilogue contract for each.  That is BasicResBlock.forward with an identity shortcut
  * (nnBlocks.py:175-189: A = conv1+bias+lrelu -> o1, B = conv2+bias+x+lrelu -> out, resB = x) and the block's data-gradient
  * chain (A = conv2^T with MIL_PACK_DGRAD weights masked by o1 -> dmid, B = conv1^T + dz masked by x -> dx).  bf16,
- * cp == 80, H == W == 8; otherwise MIL_ERR_UNSUPPORTED (the caller runs two mil_conv_igemm calls — which take the same
- * pixel-resident kernel one conv at a time on these shapes). */
-int mil_conv_pair80(const void* x, const void* wpackA, const float* biasA, const void* resA, const void* actA, int lreluA,
-                    void* outA, const void* wpackB, const float* biasB, const void* resB, const void* actB, int lreluB,
-                    void* outB, int n_img, int H, int W, int cp, float slope, int dtype, void* stream);
+ * (cp, H, W) in {(80, 8, 8), (64, 16, 16)}; otherwise MIL_ERR_UNSUPPORTED (the caller runs two mil_conv_igemm calls —
+ * which take the same pixel-resident kernel one conv at a time on these shapes). */
+int mil_conv_pair(const void* x, const void* wpackA, const float* biasA, const void* resA, const void* actA, int lreluA,
+                  void* outA, const void* wpackB, const float* biasB, const void* resB, const void* actB, int lreluB,
+                  void* outB, int n_img, int H, int W, int cp, float slope, int dtype, void* stream);
 
 int mil_conv_block_fwd(const void* x, const void* wpack1, const float* bias1, const void* wpack2, const float* bias2,
                        void* o1, void* y, int n_img, int H, int W, int cp, float slope, int dtype, void* stream);

@@ -38,7 +38,8 @@ CONV_CASES = [
     (40, 40, 3, 1, 5, 8, 8),        # 8x8 maps: 4 images per tile
     (40, 60, 3, 2, 2, 10, 10),
     (40, 60, 1, 2, 3, 9, 7),
-    (60, 60, 3, 1, 2, 16, 16),
+    (60, 60, 3, 1, 2, 16, 16),      # bf16: the pixel-resident kernel (three images per workgroup)
+    (60, 60, 3, 1, 7, 16, 16),      # three groups, two empty image slots
     (60, 60, 3, 1, 17, 4, 4),       # 4x4 maps: 16 images per tile
     (60, 80, 3, 2, 3, 16, 16),
     (60, 80, 1, 2, 2, 8, 8),
@@ -468,16 +469,18 @@ def test_stage_entry_forward_pair_one_pass(ops, case):
         assert float(y1[..., cout:].float().abs().max()) == 0.0 and float(y2[..., cout:].float().abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("n", [3, 8, 21])
-def test_conv_pair80_equals_two_launches(ops, n):
-    """mil_conv_pair80 (two 3x3 convs back to back on LDS-resident 8x8 images) in both of its roles — a whole identity block
-    forward and a block's data-gradient chain — against two mil_conv_igemm calls (which run the same kernel one conv at a
-    time on this shape: bit-identical) and against torch."""
+@pytest.mark.parametrize("shape", [(80, 8, 3), (80, 8, 8), (80, 8, 21), (60, 16, 2), (60, 16, 3), (60, 16, 10)])
+def test_conv_pair_equals_two_launches(ops, shape):
+    """mil_conv_pair (two 3x3 convs back to back on LDS-resident whole images: 80 channels on 8x8 maps, 64 on 16x16) in both
+    of its roles — a whole identity block forward and a block's data-gradient chain — against two mil_conv_igemm calls
+    and against torch.  On the 80-channel shape mil_conv_igemm runs the same kernel one conv at a time: bit-identical; on the
+    64-channel shape it runs the filter-resident kernels (another place for the bias in the sum): one bf16 rounding apart."""
     L = _lib()
     dt = torch.bfloat16
-    g = torch.Generator().manual_seed(500 + n)
-    c = 80
-    x = round_to(torch.randn(n, c, 8, 8, generator=g), dt)
+    c, hw, n = shape
+    cp = cpad(c)
+    g = torch.Generator().manual_seed(500 + n + c)
+    x = round_to(torch.randn(n, c, hw, hw, generator=g), dt)
     w1 = round_to(torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5, dt)
     w2 = round_to(torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5, dt)
     b1, b2 = torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1
@@ -485,27 +488,30 @@ def test_conv_pair80_equals_two_launches(ops, n):
     p1, bp1 = ops.pack_weights(w1.cuda(), b1.cuda(), L.PACK_FWD, dt)
     p2, bp2 = ops.pack_weights(w2.cuda(), b2.cuda(), L.PACK_FWD, dt)
     # forward block: o1 = lrelu(conv1(x)+b1), y = lrelu(conv2(o1)+b2+x)
-    both = ops.conv_pair80(xg, p1, bp1, p2, bp2, lreluA=True, resB=xg, lreluB=True)
+    both = ops.conv_pair(xg, p1, bp1, p2, bp2, lreluA=True, resB=xg, lreluB=True)
     assert both is not None
     o1, y = both
-    o1_ref = ops.conv(xg, p1, bp1, c, ks=3, stride=1, pad=1, lrelu=True)
-    y_ref = ops.conv(o1_ref, p2, bp2, c, ks=3, stride=1, pad=1, res=xg, lrelu=True)
-    assert torch.equal(o1, o1_ref) and torch.equal(y, y_ref)
+    o1_ref = ops.conv(xg, p1, bp1, cp, ks=3, stride=1, pad=1, lrelu=True)
+    y_ref = ops.conv(o1_ref, p2, bp2, cp, ks=3, stride=1, pad=1, res=xg, lrelu=True)
+    same = (lambda u, v: torch.equal(u, v)) if c == 80 else (lambda u, v: rel_err(u.float().cpu(), v.float().cpu()) < TOL[dt])
+    assert same(o1, o1_ref) and same(y, y_ref)
     t1 = F.leaky_relu(F.conv2d(x, w1, b1, padding=1), LEAK)
     t2 = F.leaky_relu(F.conv2d(round_to(t1, dt), w2, b2, padding=1) + x, LEAK)
     assert rel_err(from_nhwc(o1, c), t1) < TOL[dt] and rel_err(from_nhwc(y, c), t2) < TOL[dt]
+    if cp > c:                                              # padded channels stay exactly zero
+        assert float(o1[..., c:].float().abs().max()) == 0.0 and float(y[..., c:].float().abs().max()) == 0.0
     # data-gradient chain: dmid = lrelu'(o1) * conv2^T(dz), dx = lrelu'(x) * (conv1^T(dmid) + dz)
-    dz = to_nhwc(round_to(torch.randn(n, c, 8, 8, generator=g), dt), dt)
+    dz = to_nhwc(round_to(torch.randn(n, c, hw, hw, generator=g), dt), dt)
     d1, _ = ops.pack_weights(w1.cuda(), None, L.PACK_DGRAD, dt)
     d2, _ = ops.pack_weights(w2.cuda(), None, L.PACK_DGRAD, dt)
-    chain = ops.conv_pair80(dz, d2, None, d1, None, actA=o1, resB=dz, actB=xg)
+    chain = ops.conv_pair(dz, d2, None, d1, None, actA=o1, resB=dz, actB=xg)
     assert chain is not None
-    dmid_ref = ops.conv(dz, d2, None, c, ks=3, stride=1, pad=1, act=o1)
-    dx_ref = ops.conv(dmid_ref, d1, None, c, ks=3, stride=1, pad=1, res=dz, act=xg)
-    assert torch.equal(chain[0], dmid_ref) and torch.equal(chain[1], dx_ref)
+    dmid_ref = ops.conv(dz, d2, None, cp, ks=3, stride=1, pad=1, act=o1)
+    dx_ref = ops.conv(dmid_ref, d1, None, cp, ks=3, stride=1, pad=1, res=dz, act=xg)
+    assert same(chain[0], dmid_ref) and same(chain[1], dx_ref)
     # other shapes decline
-    assert ops.conv_pair80(torch.zeros(2, 16, 16, 80, device="cuda", dtype=dt), p1, bp1, p2, bp2) is None
-    assert ops.conv_pair80(torch.zeros(2, 8, 8, 64, device="cuda", dtype=dt), p1, bp1, p2, bp2) is None
+    assert ops.conv_pair(torch.zeros(2, 16, 16, 80, device="cuda", dtype=dt), p1, bp1, p2, bp2) is None
+    assert ops.conv_pair(torch.zeros(2, 8, 8, 64, device="cuda", dtype=dt), p1, bp1, p2, bp2) is None
 
 
 BLOCK_FWD_CASES = [

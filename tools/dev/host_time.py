@@ -1,8 +1,8 @@
 import sys, time, torch
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import mil_amd
 dev = torch.device('cuda')
-net = mil_amd.Attention(3).eval()
+net = mil_amd.Attention(3).cuda().eval()
 flat = mil_amd.FlatParams(net); opt = mil_amd.FlatAdam(flat)
 x = torch.randn(8 * 256, 3, 256, 256, device=dev).clamp_(-1, 1)
 sizes = [256] * 8
