@@ -53,6 +53,7 @@ _SIGS = {
     "mil_resize_coeffs": ([_i, _i, _vp, _vp], _i),
     "mil_tile_preprocess": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "mil_conv_block_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp], _i),
+    "mil_conv_chain": ([_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
     "mil_conv_pair": ([_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _i, _vp], _i),
     "mil_conv_s2_entry": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
     "mil_conv_wgrad_pair_workspace": ([_c.POINTER(_sz), _i, _i, _i, _i, _i, _i, _i, _i], _i),

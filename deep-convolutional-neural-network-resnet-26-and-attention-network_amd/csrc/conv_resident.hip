@@ -13,11 +13,14 @@
 // 29.5 -> 19-21 us per launch.  (Staging the filter through an LDS double buffer instead costs a barrier per two
 // k-steps and measured 22.5-25 us.)
 //
-// Whole images also mean no halo exchange between workgroups, so TWO convolutions can run back to back on the resident
-// tile: conv A's output (after its epilogue) overwrites the tile's interior and is conv B's input.  That is a whole
+// Whole images also mean no halo exchange between workgroups, so a CHAIN of convolutions can run back to back on the
+// resident tile: conv k's output (after its epilogue) overwrites the tile's interior and is conv k+1's input; a later
+// conv's residual / mask operand may be an earlier conv's output (each lane re-reads exactly the bytes it stored itself).
+// Two convs are a whole
 // identity-shortcut block forward (nnBlocks.py:175-189: o1 = lrelu(convA(x)+b), y = lrelu(convB(o1)+b+x); the residual
 // x is re-read from global memory, L2-hot) and a whole block's data-gradient chain (dmid = lrelu'(o1) * convB^T(dz),
-// dx = lrelu'(x) * (convA^T(dmid) + dz)) in ONE launch each instead of two (80 channels: 30 / 34 us against 2 x 29.5).
+// dx = lrelu'(x) * (convA^T(dmid) + dz)) in ONE launch each instead of two (80 channels: 30 / 34 us against 2 x 29.5);
+// five are everything of the last stage behind its stride-2 entry convs (forward), or its whole data-gradient chain.
 //
 // Epilogue of either conv: out = mask( lrelu?( acc + bias? + res? ) ), mask(v) = v * (act > 0 ? 1 : slope) if act — the
 // contract of mil_conv_igemm, same MFMA order as the generic kernels (bit-identical outputs).  bf16 only; every other
@@ -33,9 +36,11 @@ struct ResConv {
     __bf16* out;            // [n,S,S,C]
     int lrelu;
 };
+#define MIL_CHAIN_MAX 6
 struct ResArgs {
     const __bf16* x;        // [n,S,S,C]
-    ResConv A, B;           // B unused when the kernel runs one conv
+    ResConv conv[MIL_CHAIN_MAX];      // conv k reads conv k-1's output from the resident tile
+    int nconv;
     int n_img, ngroups;
     unsigned bytes;         // n*S*S*C*2
     float slope;
@@ -64,7 +69,7 @@ struct ResGeom {
     static_assert(TILE <= 160 * 1024, "LDS");
 };
 
-template <int C, int S, int IMGS, bool TWO>
+template <int C, int S, int IMGS>
 __global__ __launch_bounds__(512, 2) void conv_resident_kernel(ResArgs a) {
     using G = ResGeom<C, S, IMGS>;
     constexpr int CG = G::CG, NT = G::NT, PIX = G::PIX, HS = G::HS, IMG = G::IMG, KSTEPS = G::KSTEPS, TPI = G::TPI, MW = G::MW, NP = G::NP;
@@ -212,11 +217,10 @@ __global__ __launch_bounds__(512, 2) void conv_resident_kernel(ResArgs a) {
                 }
             }
         };
-        run_conv(a.A, TWO, true);
-        // keep the second conv's prologue (its bias values, its first filter fragments) out of the first conv's registers
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (TWO) run_conv(a.B, false, false);
+        // the chain: conv k's epilogue overwrites the tile interior with its output, conv k+1 reads it (a run-time loop: one
+        // copy of the unrolled k-step body, and no conv's prologue can be hoisted into its predecessor's registers)
+#pragma unroll 1
+        for (int k = 0; k < a.nconv; ++k) run_conv(a.conv[k], k + 1 < a.nconv, k == 0);
     }
 }
 
@@ -226,9 +230,9 @@ static bool mil_resident_enabled() {
 }
 
 template <int C, int S, int IMGS>
-static int launch_resident(ResArgs a, bool two, hipStream_t st) {
+static int launch_resident(ResArgs a, hipStream_t st) {
     using G = ResGeom<C, S, IMGS>;
-    auto kern = two ? conv_resident_kernel<C, S, IMGS, true> : conv_resident_kernel<C, S, IMGS, false>;
+    auto kern = conv_resident_kernel<C, S, IMGS>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::TILE) != hipSuccess)
         return MIL_ERR_LAUNCH;
     a.ngroups = (a.n_img + IMGS - 1) / IMGS;
@@ -241,11 +245,11 @@ static int launch_resident(ResArgs a, bool two, hipStream_t st) {
 }
 
 // which (channels, map) pairs have a pixel-resident kernel
-static int resident_dispatch(ResArgs a, int cp, int H, int W, bool two, hipStream_t st) {
+static int resident_dispatch(ResArgs a, int cp, int H, int W, hipStream_t st) {
     if ((size_t)a.n_img * H * W * cp * 2 >= ((size_t)1 << 31)) return MIL_ERR_UNSUPPORTED;
     a.bytes = (unsigned)((size_t)a.n_img * H * W * cp * 2);
-    if (cp == 80 && H == 8 && W == 8) return launch_resident<80, 8, 8>(a, two, st);
-    if (cp == 64 && H == 16 && W == 16) return launch_resident<64, 16, 3>(a, two, st);
+    if (cp == 80 && H == 8 && W == 8) return launch_resident<80, 8, 8>(a, st);
+    if (cp == 64 && H == 16 && W == 16) return launch_resident<64, 16, 3>(a, st);
     return MIL_ERR_UNSUPPORTED;
 }
 
@@ -259,25 +263,39 @@ int mil_resident_conv(const void* x, const void* wpack, const float* bias_pad, c
     // prefetch) and only the two-conv form pays (91 us against 2 x 52)
     if (cp != 80) return MIL_ERR_UNSUPPORTED;
     ResArgs a{};
-    a.x = (const __bf16*)x; a.n_img = n_img; a.slope = slope;
-    a.A.w = (const __bf16*)wpack; a.A.bias = bias_pad; a.A.res = (const __bf16*)res; a.A.act = (const __bf16*)act;
-    a.A.out = (__bf16*)y; a.A.lrelu = apply_lrelu;
-    return resident_dispatch(a, cp, H, W, false, st);
+    a.x = (const __bf16*)x; a.n_img = n_img; a.slope = slope; a.nconv = 1;
+    a.conv[0].w = (const __bf16*)wpack; a.conv[0].bias = bias_pad; a.conv[0].res = (const __bf16*)res; a.conv[0].act = (const __bf16*)act;
+    a.conv[0].out = (__bf16*)y; a.conv[0].lrelu = apply_lrelu;
+    return resident_dispatch(a, cp, H, W, st);
 }
 
-// Two convs back to back on the resident tile (see the header): outA = epilogueA(convA(x)), outB = epilogueB(convB(outA)).
+// A chain of up to MIL_CHAIN_MAX convs on the resident tile (see the header): out_0 = epi_0(conv_0(x)),
+// out_k = epi_k(conv_k(out_{k-1})).  A conv's res / act may be the output of an EARLIER conv of the same chain (each lane
+// re-reads exactly the bytes it stored itself).
+struct MilChainConv {            // mirrors the C-ABI struct of include/mil_hip.h
+    const void* wpack; const float* bias; const void* res; const void* act; void* out; int lrelu; int pad_;
+};
+extern "C" int mil_conv_chain(const void* x, const MilChainConv* convs, int nconv, int n_img, int H, int W, int cp, float slope,
+                              int dtype, void* stream) {
+    if (!x || !convs || nconv < 1 || nconv > MIL_CHAIN_MAX || n_img < 0) return MIL_ERR_ARG;
+    for (int k = 0; k < nconv; ++k) if (!convs[k].wpack || !convs[k].out) return MIL_ERR_ARG;
+    if (dtype != MIL_DT_BF16 || slope < 0.f || slope >= 1.f || !mil_resident_enabled()) return MIL_ERR_UNSUPPORTED;
+    if (n_img == 0) return MIL_OK;
+    ResArgs a{};
+    a.x = (const __bf16*)x; a.n_img = n_img; a.slope = slope; a.nconv = nconv;
+    for (int k = 0; k < nconv; ++k) {
+        a.conv[k].w = (const __bf16*)convs[k].wpack; a.conv[k].bias = convs[k].bias; a.conv[k].res = (const __bf16*)convs[k].res;
+        a.conv[k].act = (const __bf16*)convs[k].act; a.conv[k].out = (__bf16*)convs[k].out; a.conv[k].lrelu = convs[k].lrelu;
+    }
+    return resident_dispatch(a, cp, H, W, reinterpret_cast<hipStream_t>(stream));
+}
+
+// Two convs (a block forward, or a block's data-gradient chain): mil_conv_chain with nconv = 2.
 extern "C" int mil_conv_pair(const void* x, const void* wpackA, const float* biasA, const void* resA, const void* actA,
                              int lreluA, void* outA, const void* wpackB, const float* biasB, const void* resB,
                              const void* actB, int lreluB, void* outB, int n_img, int H, int W, int cp, float slope,
                              int dtype, void* stream) {
     if (!x || !wpackA || !wpackB || !outA || !outB || n_img < 0) return MIL_ERR_ARG;
-    if (dtype != MIL_DT_BF16 || slope < 0.f || slope >= 1.f || !mil_resident_enabled()) return MIL_ERR_UNSUPPORTED;
-    if (n_img == 0) return MIL_OK;
-    ResArgs a{};
-    a.x = (const __bf16*)x; a.n_img = n_img; a.slope = slope;
-    a.A.w = (const __bf16*)wpackA; a.A.bias = biasA; a.A.res = (const __bf16*)resA; a.A.act = (const __bf16*)actA;
-    a.A.out = (__bf16*)outA; a.A.lrelu = lreluA;
-    a.B.w = (const __bf16*)wpackB; a.B.bias = biasB; a.B.res = (const __bf16*)resB; a.B.act = (const __bf16*)actB;
-    a.B.out = (__bf16*)outB; a.B.lrelu = lreluB;
-    return resident_dispatch(a, cp, H, W, true, reinterpret_cast<hipStream_t>(stream));
+    const MilChainConv c[2] = {{wpackA, biasA, resA, actA, outA, lreluA, 0}, {wpackB, biasB, resB, actB, outB, lreluB, 0}};
+    return mil_conv_chain(x, c, 2, n_img, H, W, cp, slope, dtype, stream);
 }

@@ -224,7 +224,12 @@ def encoder_forward(net, x, dtype):
     saved = {"xs": xs, "x": x if xs is None else None, "stem_hw": stem_hw, "widx": widx, "blocks": []}      # the stem output itself is not kept
     t = pool
     stage_in = pool
-    for bi, blk in enumerate(net.blocks()):
+    all_blocks = list(net.blocks())
+    chained = 0                         # blocks already run (and recorded) by a stage-wide conv chain
+    for bi, blk in enumerate(all_blocks):
+        if chained:
+            chained -= 1
+            continue
         cout = blk.conv1.out_channels
         s = blk.stride
         if hk is not None:
@@ -254,6 +259,31 @@ def encoder_forward(net, x, dtype):
         else:
             o1 = ops.conv(t, w1, b1, ops.cpad(cout), ks=3, stride=s, pad=1, lrelu=True)
             short = ops.conv(t, wd, None, ops.cpad(cout), ks=1, stride=s, pad=0) if blk.downsample is not None else t
+        # A stage whose maps fit the pixel-resident kernel (whole images in LDS: the 80-channel stage at 256x256 tiles): this
+        # entry block's conv2 and BOTH convs of every identity block behind it as ONE chain launch
+        depth = net.block_position(bi)[2] if blk.downsample is not None else 0
+        rest = all_blocks[bi + 1:bi + depth] if depth else []
+        if (rest and net.fuse_block_forward and net.block_position(bi)[1] == 0 and len(rest) <= 2 and
+                all(b.stride == 1 and b.downsample is None for b in rest)):
+            convs = [dict(w=w2, bias=b2, res=short, lrelu=True)]
+            for j, b in enumerate(rest):
+                wa, ba = net._packed(f"b{bi + 1 + j}.c1", b.conv1.weight, b.conv1.bias, L.PACK_FWD, dtype)
+                wb, bb = net._packed(f"b{bi + 1 + j}.c2", b.conv2.weight, b.conv2.bias, L.PACK_FWD, dtype)
+                convs += [dict(w=wa, bias=ba, lrelu=True), dict(w=wb, bias=bb, res=2 * j, lrelu=True)]
+            outs = ops.conv_chain(o1, convs)
+            if outs is not None:
+                saved["blocks"].append((t, o1, outs[0]))
+                if hk is not None:
+                    net._fire_block_hooks(bi, blk, stage_in, t, o1, outs[0])
+                for j, b in enumerate(rest):
+                    xin_j, o1_j, out_j = outs[2 * j], outs[2 * j + 1], outs[2 * j + 2]
+                    saved["blocks"].append((xin_j, o1_j, out_j))
+                    if hk is not None:
+                        hooks.refuse(b, ["conv1", "conv2"])
+                        net._fire_block_hooks(bi + 1 + j, b, stage_in, xin_j, o1_j, out_j)
+                t = outs[-1]
+                chained = len(rest)
+                continue
         out = ops.conv(o1, w2, b2, ops.cpad(cout), ks=3, stride=1, pad=1, res=short, lrelu=True)
         saved["blocks"].append((t, o1, out))
         if hk is not None:
@@ -342,14 +372,70 @@ def encoder_backward(net, saved, dfeats, dtype):
         return ops.conv_bwd_fused(dzz, wd, xin, cin, cout, addend=addend, mask=mask, workspace=fws, out=out)
 
     # weight-gradient producers record their slab reductions; leaving the block runs them all in one launch
+    def stage_dgrad_chain(bi, dz_out):
+        """Every 3x3 stride-1 data gradient of the stage that ENDS with block bi in ONE launch (ops.conv_chain: whole images
+        resident in LDS — the 80-channel stage at 256x256 tiles), plus the weight gradients they feed.  Returns
+        {block: "done"} for its identity blocks and {entry block: (dz of its output, dz1)} — or None when the stage / shape
+        has no such kernel (then the per-block path below runs)."""
+        li, j, depth = net.block_position(bi)
+        e = bi - depth + 1
+        if j != depth - 1 or depth < 2 or depth > 3 or not net.fuse_backward or dtype != torch.bfloat16:
+            return None
+        ent = blocks[e]
+        if ent.stride != 2 or ent.downsample is None or any(b.stride != 1 or b.downsample is not None for b in blocks[e + 1:bi + 1]):
+            return None
+        cout = ent.conv1.out_channels
+        n, h, w, cp = dz_out.shape
+        if (cp, h, w) not in ops.RESIDENT_SHAPES or ops.bwd_fused_workspace_bytes(n, h, w, cout, cout, 3, 1, dtype) is not None:
+            return None                         # widths with a fused dgrad+wgrad kernel keep it
+        convs, src = [], None                   # src: chain output that is the gradient entering the current block (None: dz_out)
+        for k in range(bi, e, -1):
+            xin_k, o1_k, _ = saved["blocks"][k]
+            w2d_k, _ = net._packed(f"b{k}.c2", blocks[k].conv2.weight, None, L.PACK_DGRAD, dtype)
+            w1d_k, _ = net._packed(f"b{k}.c1", blocks[k].conv1.weight, None, L.PACK_DGRAD, dtype)
+            convs.append(dict(w=w2d_k, act=o1_k))                                            # dmid_k = lrelu'(o1) * conv2^T(dz_k)
+            convs.append(dict(w=w1d_k, res=dz_out if src is None else src, act=xin_k))       # dz_{k-1} = lrelu'(x) * (conv1^T(dmid_k) + dz_k)
+            src = len(convs) - 1
+        _xin_e, o1_e, _ = saved["blocks"][e]
+        w2d_e, _ = net._packed(f"b{e}.c2", ent.conv2.weight, None, L.PACK_DGRAD, dtype)
+        convs.append(dict(w=w2d_e, act=o1_e))                                                # the entry block's dz1
+        outs = ops.conv_chain(dz_out, convs)
+        if outs is None:
+            return None
+        done = {}
+        dz_k = dz_out
+        for i, k in enumerate(range(bi, e, -1)):
+            xin_k, o1_k, _ = saved["blocks"][k]
+            dmid_k, dz_prev = outs[2 * i], outs[2 * i + 1]
+            grads[f"b{k}.c2"] = wgrad(o1_k, dz_k, cout, cout, key=(k, 2), ks=3, stride=1, pad=1, out=gout(blocks[k].conv2.weight, blocks[k].conv2.bias))
+            grads[f"b{k}.c1"] = wgrad(xin_k, dmid_k, cout, cout, key=(k, 1), ks=3, stride=1, pad=1, out=gout(blocks[k].conv1.weight, blocks[k].conv1.bias))
+            done[k] = "done"
+            dz_k = dz_prev
+        grads[f"b{e}.c2"] = wgrad(o1_e, dz_k, cout, cout, key=(e, 2), ks=3, stride=1, pad=1, out=gout(ent.conv2.weight, ent.conv2.bias))
+        done[e] = (dz_k, outs[-1])
+        return done
+
+    pre = {}                                    # blocks whose data gradients a stage-wide chain has already produced
     with (batch if batch is not None else contextlib.nullcontext()):
         for bi in range(len(blocks) - 1, -1, -1):
             blk = blocks[bi]
             xin, o1, _out = saved["blocks"][bi]
             cin, cout, s = blk.conv1.in_channels, blk.conv1.out_channels, blk.stride
+            if bi not in pre:
+                chain = stage_dgrad_chain(bi, dz)
+                if chain is not None:
+                    pre.update(chain)
+            if pre.get(bi) == "done":
+                continue
             w2d, _ = net._packed(f"b{bi}.c2", blk.conv2.weight, None, L.PACK_DGRAD, dtype)
-            fused = fused_bwd(dz, w2d, o1, cout, cout, None, True, gout(blk.conv2.weight, blk.conv2.bias), key=(bi, 2)) if net.fuse_backward else None
-            if fused is not None:                       # one pass: dz1 and dW2/db2
+            if bi in pre:                               # stage entry behind a chain: dz of its output and dz1 are there, dW2/db2 too
+                dz, dz1 = pre[bi]
+                fused = "chain"
+            else:
+                fused = fused_bwd(dz, w2d, o1, cout, cout, None, True, gout(blk.conv2.weight, blk.conv2.bias), key=(bi, 2)) if net.fuse_backward else None
+            if fused == "chain":
+                pass
+            elif fused is not None:                     # one pass: dz1 and dW2/db2
                 dz1, grads[f"b{bi}.c2"] = fused[0], (fused[1], fused[2])
             elif is_dense(dz, cout):
                 raise RuntimeError("dense gradient layout without the fused backward")

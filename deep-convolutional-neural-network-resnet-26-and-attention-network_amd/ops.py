@@ -269,26 +269,52 @@ def conv_block_fwd(x, wpack1, bias1, wpack2, bias2, *, slope=LEAK):
 RESIDENT_SHAPES = ((80, 8, 8), (64, 16, 16))     # (padded channels, H, W) with a pixel-resident kernel
 
 
-def conv_pair(x, wA, biasA, wB, biasB, *, resA=None, actA=None, lreluA=False, resB=None, actB=None, lreluB=False, slope=LEAK):
-    """(outA, outB) = two 3x3 stride-1 convs back to back on LDS-resident whole images in one launch (see mil_conv_pair:
-    80 channels on 8x8 maps, 64 channels on 16x16 maps), or None when the shape/dtype has no such kernel."""
+class _ChainConv(ctypes.Structure):
+    _fields_ = [("wpack", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("res", ctypes.c_void_p), ("act", ctypes.c_void_p),
+                ("out", ctypes.c_void_p), ("lrelu", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
+def conv_chain(x, convs, *, slope=LEAK):
+    """Outputs of a chain of 3x3 stride-1 convs on LDS-resident whole images, one launch (see mil_conv_chain), or None
+    when the shape/dtype has no such kernel.  `convs`: dicts with w, and optionally bias, res, act, lrelu; res / act are
+    tensors, or an int k = the output of conv k of this chain (k earlier than the conv that names it)."""
     n, h, w, cp = x.shape
-    if x.dtype != torch.bfloat16 or (cp, h, w) not in RESIDENT_SHAPES:
+    if x.dtype != torch.bfloat16 or (cp, h, w) not in RESIDENT_SHAPES or not 1 <= len(convs) <= 6:
         return None
     _need(x, x.shape, x.dtype, "x")
-    for name, t in (("resA", resA), ("actA", actA), ("resB", resB), ("actB", actB)):
-        _need(t, x.shape, x.dtype, name)
-    outA, outB = torch.empty_like(x), torch.empty_like(x)
-    end = TIMER.bracket(("pair", cp, n, h, w)) if TIMER else None
-    rc = L.lib().mil_conv_pair(x.data_ptr(), wA.data_ptr(), L.ptr(biasA), L.ptr(resA), L.ptr(actA), 1 if lreluA else 0,
-                               outA.data_ptr(), wB.data_ptr(), L.ptr(biasB), L.ptr(resB), L.ptr(actB), 1 if lreluB else 0,
-                               outB.data_ptr(), n, h, w, cp, slope, L.dt_code(x.dtype), L.stream_ptr())
+    outs = [torch.empty_like(x) for _ in convs]
+    arr = (_ChainConv * len(convs))()
+    for k, c in enumerate(convs):
+        ops_ = {}
+        for name in ("res", "act"):
+            t = c.get(name)
+            if isinstance(t, int):
+                if not 0 <= t < k:
+                    raise ValueError(f"conv {k}: {name} refers to conv {t}, which is not earlier in the chain")
+                t = outs[t]
+            _need(t, x.shape, x.dtype, name)
+            ops_[name] = t
+        arr[k].wpack = c["w"].data_ptr()
+        arr[k].bias = L.ptr(c.get("bias"))
+        arr[k].res, arr[k].act = L.ptr(ops_["res"]), L.ptr(ops_["act"])
+        arr[k].out = outs[k].data_ptr()
+        arr[k].lrelu = 1 if c.get("lrelu") else 0
+    end = TIMER.bracket(("chain", cp, n, h, w, len(convs))) if TIMER else None
+    rc = L.lib().mil_conv_chain(x.data_ptr(), ctypes.addressof(arr), len(convs), n, h, w, cp, slope, L.dt_code(x.dtype), L.stream_ptr())
     if rc == 2:
         return None
-    L.check(rc, "mil_conv_pair")
+    L.check(rc, "mil_conv_chain")
     if end is not None:
         end.record()
-    return outA, outB
+    return outs
+
+
+def conv_pair(x, wA, biasA, wB, biasB, *, resA=None, actA=None, lreluA=False, resB=None, actB=None, lreluB=False, slope=LEAK):
+    """(outA, outB) = two 3x3 stride-1 convs back to back on LDS-resident whole images in one launch (conv_chain with two
+    convs: 80 channels on 8x8 maps, 64 channels on 16x16 maps), or None when the shape/dtype has no such kernel."""
+    outs = conv_chain(x, [dict(w=wA, bias=biasA, res=resA, act=actA, lrelu=lreluA),
+                          dict(w=wB, bias=biasB, res=resB, act=actB, lrelu=lreluB)], slope=slope)
+    return None if outs is None else (outs[0], outs[1])
 
 
 def conv_s2_entry(x, wpack3, bias_pad, wpack1, cout_p, *, slope=LEAK):

@@ -154,6 +154,24 @@ int mil_conv_pair(const void* x, const void* wpackA, const float* biasA, const v
                   void* outA, const void* wpackB, const float* biasB, const void* resB, const void* actB, int lreluB,
                   void* outB, int n_img, int H, int W, int cp, float slope, int dtype, void* stream);
 
+/* The general form: a chain of 1..6 such convs on the same resident images, one launch —
+ *     out_0 = epi_0( conv_0(x) ),   out_k = epi_k( conv_k(out_{k-1}) )
+ * where the res / act operand of a conv may be the output of an EARLIER conv of the chain (every lane re-reads exactly
+ * the bytes it stored itself).  Five convs are everything of the last stage behind its stride-2 entry convs (conv2 of the
+ * entry block + two identity blocks, gbm/model.py:29), or the stage's whole data-gradient chain.  `convs` is a HOST array.
+ * Same shapes and error behaviour as mil_conv_pair. */
+typedef struct MilChainConv {
+    const void* wpack;      /* MIL_PACK_FWD / MIL_PACK_DGRAD fragments */
+    const float* bias;      /* padded bias or NULL */
+    const void* res;        /* [n,H,W,cp] or NULL */
+    const void* act;        /* [n,H,W,cp] or NULL */
+    void* out;              /* [n,H,W,cp] */
+    int lrelu;
+    int pad_;
+} MilChainConv;
+int mil_conv_chain(const void* x, const MilChainConv* convs, int nconv, int n_img, int H, int W, int cp, float slope,
+                   int dtype, void* stream);
+
 int mil_conv_block_fwd(const void* x, const void* wpack1, const float* bias1, const void* wpack2, const float* bias2,
                        void* o1, void* y, int n_img, int H, int W, int cp, float slope, int dtype, void* stream);
 

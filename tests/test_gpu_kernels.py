@@ -509,6 +509,25 @@ def test_conv_pair_equals_two_launches(ops, shape):
     dmid_ref = ops.conv(dz, d2, None, cp, ks=3, stride=1, pad=1, act=o1)
     dx_ref = ops.conv(dmid_ref, d1, None, cp, ks=3, stride=1, pad=1, res=dz, act=xg)
     assert same(chain[0], dmid_ref) and same(chain[1], dx_ref)
+    # a five-conv chain (everything of the last stage behind its stride-2 convs): conv k reads conv k-1's output from the
+    # resident tile, residuals refer to earlier outputs of the chain by index
+    short = to_nhwc(round_to(torch.randn(n, c, hw, hw, generator=g), dt), dt)
+    convs = [dict(w=p2, bias=bp2, res=short, lrelu=True),
+             dict(w=p1, bias=bp1, lrelu=True), dict(w=p2, bias=bp2, res=0, lrelu=True),
+             dict(w=p1, bias=bp1, lrelu=True), dict(w=p2, bias=bp2, res=2, lrelu=True)]
+    outs = ops.conv_chain(xg, convs)
+    assert outs is not None and len(outs) == 5
+    r0 = ops.conv(xg, p2, bp2, cp, ks=3, stride=1, pad=1, res=short, lrelu=True)
+    r1 = ops.conv(r0, p1, bp1, cp, ks=3, stride=1, pad=1, lrelu=True)
+    r2 = ops.conv(r1, p2, bp2, cp, ks=3, stride=1, pad=1, res=r0, lrelu=True)
+    r3 = ops.conv(r2, p1, bp1, cp, ks=3, stride=1, pad=1, lrelu=True)
+    r4 = ops.conv(r3, p2, bp2, cp, ks=3, stride=1, pad=1, res=r2, lrelu=True)
+    if c == 80:
+        assert all(torch.equal(u, v) for u, v in zip(outs, (r0, r1, r2, r3, r4)))
+    else:                                                   # one bf16 rounding apart per conv, compounding down the chain
+        assert all(rel_err(u.float().cpu(), v.float().cpu()) < 3 * TOL[dt] for u, v in zip(outs, (r0, r1, r2, r3, r4)))
+    with pytest.raises(ValueError):
+        ops.conv_chain(xg, [dict(w=p1, bias=bp1, res=0)])   # a conv cannot name its own (or a later) output
     # other shapes decline
     assert ops.conv_pair(torch.zeros(2, 16, 16, 80, device="cuda", dtype=dt), p1, bp1, p2, bp2) is None
     assert ops.conv_pair(torch.zeros(2, 8, 8, 64, device="cuda", dtype=dt), p1, bp1, p2, bp2) is None
