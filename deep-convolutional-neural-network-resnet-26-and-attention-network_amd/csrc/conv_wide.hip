@@ -201,9 +201,12 @@ __global__ __launch_bounds__(256, 2) void wide_conv_pf_kernel(WideArgs<BF16> a, 
             const int hp = idx >> 2, j = idx & 3;
             const int ti = hp / (g.hh * g.hw), rem = hp - ti * (g.hh * g.hw);
             const int hy = rem / g.hw, hx = rem - hy * g.hw;
-            const int img = o.img0 + ti, iy = iy0 + hy, ix = ix0 + hx;
+            const int img = o.img0 + ti;
+            int iy = iy0 + hy, ix = ix0 + hx;
             const bool used = hp < npix;
-            const bool ok = used && img < g.n_img && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+            bool ok = used && img < g.n_img && iy >= 0 && ix >= 0;
+            if (g.zins) { ok = ok && !((iy | ix) & 1); iy >>= 1; ix >>= 1; }      // transposed stride-2 conv: zeros between the pixels of x
+            ok = ok && iy < g.H && ix < g.W;
             h_off[i] = ok ? (unsigned)((((img * g.H + iy) * g.W + ix) * a.cin) * 2 + j * 16) : MIL_OOB;
             h_lds[i] = used ? hp * PIXB + j * 16 : lds_w_off - 16;        // unused slots: 16 spare bytes behind the halo tile
         }
@@ -380,10 +383,11 @@ static int launch_wide(WideArgs<T> a, hipStream_t st) {
     const int tiles = a.g.n_groups * a.g.tiles_y * a.g.tiles_x;
     if (tiles <= 0) return MIL_OK;
     if constexpr (T::DT == MIL_DT_BF16) {
-        // stride-1 bf16 launches whose halo fits the register prefetch: the pipelined form
+        // stride-1 bf16 launches (zero-insert data gradients of the stride-2 convs included: their halo lives on the full-
+        // resolution grid) whose halo fits the register prefetch: the pipelined form
         const int halo_px = (a.g.hh * a.g.hw) << a.g.ti_log2;
         const size_t xb = (size_t)a.g.n_img * a.g.H * a.g.W * a.cin * 2;
-        if (mil_wide_pf_enabled() && a.g.stride == 1 && !a.g.zins && halo_px <= 256 && xb < ((size_t)1 << 31) && (a.g.ks == 3 || a.g.ks == 1)) {
+        if (mil_wide_pf_enabled() && a.g.stride == 1 && halo_px <= 256 && xb < ((size_t)1 << 31) && (a.g.ks == 3 || a.g.ks == 1)) {
             const int a_pf = a_bytes + 16;                    // + dump slot for the unused halo piece slots
             int lds_pf = a_pf + w_bytes;
             if (lds_pf < 128 * WIDE_NB * 4) lds_pf = 128 * WIDE_NB * 4;
