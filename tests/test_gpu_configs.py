@@ -349,7 +349,7 @@ def test_dense_gradient_layout_and_dropped_s2d_copy_change_no_bit(golden_dir, mo
     from mil_amd import ops
     monkeypatch.setenv("MIL_PF_MIN_TILES", "1")
     gen = torch.Generator().manual_seed(77)
-    for size, sizes in ((256, [20, 12]), (128, [24, 40])):
+    for size, sizes in ((256, [20, 12]), (128, [24, 40]), (300, [5, 4])):       # 300: the live driver's 75x75 first-stage maps (ragged tiles)
         x = torch.randn(sum(sizes), 3, size, size, generator=gen).clamp_(-1, 1).cuda()
         labels = torch.tensor([2, 0])
         grads, seen = {}, {}
@@ -367,8 +367,10 @@ def test_dense_gradient_layout_and_dropped_s2d_copy_change_no_bit(golden_dir, mo
             net.forward_bags((x, sizes), labels).loss.sum().backward()
             torch.cuda.synchronize()
             grads[(dense, keep)] = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
-            if not keep:
+            if not keep and size != 300:                    # (at 300x300 either layout may be chosen: only the equality below matters)
                 assert seen.get("c") == (20 if dense else 24), (size, dense, seen)
+            elif not keep and not dense:
+                assert seen.get("c", 24) == 24, (size, seen)
         monkeypatch.setattr(ops, "stem_bwd_fused_nchw", real)
         ref = grads[(True, False)]
         for key in ((False, False), (True, True)):
