@@ -46,6 +46,9 @@ struct ResArgs {
     float slope;
 };
 
+#ifndef MIL_RES_WARM
+#define MIL_RES_WARM 1          // touch the filters at kernel start (see the kernel)
+#endif
 #ifndef MIL_RES_BDEPTH
 #define MIL_RES_BDEPTH 2        // k-steps of filter fragments in flight per wave
 #endif
@@ -79,6 +82,19 @@ __global__ __launch_bounds__(512, 2) void conv_resident_kernel(ResArgs a) {
     const int r = lane & 15, gq = lane >> 4;
     const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, a.bytes);
 
+#if MIL_RES_WARM
+    // ---- pull every conv's filter into L2 now: the k-step loops read it fragment by fragment two k-steps ahead, which
+    // hides an L2 hit but not the HBM miss a filter packed 9 ms (30 GB of traffic) ago costs — every k-step's first touch
+    // would stall all waves of all workgroups at once.  One dword per 128-byte line and thread, results never used.
+    // (the results are consumed at the very end of the kernel: memory returns in order, so the first wait for pixel data
+    // covers these loads and nothing waits for them on their own)
+    unsigned sink = 0;
+    for (int k = 0; k < a.nconv; ++k) {
+        const __amdgpu_buffer_rsrc_t rs_wk = mil_rsrc(a.conv[k].w, KSTEPS * NT * 1024);
+        for (int line = tid; line < KSTEPS * NT * 8; line += 512)
+            sink ^= __builtin_amdgcn_raw_buffer_load_b32(rs_wk, (unsigned)line * 128u, 0, 0);
+    }
+#endif
     // ---- zero border records, once: the commits and the first conv's epilogue only ever write interiors ----------------
     {
         constexpr int NB = 4 * S + 4, PPR = PIX / 16;
@@ -222,6 +238,9 @@ __global__ __launch_bounds__(512, 2) void conv_resident_kernel(ResArgs a) {
 #pragma unroll 1
         for (int k = 0; k < a.nconv; ++k) run_conv(a.conv[k], k + 1 < a.nconv, k == 0);
     }
+#if MIL_RES_WARM
+    asm volatile("" :: "v"(sink));
+#endif
 }
 
 static bool mil_resident_enabled() {
