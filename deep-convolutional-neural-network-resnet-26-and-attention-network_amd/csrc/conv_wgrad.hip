@@ -45,6 +45,13 @@ __device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
 // instead of once per weight-gradient launch.  Its rows are appended to the slab behind the bias tile.
 // which instantiations take the explicit one-step-ahead operand prefetch (second operand register set): the persistent
 // bf16 forms below 64 input channels; the 64/80-channel forms sit at 232-256 VGPRs already
+__host__ __device__ constexpr int mil_wgrad_halo_max(int cinp, bool proj) {
+#ifdef MIL_WGRAD_PAIR24_64PX
+    return 400;
+#else
+    return (proj && cinp <= 24) ? 576 : 400;
+#endif
+}
 #ifdef MIL_WGRAD_NO_PIPE
 #define MIL_WGRAD_PIPE(BF, PF, CINP, NW, PROJ) false
 #else
@@ -107,7 +114,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0))
     // PF: software pipeline — the next tile's global loads are issued (into registers) before this tile's
     // MFMA loop and written to LDS after the loop's barrier, so HBM latency hides under compute.  Addressing
     // through buffer descriptors + tile-invariant tables (pf_common.cuh) keeps the per-tile VALU work small.
-    constexpr int NPX = PF ? (400 * (CINP * ESZ / 16) + NTHR - 1) / NTHR : 1;
+    // halo pixels the register prefetch is sized for: 400, or 576 for the paired 24-channel stage entry (128-pixel tiles at
+    // stride 2 stage 17x33 = 561 pixels; 64-pixel tiles left two k-steps of MFMAs per pair of barriers: 223 us for 148 us of traffic)
+    constexpr int NPX = PF ? (mil_wgrad_halo_max(CINP, PROJ) * (CINP * ESZ / 16) + NTHR - 1) / NTHR : 1;
     constexpr int NPZ = PF ? (256 * (COUTP * ESZ / 16) + NTHR - 1) / NTHR : 1;
     u32x4_t rx[NPX], rz[NPZ], rz2[PROJ ? NPZ : 1];
     char* ldsZ2 = smem + a.lds_z2_off;
@@ -380,11 +389,13 @@ static int plan_wgrad(ConvGeom& g, WgradPlan& pl, int* lds_z_off, bool proj = fa
     constexpr int MT = (RG + 1) / 2;
     // 256-px tiles when the halo fits comfortably, else 64-px tiles (stride-2 layers, f32 wide layers)
     constexpr bool PF_OK = (T::DT == MIL_DT_BF16);
-    for (int lg = 8; lg >= 6; lg -= 2) {
+    const int hmax = mil_wgrad_halo_max(CINP, proj);
+    for (int lg = 8; lg >= 6; --lg) {
+        if (lg == 7 && hmax == 400) continue;             // 128-pixel tiles only where the prefetch registers are sized for their halo
         mil_geom_tiles(g, lg);
         const int xb = ((((g.hh * g.hw) << g.ti_log2) * PIXB) + 15) & ~15;
         const int zb = (1 << lg) * PIXZ * (proj ? 2 : 1);
-        const bool halo_fits_regs = ((g.hh * g.hw) << g.ti_log2) <= 400;
+        const bool halo_fits_regs = ((g.hh * g.hw) << g.ti_log2) <= hmax;
         if ((xb + zb <= 150 * 1024 && (halo_fits_regs || !PF_OK)) || lg == 6) {
             if (xb + zb > 160 * 1024) return MIL_ERR_UNSUPPORTED;
             pl.lds = xb + zb; *lds_z_off = xb; pl.tile_px_log2 = lg;
@@ -418,7 +429,7 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     constexpr bool PF_OK = (T::DT == MIL_DT_BF16);
     const size_t xb_total = (size_t)g.n_img * g.H * g.W * CINP * T::ESZ;
     const size_t zb_total = (size_t)g.n_img * g.Ho * g.Wo * mil_nt_to_cp(NT) * T::ESZ;
-    const bool pf = PF_OK && (((g.hh * g.hw) << g.ti_log2) <= 400) && g.hh < 1024 && g.hw < 1024 &&
+    const bool pf = PF_OK && (((g.hh * g.hw) << g.ti_log2) <= mil_wgrad_halo_max(CINP, PROJ)) && g.hh < 1024 && g.hw < 1024 &&
                     xb_total < ((size_t)1 << 31) && zb_total < ((size_t)1 << 31);
     a.x_bytes = (unsigned)xb_total; a.z_bytes = (unsigned)zb_total;
     // 8-wave workgroups where the 4-wave form holds a single wave per SIMD (persistent bf16 form, >= 64 input channels)
