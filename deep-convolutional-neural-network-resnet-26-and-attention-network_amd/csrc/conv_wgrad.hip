@@ -446,6 +446,8 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
         // the activation traffic — and a partial second round leaves CUs idle behind the stragglers)
         const int per_cu = mil_resident_per_cu(kern, pl.lds, 2, nthr);
         int gx = mil_num_cus() * per_cu / MSPLIT;
+        // (fewer, longer-running workgroups to write fewer slabs do not pay: the 64/80-channel launches took 1.7x / 3.2x as long on
+        // half / a quarter of the workgroups — their time is tiles per workgroup x a load round trip per tile, not slab traffic)
         if (gx > a.ntiles) gx = a.ntiles;
         if (gx < 1) gx = 1;
         pl.grid_x = gx;
