@@ -2,7 +2,7 @@
 
 Importable as `mil_amd` (repo-root shim `mil_amd.py`); the on-disk package directory keeps the
 project's hyphenated name."""
-from ._lib import LIB_PATH, MilLibraryError, build_library, lib  # noqa: F401
+from ._lib import BF16X3, LIB_PATH, MilLibraryError, build_library, lib  # noqa: F401
 from . import alt_resnet  # noqa: F401
 from .encoder import BasicResBlock, ResNet  # noqa: F401
 from .dist import FlatAdam, FlatParams, gather_features, shard_bags  # noqa: F401
@@ -11,4 +11,4 @@ from .preprocess import TilePreprocessor  # noqa: F401
 from .model import Attention, ContextLayer, CrossEntropyWithProbs, TileParallel  # noqa: F401
 
 __all__ = ["alt_resnet", "Attention", "ResNet", "BasicResBlock", "ContextLayer", "CrossEntropyWithProbs", "TileParallel",
-           "FlatParams", "FlatAdam", "shard_bags", "gather_features", "BagTrainer", "set_stage", "stage_for_epoch", "write_attention_map", "write_map", "save_checkpoint", "load_checkpoint", "TilePreprocessor", "build_library", "lib", "MilLibraryError", "LIB_PATH"]
+           "FlatParams", "FlatAdam", "shard_bags", "gather_features", "BagTrainer", "set_stage", "stage_for_epoch", "write_attention_map", "write_map", "save_checkpoint", "load_checkpoint", "TilePreprocessor", "build_library", "lib", "MilLibraryError", "LIB_PATH", "BF16X3"]

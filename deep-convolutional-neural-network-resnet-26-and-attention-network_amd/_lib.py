@@ -2,6 +2,7 @@
 
 There is no CPU fallback: if the library is missing or a call fails this module raises.
 """
+import contextlib
 import ctypes
 import os
 import subprocess
@@ -11,7 +12,10 @@ import torch  # noqa: F401  (must be imported first: the HIP runtime torch loade
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmil_hip.so")
 
-MIL_DT_F32, MIL_DT_BF16, MIL_DT_BF16_DGRAD = 0, 1, 2
+MIL_DT_F32, MIL_DT_BF16, MIL_DT_BF16_DGRAD, MIL_DT_F32S = 0, 1, 2, 3
+# compute_dtype value of the split-precision path: fp32 tensors (every pointwise kernel of the fp32 path), convolutions
+# as three bf16 MFMAs per k-step on hi/lo-split operands (MIL_DT_F32S in include/mil_hip.h)
+BF16X3 = "bf16x3"
 PACK_FWD, PACK_DGRAD, PACK_STEM, PACK_DGRAD_S2 = 0, 1, 2, 3
 _ERR = {1: "invalid argument", 2: "unsupported shape / channel configuration", 3: "kernel launch failed"}
 
@@ -122,15 +126,40 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def dt_code(dtype, dense_grads=False):
+_F32_MMA = [MIL_DT_F32]
+
+
+@contextlib.contextmanager
+def f32_mma(code):
+    """Inside the block, the convolution entry points run fp32 tensors with `code` (MIL_DT_F32: exact-f32 MFMA,
+    MIL_DT_F32S: bf16x3 split products)."""
+    prev = _F32_MMA[0]
+    _F32_MMA[0] = code
+    try:
+        yield
+    finally:
+        _F32_MMA[0] = prev
+
+
+def storage_dtype(compute_dtype):
+    """torch dtype of the activation tensors of a compute mode."""
+    return torch.float32 if compute_dtype == BF16X3 else compute_dtype
+
+
+def mma_code(compute_dtype):
+    return MIL_DT_F32S if compute_dtype == BF16X3 else MIL_DT_F32
+
+
+def dt_code(dtype, dense_grads=False, mma=False):
     """MIL_DT_* code of a compute dtype; dense_grads selects MIL_DT_BF16_DGRAD (gradient tensors of the 20-channel layer
-    at 20 channels per pixel instead of 24; see include/mil_hip.h)."""
+    at 20 channels per pixel instead of 24; see include/mil_hip.h).  mma=True (the convolution entry points and the filter
+    packing): fp32 tensors get the code selected by `f32_mma` (exact or split products)."""
     if dense_grads:
         if dtype != torch.bfloat16:
             raise ValueError("the dense gradient layout exists for bfloat16 only")
         return MIL_DT_BF16_DGRAD
     if dtype == torch.float32:
-        return MIL_DT_F32
+        return _F32_MMA[0] if mma else MIL_DT_F32
     if dtype == torch.bfloat16:
         return MIL_DT_BF16
     raise ValueError(f"compute dtype must be torch.float32 or torch.bfloat16, got {dtype}")

@@ -21,27 +21,48 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 // dense, 20 channels = 40 bytes per pixel, instead of padded to 24; activations keep the padded layout.  Accepted by the
 // kernels that form that gradient chain: mil_conv_dgrad_s2 (its output), mil_conv_bwd_fused, mil_stem_bwd_fused(_nchw).
 #define MIL_DT_BF16_DGRAD 2
+// fp32 tensors in HBM (the layout and every pointwise kernel of MIL_DT_F32), contracted as THREE bf16 MFMAs per k-step:
+// each operand is split on its way into LDS into hi = bf16(v) and lo = bf16(v - hi) and the product is taken as
+// hi*hi + lo*hi + hi*lo with fp32 accumulation (the lo*lo term, 2^-18 relative, is dropped).  16 significant bits per
+// operand at 3/16 of the matrix-pipe time of the exact-f32 MFMA: the path that meets the 1e-3 gate on the logits at speed.
+#define MIL_DT_F32S 3
 
 // Channel padding used by every NHWC activation tensor (multiple of 8 elements = one 16-B bf16 piece).
 __host__ __device__ constexpr int mil_cpad(int c) { return (c + 7) / 8 * 8; }
 // Output-channel tile count (16-wide MFMA columns) <-> padded channel count.
 __host__ __device__ constexpr int mil_nt_to_cp(int nt) { return nt == 2 ? 24 : nt == 3 ? 40 : nt == 4 ? 64 : 80; }
 
+// ESZ: bytes per element in HBM and per element of an LDS pixel record; CGB: bytes between two 8-channel groups of one
+// LDS pixel record; TR16: the operands in LDS are bf16 (ds_read_b64_tr_b16 applies); SPLIT: hi/lo bf16 planes in LDS.
 struct F32 {
     using elem = float;
     static constexpr int ESZ = 4;
     static constexpr int DT = MIL_DT_F32;
+    static constexpr int CGB = 32;
+    static constexpr bool TR16 = false, SPLIT = false;
 };
 struct BF16 {
     using elem = __bf16;
     static constexpr int ESZ = 2;
     static constexpr int DT = MIL_DT_BF16;
+    static constexpr int CGB = 16;
+    static constexpr bool TR16 = true, SPLIT = false;
+};
+// MIL_DT_F32S: fp32 in HBM; an LDS pixel record of C channels is [hi: C bf16][lo: C bf16] (the same 4*C bytes), a packed
+// filter fragment is [hi: 8 bf16][lo: 8 bf16] per lane (the same 32 bytes as 8 floats).
+struct F32S {
+    using elem = float;
+    static constexpr int ESZ = 4;
+    static constexpr int DT = MIL_DT_F32S;
+    static constexpr int CGB = 16;
+    static constexpr bool TR16 = true, SPLIT = true;
 };
 
 // One MFMA operand fragment = 8 consecutive-k elements per lane.
 template <typename T> struct Frag8;
 template <> struct Frag8<BF16> { bf16x8_t v; };
 template <> struct Frag8<F32> { f32x4_t lo, hi; };
+template <> struct Frag8<F32S> { bf16x8_t h, l; };
 
 template <typename T>
 __device__ __forceinline__ Frag8<T> lds_frag(const char* p);
@@ -55,6 +76,37 @@ __device__ __forceinline__ Frag8<F32> lds_frag<F32>(const char* p) {
     f.lo = *reinterpret_cast<const f32x4_t*>(p);
     f.hi = *reinterpret_cast<const f32x4_t*>(p + 16);
     return f;
+}
+
+// Fragment of a packed filter (32 bytes per lane: [hi][lo]) / of an LDS pixel record whose lo plane starts LO bytes behind
+// its hi plane (LO = 2 * channels of the record).
+template <>
+__device__ __forceinline__ Frag8<F32S> lds_frag<F32S>(const char* p) {
+    Frag8<F32S> f;
+    f.h = *reinterpret_cast<const bf16x8_t*>(p);
+    f.l = *reinterpret_cast<const bf16x8_t*>(p + 16);
+    return f;
+}
+template <typename T, int LO>
+__device__ __forceinline__ Frag8<T> lds_pix_frag(const char* p) {
+    if constexpr (T::SPLIT) {
+        Frag8<T> f;
+        f.h = *reinterpret_cast<const bf16x8_t*>(p);
+        f.l = *reinterpret_cast<const bf16x8_t*>(p + LO);
+        return f;
+    } else {
+        return lds_frag<T>(p);
+    }
+}
+
+// v = hi + lo (+ a remainder below 2^-17 |v|): the two bf16 MFMA operands of a MIL_DT_F32S value.
+__device__ __forceinline__ void mil_split8(const float (&v)[8], bf16x8_t& hi, bf16x8_t& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        hi[j] = h;
+        lo[j] = (__bf16)(v[j] - (float)h);
+    }
 }
 
 // acc += A(16 x 32k) * B(32k x 16).  The bf16 form is one v_mfma_f32_16x16x32_bf16; the f32 form is
@@ -71,6 +123,13 @@ __device__ __forceinline__ f32x4_t mma8(const Frag8<F32>& a, const Frag8<F32>& b
     return c;
 }
 
+// split form: the small cross terms first, then hi*hi
+__device__ __forceinline__ f32x4_t mma8(const Frag8<F32S>& a, const Frag8<F32S>& b, f32x4_t c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, c, 0, 0, 0);
+}
+
 // 8 consecutive channels of a tensor <-> 8 floats.
 template <typename T> __device__ __forceinline__ void load8(const typename T::elem* p, float (&v)[8]);
 template <> __device__ __forceinline__ void load8<BF16>(const __bf16* p, float (&v)[8]) {
@@ -84,6 +143,7 @@ template <> __device__ __forceinline__ void load8<F32>(const float* p, float (&v
 #pragma unroll
     for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
 }
+template <> __device__ __forceinline__ void load8<F32S>(const float* p, float (&v)[8]) { load8<F32>(p, v); }
 template <typename T> __device__ __forceinline__ void store8(typename T::elem* p, const float (&v)[8]);
 template <> __device__ __forceinline__ void store8<BF16>(__bf16* p, const float (&v)[8]) {
     bf16x8_t t;
@@ -98,6 +158,8 @@ template <> __device__ __forceinline__ void store8<F32>(float* p, const float (&
     *reinterpret_cast<f32x4_t*>(p) = a;
     *reinterpret_cast<f32x4_t*>(p + 4) = b;
 }
+
+template <> __device__ __forceinline__ void store8<F32S>(float* p, const float (&v)[8]) { store8<F32>(p, v); }
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 // derivative of LeakyReLU read off the saved OUTPUT (same sign as the pre-activation for slope>0;

@@ -75,13 +75,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs<T> a) {
             int cg = q - tap * CG;
             if (tap >= ntaps) { tap = 0; cg = 0; }      // K padding: weights there are zero
             const int ky = tap / g.ks, kx = tap - ky * g.ks;
-            const int toff = (ky * g.hw + kx) * PIXB + cg * FRAGB;
+            const int toff = (ky * g.hw + kx) * PIXB + cg * T::CGB;
             Frag8<T> bf[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) bf[nt] = lds_frag<T>(ldsW + ((sl * NT + nt) * 64 + lane) * FRAGB);
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
-                const Frag8<T> af = lds_frag<T>(ldsA + pixbase[m] + toff);
+                const Frag8<T> af = lds_pix_frag<T, CINP * 2>(ldsA + pixbase[m] + toff);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(af, bf[nt], acc[m][nt]);
             }
@@ -681,6 +681,11 @@ extern "C" int mil_conv_igemm(const void* x, const void* wpack, const float* bia
         a.x = (const float*)x; a.w = (const float*)wpack; a.bias = bias_pad; a.res = (const float*)res;
         a.act = (const float*)act; a.y = (float*)y; a.g = g; a.nsteps = nsteps; a.apply_lrelu = apply_lrelu; a.slope = slope;
         return dispatch_conv<F32>(a, cin_p, cout_p, st);
+    } else if (dtype == MIL_DT_F32S) {
+        ConvArgs<F32S> a{};
+        a.x = (const float*)x; a.w = (const float*)wpack; a.bias = bias_pad; a.res = (const float*)res;
+        a.act = (const float*)act; a.y = (float*)y; a.g = g; a.nsteps = nsteps; a.apply_lrelu = apply_lrelu; a.slope = slope;
+        return dispatch_conv<F32S>(a, cin_p, cout_p, st);
     }
     return MIL_ERR_ARG;
 }

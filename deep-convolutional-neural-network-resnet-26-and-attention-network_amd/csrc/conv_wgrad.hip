@@ -93,12 +93,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0))
         mvalid[i] = (ml < MT_S) && (mt < MT);
         if (PROJ && mvalid[i] && mt >= PM0 && mt <= PM1) { proj_i = i; proj_mt = mt; }
         int rg, sub;
-        if constexpr (T::DT == MIL_DT_BF16) { const int p = lane & 3; rg = 2 * mt + (p >> 1); sub = (p & 1) * 8; }
+        if constexpr (T::TR16) { const int p = lane & 3; rg = 2 * mt + (p >> 1); sub = (p & 1) * 8; }
         else { const int row = lane & 15; rg = 2 * mt + (row >> 3); sub = (row & 7) * 4; }
         if (rg >= RG) rg = 0;                    // rows past the filter: finite duplicates, never read back
         const int tap = rg / CG, cg = rg - tap * CG;
         const int ky = tap / KS, kx = tap - ky * KS;
-        toff[i] = (ky * g.hw + kx) * PIXB + cg * (8 * ESZ) + sub;
+        toff[i] = (ky * g.hw + kx) * PIXB + cg * T::CGB + sub;
     }
 
     f32x4_t acc[MW][NT];
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0))
             mil_load_otile<T, COUTP>(ldsZ, a.dz, g, o, tid, 256, a.tile_px);
         }
         __syncthreads();
-        if constexpr (T::DT == MIL_DT_BF16) {
+        if constexpr (T::TR16) {
             const int q4 = (lane & 15) >> 2, p = lane & 3, gq = lane >> 4;
             bf16x8_t ones;
 #pragma unroll
@@ -225,6 +225,32 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0))
                 bf16x8_t bf[NT], bf2[PROJ ? NT : 1];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bf[nt] = tr_pair(z0 + nt * 32, z1 + nt * 32);
+                if constexpr (T::SPLIT) {        // MIL_DT_F32S: dW += x_lo*dz_hi + x_hi*dz_lo + x_hi*dz_hi from the hi/lo planes of both tiles
+                    bf16x8_t bl[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bl[nt] = tr_pair(z0 + COUTP * 2 + nt * 32, z1 + COUTP * 2 + nt * 32);
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) {
+                        if (mvalid[i]) {         // wave-uniform
+                            const bf16x8_t af = tr_pair(ldsX + pb0 + toff[i], ldsX + pb1 + toff[i]);
+                            const bf16x8_t al = tr_pair(ldsX + pb0 + CINP * 2 + toff[i], ldsX + pb1 + CINP * 2 + toff[i]);
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bf[nt], acc[i][nt], 0, 0, 0);
+                                acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bl[nt], acc[i][nt], 0, 0, 0);
+                                acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[nt], acc[i][nt], 0, 0, 0);
+                            }
+                        }
+                    }
+                    if (bias_wave) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            accb[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bl[nt], accb[nt], 0, 0, 0);
+                            accb[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bf[nt], accb[nt], 0, 0, 0);
+                        }
+                    }
+                    continue;
+                }
                 if constexpr (PROJ) {
                     if (proj_i >= 0) {           // wave-uniform
                         const char* y0 = ldsZ2 + (k32 + 8 * gq + q4) * PIXZ + p * 8;
@@ -526,6 +552,7 @@ static int wgrad_entry(const void* x, const void* dz, float* dw, float* db, void
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MIL_DT_BF16) return dispatch_wgrad<BF16>(x, dz, dw, db, ws, ws_bytes, g, cout, cin, stem_mode, accumulate, query, need, st);
     if (dtype == MIL_DT_F32) return dispatch_wgrad<F32>(x, dz, dw, db, ws, ws_bytes, g, cout, cin, stem_mode, accumulate, query, need, st);
+    if (dtype == MIL_DT_F32S) return dispatch_wgrad<F32S>(x, dz, dw, db, ws, ws_bytes, g, cout, cin, stem_mode, accumulate, query, need, st);
     return MIL_ERR_ARG;
 }
 

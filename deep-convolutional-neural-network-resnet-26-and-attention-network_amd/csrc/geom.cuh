@@ -87,6 +87,23 @@ __device__ __forceinline__ void mil_load_halo(char* lds, const typename T::elem*
         row_ok = row_ok && iy < g.H;
         const char* src_row = reinterpret_cast<const char*>(x) + ((size_t)img * g.H + iy) * g.W * (CINP * ESZ);
         char* dst_row = lds + (size_t)row * g.hw * PIXB;
+        if constexpr (T::SPLIT) {               // 8 floats -> 16 bytes of the record's hi plane + 16 bytes of its lo plane
+            constexpr int N8 = CINP / 8;
+            for (int piece = lane; piece < g.hw * N8; piece += 64) {
+                const int hx = piece / N8, j = piece - hx * N8;
+                int ix = ix0 + hx;
+                bool ok = row_ok && ix >= 0;
+                if (g.zins) { ok = ok && !(ix & 1); ix >>= 1; }
+                ok = ok && ix < g.W;
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (ok) load8<F32>(reinterpret_cast<const float*>(src_row + (size_t)ix * (CINP * 4) + j * 32), v);
+                bf16x8_t hi, lo;
+                mil_split8(v, hi, lo);
+                *reinterpret_cast<bf16x8_t*>(dst_row + hx * PIXB + j * 16) = hi;
+                *reinterpret_cast<bf16x8_t*>(dst_row + hx * PIXB + CINP * 2 + j * 16) = lo;
+            }
+            continue;
+        }
         for (int piece = lane; piece < ppr; piece += 64) {
             const int hx = piece / N16, j = piece - hx * N16;
             int ix = ix0 + hx;
@@ -109,6 +126,23 @@ __device__ __forceinline__ void mil_load_otile(char* lds, const typename T::elem
     constexpr int PIXZ = mil_pix_pitch(CP, ESZ);
     constexpr int N16 = CP * ESZ / 16;
     const int tw_mask = (1 << g.tw_log2) - 1, th_mask = (1 << g.th_log2) - 1;
+    if constexpr (T::SPLIT) {
+        constexpr int N8 = CP / 8;
+        for (int idx = tid; idx < tile_px * N8; idx += nthreads) {
+            const int tp = idx / N8, j = idx - tp * N8;
+            const int ox = o.ox0 + (tp & tw_mask);
+            const int oy = o.oy0 + ((tp >> g.tw_log2) & th_mask);
+            const int img = o.img0 + (tp >> (g.tw_log2 + g.th_log2));
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (img < g.n_img && oy < g.Ho && ox < g.Wo)
+                load8<F32>(reinterpret_cast<const float*>(z) + (((size_t)img * g.Ho + oy) * g.Wo + ox) * CP + j * 8, v);
+            bf16x8_t hi, lo;
+            mil_split8(v, hi, lo);
+            *reinterpret_cast<bf16x8_t*>(lds + tp * PIXZ + j * 16) = hi;
+            *reinterpret_cast<bf16x8_t*>(lds + tp * PIXZ + CP * 2 + j * 16) = lo;
+        }
+        return;
+    }
     for (int idx = tid; idx < tile_px * N16; idx += nthreads) {
         const int tp = idx / N16, j = idx - tp * N16;
         const int ox = o.ox0 + (tp & tw_mask);

@@ -75,5 +75,11 @@ __device__ __forceinline__ void mil_pack_job_elem(const PackJob& j, int idx) {
         }
     }
     if (j.dtype == MIL_DT_BF16) reinterpret_cast<__bf16*>(j.out)[idx] = (__bf16)val;
+    else if (j.dtype == MIL_DT_F32S) {          // fragment = [hi: 8 bf16][lo: 8 bf16] per lane (32 bytes, as 8 floats)
+        const __bf16 h = (__bf16)val;
+        __bf16* o = reinterpret_cast<__bf16*>(j.out) + (size_t)(idx >> 3) * 16 + (idx & 7);
+        o[0] = h;
+        o[8] = (__bf16)(val - (float)h);
+    }
     else reinterpret_cast<float*>(j.out)[idx] = val;
 }

@@ -68,7 +68,7 @@ extern "C" int mil_packed_weight_elems(size_t* elems, int cout, int cin, int ks,
 extern "C" int mil_pack_conv_weights(const float* w, const float* bias, void* wpack, float* bias_pad, int cout, int cin,
                                      int ks, int mode, int dtype, void* stream) {
     if (!w || !wpack || cout <= 0 || cin <= 0 || mode < 0 || mode > 3 || (mode == 3 && ks != 3)) return MIL_ERR_ARG;
-    if (dtype != MIL_DT_BF16 && dtype != MIL_DT_F32) return MIL_ERR_ARG;
+    if (dtype != MIL_DT_BF16 && dtype != MIL_DT_F32 && dtype != MIL_DT_F32S) return MIL_ERR_ARG;
     PackJob j{};
     j.w = w; j.bias = bias; j.out = wpack; j.bias_pad = bias_pad;
     j.cout = cout; j.cin = cin; j.ks = ks; j.mode = mode; j.dtype = dtype;

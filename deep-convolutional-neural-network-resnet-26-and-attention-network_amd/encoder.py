@@ -131,7 +131,7 @@ class ResNet(nn.Module):
         import ctypes
         lib = L.lib()
         specs = self._pack_specs()
-        ptr_tag = (dtype,) + tuple(w.data_ptr() for _k, w, _b, _m in specs) + tuple(0 if b is None else b.data_ptr() for _k, _w, b, _m in specs)
+        ptr_tag = (dtype, L.dt_code(dtype, mma=True)) + tuple(w.data_ptr() for _k, w, _b, _m in specs) + tuple(0 if b is None else b.data_ptr() for _k, _w, b, _m in specs)
         if self._pack_table is None or self._pack_table[0] != ptr_tag:
             dev = self.conv1.weight.device
             rec = lib.mil_pack_job_bytes()
@@ -147,7 +147,7 @@ class ResNet(nn.Module):
                 n_out = cin if mode == L.PACK_DGRAD else cout
                 bias_pad = torch.empty((ops.cpad(n_out) + 15) // 16 * 16, dtype=torch.float32, device=dev)
                 L.check(lib.mil_pack_job_fill(ctypes.byref(host, i * rec), w.data_ptr(), L.ptr(b), packed.data_ptr(),
-                                              bias_pad.data_ptr(), cout, cin, ks, mode, L.dt_code(dtype)), "mil_pack_job_fill")
+                                              bias_pad.data_ptr(), cout, cin, ks, mode, L.dt_code(dtype, mma=True)), "mil_pack_job_fill")
                 store[(key, mode)] = (packed, bias_pad)
             table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev)
             self._pack_table = (ptr_tag, table, store, len(specs))
@@ -541,13 +541,16 @@ def encoder_backward(net, saved, dfeats, dtype):
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x, *params):
-        dtype = net.compute_dtype
-        feats, saved = encoder_forward(net, x.detach(), dtype)
-        ctx.net, ctx.saved, ctx.dtype = net, saved, dtype
+        mode = net.compute_dtype            # torch.bfloat16, torch.float32 (exact-f32 MFMA) or L.BF16X3 (fp32 tensors, split products)
+        dtype = L.storage_dtype(mode)
+        with L.f32_mma(L.mma_code(mode)):
+            feats, saved = encoder_forward(net, x.detach(), dtype)
+        ctx.net, ctx.saved, ctx.dtype, ctx.mode = net, saved, dtype, mode
         return feats
 
     @staticmethod
     def backward(ctx, dfeats):
-        grads = encoder_backward(ctx.net, ctx.saved, dfeats, ctx.dtype)
+        with L.f32_mma(L.mma_code(ctx.mode)):
+            grads = encoder_backward(ctx.net, ctx.saved, dfeats, ctx.dtype)
         ctx.saved = None
         return (None, None, *grads)

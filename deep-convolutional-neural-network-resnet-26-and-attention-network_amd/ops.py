@@ -107,13 +107,16 @@ def pack_weights(w, bias, mode, dtype):
     cout, cin, ks, _ = w.shape
     elems = ctypes.c_size_t(0)
     L.check(L.lib().mil_packed_weight_elems(ctypes.byref(elems), cout, cin, ks, mode), "mil_packed_weight_elems")
+    if dtype == L.BF16X3:                 # the split path's filters: fp32-sized fragments [hi | lo], packed under MIL_DT_F32S
+        with L.f32_mma(L.MIL_DT_F32S):
+            return pack_weights(w, bias, mode, torch.float32)
     packed = torch.empty(elems.value, dtype=dtype, device=w.device)
     n_out = cin if mode == L.PACK_DGRAD else cout
     nt = (cpad(n_out) + 15) // 16
     bias_pad = torch.empty(nt * 16, dtype=torch.float32, device=w.device)
     b = None if bias is None else bias.detach().contiguous()
     L.check(L.lib().mil_pack_conv_weights(w.data_ptr(), L.ptr(b), packed.data_ptr(), bias_pad.data_ptr(), cout, cin, ks,
-                                          mode, L.dt_code(dtype), L.stream_ptr()), "mil_pack_conv_weights")
+                                          mode, L.dt_code(dtype, mma=True), L.stream_ptr()), "mil_pack_conv_weights")
     return packed, bias_pad
 
 
@@ -135,7 +138,7 @@ def conv(x, wpack, bias_pad, cout_p, *, ks, stride, pad, out_hw=None, res=None, 
     end = TIMER.bracket(("conv", cin_p, cout_p, ks, stride, bool(zero_insert), n, ho, wo)) if TIMER else None
     L.check(L.lib().mil_conv_igemm(x.data_ptr(), wpack.data_ptr(), L.ptr(bias_pad), L.ptr(res), L.ptr(act), y.data_ptr(),
                                    n, h, w, cin_p, ho, wo, cout_p, ks, 1 if zero_insert else stride, pad,
-                                   1 if zero_insert else 0, 1 if lrelu else 0, slope, L.dt_code(x.dtype), L.stream_ptr()),
+                                   1 if zero_insert else 0, 1 if lrelu else 0, slope, L.dt_code(x.dtype, mma=True), L.stream_ptr()),
             "mil_conv_igemm")
     if end is not None:
         end.record()
@@ -145,7 +148,7 @@ def conv(x, wpack, bias_pad, cout_p, *, ks, stride, pad, out_hw=None, res=None, 
 def wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, ks, stride, pad, stem, dtype):
     need = ctypes.c_size_t(0)
     L.check(L.lib().mil_conv_wgrad_workspace(ctypes.byref(need), n, h, w, cin, ho, wo, cout, ks, stride, pad,
-                                             1 if stem else 0, L.dt_code(dtype)), "mil_conv_wgrad_workspace")
+                                             1 if stem else 0, L.dt_code(dtype, mma=True)), "mil_conv_wgrad_workspace")
     return need.value
 
 
@@ -168,7 +171,7 @@ def conv_wgrad(x, dz, cin, cout, *, ks, stride, pad, stem=False, want_bias=True,
         _need(db, (cout,), torch.float32, "db")
     L.check(L.lib().mil_conv_wgrad(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), L.ptr(db), workspace.data_ptr(),
                                    workspace.numel() * workspace.element_size(), n, h, w, cin, ho, wo, cout, ks, stride,
-                                   pad, 1 if stem else 0, 0 if out is None else 1, L.dt_code(x.dtype), L.stream_ptr()),
+                                   pad, 1 if stem else 0, 0 if out is None else 1, L.dt_code(x.dtype, mma=True), L.stream_ptr()),
             "mil_conv_wgrad")
     return dw, db
 

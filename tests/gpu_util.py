@@ -2,6 +2,12 @@
 tensors and the kernels' channel-padded NHWC tensors)."""
 import torch
 
+X3 = "bf16x3"        # compute mode of the split-precision path: fp32 tensors, three bf16 MFMAs per k-step (mil_amd._lib.BF16X3)
+
+
+def storage(dtype):
+    return torch.float32 if dtype == X3 else dtype
+
 
 def cpad(c):
     return (c + 7) // 8 * 8
@@ -11,7 +17,7 @@ def to_nhwc(x_nchw, dtype, device="cuda"):
     n, c, h, w = x_nchw.shape
     out = torch.zeros((n, h, w, cpad(c)), dtype=torch.float32)
     out[..., :c] = x_nchw.permute(0, 2, 3, 1)
-    return out.to(device=device, dtype=dtype).contiguous()
+    return out.to(device=device, dtype=storage(dtype)).contiguous()
 
 
 def from_nhwc(y, c):
@@ -20,7 +26,7 @@ def from_nhwc(y, c):
 
 def round_to(x, dtype):
     """What the kernel sees after the operand is stored in `dtype`."""
-    return x.to(dtype).float()
+    return x.to(storage(dtype)).float()
 
 
 def rel_err(a, b):

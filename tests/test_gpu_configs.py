@@ -23,6 +23,7 @@ import pytest
 import torch
 
 from fixture_inputs import synth_bag
+from gpu_util import X3
 from oracle import mil_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -58,7 +59,7 @@ def _oracle_features(sd, x, chunk=64):
 
 
 # ---- configs[0]: the committed reference golden at the configuration's own size ---------------------------------
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, X3], ids=["fp32", "bf16", "bf16x3"])
 def test_config1_golden_64_tiles_256(golden_dir, dtype):
     g = np.load(os.path.join(golden_dir, "eval_n64_256_cfg1.npz"))
     x = synth_bag(64, 256, 256, 20260104)                    # the fixture stores no input: rebuilt from its seed
@@ -84,6 +85,14 @@ def test_config1_golden_64_tiles_256(golden_dir, dtype):
         # gradient norms: 5e-3 — the bias gradients are cancellation-heavy sums over 64*64*64 pixels, where fp32 summation
         # order alone moves the reference itself by 5e-4 (tests/test_oracle_golden.py); measured here 1.2e-3
         assert gerr[worst] < 5e-3, (worst, gerr[worst])
+    elif dtype == X3:
+        # split-precision path (fp32 tensors, bf16x3 products): the north-star gate on every output, with margin — the CPU
+        # emulation of this arithmetic (tools/numerics_formats.py) gives Mterm 2.5e-4, Aterm 1.6e-6, y_pred 8e-7, Bterm 5.6e-4
+        for k, e in err.items():
+            assert e < 1e-3, (k, e)
+        assert err["Aterm"] < 2e-5 and err["y_pred"] < 2e-5 and err["loss"] < 2e-5, err
+        assert frel < 5e-5
+        assert gerr[worst] < 2e-2, (worst, gerr[worst])     # measured 5.4e-3 on a bias gradient (cancellation-heavy pixel sum)
     else:
         # measured on MI355X: Aterm 1.1e-3, Mterm 9.8e-2, y_pred 9.4e-4, loss 2.0e-3, wROIs 5.6e-3, Bterm 0.20, Fterm 4.7e-3,
         # worst gradient norm 12 % (a bias gradient) — the emulating oracle gives the same figures (see module docstring)
@@ -94,7 +103,7 @@ def test_config1_golden_64_tiles_256(golden_dir, dtype):
 
 
 # ---- configs[1]: one bag of the benchmark's shape, against the fp32 oracle --------------------------------------
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, X3], ids=["fp32", "bf16", "bf16x3"])
 def test_config2_bag_256_tiles_vs_oracle(golden_dir, dtype):
     """One 256-tile bag @256x256 — the unit bench.py's step is made of — through the path bench.py times (bf16) and the
     fp32 path, against the fp32 CPU oracle, forward and backward."""
@@ -119,11 +128,11 @@ def test_config2_bag_256_tiles_vs_oracle(golden_dir, dtype):
     print(f"cfg2-bag[{dtype}]: abs err {err}  Aterm rel {arel:.2e}  Fterm rel {frel:.2e}  worst grad-norm rel "
           f"{gerr[worst]:.2e} ({worst})")
     assert int(out["y_pred_hat"]) == int(ref["y_pred_hat"])
-    if dtype == torch.float32:
+    if dtype in (torch.float32, X3):
         for k, e in err.items():
             assert e < 1e-3, (k, e)
         assert arel < 1e-3 and frel < 5e-5, (arel, frel)
-        assert gerr[worst] < 5e-3, (worst, gerr[worst])     # measured 2.4e-3 on a bias gradient (16.8 M-term fp32 sums)
+        assert gerr[worst] < (5e-3 if dtype == torch.float32 else 2e-2), (worst, gerr[worst])     # fp32: measured 2.4e-3 on a bias gradient (16.8 M-term fp32 sums)
         return
     # bf16: measured on MI355X — Aterm 3.2e-4 (3.5 % of the largest weight), Mterm 9.3e-2, y_pred 7.8e-4, loss 6.6e-4,
     # wROIs 2.1e-3, Bterm 0.25, Fterm 4.4e-3, worst gradient norm 23 % (a layer-1 bias gradient)
@@ -158,23 +167,26 @@ def test_config2_bag_256_tiles_vs_oracle(golden_dir, dtype):
 
 
 # ---- configs[2]: 512x512 tiles ---------------------------------------------------------------------------------------
-def test_config3_512_tiles_fp32_vs_oracle(golden_dir):
+@pytest.mark.parametrize("dtype", [torch.float32, X3], ids=["fp32", "bf16x3"])
+def test_config3_512_tiles_fp32_vs_oracle(golden_dir, dtype):
     torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
     x = synth_bag(6, 512, 512, 20260112)
     y = torch.tensor([0])
     sd = orc.load_state(_weights(golden_dir), requires_grad=True)
     ref = orc.attention_forward(sd, x, y)
     ref["loss"].backward()
-    net = _model(golden_dir, torch.float32)
+    net = _model(golden_dir, dtype)
     out = net(x.cuda(), y.cuda())
     out["loss"].backward()
     for k in ("Aterm", "Mterm", "y_pred", "loss", "wROIs", "Bterm"):
-        assert _maxabs(_np(out[k]), ref[k].detach().numpy()) < 1e-3, k
+        e = _maxabs(_np(out[k]), ref[k].detach().numpy())
+        print(f"cfg3[{dtype}] {k}: abs err {e:.2e}")
+        assert e < 1e-3, k
     for k in ("Aterm", "Fterm", "Mterm", "Bterm", "KLD", "loss"):
-        assert _rel(_np(out[k]), ref[k].detach().numpy()) < 2e-4, k
+        assert _rel(_np(out[k]), ref[k].detach().numpy()) < (2e-4 if dtype == torch.float32 else 1e-3), k
     for k, p in net.named_parameters():
         nref = float(sd[k].grad.double().norm())
-        assert abs(float(p.grad.double().norm()) - nref) <= 2e-3 * max(nref, 1e-3), k
+        assert abs(float(p.grad.double().norm()) - nref) <= (2e-3 if dtype == torch.float32 else 2e-2) * max(nref, 1e-3), k
 
 
 def test_config3_full_size_bf16_properties(golden_dir):
@@ -228,7 +240,7 @@ def test_config5_full_bag_attention_map(golden_dir):
         feats.append(_oracle_features(sd, xc))
     with torch.no_grad():
         ref = orc.mil_head(sd, torch.cat(feats), y)
-    for dtype, a_abs, a_rel in ((torch.float32, 1e-3, 1e-3), (torch.bfloat16, 1e-3, 0.1)):      # measured: 1.2e-8 / 1.8e-5; 3.0e-5 / 4.7e-2
+    for dtype, a_abs, a_rel in ((torch.float32, 1e-3, 1e-3), (X3, 1e-3, 1e-3), (torch.bfloat16, 1e-3, 0.1)):      # measured: 1.2e-8 / 1.8e-5; 3.0e-5 / 4.7e-2 (bf16)
         net = _model(golden_dir, dtype)
         with torch.no_grad():
             out = net(xg, y.cuda())
@@ -237,7 +249,7 @@ def test_config5_full_bag_attention_map(golden_dir):
             m_abs = _maxabs(_np(out["Mterm"]), ref["Mterm"].numpy())
             print(f"cfg5[{dtype}]: Aterm abs {e_abs:.2e} rel {e_rel:.2e}  Mterm abs {m_abs:.2e}")
             assert e_abs < a_abs and e_rel < a_rel, (dtype, e_abs, e_rel)
-            assert m_abs < (1e-3 if dtype == torch.float32 else 0.2)      # bf16 logits: stated bound (measured 8.9e-2)
+            assert m_abs < (0.2 if dtype == torch.bfloat16 else 1e-3)      # bf16 logits: stated bound (measured 8.9e-2)
             assert int(out["y_pred_hat"]) == int(ref["y_pred_hat"])
             assert torch.allclose(out["Aterm"].sum(dim=1), torch.ones(3, device="cuda"), atol=1e-5)
             # what 8 ranks do (Attention.forward_tile_parallel): encode a slice each, gather, replicated head
@@ -245,6 +257,9 @@ def test_config5_full_bag_attention_map(golden_dir):
             _l, _l2, a1, *_ = head_apply(H, BagLayout([n], H.device), y.cuda(), None, None, net.head_weights())
             if dtype == torch.float32:          # fp32: the same bits whatever the launch a tile shares
                 assert torch.equal(H, out["Fterm"]) and torch.equal(a1.t(), out["Aterm"])
+            elif dtype == X3:                   # split products: other kernels / tile shapes for a 512-tile launch, fp32 storage
+                assert float((H - out["Fterm"]).abs().max() / out["Fterm"].abs().max()) < 1e-4
+                assert _maxabs(_np(a1.t()), ref["Aterm"].numpy()) < a_abs
             else:
                 # bf16: a 512-tile launch picks other tile shapes / kernels for the small late maps than a 4096-tile one
                 # (different MFMA summation order -> a bf16 store lands on the neighbouring value now and then): same map

@@ -6,13 +6,29 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from gpu_util import cpad, from_nhwc, rel_err, round_to, to_nhwc
+from gpu_util import X3, cpad, from_nhwc, rel_err, round_to, storage, to_nhwc
 
 pytestmark = pytest.mark.gpu
 
 DTYPES = [torch.float32, torch.bfloat16]
-TOL = {torch.float32: 2e-5, torch.bfloat16: 8e-3}
+# the convolution entry points also run fp32 tensors as bf16x3 split products (MIL_DT_F32S): un-rounded fp32 operands, 16
+# significant bits per operand (2^-17 relative per product, random signs), fp32 accumulation
+CONV_DTYPES = DTYPES + [X3]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 8e-3, X3: 6e-5}
+WTOL = {torch.float32: 3e-5, torch.bfloat16: 3e-5, X3: 6e-5}
 LEAK = 0.1
+
+
+@pytest.fixture(autouse=True)
+def _mma_mode(request):
+    """dtype == "bf16x3": the convolution wrappers pass MIL_DT_F32S for their fp32 tensors inside the test."""
+    params = request.node.callspec.params if hasattr(request.node, "callspec") else {}
+    if params.get("dtype") == X3:
+        from mil_amd import _lib as L
+        with L.f32_mma(L.MIL_DT_F32S):
+            yield
+    else:
+        yield
 
 
 @pytest.fixture(scope="module")
@@ -57,7 +73,7 @@ def kernel_path(request, monkeypatch):
     return request.param
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype", CONV_DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_forward_epilogues(ops, dtype, case, kernel_path):
     L = _lib()
@@ -84,7 +100,7 @@ def test_conv_forward_epilogues(ops, dtype, case, kernel_path):
     assert rel_err(from_nhwc(y, cout), F.conv2d(x, wt, None, stride=stride, padding=pad)) < TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype", CONV_DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_dgrad_and_wgrad(ops, dtype, case, kernel_path):
     L = _lib()
@@ -113,14 +129,14 @@ def test_conv_dgrad_and_wgrad(ops, dtype, case, kernel_path):
 
     dw, db = ops.conv_wgrad(to_nhwc(x.detach(), dtype), dzg, cin, cout, ks=ks, stride=stride, pad=pad)
     assert dw.shape == wt.shape
-    assert rel_err(dw.cpu(), wt.grad) < 3e-5      # operands are exact in both dtypes; accumulation is fp32
-    assert rel_err(db.cpu(), b.grad) < 3e-5
+    assert rel_err(dw.cpu(), wt.grad) < WTOL[dtype]      # fp32 / bf16: operands are exact, accumulation is fp32
+    assert rel_err(db.cpu(), b.grad) < WTOL[dtype]
     # bitwise reproducible (fixed-order slab reduction, no float atomics)
     dw2, db2 = ops.conv_wgrad(to_nhwc(x.detach(), dtype), dzg, cin, cout, ks=ks, stride=stride, pad=pad)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype", CONV_DTYPES)
 @pytest.mark.parametrize("shape", [(2, 32, 32), (3, 50, 70), (1, 37, 41), (2, 64, 64)])
 def test_stem_conv_and_wgrad(ops, dtype, shape, kernel_path):
     L = _lib()
@@ -131,7 +147,7 @@ def test_stem_conv_and_wgrad(ops, dtype, shape, kernel_path):
     b = (torch.randn(20, generator=g) * 0.1).requires_grad_(True)
     lin = F.conv2d(x, wt, b, stride=2, padding=3)
     ref = F.leaky_relu(lin, LEAK)
-    xs = ops.stem_s2d(x.cuda(), dtype)
+    xs = ops.stem_s2d(x.cuda(), storage(dtype))
     assert xs.shape == (n, (h + 1) // 2, (w + 1) // 2, 16)
     wp, bp = ops.pack_weights(wt.detach().cuda(), b.detach().cuda(), L.PACK_STEM, dtype)
     y = ops.conv(xs, wp, bp, 24, ks=4, stride=1, pad=2, lrelu=True)
@@ -141,8 +157,8 @@ def test_stem_conv_and_wgrad(ops, dtype, shape, kernel_path):
     lin.backward(dz)
     dw, db = ops.conv_wgrad(xs, to_nhwc(dz, dtype), 3, 20, ks=4, stride=1, pad=2, stem=True)
     assert dw.shape == (20, 3, 7, 7)
-    assert rel_err(dw.cpu(), wt.grad) < 3e-5
-    assert rel_err(db.cpu(), b.grad) < 3e-5
+    assert rel_err(dw.cpu(), wt.grad) < WTOL[dtype]
+    assert rel_err(db.cpu(), b.grad) < WTOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
