@@ -167,17 +167,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs<T> a) {
 #endif
 // NW = waves per workgroup: 4, or 8 for the layers whose resident filter leaves room for only ONE workgroup per CU
 // (64 channels: 72 KB of filter) — eight waves on the same LDS tiles give every SIMD a second wave to overlap with.
-template <int CINP, int NT, int KS, int MTW, int FLAGS = -1, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? (CINP <= 40 ? 4 : 2) : ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 24 && FLAGS >= 0 && FLAGS != 3) ? MIL_PF_WAVES_24 : (CINP <= 40 ? 2 : 1)))
-void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsigned y_bytes) {
+// T = BF16, or F32S: the same pipeline on fp32 tensors with split-precision products (MIL_DT_F32S) — the halo pieces are
+// split into hi/lo bf16 planes when they are committed to LDS, every (filter, pixel) fragment pair costs three MFMAs, and
+// the register epilogue loads / stores its 8 channels per lane as two 16-byte accesses.  At most two waves per SIMD there
+// (the prefetch and epilogue register sets double).
+template <typename T> struct Epi8;          // 8 consecutive channels of one pixel, as fetched: residual / mask operands
+template <> struct Epi8<BF16> { u32x4_t v[1]; };
+template <> struct Epi8<F32S> { u32x4_t v[2]; };
+
+template <typename T, int CINP, int NT, int KS, int MTW, int FLAGS = -1, int NW = 4>
+__global__ __launch_bounds__(64 * NW, T::SPLIT ? (NW == 8 ? 2 : (CINP <= 24 ? 2 : 1)) : (NW == 8 ? (CINP <= 40 ? 4 : 2) : ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 24 && FLAGS >= 0 && FLAGS != 3) ? MIL_PF_WAVES_24 : (CINP <= 40 ? 2 : 1))))
+void conv_igemm_pf_kernel(ConvArgs<T> a, int ntiles, unsigned x_bytes, unsigned y_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using T = BF16;
-    constexpr bool PIPE = MIL_PF_PIPE(CINP, NT, MTW, NW);
-    constexpr int PIXB = mil_pix_pitch(CINP, 2);
+    constexpr int ESZ = T::ESZ;
+    constexpr int FRAGB = 8 * ESZ;              // bytes of one packed filter fragment per lane
+    constexpr bool PIPE = !T::SPLIT && MIL_PF_PIPE(CINP, NT, MTW, NW);
+    constexpr int PIXB = mil_pix_pitch(CINP, ESZ);
     constexpr int CG = CINP / 8;
     constexpr int COUTP = mil_nt_to_cp(NT);
     constexpr int NTHR = 64 * NW;
-    constexpr int NPX = (mil_halo_px_max(NW * MTW == 16 ? 4 : 2) * (CINP * 2 / 16) + NTHR - 1) / NTHR;
+    constexpr int NPX = (mil_halo_px_max(NW * MTW == 16 ? 4 : 2) * (CINP * ESZ / 16) + NTHR - 1) / NTHR;
     constexpr int KSTEPS = (KS * KS * CG + 3) / 4;
     constexpr bool LAST_PARTIAL = (COUTP % 16) != 0;        // the last column tile holds only 8 channels
     const ConvGeom& g = a.g;
@@ -190,7 +199,7 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
     const bool has_act = FLAGS < 0 ? (a.act != nullptr) : (FLAGS & 2) != 0;
     const bool do_lrelu = FLAGS < 0 ? (a.apply_lrelu != 0) : (FLAGS & 4) != 0;
 
-    mil_stage_filter(ldsW, a.w, KSTEPS * NT * 64 * 16, tid, NTHR);
+    mil_stage_filter(ldsW, a.w, KSTEPS * NT * 64 * FRAGB, tid, NTHR);
     const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, x_bytes);
     const __amdgpu_buffer_rsrc_t rs_res = mil_rsrc(a.res, a.res ? y_bytes : 0);
     const __amdgpu_buffer_rsrc_t rs_act = mil_rsrc(a.act, a.act ? y_bytes : 0);
@@ -200,8 +209,8 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
 
     // ---- tile-invariant tables ---------------------------------------------------------------------
     HaloTables<NPX> ht;
-    mil_build_halo_tables<CINP, NPX, NTHR>(ht, g, tid);
-    mil_halo_tables_use_dump<NPX>(ht, a.lds_dump_rel);                           // 16 spare bytes behind each halo buffer
+    mil_build_halo_tables<CINP, NPX, NTHR, T>(ht, g, tid);
+    mil_halo_tables_use_dump<NPX>(ht, a.lds_dump_rel);                           // spare bytes behind each halo buffer
     int toff[KSTEPS];
 #pragma unroll
     for (int sl = 0; sl < KSTEPS; ++sl) {
@@ -231,7 +240,7 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
     for (int p = 0; p < NPAIR; ++p) {
         const int tp = PAIRED ? (wave * MTW + 2 * p + (gq & 1)) * 16 + r : wave * 16 + r;
         const int tx = tp & (TW - 1), ty = (tp >> g.tw_log2) & (TH - 1), ti = tp >> (g.tw_log2 + g.th_log2);
-        o_rel[p] = ((ti * g.Ho + ty) * g.Wo + tx) * (COUTP * 2) + (PAIRED ? (gq >> 1) * 16 : gq * 8);
+        o_rel[p] = ((ti * g.Ho + ty) * g.Wo + tx) * (COUTP * ESZ) + (PAIRED ? (gq >> 1) * 8 : gq * 4) * ESZ;
         o_pos[p] = (ti << 20) | (ty << 10) | tx;
     }
     // channels of the last column tile this lane owns exist
@@ -247,8 +256,8 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
     cur.init(g, bid, gridDim.x);
     nxt = cur; nxt.advance();
     // epilogue operand offsets + loads of one tile (16 bytes = 8 channels per lane per (row-tile pair, column tile))
-    auto fetch_epi = [&](const TileOrigin& o, unsigned (&ooff)[NPAIR], u32x4_t (&rres)[NPAIR][NT], u32x4_t (&ract)[NPAIR][NT]) {
-        const int obase = ((o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (COUTP * 2);
+    auto fetch_epi = [&](const TileOrigin& o, unsigned (&ooff)[NPAIR], Epi8<T> (&rres)[NPAIR][NT], Epi8<T> (&ract)[NPAIR][NT]) {
+        const int obase = ((o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (COUTP * ESZ);
         const int ylim = g.Ho - o.oy0, xlim = g.Wo - o.ox0, ilim = g.n_img - o.img0;
 #pragma unroll
         for (int p = 0; p < NPAIR; ++p) {
@@ -256,13 +265,21 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
             ooff[p] = ok ? (unsigned)(obase + o_rel[p]) : MIL_OOB;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 32;
+                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 16 * ESZ;
                 if constexpr (PAIRED) {
-                    if (has_res) rres[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0);
-                    if (has_act) ract[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, off, 0, 0);
+                    if (has_res) rres[p][nt].v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0);
+                    if (has_act) ract[p][nt].v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, off, 0, 0);
+                    if constexpr (T::SPLIT) {           // fp32: channels 4-7 of the lane's eight
+                        const unsigned off2 = off == MIL_OOB ? MIL_OOB : off + 16;
+                        if (has_res) rres[p][nt].v[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off2, 0, 0);
+                        if (has_act) ract[p][nt].v[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, off2, 0, 0);
+                    }
+                } else if constexpr (T::SPLIT) {        // four fp32 channels per lane
+                    if (has_res) rres[p][nt].v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0);
+                    if (has_act) ract[p][nt].v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, off, 0, 0);
                 } else {
-                    if (has_res) { const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rs_res, off, 0, 0); rres[p][nt][0] = t[0]; rres[p][nt][1] = t[1]; }
-                    if (has_act) { const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rs_act, off, 0, 0); ract[p][nt][0] = t[0]; ract[p][nt][1] = t[1]; }
+                    if (has_res) { const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rs_res, off, 0, 0); rres[p][nt].v[0][0] = t[0]; rres[p][nt].v[0][1] = t[1]; }
+                    if (has_act) { const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rs_act, off, 0, 0); ract[p][nt].v[0][0] = t[0]; ract[p][nt].v[0][1] = t[1]; }
                 }
             }
         }
@@ -273,7 +290,7 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
     // DEPTH: how many tiles ahead the halo loads run.  A load round trip under load is ~2 us whether it hits
     // L2 or HBM, about one tile time, so the narrowest layers keep TWO tiles of halo loads in flight (two
     // register sets, tile loop unrolled by two).
-    constexpr bool EPI_AHEAD = CINP <= 24;
+    constexpr bool EPI_AHEAD = CINP <= 24 && !T::SPLIT;
 #ifndef MIL_PF_DEPTH40
 #define MIL_PF_DEPTH40 1
 #endif
@@ -291,13 +308,13 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
     // as this tile's epilogue has consumed it (the loads then fly under the next tile's barriers and MFMA loop instead of
     // being issued at its start and waited for right after its MFMA loop).
     unsigned ooff_n[NPAIR];
-    u32x4_t rres_n[NPAIR][NT], ract_n[NPAIR][NT];
+    Epi8<T> rres_n[NPAIR][NT], ract_n[NPAIR][NT];
     if (bid < ntiles) {
-        mil_fetch_halo<CINP, NPX>(rxA, rs_x, ht, g, cur.origin(g));
+        mil_fetch_halo<CINP, NPX, T>(rxA, rs_x, ht, g, cur.origin(g));
         fetch_epi(cur.origin(g), ooff_n, rres_n, ract_n);
     }
     if constexpr (DEPTH == 2) {
-        if (bid + G < ntiles) mil_fetch_halo<CINP, NPX>(rxB, rs_x, ht, g, nxt.origin(g));
+        if (bid + G < ntiles) mil_fetch_halo<CINP, NPX, T>(rxB, rs_x, ht, g, nxt.origin(g));
     }
 
     // Two halo buffers (when LDS allows): the next tile's halo is committed into the buffer the tile BEFORE the current
@@ -309,10 +326,10 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
         if (buf_step == 0) __syncthreads();    // single buffer: every wave has finished reading ldsA for the previous tile
         char* ldsA_t = ldsA + buf;
         buf = buf_step - buf;
-        mil_commit_halo_all<NPX>(rx, ldsA_t, ht);
+        mil_commit_halo_all<NPX, T, CINP>(rx, ldsA_t, ht);
         // this tile's epilogue operands were requested one tile ago; take them over before re-issuing
         unsigned ooff_l[NPAIR];
-        u32x4_t rres_l[NPAIR][NT], ract_l[NPAIR][NT];
+        Epi8<T> rres_l[NPAIR][NT], ract_l[NPAIR][NT];
         if constexpr (EPI_AHEAD) {
 #pragma unroll
             for (int p = 0; p < NPAIR; ++p) {
@@ -326,7 +343,7 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
         auto& ract = *(EPI_AHEAD ? &ract_l : &ract_n);
         __syncthreads();
         // issue-early: refill the register set just written to LDS with the halo of the tile DEPTH ahead
-        if (tile + DEPTH * G < ntiles) mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, (DEPTH == 2 ? nx2 : nxt).origin(g));
+        if (tile + DEPTH * G < ntiles) mil_fetch_halo<CINP, NPX, T>(rx, rs_x, ht, g, (DEPTH == 2 ? nx2 : nxt).origin(g));
         if constexpr (EPI_AHEAD) {
             if (tile + G < ntiles) fetch_epi(nxt.origin(g), ooff_n, rres_n, ract_n);
         }
@@ -369,10 +386,10 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
         for (int sl = 0; sl < KSTEPS; ++sl) {
             Frag8<T> wf[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<T>(ldsW + ((sl * NT + nt) * 64 + lane) * 16);
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<T>(ldsW + ((sl * NT + nt) * 64 + lane) * FRAGB);
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
-                const Frag8<T> xf = lds_frag<T>(ldsA_t + pixbase[m] + toff[sl]);
+                const Frag8<T> xf = lds_pix_frag<T, CINP * 2>(ldsA_t + pixbase[m] + toff[sl]);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wf[nt], xf, acc[m][nt]);   // D[channel][pixel]
             }
@@ -387,25 +404,42 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
                 float v[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = acc[0][nt][i];
-                if (has_res) {
-                    const bf16x4_t t = __builtin_bit_cast(bf16x4_t, u32x2_t{rres[0][nt][0], rres[0][nt][1]});
+                auto four = [](const Epi8<T>& e, float (&f)[4]) {
+                    if constexpr (T::SPLIT) {
+                        const f32x4_t t = __builtin_bit_cast(f32x4_t, e.v[0]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += (float)t[i];
+                        for (int i = 0; i < 4; ++i) f[i] = t[i];
+                    } else {
+                        const bf16x4_t t = __builtin_bit_cast(bf16x4_t, u32x2_t{e.v[0][0], e.v[0][1]});
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) f[i] = (float)t[i];
+                    }
+                };
+                if (has_res) {
+                    float rv[4];
+                    four(rres[0][nt], rv);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += rv[i];
                 }
                 if (do_lrelu) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], v[i] * a.slope);
                 }
                 if (has_act) {
-                    const bf16x4_t t = __builtin_bit_cast(bf16x4_t, u32x2_t{ract[0][nt][0], ract[0][nt][1]});
+                    float av[4];
+                    four(ract[0][nt], av);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] *= ((float)t[i] > 0.f ? 1.f : a.slope);
+                    for (int i = 0; i < 4; ++i) v[i] *= (av[i] > 0.f ? 1.f : a.slope);
                 }
-                bf16x4_t ov;
+                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[0] + nt * 16 * ESZ;
+                if constexpr (T::SPLIT) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4_t{v[0], v[1], v[2], v[3]}), rs_y, off, 0, 0);
+                } else {
+                    bf16x4_t ov;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ov[i] = (__bf16)v[i];
-                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[0] + nt * 32;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, ov), rs_y, off, 0, 0);
+                    for (int i = 0; i < 4; ++i) ov[i] = (__bf16)v[i];
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, ov), rs_y, off, 0, 0);
+                }
             }
         } else {
 #pragma unroll
@@ -420,25 +454,46 @@ void conv_igemm_pf_kernel(ConvArgs<BF16> a, int ntiles, unsigned x_bytes, unsign
                     v[i] = lo;
                     v[4 + i] = hi;
                 }
-                if (has_res) {
-                    const bf16x8_t t = __builtin_bit_cast(bf16x8_t, rres[p][nt]);
+                auto eight = [](const Epi8<T>& e, float (&f)[8]) {
+                    if constexpr (T::SPLIT) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] += (float)t[i];
+                        for (int h = 0; h < 2; ++h) {
+                            const f32x4_t t = __builtin_bit_cast(f32x4_t, e.v[h]);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) f[4 * h + i] = t[i];
+                        }
+                    } else {
+                        const bf16x8_t t = __builtin_bit_cast(bf16x8_t, e.v[0]);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) f[i] = (float)t[i];
+                    }
+                };
+                if (has_res) {
+                    float rv[8];
+                    eight(rres[p][nt], rv);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] += rv[i];
                 }
                 if (do_lrelu) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], v[i] * a.slope);      // 0 < slope < 1
                 }
                 if (has_act) {
-                    const bf16x8_t t = __builtin_bit_cast(bf16x8_t, ract[p][nt]);
+                    float av[8];
+                    eight(ract[p][nt], av);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] *= ((float)t[i] > 0.f ? 1.f : a.slope);
+                    for (int i = 0; i < 8; ++i) v[i] *= (av[i] > 0.f ? 1.f : a.slope);
                 }
-                bf16x8_t ov;
+                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 16 * ESZ;
+                if constexpr (T::SPLIT) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4_t{v[0], v[1], v[2], v[3]}), rs_y, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4_t{v[4], v[5], v[6], v[7]}), rs_y, off == MIL_OOB ? MIL_OOB : off + 16, 0, 0);
+                } else {
+                    bf16x8_t ov;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) ov[i] = (__bf16)v[i];
-                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 32;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), rs_y, off, 0, 0);
+                    for (int i = 0; i < 8; ++i) ov[i] = (__bf16)v[i];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), rs_y, off, 0, 0);
+                }
             }
         }
         }
@@ -519,20 +574,22 @@ static int mil_pf_waves64() {
 #ifndef MIL_PF_MTW_24
 #define MIL_PF_MTW_24 4
 #endif
-template <int CINP, int NT, int KS, int MTW, int FLAGS, int NW = 4>
-static auto conv_pf_variant() { return conv_igemm_pf_kernel<CINP, NT, KS, MTW, FLAGS, NW>; }
+template <typename T, int CINP, int NT, int KS, int MTW, int FLAGS, int NW = 4>
+static auto conv_pf_variant() { return conv_igemm_pf_kernel<T, CINP, NT, KS, MTW, FLAGS, NW>; }
 
-template <int CINP, int NT, int KS, int MTW = 4, int NW = 4>
-static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool* taken) {
-    ConvArgs<BF16> a = a0;
-    constexpr int PIXB = mil_pix_pitch(CINP, 2);
+template <typename T, int CINP, int NT, int KS, int MTW = 4, int NW = 4>
+static int launch_conv_pf_ks(const ConvArgs<T>& a0, hipStream_t stream, bool* taken) {
+    ConvArgs<T> a = a0;
+    constexpr int ESZ = T::ESZ;
+    constexpr int PIXB = mil_pix_pitch(CINP, ESZ);
     constexpr int COUTP = mil_nt_to_cp(NT);
+    constexpr int DUMPB = T::SPLIT ? CINP * 2 + 16 : 16;        // spare bytes behind a halo buffer for the branch-free commit (split: hi + lo)
     *taken = false;
     mil_geom_tiles(a.g, NW * MTW == 16 ? 8 : 7);
     const int halo_px = (a.g.hh * a.g.hw) << a.g.ti_log2;
     if (halo_px > mil_halo_px_max(NW * MTW == 16 ? 4 : 2)) return MIL_OK;
-    const int a_bytes = ((halo_px * PIXB + 15) & ~15) + 16;  // + dump slot for the branch-free halo commit
-    const int w_bytes = a.nsteps * NT * 64 * 16;
+    const int a_bytes = ((halo_px * PIXB + 15) & ~15) + DUMPB;  // + dump slot for the branch-free halo commit
+    const int w_bytes = a.nsteps * NT * 64 * 8 * ESZ;
     // a second halo buffer (one barrier per tile instead of two) when it does not cost a resident workgroup
     const bool dbuf = mil_pf_double_buffer() && (160 * 1024) / (2 * a_bytes + w_bytes) >= ((160 * 1024) / (a_bytes + w_bytes) > 2 ? 3 : (160 * 1024) / (a_bytes + w_bytes));
     const int lds = (dbuf ? 2 : 1) * a_bytes + w_bytes;
@@ -542,15 +599,15 @@ static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool*
     a.kc = a.nsteps;
     a.lds_w_off = (dbuf ? 2 : 1) * a_bytes;
     a.lds_a2_off = dbuf ? a_bytes : 0;
-    a.lds_dump_rel = a_bytes - 16;
-    auto kern = conv_igemm_pf_kernel<CINP, NT, KS, MTW, -1, NW>;
+    a.lds_dump_rel = a_bytes - DUMPB;
+    auto kern = conv_igemm_pf_kernel<T, CINP, NT, KS, MTW, -1, NW>;
     // the hot square 3x3 layers get the epilogue options as compile-time constants
     if constexpr (KS == 3 && ((CINP == 24 && NT == 2) || (CINP == 40 && NT == 3) || (CINP == 64 && NT == 4) || (CINP == 80 && NT == 5))) {
         const int fl = (a.res ? 1 : 0) | (a.act ? 2 : 0) | (a.apply_lrelu ? 4 : 0);
-        if (fl == 4) kern = conv_pf_variant<CINP, NT, KS, MTW, 4, NW>();
-        else if (fl == 5) kern = conv_pf_variant<CINP, NT, KS, MTW, 5, NW>();
-        else if (fl == 2) kern = conv_pf_variant<CINP, NT, KS, MTW, 2, NW>();
-        else if (fl == 3) kern = conv_pf_variant<CINP, NT, KS, MTW, 3, NW>();
+        if (fl == 4) kern = conv_pf_variant<T, CINP, NT, KS, MTW, 4, NW>();
+        else if (fl == 5) kern = conv_pf_variant<T, CINP, NT, KS, MTW, 5, NW>();
+        else if (fl == 2) kern = conv_pf_variant<T, CINP, NT, KS, MTW, 2, NW>();
+        else if (fl == 3) kern = conv_pf_variant<T, CINP, NT, KS, MTW, 3, NW>();
     }
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -558,19 +615,19 @@ static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool*
     }
     const int per_cu = mil_resident_per_cu(kern, lds, MIL_PF_WG_PER_CU, 64 * NW) * mil_pf_rounds();   // rounds of resident workgroups
     // buffer descriptors address < 2 GiB: split the launch by images when a tensor is larger
-    const size_t x_img = (size_t)a.g.H * a.g.W * CINP * 2, y_img = (size_t)a.g.Ho * a.g.Wo * COUTP * 2;
+    const size_t x_img = (size_t)a.g.H * a.g.W * CINP * ESZ, y_img = (size_t)a.g.Ho * a.g.Wo * COUTP * ESZ;
     int chunk = mil_imgs_under_2g(x_img > y_img ? x_img : y_img);
     if (chunk >= 16) chunk &= ~15;                       // keep image groups (<= 16 images per tile) intact
     const int n_total = a0.g.n_img;
     for (int i0 = 0; i0 < n_total; i0 += chunk) {
         const int n = (n_total - i0 < chunk) ? n_total - i0 : chunk;
-        ConvArgs<BF16> c = a;
+        ConvArgs<T> c = a;
         c.g.n_img = n;
         c.g.n_groups = (n + (1 << c.g.ti_log2) - 1) >> c.g.ti_log2;
-        c.x = a.x + (size_t)i0 * (x_img / 2);
-        c.y = a.y + (size_t)i0 * (y_img / 2);
-        if (a.res) c.res = a.res + (size_t)i0 * (y_img / 2);
-        if (a.act) c.act = a.act + (size_t)i0 * (y_img / 2);
+        c.x = a.x + (size_t)i0 * (x_img / ESZ);
+        c.y = a.y + (size_t)i0 * (y_img / ESZ);
+        if (a.res) c.res = a.res + (size_t)i0 * (y_img / ESZ);
+        if (a.act) c.act = a.act + (size_t)i0 * (y_img / ESZ);
         const int ntiles = c.g.n_groups * c.g.tiles_y * c.g.tiles_x;
         int grid = mil_num_cus() * per_cu;
         if (grid > ntiles) grid = ntiles;
@@ -581,36 +638,36 @@ static int launch_conv_pf_ks(const ConvArgs<BF16>& a0, hipStream_t stream, bool*
     return MIL_OK;
 }
 
-template <int CINP, int NT>
-static int launch_conv_pf(const ConvArgs<BF16>& a, hipStream_t stream, bool* taken) {
+template <typename T, int CINP, int NT>
+static int launch_conv_pf(const ConvArgs<T>& a, hipStream_t stream, bool* taken) {
     *taken = false;
-    if constexpr (CINP == 16 && NT == 2) { if (a.g.ks == 4) return launch_conv_pf_ks<16, 2, 4>(a, stream, taken); }
-    if constexpr (CINP == 24 && NT == 2) { if (a.g.ks == 3) return launch_conv_pf_ks<24, 2, 3, MIL_PF_MTW_24>(a, stream, taken); }
+    if constexpr (CINP == 16 && NT == 2) { if (a.g.ks == 4) return launch_conv_pf_ks<T, 16, 2, 4>(a, stream, taken); }
+    if constexpr (CINP == 24 && NT == 2) { if (a.g.ks == 3) return launch_conv_pf_ks<T, 24, 2, 3, MIL_PF_MTW_24>(a, stream, taken); }
 #ifndef MIL_PF40_WAVES
 #define MIL_PF40_WAVES 8        // measured in the model: 122 / 100 us per launch with 4 waves, 114 / 88 us with 8 (four waves per SIMD)
 #endif
     if constexpr (CINP == 40 && NT == 3) {
-        if (a.g.ks == 3) return MIL_PF40_WAVES == 8 ? launch_conv_pf_ks<40, 3, 3, 2, 8>(a, stream, taken) : launch_conv_pf_ks<40, 3, 3>(a, stream, taken);
+        if (a.g.ks == 3) return MIL_PF40_WAVES == 8 ? launch_conv_pf_ks<T, 40, 3, 3, 2, 8>(a, stream, taken) : launch_conv_pf_ks<T, 40, 3, 3>(a, stream, taken);
     }
     if constexpr (CINP == 40 && NT == 2) {
-        if (a.g.ks == 3) return launch_conv_pf_ks<40, 2, 3>(a, stream, taken);
-        if (a.g.ks == 1) return launch_conv_pf_ks<40, 2, 1>(a, stream, taken);
+        if (a.g.ks == 3) return launch_conv_pf_ks<T, 40, 2, 3>(a, stream, taken);
+        if (a.g.ks == 1) return launch_conv_pf_ks<T, 40, 2, 1>(a, stream, taken);
     }
     if constexpr (CINP == 64 && NT == 4) {
-        if (a.g.ks == 3) return mil_pf_waves64() == 8 ? launch_conv_pf_ks<64, 4, 3, 2, 8>(a, stream, taken) : launch_conv_pf_ks<64, 4, 3>(a, stream, taken);
+        if (a.g.ks == 3) return mil_pf_waves64() == 8 ? launch_conv_pf_ks<T, 64, 4, 3, 2, 8>(a, stream, taken) : launch_conv_pf_ks<T, 64, 4, 3>(a, stream, taken);
     }
     if constexpr (CINP == 64 && NT == 3) {
-        if (a.g.ks == 3) return launch_conv_pf_ks<64, 3, 3>(a, stream, taken);
-        if (a.g.ks == 1) return launch_conv_pf_ks<64, 3, 1>(a, stream, taken);
+        if (a.g.ks == 3) return launch_conv_pf_ks<T, 64, 3, 3>(a, stream, taken);
+        if (a.g.ks == 1) return launch_conv_pf_ks<T, 64, 3, 1>(a, stream, taken);
     }
     // 80-channel layers: the whole filter (115 KB) stays resident, so the tile shrinks to 128 px
     // (eight waves with one row tile each by default: one workgroup per CU either way, but two waves per SIMD)
     if constexpr (CINP == 80 && NT == 5) {
-        if (a.g.ks == 3) return mil_pf_waves64() == 8 ? launch_conv_pf_ks<80, 5, 3, 1, 8>(a, stream, taken) : launch_conv_pf_ks<80, 5, 3, 2>(a, stream, taken);
+        if (a.g.ks == 3) return mil_pf_waves64() == 8 ? launch_conv_pf_ks<T, 80, 5, 3, 1, 8>(a, stream, taken) : launch_conv_pf_ks<T, 80, 5, 3, 2>(a, stream, taken);
     }
     if constexpr (CINP == 80 && NT == 4) {
-        if (a.g.ks == 3) return mil_pf_waves64() == 8 ? launch_conv_pf_ks<80, 4, 3, 1, 8>(a, stream, taken) : launch_conv_pf_ks<80, 4, 3, 2>(a, stream, taken);
-        if (a.g.ks == 1) return launch_conv_pf_ks<80, 4, 1, 2>(a, stream, taken);
+        if (a.g.ks == 3) return mil_pf_waves64() == 8 ? launch_conv_pf_ks<T, 80, 4, 3, 1, 8>(a, stream, taken) : launch_conv_pf_ks<T, 80, 4, 3, 2>(a, stream, taken);
+        if (a.g.ks == 1) return launch_conv_pf_ks<T, 80, 4, 1, 2>(a, stream, taken);
     }
     return MIL_OK;
 }
@@ -618,10 +675,10 @@ static int launch_conv_pf(const ConvArgs<BF16>& a, hipStream_t stream, bool* tak
 // 256-px tiles (4 MFMA row tiles per wave) when the halo + a weight chunk fit in LDS, else 64-px tiles.
 template <typename T, int CINP, int NT>
 static int launch_conv_auto(const ConvArgs<T>& a, bool small_tile, hipStream_t stream) {
-    if constexpr (T::DT == MIL_DT_BF16) {
+    if constexpr (T::DT != MIL_DT_F32) {        // bf16 and split-precision fp32: the persistent prefetch-pipelined kernel when it fits
         if (!small_tile) {
             bool taken = false;
-            const int rc = launch_conv_pf<CINP, NT>(a, stream, &taken);
+            const int rc = launch_conv_pf<T, CINP, NT>(a, stream, &taken);
             if (rc != MIL_OK || taken) return rc;
         }
     }

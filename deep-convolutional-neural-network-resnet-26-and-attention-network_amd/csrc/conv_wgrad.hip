@@ -130,26 +130,26 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0))
         rs_x = mil_rsrc(a.x, a.x_bytes);
         rs_z = mil_rsrc(a.dz, a.z_bytes);
         if constexpr (PROJ) rs_z2 = mil_rsrc(a.dz2, a.z_bytes);
-        mil_build_halo_tables<CINP, NPX, NTHR>(ht, g, tid);
-        mil_build_otile_tables<COUTP, NPZ, NTHR>(zt, g, tid, a.tile_px);
+        mil_build_halo_tables<CINP, NPX, NTHR, T>(ht, g, tid);
+        mil_build_otile_tables<COUTP, NPZ, NTHR, T>(zt, g, tid, a.tile_px);
         cur.init(g, bid, gridDim.x);
         nxt = cur; nxt.advance();
         if (bid < a.ntiles) {
-            mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, cur.origin(g));
-            mil_fetch_otile<COUTP, NPZ>(rz, rs_z, zt, g, cur.origin(g));
-            if constexpr (PROJ) mil_fetch_otile<COUTP, NPZ>(rz2, rs_z2, zt, g, cur.origin(g));
+            mil_fetch_halo<CINP, NPX, T>(rx, rs_x, ht, g, cur.origin(g));
+            mil_fetch_otile<COUTP, NPZ, T>(rz, rs_z, zt, g, cur.origin(g));
+            if constexpr (PROJ) mil_fetch_otile<COUTP, NPZ, T>(rz2, rs_z2, zt, g, cur.origin(g));
         }
     }
     for (int tile = bid; tile < a.ntiles; tile += gridDim.x) {
         __syncthreads();
         if constexpr (PF) {
-            mil_commit_halo<NPX>(rx, ldsX, ht);
-            mil_commit_otile<NPZ>(rz, ldsZ, zt);
-            if constexpr (PROJ) mil_commit_otile<NPZ>(rz2, ldsZ2, zt);
+            mil_commit_halo<NPX, T, CINP>(rx, ldsX, ht);
+            mil_commit_otile<NPZ, T, COUTP>(rz, ldsZ, zt);
+            if constexpr (PROJ) mil_commit_otile<NPZ, T, COUTP>(rz2, ldsZ2, zt);
             if (tile + (int)gridDim.x < a.ntiles) {
-                mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, nxt.origin(g));
-                mil_fetch_otile<COUTP, NPZ>(rz, rs_z, zt, g, nxt.origin(g));
-                if constexpr (PROJ) mil_fetch_otile<COUTP, NPZ>(rz2, rs_z2, zt, g, nxt.origin(g));
+                mil_fetch_halo<CINP, NPX, T>(rx, rs_x, ht, g, nxt.origin(g));
+                mil_fetch_otile<COUTP, NPZ, T>(rz, rs_z, zt, g, nxt.origin(g));
+                if constexpr (PROJ) mil_fetch_otile<COUTP, NPZ, T>(rz2, rs_z2, zt, g, nxt.origin(g));
             }
             cur = nxt; nxt.advance();
         } else {
@@ -414,7 +414,7 @@ static int plan_wgrad(ConvGeom& g, WgradPlan& pl, int* lds_z_off, bool proj = fa
     constexpr int RG = KS * KS * (CINP / 8);
     constexpr int MT = (RG + 1) / 2;
     // 256-px tiles when the halo fits comfortably, else 64-px tiles (stride-2 layers, f32 wide layers)
-    constexpr bool PF_OK = (T::DT == MIL_DT_BF16);
+    constexpr bool PF_OK = T::TR16 && (!T::SPLIT || CINP < 64);            // bf16, and fp32 with split-precision products: the register-prefetch pipeline
     const int hmax = mil_wgrad_halo_max(CINP, proj);
     for (int lg = 8; lg >= 6; --lg) {
         if (lg == 7 && hmax == 400) continue;             // 128-pixel tiles only where the prefetch registers are sized for their halo
@@ -452,7 +452,8 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     a.dz2 = (const typename T::elem*)dz2;
     a.lds_z2_off = lds_z_off + (1 << pl.tile_px_log2) * mil_pix_pitch(mil_nt_to_cp(NT), T::ESZ);
     // register-prefetch pipeline for the bf16 path when the halo is small enough for its register budget
-    constexpr bool PF_OK = (T::DT == MIL_DT_BF16);
+    // (split precision at >= 64 channels: the doubled prefetch registers spill — 130-250 VGPRs — so those keep the plain loader)
+    constexpr bool PF_OK = T::TR16 && (!T::SPLIT || CINP < 64);
     const size_t xb_total = (size_t)g.n_img * g.H * g.W * CINP * T::ESZ;
     const size_t zb_total = (size_t)g.n_img * g.Ho * g.Wo * mil_nt_to_cp(NT) * T::ESZ;
     const bool pf = PF_OK && (((g.hh * g.hw) << g.ti_log2) <= mil_wgrad_halo_max(CINP, PROJ)) && g.hh < 1024 && g.hw < 1024 &&

@@ -72,10 +72,13 @@ __device__ __forceinline__ int mil_xcd_block_id() {
 template <int NP>
 struct HaloTables { int pos[NP], lds[NP], rel[NP]; };
 
-template <int CP, int NP, int NTHR = 256>
+// T: element type of the tensor (BF16 default).  For T = F32S (fp32 in HBM, [hi | lo] bf16 planes in LDS) a 16-byte piece is
+// four fp32 channels and lands as 8 bytes in the hi plane + 8 bytes in the lo plane (t.lds = the hi address).
+template <int CP, int NP, int NTHR = 256, typename T = BF16>
 __device__ __forceinline__ void mil_build_halo_tables(HaloTables<NP>& t, const ConvGeom& g, int tid) {
-    constexpr int N16 = CP / 8;
-    constexpr int PIXB = mil_pix_pitch(CP, 2);
+    constexpr int N16 = CP * T::ESZ / 16;
+    constexpr int PIXB = mil_pix_pitch(CP, T::ESZ);
+    constexpr int JB = T::SPLIT ? 8 : 16;
     const int ppr = g.hw * N16;
     const int total = (g.hh << g.ti_log2) * ppr;
 #pragma unroll
@@ -87,21 +90,21 @@ __device__ __forceinline__ void mil_build_halo_tables(HaloTables<NP>& t, const C
             const int ti = row / g.hh, hy = row - ti * g.hh;
             const int hx = piece / N16, j = piece - hx * N16;
             t.pos[i] = (ti << 20) | (hy << 10) | hx;
-            t.lds[i] = (row * g.hw + hx) * PIXB + j * 16;
-            t.rel[i] = g.zins ? j * 16 : ((ti * g.H + hy) * g.W + hx) * (CP * 2) + j * 16;
+            t.lds[i] = (row * g.hw + hx) * PIXB + j * JB;
+            t.rel[i] = g.zins ? j * 16 : ((ti * g.H + hy) * g.W + hx) * (CP * T::ESZ) + j * 16;
         }
     }
 }
 
 // Issue the loads of one halo tile into registers (zero for padding / outside the image).
-template <int CP, int NP>
+template <int CP, int NP, typename T = BF16>
 __device__ __forceinline__ void mil_fetch_halo(u32x4_t (&rx)[NP], __amdgpu_buffer_rsrc_t src, const HaloTables<NP>& t,
                                                const ConvGeom& g, const TileOrigin& o) {
     const int s = g.zins ? 1 : g.stride;
     const int iy0 = o.oy0 * s - g.pad, ix0 = o.ox0 * s - g.pad;
     const int ilim = g.n_img - o.img0;
     if (!g.zins) {
-        const int base = ((o.img0 * g.H + iy0) * g.W + ix0) * (CP * 2);      // may be negative; valid lanes are not
+        const int base = ((o.img0 * g.H + iy0) * g.W + ix0) * (CP * T::ESZ);      // may be negative; valid lanes are not
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int p = t.pos[i];
@@ -115,17 +118,37 @@ __device__ __forceinline__ void mil_fetch_halo(u32x4_t (&rx)[NP], __amdgpu_buffe
             const int p = t.pos[i];
             const int iy = iy0 + ((p >> 10) & 1023), ix = ix0 + (p & 1023);
             const bool ok = p >= 0 && (p >> 20) < ilim && iy >= 0 && ix >= 0 && !((iy | ix) & 1) && (iy >> 1) < g.H && (ix >> 1) < g.W;
-            const int off = (((o.img0 + (p >> 20)) * g.H + (iy >> 1)) * g.W + (ix >> 1)) * (CP * 2) + t.rel[i];
+            const int off = (((o.img0 + (p >> 20)) * g.H + (iy >> 1)) * g.W + (ix >> 1)) * (CP * T::ESZ) + t.rel[i];
             rx[i] = __builtin_amdgcn_raw_buffer_load_b128(src, ok ? (unsigned)off : MIL_OOB, 0, 0);
         }
     }
 }
 
-template <int NP>
+// One fetched 16-byte piece -> LDS.  F32S: four fp32 channels -> 8 bytes of the record's hi plane + 8 bytes, LO behind,
+// of its lo plane.
+template <typename T, int LO>
+__device__ __forceinline__ void mil_commit_piece(char* p, const u32x4_t& r) {
+    if constexpr (T::SPLIT) {
+        const f32x4_t v = __builtin_bit_cast(f32x4_t, r);
+        bf16x4_t hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const __bf16 h = (__bf16)v[j];
+            hi[j] = h;
+            lo[j] = (__bf16)(v[j] - (float)h);
+        }
+        *reinterpret_cast<bf16x4_t*>(p) = hi;
+        *reinterpret_cast<bf16x4_t*>(p + LO) = lo;
+    } else {
+        *reinterpret_cast<u32x4_t*>(p) = r;
+    }
+}
+
+template <int NP, typename T = BF16, int CP = 0>
 __device__ __forceinline__ void mil_commit_halo(const u32x4_t (&rx)[NP], char* lds, const HaloTables<NP>& t) {
 #pragma unroll
     for (int i = 0; i < NP; ++i)
-        if (t.pos[i] >= 0) *reinterpret_cast<u32x4_t*>(lds + t.lds[i]) = rx[i];
+        if (t.pos[i] >= 0) mil_commit_piece<T, CP * 2>(lds + t.lds[i], rx[i]);
 }
 
 // Branch-free commit: tables built with mil_halo_tables_use_dump() send the unused slots to a 16-byte dump area, so
@@ -135,20 +158,21 @@ __device__ __forceinline__ void mil_halo_tables_use_dump(HaloTables<NP>& t, int 
 #pragma unroll
     for (int i = 0; i < NP; ++i) if (t.pos[i] < 0) t.lds[i] = dump_off;
 }
-template <int NP>
+template <int NP, typename T = BF16, int CP = 0>
 __device__ __forceinline__ void mil_commit_halo_all(const u32x4_t (&rx)[NP], char* lds, const HaloTables<NP>& t) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) *reinterpret_cast<u32x4_t*>(lds + t.lds[i]) = rx[i];
+    for (int i = 0; i < NP; ++i) mil_commit_piece<T, CP * 2>(lds + t.lds[i], rx[i]);
 }
 
 // Output-space tile (no halo) pieces owned by a thread: flat piece id = tid + 256*i -> (tile pixel, 16-B piece).
 template <int NP>
 struct OtileTables { int pos[NP], lds[NP], rel[NP]; };
 
-template <int CP, int NP, int NTHR = 256>
+template <int CP, int NP, int NTHR = 256, typename T = BF16>
 __device__ __forceinline__ void mil_build_otile_tables(OtileTables<NP>& t, const ConvGeom& g, int tid, int tile_px) {
-    constexpr int N16 = CP / 8;
-    constexpr int PIXZ = mil_pix_pitch(CP, 2);
+    constexpr int N16 = CP * T::ESZ / 16;
+    constexpr int PIXZ = mil_pix_pitch(CP, T::ESZ);
+    constexpr int JB = T::SPLIT ? 8 : 16;
     const int tw_mask = (1 << g.tw_log2) - 1, th_mask = (1 << g.th_log2) - 1;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -158,16 +182,16 @@ __device__ __forceinline__ void mil_build_otile_tables(OtileTables<NP>& t, const
             const int tp = idx / N16, j = idx - tp * N16;
             const int tx = tp & tw_mask, ty = (tp >> g.tw_log2) & th_mask, ti = tp >> (g.tw_log2 + g.th_log2);
             t.pos[i] = (ti << 20) | (ty << 10) | tx;
-            t.lds[i] = tp * PIXZ + j * 16;
-            t.rel[i] = ((ti * g.Ho + ty) * g.Wo + tx) * (CP * 2) + j * 16;
+            t.lds[i] = tp * PIXZ + j * JB;
+            t.rel[i] = ((ti * g.Ho + ty) * g.Wo + tx) * (CP * T::ESZ) + j * 16;
         }
     }
 }
 
-template <int CP, int NP>
+template <int CP, int NP, typename T = BF16>
 __device__ __forceinline__ void mil_fetch_otile(u32x4_t (&rz)[NP], __amdgpu_buffer_rsrc_t src, const OtileTables<NP>& t,
                                                 const ConvGeom& g, const TileOrigin& o) {
-    const int base = ((o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (CP * 2);
+    const int base = ((o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (CP * T::ESZ);
     const int ylim = g.Ho - o.oy0, xlim = g.Wo - o.ox0, ilim = g.n_img - o.img0;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -177,11 +201,11 @@ __device__ __forceinline__ void mil_fetch_otile(u32x4_t (&rz)[NP], __amdgpu_buff
     }
 }
 
-template <int NP>
+template <int NP, typename T = BF16, int CP = 0>
 __device__ __forceinline__ void mil_commit_otile(const u32x4_t (&rz)[NP], char* lds, const OtileTables<NP>& t) {
 #pragma unroll
     for (int i = 0; i < NP; ++i)
-        if (t.pos[i] >= 0) *reinterpret_cast<u32x4_t*>(lds + t.lds[i]) = rz[i];
+        if (t.pos[i] >= 0) mil_commit_piece<T, CP * 2>(lds + t.lds[i], rz[i]);
 }
 
 // v_permlane16_swap: odd 16-lane rows of `a` <-> even rows of `b` (a' = [a.r0 b.r0 a.r2 b.r2], b' = [a.r1 b.r1
