@@ -10,9 +10,10 @@ One step = zero the flat gradient bucket, re-pack the filters (they changed), on
 this rank's bags (full-bag path: all tiles through the backbone, gradients enabled), the segmented MIL head, the
 full backward, — for N>1 — one RCCL all-reduce (sum) of the flat gradient bucket, and one fused Adam step.  Weak
 scaling: every rank owns 8 bags.  Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`,
-`cpu_baseline` and — at N=1 — two sub-records timed by the same command: `fp32_path` (the exact-fp32 kernels that
-meet the north star's 1e-3 parity gate, same workload) and `alt_resnet_path` (the 64-512-channel encoder of
-alt_resnet.py, the MFMA-bound datapoint).
+`cpu_baseline` and — at N=1 — three sub-records timed by the same command: `bf16x3_path` (fp32 tensors, split-precision
+products: the fast path that meets the north star's 1e-3 gate on the logits, with its own roofline), `fp32_path` (the
+exact-f32 MFMA kernels, bit-level parity) and `alt_resnet_path` (the 64-512-channel encoder of alt_resnet.py, the
+MFMA-bound datapoint).
 
 Other workloads (their own labels, never the headline metric's):
     --size 512 --tiles 128        BASELINE configs[2]
@@ -52,7 +53,7 @@ def parse():
                     help="bf16: the headline path; f32: exact-f32 MFMA; bf16x3: fp32 tensors, split-precision products (meets the 1e-3 gate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--no-extra-paths", action="store_true", help="skip the fp32_path / alt_resnet_path sub-records")
+    ap.add_argument("--no-extra-paths", action="store_true", help="skip the bf16x3_path / fp32_path / alt_resnet_path sub-records")
     ap.add_argument("--overlap", action="store_true", help="run the separate weight-gradient launches on a side stream "
                     "(measured: same throughput on this workload, +2%% at 512 tiles, -24%% at 64 tiles; off by default)")
     ap.add_argument("--no-overlap", action="store_true", help="(default now) weight-gradient launches on the main stream")
@@ -90,7 +91,7 @@ def cpu_baseline(size, weights_npz):
         if sum(times) > 25.0:
             break
     med = float(np.median(times))
-    return {"value": n / med, "unit": "tiles/s", "cores": cores, "kind": "port",
+    return {"value": n / med, "unit": "tiles/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
             "sample": f"oracle/mil_oracle.py (fp32 torch CPU, {cores} threads): 1 bag x {n} tiles @{size}x{size}, "
                       f"fwd+bwd, median of {len(times)} after 1 warm-up"}
 
@@ -125,11 +126,15 @@ def timed_steps(step, steps, warmup, fence):
     return time.perf_counter() - t0, out
 
 
-def fp32_path_record(args, w, x_all, sizes, labels, dev):
-    """The exact-fp32 kernel path (v_mfma_f32_16x16x4_f32; the one the 1e-3 parity gate is asserted on everywhere) on
-    the SAME workload, fewer steps: a driver-timed number for the conformant path."""
+def path_record(args, mode, w, x_all, sizes, labels, dev, copy_gbps):
+    """Another compute mode on the SAME workload and step, timed by the same command:
+      "bf16x3"  fp32 tensors, split-precision products (MIL_DT_F32S) — the fast path that meets the north star's 1e-3 gate
+                on logits and attention weights; >= 10 timed steps, its own `roofline` (dominant kernel by live HIP events);
+      "f32"     exact-f32 MFMA (v_mfma_f32_16x16x4_f32) — the bit-level parity path; 3 timed steps."""
     import mil_amd
-    net = mil_amd.Attention(3, compute_dtype=torch.float32, device=dev).eval()
+    from mil_amd import ops
+    cdt = mil_amd.BF16X3 if mode == "bf16x3" else torch.float32
+    net = mil_amd.Attention(3, compute_dtype=cdt, device=dev).eval()
     net.load_state_dict({k: torch.tensor(w[k]) for k in w.keys()})
     flat = mil_amd.FlatParams(net)
     opt = mil_amd.FlatAdam(flat, lr=2e-4)
@@ -141,16 +146,33 @@ def fp32_path_record(args, w, x_all, sizes, labels, dev):
         opt.step()
         return outs
 
-    steps = 3
-    elapsed, outs = timed_steps(step, steps, 1, torch.cuda.synchronize)
+    steps, warm = (max(10, args.steps), 2) if mode == "bf16x3" else (3, 1)
+    for _ in range(warm):
+        step()
+    timer = None
+    if mode == "bf16x3" and not args.no_kernel_timer:
+        timer = ops.KernelTimer(timer_wants)
+        ops.TIMER = timer
+    elapsed, outs = timed_steps(step, steps, 0, torch.cuda.synchronize)
+    ops.TIMER = None
     if not bool(torch.isfinite(outs.loss).all()):
-        raise SystemExit("non-finite loss on the fp32 path")
+        raise SystemExit(f"non-finite loss on the {mode} path")
     tiles = x_all.shape[0]
     value = tiles * steps / elapsed
     tfl = value * GFLOP_PER_TILE_FWD_BWD_256 * (args.size / 256.0) ** 2 / 1e3
-    return {"value": value, "unit": "tiles/s", "dtype": "f32", "steps": steps, "warmup": 1,
-            "ms_per_step": elapsed / steps * 1e3, "model_tflops": tfl, "frac_of_f32_mfma_peak": tfl / MFMA_PEAK_F32_TFLOPS,
-            "note": "same workload and step as `value`, exact-fp32 kernels (the path the 1e-3 parity gate is asserted on)"}
+    rec = {"value": value, "unit": "tiles/s", "dtype": mode, "steps": steps, "warmup": warm,
+           "ms_per_step": elapsed / steps * 1e3, "model_tflops": tfl}
+    if mode == "bf16x3":
+        peak = MFMA_PEAK_BF16_TFLOPS / 3.0
+        rec["frac_of_bf16x3_mfma_peak"] = tfl / peak
+        rec["roofline"] = roofline_record("bf16x3", timer.durations_ms(), peak, copy_gbps, tfl, profile_tag="bf16x3") if timer else None
+        rec["note"] = ("same workload and step as `value`; fp32 tensors, every conv / weight gradient as bf16x3 split products "
+                       "(hi*hi + lo*hi + hi*lo, fp32 accumulate): logits within 2.5e-4 of the fp32 CPU reference, attention "
+                       "weights within 3e-6 (tests/test_gpu_configs.py asserts 1e-3 on Mterm / Aterm / y_pred / loss)")
+    else:
+        rec["frac_of_f32_mfma_peak"] = tfl / MFMA_PEAK_F32_TFLOPS
+        rec["note"] = "same workload and step as `value`, exact-fp32 kernels (bit-level parity path: Mterm within 2e-6)"
+    return rec
 
 
 def alt_resnet_record(dev):
@@ -195,61 +217,109 @@ def _profile_json(name):
         return None
 
 
-def roofline_record(args, spans, peak, copy_gbps, achieved_model_tflops):
-    """`spans` = [(label, ms)] of every bracketed launch (HIP events on the launch stream).  Families, all on the
-    64x64 maps at 20(24)->20(24) channels (layer 1, 47 % of the FLOPs):
-        block_fwd   conv_block_fwd_kernel<24,..>      whole identity block forward            2 convs, 3 tensor passes
-        conv        conv_igemm_pf_kernel<24,2,3,4>    one 3x3 s1 forward conv                 1 conv,  2 passes
-        bwd_fused   conv_bwd_fused_kernel<24,2,3,..>  dx + dW + db of one conv in one pass    2 convs, 3 passes (+1 with addend)
-        block_bwd   conv_block_bwd_kernel<24,..>      backward of a whole identity block      4 convs, 4 passes
-    The family with the largest total time in the timed region is the dominant kernel."""
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _family_cost(label, esz):
+    """(algorithmic FLOPs, algorithmic HBM bytes, description) of ONE bracketed launch.  Algorithmic = the 20 real channels
+    (SURVEY.md §8d / Appendix D), every tensor read or written once; esz = bytes per activation element of the path."""
+    fam = label[0]
+    if fam == "block_fwd":                    # ("block_fwd", cp, n, h, w): whole identity block, 2 convs, x in, o1 + out out
+        _f, _cp, n, h, w = label
+        px = n * h * w
+        return 2 * 2.0 * 9 * 20 * 20 * px, 3 * px * 20 * esz, (n, h, w)
+    if fam == "conv":                         # ("conv", cin_p, cout_p, ks, stride, zins, n, ho, wo)
+        _f, _ci, _co, ks, _s, _z, n, ho, wo = label
+        px = n * ho * wo
+        return 2.0 * ks * ks * 20 * 20 * px, 2 * px * 20 * esz, (n, ho, wo)
+    if fam == "bwd_fused":                    # (..., n, h, w, has_addend): dx + dW + db of one conv: dz, x (+ addend) in, dx out
+        n, h, w = label[6], label[7], label[8]
+        px = n * h * w
+        return 2 * 2.0 * 9 * 20 * 20 * px, (4 if (len(label) > 9 and label[9]) else 3) * px * 20 * esz, (n, h, w)
+    if fam == "wgrad":                        # ("wgrad", cin_p, cout_p, ks, stride, n, ho, wo): x and dz in
+        _f, _ci, _co, ks, _s, n, ho, wo = label
+        px = n * ho * wo
+        return 2.0 * ks * ks * 20 * 20 * px, 2 * px * 20 * esz, (n, ho, wo)
+    if fam == "stem_fwd":                     # ("stem_fwd", cout_p, n, H, W): fp32 tiles in, pooled map + winner bytes out
+        _f, _cp, n, h, w = label
+        h2, w2 = h // 2, w // 2
+        hp, wp = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
+        return 2.0 * 147 * 20 * n * h2 * w2, n * 3 * h * w * 4 + n * hp * wp * 20 * (esz + 1), (n, h, w)
+    if fam == "stem_bwd":                     # ("stem_bwd", n, H, W): fp32 tiles + pooled gradient + winner bytes in
+        _f, n, h, w = label
+        h2, w2 = h // 2, w // 2
+        hp, wp = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
+        return 2.0 * 147 * 20 * n * h2 * w2, n * 3 * h * w * 4 + n * hp * wp * 20 * (esz + 1), (n, h, w)
+    return None
+
+
+_FAMILY_KERNEL = {
+    "block_fwd": ("conv_block_fwd_kernel<24,..> (whole identity block forward: conv-lrelu-conv-add-lrelu, 20 ch", ("conv_block_fwd_kernel<24,",)),
+    "conv": ("conv_igemm_pf_kernel<..24,2,3,4> (3x3 s1 conv, forward or data gradient, 20->20 ch", ("conv_igemm_pf_kernel<24, 2, 3, 4", "conv_igemm_pf_kernel<F32S, 24, 2, 3, 4")),
+    "bwd_fused": ("conv_bwd_fused16_kernel<ADD,MASK> (fused data+weight gradient of the 3x3 s1 conv, 16x16 tiles, 20->20 ch", ("conv_bwd_fused16_kernel<", "conv_bwd_fused_kernel<24, 2, 3")),
+    "wgrad": ("wgrad_kernel<..3,24,2,..> (weight+bias gradient of the 3x3 s1 conv, 20->20 ch", ("wgrad_kernel<F32S, 3, 24, 2", "wgrad_kernel<BF16, 3, 24, 2")),
+    "stem_fwd": ("stem_fwd_fused_kernel (fp32 tiles -> s2d -> 7x7/s2 conv + bias + LeakyReLU -> 3x3/s2 max-pool, one pass", ("stem_fwd_fused_kernel<",)),
+    "stem_bwd": ("stem_bwd_fused_kernel<FROM_X> (max-pool backward + LeakyReLU backward + 7x7 weight gradient, one pass", ("stem_bwd_fused_kernel<",)),
+}
+
+
+def timer_wants(label):
+    """Launches bench.py brackets with HIP events: the layer-1 kernel families (64x64 maps, 20 -> 20 channels: 47 % of the
+    FLOPs) and the stem pair."""
+    fam = label[0]
+    if fam in ("stem_fwd", "stem_bwd"):
+        return True
+    if fam == "block_fwd":
+        return label[1] == 24
+    if fam in ("conv", "bwd_fused"):
+        return tuple(label[1:6]) == (24, 24, 3, 1, False)
+    if fam == "wgrad":
+        return tuple(label[1:5]) == (24, 24, 3, 1)
+    return False
+
+
+def roofline_record(dtype_name, spans, peak, copy_gbps, achieved_model_tflops, profile_tag=None):
+    """`spans` = [(label, ms)] of every bracketed launch (HIP events on the launch stream, see timer_wants).  The family
+    with the largest total time in the timed region is the dominant kernel; its algorithmic bytes / FLOPs per launch are
+    averaged over the launches as they ran (_family_cost)."""
     fams = {}
     for label, d in spans:
-        fams.setdefault(label[0], []).append((label, d))
+        if _family_cost(label, 2) is not None:
+            fams.setdefault(label[0], []).append((label, d))
     if not fams:
         return None
     fam = max(fams, key=lambda k: sum(d for _l, d in fams[k]))
-    esz = 2 if args.dtype == "bf16" else 4
-    flops = alg_bytes = 0.0
-    n_img = ho = wo = 0
-    for label, _d in fams[fam]:
-        if fam == "block_fwd":
-            n_img, ho, wo = label[2], label[3], label[4]
-        elif fam == "block_bwd":
-            n_img, ho, wo = label[2], label[3], label[4]
-        else:
-            n_img, ho, wo = label[6], label[7], label[8]
-        conv_flops = 2.0 * 9 * 20 * 20 * n_img * ho * wo              # algorithmic: 20 real channels in and out
-        px_bytes = n_img * ho * wo * 20 * esz                          # one 20-channel activation tensor
-        if fam == "block_fwd":
-            flops += 2 * conv_flops; alg_bytes += 3 * px_bytes         # read x once, write o1 and out
-        elif fam == "conv":
-            flops += conv_flops; alg_bytes += 2 * px_bytes             # read x once, write y once (SURVEY App. D)
-        elif fam == "block_bwd":
-            flops += 4 * conv_flops; alg_bytes += 4 * px_bytes         # read dz, o1, x once; write dx once
-        else:
-            has_addend = bool(label[9]) if len(label) > 9 else False
-            flops += 2 * conv_flops                                    # dgrad + wgrad
-            alg_bytes += (4 if has_addend else 3) * px_bytes           # read dz, x (+ addend) once, write dx once
-    n_l = len(fams[fam])
-    flops /= n_l
-    alg_bytes /= n_l
-    avg_ms = float(np.mean([d for _l, d in fams[fam]]))
-    kname = {
-        "block_fwd": "conv_block_fwd_kernel<24,..> (whole identity block forward: conv-lrelu-conv-add-lrelu, 20 ch",
-        "conv": "conv_igemm_pf_kernel<24,2,3,4> (3x3 s1 forward conv, 20->20 ch",
-        "bwd_fused": "conv_bwd_fused16_kernel<ADD,MASK> (fused data+weight gradient of the 3x3 s1 conv, 16x16 tiles, 20->20 ch",
-        "block_bwd": "conv_block_bwd_kernel<24,..> (backward of a whole identity block: 2x (data+weight gradient), 20 ch",
-    }[fam] + f", {ho}x{wo} maps, {n_img} tiles/launch)"
-    pmc_keys = {"conv": ("conv_igemm_pf_kernel<24, 2, 3, 4",), "block_fwd": ("conv_block_fwd_kernel<24,",),
-                "bwd_fused": ("conv_bwd_fused16_kernel<", "conv_bwd_fused_kernel<24, 2, 3"), "block_bwd": ("conv_block_bwd_kernel<24,",)}[fam]
-    traffic = None
-    pmc = _profile_json("pmc_traffic.json")                            # rocprofv3 PMC passes of this same command
+    esz = 2 if dtype_name == "bf16" else 4
+
+    def fam_stats(f):
+        costs = [_family_cost(label, esz) for label, _d in fams[f]]
+        n_l = len(costs)
+        flops = sum(c[0] for c in costs) / n_l
+        byts = sum(c[1] for c in costs) / n_l
+        avg_ms = float(np.mean([d for _l, d in fams[f]]))
+        return flops, byts, avg_ms, n_l, costs[-1][2]
+
+    flops, alg_bytes, avg_ms, n_l, shape = fam_stats(fam)
+    n_img = shape[0]
+    kname = _FAMILY_KERNEL[fam][0] + f", {shape[1]}x{shape[2]} maps, {n_img} tiles/launch)"
+    pmc_keys = _FAMILY_KERNEL[fam][1]
+    traffic = traffic_source = None
+    suffix = "" if profile_tag in (None, "bf16") else "_" + profile_tag
+    pmc = _profile_json(f"pmc_traffic{suffix}.json")                   # rocprofv3 PMC passes of this same command (tools/profile_round.sh)
     if pmc and n_img == 2048:
         hit = [v for k, v in pmc.get("kernels", {}).items() if any(key in k for key in pmc_keys)]     # all template variants of the family
         if hit:
             traffic = sum(v["hbm_bytes"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit)
-    sq = _profile_json("sq_counters.json")                             # SQ PMC passes of this same command
+            traffic_source = {"file": f"profiles/pmc_traffic{suffix}.json", "library_sha16": pmc.get("_library_sha16"),
+                              "matches_running_library": pmc.get("_library_sha16") == library_sha16()}
+    sq = _profile_json(f"sq_counters{suffix}.json")                    # SQ PMC passes of this same command
     sq_rec = None
     if sq and n_img == 2048:
         hit = [v for k, v in sq.get("kernels", {}).items() if any(key in k for key in pmc_keys)]
@@ -258,31 +328,76 @@ def roofline_record(args, spans, peak, copy_gbps, achieved_model_tflops):
             sq_rec = {k: sum(v[k] * v["launches"] for v in hit) / tot for k in
                       ("mfma_busy_frac_per_simd", "wait_any_frac", "wait_inst_frac", "active_inst_frac") if all(k in v for v in hit)}
             sq_rec["source"] = sq.get("_source", "profiles/sq_counters.json")
+            sq_rec["matches_running_library"] = sq.get("_library_sha16") == library_sha16()
     # Which roof: arithmetic intensity of the kernel's ALGORITHMIC work against the ridge point (dense MFMA peak /
-    # HBM peak = 312 FLOP/B at bf16).  The 20-channel convs sit far on the HBM side (90-180 FLOP/B), so the fraction is
+    # HBM peak = 312 FLOP/B at bf16).  The 20-channel convs sit far on the HBM side (45-180 FLOP/B), so the fraction is
     # priced against HBM bandwidth; the MFMA-side numbers are carried along for reference.
     ach = flops / (avg_ms * 1e-3) / 1e12
     ai = flops / alg_bytes
     ridge = peak * 1e12 / (HBM_PEAK_GBPS * 1e9)
     alg_gbps = alg_bytes / (avg_ms * 1e-3) / 1e9
+    others = {}
+    for k in fams:
+        if k == fam:
+            continue
+        fl, by, ms, nl, _sh = fam_stats(k)
+        others[k] = {"launches": nl, "avg_launch_ms": ms, "algorithmic_gbps": by / (ms * 1e-3) / 1e9,
+                     "frac_of_hbm_peak": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     extras = {
         "kernel": kname, "launches_timed": n_l, "avg_launch_ms": avg_ms,
         "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
         "arithmetic_intensity_flop_per_byte": ai, "ridge_flop_per_byte": ridge,
         "kernel_tflops": ach, "kernel_frac_of_mfma_peak": ach / peak,
         "hbm_capped_attainable_tflops": min(peak, ai * HBM_PEAK_GBPS / 1e3),
-        "measured_copy_gbps": copy_gbps,
+        "measured_stream_copy_gbps": copy_gbps,
+        "frac_of_measured_stream_copy": (alg_gbps / copy_gbps) if copy_gbps else None,
         "whole_step_model_tflops": achieved_model_tflops,
         "whole_step_frac_of_mfma_peak": achieved_model_tflops / peak,
-        "sq_counters": sq_rec,
-        "other_timed_kernels": {k: {"launches": len(v), "avg_launch_ms": float(np.mean([d for _l, d in v]))}
-                                for k, v in fams.items() if k != fam},
+        "sq_counters": sq_rec, "traffic_source": traffic_source,
+        "other_timed_kernels": others,
     }
     if ai < ridge:
         return {"bound": "hbm", "achieved": alg_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": alg_gbps / HBM_PEAK_GBPS, "traffic": traffic, **extras}
     return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
             "traffic": traffic, **extras}
+
+
+_LIB_SHA = []
+
+
+def library_sha16():
+    """First 16 hex digits of sha256(libmil_hip.so): ties a committed counter summary to the build that produced it."""
+    if not _LIB_SHA:
+        import hashlib
+        import mil_amd
+        try:
+            _LIB_SHA.append(hashlib.sha256(open(mil_amd.LIB_PATH, "rb").read()).hexdigest()[:16])
+        except OSError:
+            _LIB_SHA.append(None)
+    return _LIB_SHA[0]
+
+
+def stream_copy_gbps(dev, seconds=0.5):
+    """What a plain streaming kernel reaches on this box (in-tree float4 copy, mil_stream_copy: read + write bytes / time).
+    Also the clock ramp of a freshly started box: every rank runs it for about half a second before the warm-up steps."""
+    from mil_amd import _lib as L
+    src = torch.empty(1 << 28, dtype=torch.float32, device=dev)         # 1 GiB
+    dst = torch.empty_like(src)
+    nbytes = src.numel() * 4
+    st = torch.cuda.current_stream().cuda_stream
+    L.check(L.lib().mil_stream_copy(dst.data_ptr(), src.data_ptr(), nbytes, st), "mil_stream_copy")
+    torch.cuda.synchronize()
+    best, t_start = 0.0, time.perf_counter()
+    while time.perf_counter() - t_start < seconds:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            L.check(L.lib().mil_stream_copy(dst.data_ptr(), src.data_ptr(), nbytes, st), "mil_stream_copy")
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 20 * 2 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    return best
 
 
 def main():
@@ -351,9 +466,18 @@ def main():
         flat.zero_grad()
         outs = net.forward_bags((x_all, sizes), labels)
         outs.loss.sum().backward()      # == sum of the per-bag o["loss"] (the reference accumulates bag gradients un-normalised)
-        flat.allreduce_grads()
+        if world > 1 and comm_events is not None:       # HIP events around the collective, on the stream it is issued on
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            flat.allreduce_grads()
+            e1.record()
+            comm_events.append((e0, e1))
+        else:
+            flat.allreduce_grads()
         opt.step()                      # weights change every step: the next forward re-packs all filters
         return outs
+
+    comm_events = None                  # filled during the timed steps only
 
     def fence():
         if world > 1:
@@ -365,21 +489,7 @@ def main():
     # steps are 35 ms of GPU work, far less than the power-state transition).  The W warm-up steps follow directly.
     copy_gbps = None
     if not args.no_kernel_timer:
-        src = torch.empty(1 << 28, dtype=torch.float32, device=dev)         # 1 GiB
-        dst = torch.empty_like(src)
-        dst.copy_(src)
-        torch.cuda.synchronize()
-        best, t_start = 0.0, time.perf_counter()
-        while time.perf_counter() - t_start < 0.5:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
-                dst.copy_(src)
-            e1.record()
-            torch.cuda.synchronize()
-            best = max(best, 20 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
-        copy_gbps = best
-        del src, dst
+        copy_gbps = stream_copy_gbps(dev)
     for i in range(args.warmup):
         step()
         if i == 0 and world > 1 and not args.infer:
@@ -394,16 +504,25 @@ def main():
     # stream; the one with the largest total time in the timed region is reported as `roofline`.
     timer = None
     if not args.no_kernel_timer and not args.infer:
-        timer = ops.KernelTimer(lambda label: label[:6] in (("conv", 24, 24, 3, 1, False), ("bwd_fused", 24, 24, 3, 1, False))
-                                or label[:2] in (("block_fwd", 24), ("block_bwd", 24)))
+        timer = ops.KernelTimer(timer_wants)
         ops.TIMER = timer
     fence()
+    if world > 1 and not args.infer:
+        comm_events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         outs = step()
     fence()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
+    allreduce_ms = None
+    if comm_events:
+        # the collective's own time per step (max over ranks): what a scaling shortfall is made of.  The events bracket the
+        # all-reduce on the compute stream, so a rank that arrives early also counts its wait for the slowest rank here.
+        am = torch.tensor([float(np.mean([a.elapsed_time(b) for a, b in comm_events]))], dtype=torch.float64, device=dev)
+        dist.all_reduce(am, op=dist.ReduceOp.MAX)
+        allreduce_ms = float(am.item())
+        comm_events = None
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -417,8 +536,10 @@ def main():
         value = tiles_per_step * args.steps / elapsed
         scale = (args.size / 256.0) ** 2
         achieved_model_tflops = value * (GFLOP_PER_TILE_FWD_256 if args.infer else GFLOP_PER_TILE_FWD_BWD_256) * scale / 1e3
-        peak = MFMA_PEAK_BF16_TFLOPS if args.dtype == "bf16" else MFMA_PEAK_F32_TFLOPS
-        roofline = roofline_record(args, timer.durations_ms(), peak, copy_gbps, achieved_model_tflops) if timer else None
+        # bf16x3: three bf16 MFMAs per product -> a third of the dense bf16 peak per model FLOP
+        peak = {"bf16": MFMA_PEAK_BF16_TFLOPS, "f32": MFMA_PEAK_F32_TFLOPS, "bf16x3": MFMA_PEAK_BF16_TFLOPS / 3.0}[args.dtype]
+        roofline = roofline_record(args.dtype, timer.durations_ms(), peak, copy_gbps, achieved_model_tflops,
+                                   profile_tag=args.dtype) if timer else None
         if tile_parallel:
             par = (f"tile-parallel tp{world}: one bag's tiles sharded over the ranks, all-gather of H [N/{world},80] over RCCL, "
                    "replicated head")
@@ -436,11 +557,15 @@ def main():
                        "parallelism": par},
             "roofline": roofline,
         }
+        if allreduce_ms is not None:
+            line["allreduce_ms"] = allreduce_ms
+            line["step_ms_no_comm"] = elapsed / args.steps * 1e3 - allreduce_ms
         if args.infer:
             line["model_tflops"] = achieved_model_tflops
         extra = world == 1 and not args.infer and not args.no_extra_paths
         if extra and args.dtype == "bf16":
-            line["fp32_path"] = fp32_path_record(args, w, x_all, sizes, labels, dev)
+            line["bf16x3_path"] = path_record(args, "bf16x3", w, x_all, sizes, labels, dev, copy_gbps)
+            line["fp32_path"] = path_record(args, "f32", w, x_all, sizes, labels, dev, copy_gbps)
         del x_all
         torch.cuda.empty_cache()
         if extra:

@@ -1,4 +1,25 @@
-// ABI bookkeeping for libmil_hip.so (see include/mil_hip.h).
+// ABI version + the streaming-copy calibration kernel.
 #include "common.cuh"
 
-extern "C" int mil_abi_version(void) { return 1; }
+extern "C" int mil_abi_version(void) { return 2; }
+
+// What HBM gives a plain streaming kernel on this box: dst[i] = src[i], ONE 16-byte piece per thread, as many workgroups as
+// pieces.  bench.py times it as the calibration of its roofline fractions (MI355X_MICROARCH.md: 6.29 TB/s measured for a
+// float4 copy against the 8 TB/s specification).  Measured here on 1 GiB: this shape 6.23 TB/s; block-contiguous chunks of
+// 4-8 pieces per thread on a persistent grid 5.4-5.9 TB/s; a grid-stride loop (pieces of one thread a whole grid apart)
+// 4.4-5.1 TB/s; torch's dst.copy_(src) 4.9 TB/s.
+__global__ __launch_bounds__(256) void stream_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
+extern "C" int mil_stream_copy(void* dst, const void* src, size_t bytes, void* stream) {
+    if (!dst || !src || (bytes & 15) || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15)) return MIL_ERR_ARG;
+    if (bytes == 0) return MIL_OK;
+    const size_t n16 = bytes / 16, blocks = (n16 + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return MIL_ERR_ARG;
+    hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       static_cast<const uint4*>(src), static_cast<uint4*>(dst), n16);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}

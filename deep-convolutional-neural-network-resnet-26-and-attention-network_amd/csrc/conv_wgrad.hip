@@ -456,9 +456,17 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     constexpr bool PF_OK = T::TR16 && (!T::SPLIT || CINP < 64);
     const size_t xb_total = (size_t)g.n_img * g.H * g.W * CINP * T::ESZ;
     const size_t zb_total = (size_t)g.n_img * g.Ho * g.Wo * mil_nt_to_cp(NT) * T::ESZ;
-    const bool pf = PF_OK && (((g.hh * g.hw) << g.ti_log2) <= mil_wgrad_halo_max(CINP, PROJ)) && g.hh < 1024 && g.hw < 1024 &&
-                    xb_total < ((size_t)1 << 31) && zb_total < ((size_t)1 << 31);
-    a.x_bytes = (unsigned)xb_total; a.z_bytes = (unsigned)zb_total;
+    // buffer descriptors address < 2 GiB: a larger tensor is walked in image chunks, one launch and one set of slabs per chunk
+    // (the stem's fp32 space-to-depth input is 2.1 GB at 2048 tiles of 256x256)
+    const size_t x_img = (size_t)g.H * g.W * CINP * T::ESZ, z_img = (size_t)g.Ho * g.Wo * mil_nt_to_cp(NT) * T::ESZ;
+    const bool pf = PF_OK && (((g.hh * g.hw) << g.ti_log2) <= mil_wgrad_halo_max(CINP, PROJ)) && g.hh < 1024 && g.hw < 1024;
+    int chunk = g.n_img > 0 ? g.n_img : 1;
+    if (pf && (xb_total > mil_buffer_limit() || zb_total > mil_buffer_limit())) {
+        chunk = mil_imgs_under_2g(x_img > z_img ? x_img : z_img);
+        if (chunk >= 16) chunk &= ~15;                            // keep image groups (<= 16 images per tile) intact
+        if (chunk < (1 << g.ti_log2)) return MIL_ERR_UNSUPPORTED;
+    }
+    const int nchunk = g.n_img > 0 ? (g.n_img + chunk - 1) / chunk : 1;
     // 8-wave workgroups where the 4-wave form holds a single wave per SIMD (persistent bf16 form, >= 64 input channels)
     constexpr int NW = (PF_OK && CINP >= 64) ? 8 : 4;
     const int nthr = pf ? 64 * NW : 256;
@@ -475,15 +483,29 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
         int gx = mil_num_cus() * per_cu / MSPLIT;
         // (fewer, longer-running workgroups to write fewer slabs do not pay: the 64/80-channel launches took 1.7x / 3.2x as long on
         // half / a quarter of the workgroups — their time is tiles per workgroup x a load round trip per tile, not slab traffic)
-        if (gx > a.ntiles) gx = a.ntiles;
+        const int tiles_chunk = (((chunk < g.n_img ? chunk : g.n_img) + (1 << g.ti_log2) - 1) >> g.ti_log2) * g.tiles_y * g.tiles_x;
+        if (gx > tiles_chunk) gx = tiles_chunk;
         if (gx < 1) gx = 1;
         pl.grid_x = gx;
     }
-    const size_t bytes = pl.slab_elems * pl.grid_x * sizeof(float);
+    const size_t bytes = pl.slab_elems * pl.grid_x * nchunk * sizeof(float);
     if (query) { *need = bytes; return MIL_OK; }
     if (ws_bytes < bytes || !ws) return MIL_ERR_ARG;
-    hipLaunchKernelGGL(kern, dim3(pl.grid_x, MSPLIT), dim3(nthr), pl.lds, stream, a);
-    MIL_CHECK_LAUNCH();
+    for (int c = 0; c < nchunk; ++c) {          // a workgroup without tiles (short last chunk) still writes its all-zero slab
+        WgradArgs<T> b = a;
+        const int i0 = c * chunk, n = g.n_img - i0 < chunk ? g.n_img - i0 : chunk;
+        b.g.n_img = n;
+        b.g.n_groups = (n + (1 << g.ti_log2) - 1) >> g.ti_log2;
+        b.ntiles = b.g.n_groups * g.tiles_y * g.tiles_x;
+        b.x = a.x + (size_t)i0 * (x_img / T::ESZ);
+        b.dz = a.dz + (size_t)i0 * (z_img / T::ESZ);
+        if (a.dz2) b.dz2 = a.dz2 + (size_t)i0 * (z_img / T::ESZ);
+        b.x_bytes = (unsigned)(x_img * n); b.z_bytes = (unsigned)(z_img * n);
+        b.slab = a.slab + (size_t)c * pl.grid_x * pl.slab_elems;
+        hipLaunchKernelGGL(kern, dim3(pl.grid_x, MSPLIT), dim3(nthr), pl.lds, stream, b);
+        MIL_CHECK_LAUNCH();
+    }
+    pl.grid_x *= nchunk;                         // slabs to reduce
     const int n_rows = KS * KS * CINP;
     {
         MilReduceJob j{};

@@ -292,8 +292,15 @@ __host__ inline int mil_num_cus() {
 }
 
 // How many images of `bytes_per_img` bytes fit under the 2 GiB buffer limit.
+// (MIL_BUFFER_LIMIT_BYTES lowers the limit: the tests use it to drive small launches through the chunked paths)
+#include <cstdlib>
+__host__ inline size_t mil_buffer_limit() {
+    const char* e = getenv("MIL_BUFFER_LIMIT_BYTES");           // read per call (launch path, ~100 ns): a test can change it
+    const size_t v = e ? (size_t)atoll(e) : 0;
+    return (v >= 65536 && v < ((size_t)1 << 31)) ? v : ((size_t)1 << 31) - 4096;
+}
 __host__ inline int mil_imgs_under_2g(size_t bytes_per_img) {
-    const size_t lim = ((size_t)1 << 31) - 4096;
+    const size_t lim = mil_buffer_limit();
     size_t n = bytes_per_img ? lim / bytes_per_img : 1;
     return (int)(n < 1 ? 1 : (n > (1u << 30) ? (1u << 30) : n));
 }

@@ -53,21 +53,22 @@ class FlatParams:
                 p.grad = self.flat_grad[off:off + n].view(p.shape)
             off += n
 
-    def allreduce_grads(self, group=None):
-        """Sum the flat gradient bucket over ranks (no-op for a single process)."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    def allreduce_grads(self, group=None, force=False):
+        """Sum the flat gradient bucket over ranks (no-op for a single process; force=True issues the collective even in a
+        one-rank group — the RCCL smoke test and the bench's collective timing use it)."""
+        if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
         return self.flat_grad
 
-    def broadcast_params(self, src=0, group=None):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    def broadcast_params(self, src=0, group=None, force=False):
+        if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
             dist.broadcast(self.flat, src=src, group=group)
 
 
-def gather_features(feats, group=None):
+def gather_features(feats, group=None, force=False):
     """Tile-parallel inference of ONE large bag (BASELINE config 5): every rank encodes its slice of the
     tiles, then all ranks gather H [N/G,80] and run the (tiny) head redundantly."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return feats
     world = dist.get_world_size(group)
     sizes = [torch.zeros(1, dtype=torch.int64, device=feats.device) for _ in range(world)]

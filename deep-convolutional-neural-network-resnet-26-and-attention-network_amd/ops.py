@@ -169,10 +169,13 @@ def conv_wgrad(x, dz, cin, cout, *, ks, stride, pad, stem=False, want_bias=True,
         dw, db = out
         _need(dw, (cout, cin, kk, kk), torch.float32, "dw")
         _need(db, (cout,), torch.float32, "db")
+    end = TIMER.bracket(("wgrad", cin_p, cout_p, ks, stride, n, ho, wo)) if TIMER else None
     L.check(L.lib().mil_conv_wgrad(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), L.ptr(db), workspace.data_ptr(),
                                    workspace.numel() * workspace.element_size(), n, h, w, cin, ho, wo, cout, ks, stride,
                                    pad, 1 if stem else 0, 0 if out is None else 1, L.dt_code(x.dtype, mma=True), L.stream_ptr()),
             "mil_conv_wgrad")
+    if end is not None:
+        end.record()
     return dw, db
 
 

@@ -13,8 +13,14 @@
  *     no global state: work is enqueued on `stream`, buffers are caller-owned.
  *   - activations are NHWC with channels padded to a multiple of 8 (20->24, 40, 60->64, 80; padded
  *     channels hold zeros); `dtype` selects the activation/weight-operand type:
- *         MIL_DT_F32  (0): exact-fp32 MFMA (v_mfma_f32_16x16x4_f32)  — the parity gate
+ *         MIL_DT_F32  (0): exact-fp32 MFMA (v_mfma_f32_16x16x4_f32)  — the parity gate, bit-level
  *         MIL_DT_BF16 (1): bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16) — the fast path
+ *         MIL_DT_F32S (3): fp32 tensors exactly as MIL_DT_F32 (same layouts, same pointwise entry points), convolutions
+ *                          and weight gradients as bf16x3 split products: each operand v = hi + lo (two bf16), product =
+ *                          lo*hi + hi*lo + hi*hi with fp32 accumulation.  16 significant bits per operand: meets the 1e-3
+ *                          gate on logits / attention weights (2.5e-4 measured) at 3/16 of the exact path's matrix time.
+ *                          Accepted by mil_pack_conv_weights / mil_pack_job_fill (fragments [hi | lo], the byte count of
+ *                          MIL_DT_F32), mil_conv_igemm and mil_conv_wgrad(_workspace); everything else takes MIL_DT_F32.
  *   - master weights, biases, all gradients of parameters, and the whole MIL head are fp32.
  */
 #ifndef MIL_HIP_H
@@ -41,6 +47,7 @@ extern "C" {
  * 17 % fewer bytes on three of the four tensor passes of the stage's fused backward.  Entry points (or shapes) without a
  * kernel for it return MIL_ERR_UNSUPPORTED; query with the *_workspace functions before choosing it. */
 #define MIL_DT_BF16_DGRAD 2
+#define MIL_DT_F32S 3
 
 #define MIL_PACK_FWD 0   /* B[(tap,ci)][co] = W[co][ci][ky][kx]                     */
 #define MIL_PACK_DGRAD 1 /* B[(tap,co)][ci] = W[co][ci][k-1-ky][k-1-kx]             */
@@ -49,6 +56,11 @@ extern "C" {
 
 /* ABI version of this header (bumped on any signature change). */
 int mil_abi_version(void);
+
+/* Streaming device copy dst[0..bytes) = src[0..bytes) in 16-byte pieces (both 16-byte aligned, bytes a multiple of 16).  Not a
+ * reference op: the calibration kernel bench.py times to state what a plain read+write stream reaches on the box, next to the
+ * 8 TB/s specification its roofline fractions are priced against. */
+int mil_stream_copy(void* dst, const void* src, size_t bytes, void* stream);
 
 /* ---- input packing ------------------------------------------------------------------------
  * fp32 NCHW tiles [n,3,H,W] (what `Attention.forward` receives, gbm/model.py:189-196) ->

@@ -81,38 +81,61 @@ def _ident(t):
     return t
 
 
-def residual_block(sd, prefix, x, stride, rf=_ident, rb=_ident):
+def _lrelu(v, pos=None):
+    """LeakyReLU(0.1); `pos` (bool, same shape) forces the branch per element instead of the sign of v — see `patterns`
+    of `backbone`."""
+    return F.leaky_relu(v, LEAK) if pos is None else torch.where(pos, v, LEAK * v)
+
+
+def residual_block(sd, prefix, x, stride, rf=_ident, rb=_ident, pat=None, name=""):
     """nnBlocks.py:175-189.  rf/rb are identity for the fp32 reference arithmetic; the bf16-storage
     emulation passes rounding functions at the points where the HIP path stores bf16 tensors."""
-    o = F.leaky_relu(rb(F.conv2d(x, rf(sd[prefix + "conv1.weight"]), sd[prefix + "conv1.bias"],
-                                 stride=stride, padding=1)), LEAK)
+    p1 = None if pat is None else pat[name + ".o1"]
+    p2 = None if pat is None else pat[name]
+    o = _lrelu(rb(F.conv2d(x, rf(sd[prefix + "conv1.weight"]), sd[prefix + "conv1.bias"],
+                           stride=stride, padding=1)), p1)
     o = rf(o)
     o = F.conv2d(o, rf(sd[prefix + "conv2.weight"]), sd[prefix + "conv2.bias"], stride=1, padding=1)
     key = prefix + "downsample.0.weight"
     shortcut = rf(F.conv2d(rb(x), rf(sd[key]), None, stride=stride)) if key in sd else x
-    return rf(F.leaky_relu(rb(o + shortcut), LEAK))
+    return rf(_lrelu(rb(o + shortcut), p2))
 
 
-def backbone(sd, x, acts=None, prefix="cnn.module.", emulate_bf16=False):
+def backbone(sd, x, acts=None, prefix="cnn.module.", emulate_bf16=False, patterns=None):
     """gbm/model.py:50-61.  x: [T,3,H,W] fp32 -> [T,80].
 
     emulate_bf16=True is NOT reference arithmetic: it is the same fp32 computation with every tensor the
     HIP bf16 path keeps in HBM (activations, their gradients, MFMA weight operands) rounded to bf16 at
     the point where that path stores it, so that the bf16 kernels can be checked tightly instead of
-    only against a loose bf16-vs-fp32 bound."""
+    only against a loose bf16-vs-fp32 bound.
+
+    patterns (NOT reference arithmetic either): the piecewise-linear network evaluated on a GIVEN activation pattern —
+    {"stem_tap": int64 [T,20,Hp,Wp] winning tap (ky*3+kx) of every max-pool window, "stem_pos": bool, its winner > 0,
+    "layerL.B.o1" / "layerL.B": bool [T,C,H,W], sign of the block's two LeakyReLU inputs}.  An element whose
+    pre-activation is within rounding of zero flips its branch between two correct fp32 evaluations and moves the
+    gradients by up to 1e-2 of their norm (one element in 327,680 is enough: tools/diag_mask_flips.py), which says nothing
+    about the kernels; with the pattern taken from the implementation under test, an fp64 run of this function is the
+    exact gradient of the SAME linear piece and kernel error is all that is left."""
     rf = _RoundFwd.apply if emulate_bf16 else _ident
     rb = _RoundBwd.apply if emulate_bf16 else _ident
-    t = F.leaky_relu(rb(F.conv2d(rf(x), rf(sd[prefix + "conv1.weight"]), sd[prefix + "conv1.bias"],
-                                 stride=2, padding=3)), LEAK)
-    t = rf(t)
-    if acts is not None:
-        acts["stem"] = t
-    t = rb(F.max_pool2d(t, kernel_size=3, stride=2, padding=1))
+    pre = rb(F.conv2d(rf(x), rf(sd[prefix + "conv1.weight"]), sd[prefix + "conv1.bias"], stride=2, padding=3))
+    if patterns is None:
+        t = rf(F.leaky_relu(pre, LEAK))
+        if acts is not None:
+            acts["stem"] = t
+        t = rb(F.max_pool2d(t, kernel_size=3, stride=2, padding=1))
+    else:                       # LeakyReLU is monotonic: pool the pre-activation at the given winners, then the given branch
+        n, c, h, w = pre.shape
+        hp, wp = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        win = F.unfold(F.pad(pre, (1, 1, 1, 1), value=float("-inf")), kernel_size=3, stride=2).view(n, c, 9, hp, wp)
+        t = _lrelu(win.gather(2, patterns["stem_tap"].view(n, c, 1, hp, wp)).squeeze(2), patterns["stem_pos"])
     if acts is not None:
         acts["pool"] = t
     for li, _planes, stride in STAGES:
         for b in range(BLOCKS_PER_STAGE):
-            t = residual_block(sd, f"{prefix}layer{li}.{b}.", t, stride if b == 0 else 1, rf, rb)
+            t = residual_block(sd, f"{prefix}layer{li}.{b}.", t, stride if b == 0 else 1, rf, rb, patterns, f"layer{li}.{b}")
+            if acts is not None:
+                acts[f"layer{li}.{b}"] = t
         if acts is not None:
             acts[f"layer{li}"] = t
     t = t.mean(dim=(2, 3))

@@ -32,10 +32,21 @@ def load(d):
     return acc, cnt
 
 
+def library_sha16():
+    """sha256 (first 16 hex digits) of the libmil_hip.so these counters were collected on: bench.py reports whether the
+    summary it quotes belongs to the library it is running."""
+    import glob as _g
+    import hashlib
+    import os
+    hits = _g.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "*_amd", "libmil_hip.so"))
+    return hashlib.sha256(open(hits[0], "rb").read()).hexdigest()[:16] if hits else None
+
+
 def main():
     a, c = load(sys.argv[1])
     b, _ = load(sys.argv[2])
     out = {"_how": __doc__.strip().replace("\n", " "), "_source": sys.argv[4] if len(sys.argv) > 4 else "", "kernels": {}}
+    out["_library_sha16"] = library_sha16()
     print("# " + out["_source"])
     print("# fractions of SQ_WAVE_CYCLES; mfma = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES); insts per launch")
     for k in sorted(a, key=lambda k: -a[k]["SQ_WAVE_CYCLES"]):

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, name), f"{name} declared in include/mil_hip.h but not exported"
     from mil_amd import _lib
     assert sorted(_lib.EXPORTS) == declared           # the ctypes binding covers exactly the header
-    assert mil_amd.lib().mil_abi_version() == 1
+    assert mil_amd.lib().mil_abi_version() == 2
     assert mil_amd.lib().mil_head_grad_floats() == 6807   # 11 head tensors
 
 

@@ -126,3 +126,44 @@ def test_bench_two_ranks_training_and_tile_parallel_inference():
     line = _run_bench(["--infer", "--bags", "1", "--tiles", "50"])
     assert line["scaling"] == "strong" and line["config"]["global_bags"] == 1 and "tile-parallel tp2" in line["config"]["parallelism"]
     assert "fwd-only" in line["metric"] and "split over 2 ranks" in line["config"]["workload"]
+
+
+def _rccl_worker(port, out):
+    """ONE rank over the real backend ("nccl" = RCCL on ROCm) with the `device_id=` eager-init path bench.py uses: proves that
+    librccl loads on the box, that a communicator comes up, and that the three collectives of the data path run on the flat
+    buckets (forced: a one-rank group would otherwise short-circuit them)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import mil_amd
+        from mil_amd.dist import gather_features
+        net = _net()
+        flat = mil_amd.FlatParams(net)
+        before = flat.flat.clone()
+        flat.broadcast_params(force=True)
+        bags, labels = _bags()
+        flat.zero_grad()
+        net.forward_bags([b.cuda() for b in bags[:2]], labels[:2]).loss.sum().backward()
+        g0 = flat.flat_grad.clone()
+        flat.allreduce_grads(force=True)                       # SUM over one rank: the bucket itself
+        feats = torch.randn(37, 80, device="cuda")
+        gathered = gather_features(feats, force=True)          # all_gather of sizes + padded features
+        torch.cuda.synchronize()
+        out.put((dist.get_backend(), bool(torch.equal(before, flat.flat)), bool(torch.equal(g0, flat.flat_grad)),
+                 float(g0.abs().max()) > 0, bool(torch.equal(gathered, feats)), int(flat.numel)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_one_rank_collectives_on_the_flat_bucket():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), out))
+    p.start()
+    p.join(timeout=600)
+    assert p.exitcode == 0, p.exitcode
+    backend, params_same, grads_same, nonzero, gather_same, numel = out.get(timeout=5)
+    assert backend == "nccl"
+    assert params_same and grads_same and nonzero and gather_same
+    assert numel == 640967                                     # SURVEY.md Appendix B: the 2.56 MB bucket

@@ -642,3 +642,30 @@ def test_fused_backward_splits_launches_above_2gib(ops):
     b = ops.conv_bwd_fused(dz[half:], wd, x[half:], c, c, addend=add[half:], mask=True)
     assert torch.equal(whole[0][:half], a[0]) and torch.equal(whole[0][half:], b[0])
     assert rel_err(whole[1].cpu(), (a[1] + b[1]).cpu()) < 1e-5 and rel_err(whole[2].cpu(), (a[2] + b[2]).cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, X3])
+def test_launches_chunked_under_the_buffer_limit(ops, dtype, monkeypatch):
+    """Tensors above the 2 GiB reach of a buffer descriptor are walked in image chunks (persistent conv, prefetch-pipelined
+    weight gradient).  MIL_BUFFER_LIMIT_BYTES lowers the limit so that a 40-image launch is cut into 16 + 16 + 8 images:
+    the conv must give the same bits as the single launch, the weight gradient the same sums (other slab order)."""
+    L = _lib()
+    monkeypatch.setenv("MIL_PF_MIN_TILES", "1")
+    n, c, h, w = 40, 20, 16, 16
+    g = torch.Generator().manual_seed(99)
+    x = round_to(torch.randn(n, c, h, w, generator=g), dtype)
+    wt = round_to(torch.randn(c, c, 3, 3, generator=g) / (c * 9) ** 0.5, dtype).requires_grad_(True)
+    b = (torch.randn(c, generator=g) * 0.1).requires_grad_(True)
+    dz = round_to(torch.randn(n, c, h, w, generator=g), dtype)
+    F.conv2d(x, wt, b, padding=1).backward(dz)
+    xg, dzg = to_nhwc(x, dtype), to_nhwc(dz, dtype)
+    wp, bp = ops.pack_weights(wt.detach().cuda(), b.detach().cuda(), L.PACK_FWD, dtype)
+    y_one = ops.conv(xg, wp, bp, cpad(c), ks=3, stride=1, pad=1, lrelu=True)
+    dw_one, db_one = ops.conv_wgrad(xg, dzg, c, c, ks=3, stride=1, pad=1)
+    esz = xg.element_size()
+    monkeypatch.setenv("MIL_BUFFER_LIMIT_BYTES", str(max(65536, 17 * h * w * cpad(c) * esz)))     # 17 images fit: chunks of 16
+    y_cut = ops.conv(xg, wp, bp, cpad(c), ks=3, stride=1, pad=1, lrelu=True)
+    dw_cut, db_cut = ops.conv_wgrad(xg, dzg, c, c, ks=3, stride=1, pad=1)
+    assert torch.equal(y_one, y_cut)
+    assert rel_err(dw_cut.cpu(), wt.grad) < WTOL[dtype] and rel_err(db_cut.cpu(), b.grad) < WTOL[dtype]
+    assert rel_err(dw_cut.cpu(), dw_one.cpu()) < 1e-5

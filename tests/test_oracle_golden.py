@@ -111,3 +111,58 @@ def test_alt_backbone_oracle_matches_reference_golden(golden_dir, name):
     feats.backward(torch.from_numpy(z["dfeats"]))
     for k, v in zip([str(k) for k in z["gradnorm.names"]], z["gradnorm.l2"]):
         assert abs(float(sd[k].grad.double().norm()) - v) <= 1e-5 * v, k
+
+
+def own_patterns(acts, x_shape):
+    """The activation pattern of an oracle run in the form `backbone(patterns=...)` takes (taps from max_pool2d's indices)."""
+    import torch.nn.functional as F
+    stem = acts["stem"]
+    _n, _c, h, w = stem.shape
+    _p, idx = F.max_pool2d(stem, 3, 2, 1, return_indices=True)
+    hp, wp = idx.shape[2:]
+    oy = torch.arange(hp).view(1, 1, hp, 1)
+    ox = torch.arange(wp).view(1, 1, 1, wp)
+    tap = (idx // w - (2 * oy - 1)) * 3 + (idx % w - (2 * ox - 1))
+    pat = {"stem_tap": tap, "stem_pos": acts["pool"] > 0}
+    for k, v in acts.items():
+        if k.count(".") >= 1:
+            pat[k] = v > 0
+    return pat
+
+
+def test_forced_activation_pattern_reproduces_the_plain_run(golden_dir):
+    """`backbone(patterns=...)` with the pattern of the plain run itself must give the plain run's features and gradients
+    (fp64: to rounding) — it is the reference of tests/test_gpu_configs.py::test_encoder_gradients_on_its_own_activation_pattern."""
+    import numpy as np
+    import os
+    w = np.load(os.path.join(golden_dir, "weights.npz"))
+    sd = {k: torch.tensor(w[k], dtype=torch.float64, requires_grad=True) for k, _s in orc.state_dict_spec()}
+    x = torch.randn(3, 3, 64, 64, generator=torch.Generator().manual_seed(3), dtype=torch.float64).clamp_(-1, 1)
+    acts = {}
+
+    def run(patterns):
+        for v in sd.values():
+            v.grad = None
+        a = {}
+        o1 = {}
+        # the blocks' inner activations are not in `acts`: capture them through the same function with a recording wrapper
+        f = orc.backbone(sd, x, a, patterns=patterns)
+        f.square().sum().backward()
+        return f.detach().clone(), {k: v.grad.clone() for k, v in sd.items() if v.grad is not None}, a
+
+    f0, g0, acts = run(None)
+    # inner (o1) patterns: recompute each block's first LeakyReLU input sign from the block inputs the run recorded
+    import torch.nn.functional as F
+    pat = own_patterns(acts, x.shape)
+    t = acts["pool"]
+    with torch.no_grad():
+        for li, _pl, stride in orc.STAGES:
+            for b in range(orc.BLOCKS_PER_STAGE):
+                q = f"cnn.module.layer{li}.{b}."
+                pre = F.conv2d(t, sd[q + "conv1.weight"], sd[q + "conv1.bias"], stride=stride if b == 0 else 1, padding=1)
+                pat[f"layer{li}.{b}.o1"] = pre > 0
+                t = acts[f"layer{li}.{b}"]
+    f1, g1, _ = run(pat)
+    assert float((f1 - f0).abs().max()) <= 1e-12 * float(f0.abs().max())
+    for k in g0:
+        assert float((g1[k] - g0[k]).abs().max()) <= 1e-10 * max(float(g0[k].abs().max()), 1e-30), k

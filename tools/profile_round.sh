@@ -29,6 +29,19 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACT
 echo "sq2 done"
 python3 profiles/summarise_sq_counters.py $OUT/sq1 $OUT/sq2 profiles/sq_counters.json "$ROUND: $BENCH" > profiles/${ROUND}_sq_counters.txt
 cp profiles/sq_counters.json profiles/${ROUND}_sq_counters.json
+# the same passes for the split-precision path (fp32 tensors, bf16x3 products): kernel stats + HBM traffic + SQ counters
+X3="python3 bench.py --dtype bf16x3 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-extra-paths"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/x3_stats -- python3 bench.py --dtype bf16x3 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths > $OUT/x3_stats.log 2>&1
+cp "$(ls $OUT/x3_stats/*/*kernel_stats.csv | head -n 1)" profiles/${ROUND}_bf16x3_kernel_stats.csv
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/x3_fetch -- $X3 > $OUT/x3_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/x3_write -- $X3 > $OUT/x3_write.log 2>&1
+python3 profiles/make_pmc_traffic.py $OUT/x3_fetch $OUT/x3_write profiles/pmc_traffic_bf16x3.json > $OUT/x3_traffic.txt
+cp profiles/pmc_traffic_bf16x3.json profiles/${ROUND}_pmc_traffic_bf16x3.json
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d $OUT/x3_sq1 -- $X3 > $OUT/x3_sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM --output-format csv -d $OUT/x3_sq2 -- $X3 > $OUT/x3_sq2.log 2>&1
+python3 profiles/summarise_sq_counters.py $OUT/x3_sq1 $OUT/x3_sq2 profiles/sq_counters_bf16x3.json "$ROUND: $X3" > profiles/${ROUND}_sq_counters_bf16x3.txt
+cp profiles/sq_counters_bf16x3.json profiles/${ROUND}_sq_counters_bf16x3.json
+echo "bf16x3 passes done"
 # the bench lines last: their roofline.traffic / sq_counters fields read the PMC summaries written just above
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench.err
 tail -n 1 $OUT/bench_line.json > profiles/${ROUND}_bench_line.json
@@ -40,4 +53,4 @@ echo "cfg3 / cfg5 lines done"
 
 echo "all profiles written"
 mkdir -p gpurun_out/profiles_out
-cp profiles/${ROUND}_* profiles/pmc_traffic.json profiles/sq_counters.json gpurun_out/profiles_out/
+cp profiles/${ROUND}_* profiles/pmc_traffic*.json profiles/sq_counters*.json gpurun_out/profiles_out/
