@@ -10,7 +10,8 @@ import subprocess
 import torch  # noqa: F401  (must be imported first: the HIP runtime torch loaded is the one we bind to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmil_hip.so")
+# MIL_LIB_PATH selects another build of the same library (the NaN-poisoned diagnostic build, `make -C csrc POISON=1`)
+LIB_PATH = os.environ.get("MIL_LIB_PATH") or os.path.join(_HERE, "libmil_hip.so")
 
 MIL_DT_F32, MIL_DT_BF16, MIL_DT_BF16_DGRAD, MIL_DT_F32S = 0, 1, 2, 3
 # compute_dtype value of the split-precision path: fp32 tensors (every pointwise kernel of the fp32 path), convolutions

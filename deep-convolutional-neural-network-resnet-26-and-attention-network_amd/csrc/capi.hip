@@ -23,3 +23,20 @@ extern "C" int mil_stream_copy(void* dst, const void* src, size_t bytes, void* s
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
+
+#ifdef MIL_POISON_LDS
+// Diagnostic build only: proves that the poisoning reaches the whole dynamic segment (out[i] = LDS word i after MIL_POISON).
+__global__ void poison_probe_kernel(unsigned* out, int words) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    MIL_POISON(smem);
+    for (int i = threadIdx.x; i < words; i += blockDim.x) out[i] = reinterpret_cast<const unsigned*>(smem)[i];
+}
+extern "C" int mil_poison_probe(unsigned* out, int lds_bytes, void* stream) {
+    if (!out || lds_bytes <= 0 || (lds_bytes & 3) || lds_bytes > 160 * 1024) return MIL_ERR_ARG;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(poison_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+        return MIL_ERR_LAUNCH;
+    hipLaunchKernelGGL(poison_probe_kernel, dim3(1), dim3(256), lds_bytes, reinterpret_cast<hipStream_t>(stream), out, lds_bytes / 4);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+#endif

@@ -173,4 +173,22 @@ __host__ __device__ constexpr int mil_pix_pitch(int cp, int esz) {
     return ((n16 & 1) ? n16 : n16 + 1) * 16;
 }
 
+// -DMIL_POISON_LDS (diagnostic build, `make POISON=1` -> libmil_hip_poison.so): every kernel fills its whole dynamic LDS
+// segment with bf16 NaNs (0x7FC0 0x7FC0 = an fp32 NaN too) before doing anything else, so that a read of LDS bytes the
+// kernel never wrote — a zero-weight padding k-step reading behind a tile, a row tile that does not exist — turns into a
+// NaN in the output deterministically (0 x NaN) instead of depending on what the previous workgroup left there.
+// The segment size is the `hidden_dynamic_lds_size` implicit kernel argument (code object v5: byte 120).
+#ifdef MIL_POISON_LDS
+__device__ __forceinline__ void mil_poison_lds(void* base) {
+    typedef __attribute__((address_space(4))) const unsigned* cu32p;
+    const unsigned bytes = ((cu32p)__builtin_amdgcn_implicitarg_ptr())[30];
+    unsigned* w = reinterpret_cast<unsigned*>(base);
+    for (unsigned i = threadIdx.x; i < bytes / 4; i += blockDim.x) w[i] = 0x7FC07FC0u;
+    __syncthreads();
+}
+#define MIL_POISON(base) mil_poison_lds(base)
+#else
+#define MIL_POISON(base) ((void)0)
+#endif
+
 #define MIL_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return MIL_ERR_LAUNCH; } while (0)

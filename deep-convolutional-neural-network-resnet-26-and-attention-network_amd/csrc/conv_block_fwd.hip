@@ -36,6 +36,7 @@ struct BlockFwdArgs {
 template <int CP, int NT, int NW>
 __global__ __launch_bounds__(64 * NW, (CP <= 24 ? 2 : 1) * (NW == 8 ? 2 : 1)) void conv_block_fwd_kernel(BlockFwdArgs a, int ntiles, unsigned bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MIL_POISON(smem);
     constexpr int PIXB = mil_pix_pitch(CP, 2);
     constexpr int CG = CP / 8;
     constexpr int KSTEPS = (9 * CG + 3) / 4;

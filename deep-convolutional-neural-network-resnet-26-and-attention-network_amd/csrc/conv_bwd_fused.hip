@@ -60,6 +60,7 @@ struct BwdFusedArgs {
 template <int CZ, int NTX, int KS, bool ADD, bool MASK, int NW = 4>
 __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES) void conv_bwd_fused_kernel(BwdFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MIL_POISON(smem);
     constexpr bool PIPE = CZ <= MIL_BWD_PIPE_MAXC;
     constexpr int PIXB = mil_pix_pitch(CZ, 2);            // dz halo pixel pitch
     constexpr int CG = CZ / 8;
@@ -434,6 +435,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
 template <bool ADD, bool MASK>
 __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MIL_POISON(smem);
     constexpr int CZ = 24, NTX = 2, KS = 3, NW = 8;
     constexpr int PIXB = 48, PIXX = 48, CX = 24, HW = 18, ROWB = HW * PIXB;      // 864 B per halo row
     constexpr int KSTEPS_STD = 7;

@@ -28,6 +28,7 @@ struct DgradS2Args {
 template <int CZ, int NT>
 __global__ __launch_bounds__(256, CZ <= 40 ? 2 : 1) void conv_dgrad_s2_kernel(DgradS2Args a, int ntiles, unsigned z_bytes, unsigned y_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MIL_POISON(smem);
     constexpr int CG = CZ / 8;
     constexpr int PIXZ = mil_pix_pitch(CZ, 2);
     constexpr int CXP = mil_nt_to_cp(NT);

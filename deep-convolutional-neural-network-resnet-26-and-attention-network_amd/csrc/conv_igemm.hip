@@ -33,6 +33,7 @@ struct ConvArgs {
 template <typename T, int CINP, int NT, int MTW>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MIL_POISON(smem);
     constexpr int ESZ = T::ESZ;
     constexpr int PIXB = mil_pix_pitch(CINP, ESZ);
     constexpr int CG = CINP / 8;
@@ -179,6 +180,7 @@ template <typename T, int CINP, int NT, int KS, int MTW, int FLAGS = -1, int NW 
 __global__ __launch_bounds__(64 * NW, T::SPLIT ? (NW == 8 ? 2 : (CINP <= 24 ? 2 : 1)) : (NW == 8 ? (CINP <= 40 ? 4 : 2) : ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 24 && FLAGS >= 0 && FLAGS != 3) ? MIL_PF_WAVES_24 : (CINP <= 40 ? 2 : 1))))
 void conv_igemm_pf_kernel(ConvArgs<T> a, int ntiles, unsigned x_bytes, unsigned y_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MIL_POISON(smem);
     constexpr int ESZ = T::ESZ;
     constexpr int FRAGB = 8 * ESZ;              // bytes of one packed filter fragment per lane
     constexpr bool PIPE = !T::SPLIT && MIL_PF_PIPE(CINP, NT, MTW, NW);

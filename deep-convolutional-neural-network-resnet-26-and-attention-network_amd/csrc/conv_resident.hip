@@ -77,6 +77,7 @@ __global__ __launch_bounds__(512, 2) void conv_resident_kernel(ResArgs a) {
     using G = ResGeom<C, S, IMGS>;
     constexpr int CG = G::CG, NT = G::NT, PIX = G::PIX, HS = G::HS, IMG = G::IMG, KSTEPS = G::KSTEPS, TPI = G::TPI, MW = G::MW, NP = G::NP;
     extern __shared__ __attribute__((aligned(16))) char tile[];
+    MIL_POISON(tile);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, gq = lane >> 4;

@@ -24,6 +24,7 @@ struct S2EntryArgs {
 template <int CINP, int NT, int MTW = 2>
 __global__ __launch_bounds__(256, CINP <= 24 ? 2 : 1) void conv_s2_entry_kernel(S2EntryArgs a, int ntiles, unsigned x_bytes, unsigned y_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MIL_POISON(smem);
     constexpr int PIXB = mil_pix_pitch(CINP, 2);
     constexpr int CG = CINP / 8;
     constexpr int COUTP = mil_nt_to_cp(NT);

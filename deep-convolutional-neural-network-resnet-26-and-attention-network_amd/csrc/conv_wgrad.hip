@@ -60,6 +60,7 @@ __host__ __device__ constexpr int mil_wgrad_halo_max(int cinp, bool proj) {
 template <typename T, int KS, int CINP, int NT, int MSPLIT, bool PF, int NW = 4, bool PROJ = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : ((PF && CINP > 40) ? 1 : 0)) void wgrad_kernel(WgradArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MIL_POISON(smem);
     constexpr int ESZ = T::ESZ;
     constexpr int PIXB = mil_pix_pitch(CINP, ESZ);
     constexpr int COUTP = mil_nt_to_cp(NT);
@@ -613,6 +614,7 @@ struct StemBwdArgs {
 template <bool FROM_X>
 __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel(StemBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MIL_POISON(smem);
     constexpr int CINP = 16, NT = 2, KS = 4, COUTP = 24;
     constexpr int PIXB = mil_pix_pitch(CINP, 2);
     constexpr int PIXZ = mil_pix_pitch(COUTP, 2);           // 48: dz tile and pooled-gradient tile

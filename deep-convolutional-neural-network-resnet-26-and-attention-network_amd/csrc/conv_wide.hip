@@ -61,6 +61,7 @@ __device__ __forceinline__ void wide_load_halo(char* lds, const typename T::elem
 template <typename T>
 __global__ __launch_bounds__(256) void wide_conv_kernel(WideArgs<T> a, int lds_w_off) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MIL_POISON(smem);
     constexpr int ESZ = T::ESZ;
     constexpr int PIXB = mil_pix_pitch(WIDE_CK, ESZ);
     constexpr int FRAGB = 8 * ESZ;
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(256) void wide_conv_kernel(WideArgs<T> a, int lds_w
 template <int KS>
 __global__ __launch_bounds__(256, 2) void wide_conv_pf_kernel(WideArgs<BF16> a, int lds_w_off, unsigned x_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MIL_POISON(smem);
     using T = BF16;
     constexpr int PIXB = mil_pix_pitch(WIDE_CK, 2);
     constexpr int NTAP = KS * KS;
@@ -466,6 +468,7 @@ __device__ __forceinline__ void wide_load_otile(char* lds, const typename T::ele
 template <typename T, int KS>
 __global__ __launch_bounds__(256) void wide_wgrad_kernel(WideWgradArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MIL_POISON(smem);
     constexpr int ESZ = T::ESZ;
     constexpr int PIXB = mil_pix_pitch(WIDE_CK, ESZ);
     constexpr int PIXZ = mil_pix_pitch(WIDE_NB, ESZ);
@@ -566,6 +569,7 @@ __global__ __launch_bounds__(256) void wide_wgrad_kernel(WideWgradArgs<T> a) {
 template <int KS>
 __global__ __launch_bounds__(256, 2) void wide_wgrad_pf_kernel(WideWgradArgs<BF16> a, unsigned x_bytes, unsigned z_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MIL_POISON(smem);
     constexpr int PIXB = mil_pix_pitch(WIDE_CK, 2);
     constexpr int PIXZ = mil_pix_pitch(WIDE_NB, 2);
     constexpr int CG = WIDE_CK / 8;

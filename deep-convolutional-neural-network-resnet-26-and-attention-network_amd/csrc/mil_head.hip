@@ -412,6 +412,7 @@ __global__ __launch_bounds__(1024) void head_wgrad_partial_kernel(const float* _
                                                                  const float* __restrict__ dhz, float* __restrict__ partial,
                                                                  int ntot, float slope, float keep_scale) {
     extern __shared__ float rows[];                       // [WGS][R_STRIDE]
+    MIL_POISON(rows);
     const int tid = threadIdx.x, n0 = blockIdx.x * WGS;
     for (int idx = tid; idx < WGS * HL; idx += 1024) {      // the 80-wide operands
         const int nl = idx / HL, i = idx - nl * HL, n = n0 + nl;

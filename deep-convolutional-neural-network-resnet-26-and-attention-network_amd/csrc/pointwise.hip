@@ -343,6 +343,7 @@ __global__ __launch_bounds__(256) void fc_wgrad_kernel(const float* __restrict__
 __global__ __launch_bounds__(1024) void fc_wgrad_partial_kernel(const float* __restrict__ dfeats, const float* __restrict__ pooled,
                                                                float* __restrict__ partial, int n, int C, int NF, int want_bias) {
     extern __shared__ float frows[];                        // [FCS][NF + C + 1 (+pad)]
+    MIL_POISON(frows);
     const int stride = (NF + C + 2) & ~1;
     const int tid = threadIdx.x, n0 = blockIdx.x * FCS;
     for (int idx = tid; idx < FCS * NF; idx += 1024) {

@@ -34,6 +34,7 @@ __device__ __forceinline__ unsigned prep_clip8(int v) { v >>= PREP_BITS; return 
 template <int KS>
 __global__ __launch_bounds__(256) void tile_preprocess_kernel(PrepArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    MIL_POISON(psm);
     unsigned char* rows = psm;
     unsigned char* hres = psm + a.lds_h_off;
     int* kks = reinterpret_cast<int*>(psm + a.lds_k_off);

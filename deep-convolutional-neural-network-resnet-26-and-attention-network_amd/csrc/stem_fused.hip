@@ -58,6 +58,7 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 
     constexpr int NPOOL = (128 * NG4 + NTHR - 1) / NTHR;      // (pooled pixel, 4-channel group) items per thread
     constexpr bool LAST_PARTIAL = (COUTP % 16) != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MIL_POISON(smem);
     char* ldsX = smem;
     char* ldsS = smem + SF_XBYTES;
     char* ldsW = ldsS + ((SF_NSTEM * SPIX + 15) & ~15);

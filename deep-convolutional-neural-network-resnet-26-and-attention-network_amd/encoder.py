@@ -200,6 +200,7 @@ class ResNet(nn.Module):
 def encoder_forward(net, x, dtype):
     """Runs the kernels; returns (feats [T,80] fp32, saved-state dict for the backward)."""
     net.refresh_packed(dtype)
+    x = x.contiguous()                  # the tensor the kernels read — and, without a kept s2d copy, the one the backward re-reads
     hk = net.child_hooks()              # None unless a forward hook sits on a child module (then views are built for it)
     wp, bp = net._packed("stem", net.conv1.weight, net.conv1.bias, L.PACK_STEM, dtype)
     stem_hooked = hk is not None and hooks.any_hooked((net.conv1, net.relu, net.maxpool))
@@ -221,7 +222,10 @@ def encoder_forward(net, x, dtype):
             stem_v = hooks.nchw(stem, STEM_WIDTH)
             hooks.fire(net.relu, stem_v, stem_v)            # in place upstream (gbm/model.py:25): input is the output
             hooks.fire(net.maxpool, stem_v, hooks.nchw(pool, STEM_WIDTH))
-    saved = {"xs": xs, "x": x if xs is None else None, "stem_hw": stem_hw, "widx": widx, "blocks": []}      # the stem output itself is not kept
+    # the stem output itself is not kept.  Without an s2d copy the backward rebuilds its tiles from the INPUT tensor: its
+    # version counter is recorded so that an in-place change between forward and backward raises instead of silently
+    # giving a wrong conv1 gradient (keep_s2d=True keeps a library-owned copy where the caller cannot promise that)
+    saved = {"xs": xs, "x": x if xs is None else None, "x_version": x._version, "stem_hw": stem_hw, "widx": widx, "blocks": []}
     t = pool
     stage_in = pool
     all_blocks = list(net.blocks())
@@ -304,6 +308,10 @@ def encoder_backward(net, saved, dfeats, dtype):
     the reference, gbm/model.py:194-196, so no data-gradient is produced for the tiles)."""
     blocks = list(net.blocks())
     grads = {}
+    if saved["x"] is not None and saved["x"]._version != saved["x_version"]:
+        raise RuntimeError("the input tiles were modified in place between the encoder's forward and backward: conv1's gradient is "
+                           "computed from them (no space-to-depth copy is kept).  Keep the tensor untouched until backward, or set "
+                           "`net.cnn.module.keep_s2d = True` (MIL_KEEP_S2D=1) to have the forward keep its own copy")
     last_out = saved["blocks"][-1][2]
     dz, dwfc = ops.avgpool_fc_bwd(dfeats.contiguous(), net.fc.weight.detach(), saved["pooled"], last_out,
                                   STAGE_WIDTHS[-1],
@@ -334,6 +342,7 @@ def encoder_backward(net, saved, dfeats, dtype):
         need = ops.wgrad_workspace_bytes(n, h, w, cin, ho, wo, cout, kw["ks"], kw["stride"], kw["pad"],
                                          kw.get("stem", False), xin.dtype)
         if batch is not None:                # deferred reduction: a slab buffer of its own, alive until the batched launch
+            assert key is not None, "deferred reductions need one workspace per call site: pass key="
             return ops.conv_wgrad(xin, dzz, cin, cout, workspace=batch.workspace(("w", key), need), **kw)
         if not use_side:
             if ws[-1] is None or ws[-1].numel() * 4 < need:

@@ -48,9 +48,15 @@ class ReduceBatch:
         self.host = (ctypes.c_char * (self.rec * self.MAX_JOBS))()
         self.dev = torch.empty(self.rec * self.MAX_JOBS, dtype=torch.uint8, device=device)
         self.uploaded = None                 # bytes of the table the device copy holds
-        self.ws = {}
+        self.ws = {}                         # persistent slab buffers, one per call site (about 0.7 GB at 2048 tiles of 256x256)
+        self.handed = None                   # keys handed out inside the current `with` block
 
     def workspace(self, key, nbytes):
+        if self.handed is not None:
+            if key in self.handed:
+                raise RuntimeError(f"slab workspace {key!r} handed out twice inside one deferred-reduction block: the second "
+                                   "producer would overwrite slabs the batched reduction has not read yet")
+            self.handed.add(key)
         t = self.ws.get(key)
         if t is None or t.numel() * 4 < nbytes:
             t = self.ws[key] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
@@ -58,10 +64,12 @@ class ReduceBatch:
 
     def __enter__(self):
         L.check(L.lib().mil_reduce_defer_begin(ctypes.addressof(self.host), self.MAX_JOBS), "mil_reduce_defer_begin")
+        self.handed = set()
         return self
 
     def __exit__(self, exc_type, exc, tb):
         n = ctypes.c_int(0)
+        self.handed = None
         L.check(L.lib().mil_reduce_defer_end(ctypes.byref(n)), "mil_reduce_defer_end")
         if exc_type is not None or n.value == 0:
             return False

@@ -669,3 +669,22 @@ def test_launches_chunked_under_the_buffer_limit(ops, dtype, monkeypatch):
     assert torch.equal(y_one, y_cut)
     assert rel_err(dw_cut.cpu(), wt.grad) < WTOL[dtype] and rel_err(db_cut.cpu(), b.grad) < WTOL[dtype]
     assert rel_err(dw_cut.cpu(), dw_one.cpu()) < 1e-5
+
+
+def test_poisoned_lds_build_really_poisons():
+    """Only under MIL_LIB_PATH=<libmil_hip_poison.so> (`make -C csrc POISON=1`: every kernel fills its dynamic LDS with NaNs at
+    entry, so that a read of never-written LDS shows up as a NaN deterministically): the probe kernel must see the pattern in
+    every word of a 100 KB segment.  The whole kernel suite is then run once on that build."""
+    import ctypes
+    import os
+    path = os.environ.get("MIL_LIB_PATH", "")
+    if "poison" not in os.path.basename(path):
+        pytest.skip("runs on the poisoned diagnostic build only")
+    lib = ctypes.CDLL(path)
+    lib.mil_poison_probe.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.mil_poison_probe.restype = ctypes.c_int
+    nbytes = 100 * 1024
+    out = torch.zeros(nbytes // 4, dtype=torch.int32, device="cuda")
+    assert lib.mil_poison_probe(out.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert bool((out == 0x7FC07FC0).all())

@@ -425,3 +425,20 @@ def test_side_stream_weight_gradients_equal_main_stream(golden_dir):
         torch.cuda.synchronize()
         grads.append(flat.flat_grad.clone())
     assert torch.equal(grads[0], grads[1]) and float(grads[0].abs().max()) > 0
+
+
+def test_input_modified_between_forward_and_backward_raises(golden_dir):
+    """Without a kept space-to-depth copy the fused stem backward re-reads the caller's input tiles: an in-place change between
+    forward and backward must raise (the tensor's version counter is checked) instead of silently corrupting conv1's gradient;
+    keep_s2d=True keeps a library-owned copy and is immune."""
+    net = _model(golden_dir, torch.bfloat16).eval()
+    x = torch.randn(8, 3, 64, 64, generator=torch.Generator().manual_seed(1)).clamp_(-1, 1).cuda()
+    out = net(x, torch.tensor([1]).cuda())
+    x.mul_(0.5)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        out["loss"].backward()
+    net.cnn.module.keep_s2d = True
+    out = net(x, torch.tensor([1]).cuda())
+    x.mul_(0.5)
+    out["loss"].backward()
+    assert float(net.cnn.module.conv1.weight.grad.abs().max()) > 0
