@@ -592,8 +592,8 @@ struct StemBwdArgs {
     int H, W;                // input dims (FROM_X)
     unsigned x_bytes;
     int lds_dump_off;
-    const __bf16* gp;        // [n,Hp,Wp,24] gradient of the pooled output ([n,Hp,Wp,20] when gpx == 40: MIL_DT_BF16_DGRAD)
-    int gpx;                 // bytes per pixel of gp: 48 or 40
+    const __bf16* gp;        // [n,Hp,Wp,24] gradient of the pooled output ([n,Hp,Wp,20] when gpx == 40: MIL_DT_BF16_DGRAD; fp32 when gpx == 96: MIL_DT_F32S)
+    int gpx;                 // bytes per pixel of gp: 48, 40 or 96
     const uint8_t* widx;     // [n,Hp,Wp,24] winner tap (bits 0-3) + "winner <= 0" (bit 4)
     float* slab;
     ConvGeom g;              // geometry of the stem conv as executed (ks 4, stride 1, pad 2, Ho=H2, Wo=W2)
@@ -611,13 +611,17 @@ struct StemBwdArgs {
 #ifndef MIL_STEM_BWD_PIPE
 #define MIL_STEM_BWD_PIPE 1
 #endif
-template <bool FROM_X>
+// X3 (MIL_DT_F32S, FROM_X only): fp32 pooled gradient; the s2d tile and the dz tile hold hi and lo bf16 planes ([hi | lo] per
+// pixel record), the weight-gradient GEMM takes x_lo*dz_hi + x_hi*dz_lo + x_hi*dz_hi, the bias sums are the un-rounded fp32 values.
+template <bool FROM_X, bool X3 = false>
 __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel(StemBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MIL_POISON(smem);
+    static_assert(!X3 || FROM_X, "the split-precision form reads the fp32 tiles");
     constexpr int CINP = 16, NT = 2, KS = 4, COUTP = 24;
-    constexpr int PIXB = mil_pix_pitch(CINP, 2);
-    constexpr int PIXZ = mil_pix_pitch(COUTP, 2);           // 48: dz tile and pooled-gradient tile
+    constexpr int PIXB = mil_pix_pitch(CINP, X3 ? 4 : 2);   // 48; X3: 80 = [hi 32 B][lo 32 B] + pad
+    constexpr int PIXZ = mil_pix_pitch(COUTP, X3 ? 4 : 2);  // dz tile: 48; X3: 112 = [hi 48 B][lo 48 B] + pad
+    constexpr int PIXG = X3 ? 96 : PIXZ;                    // pooled-gradient tile: bf16 record, or 24 fp32
     // GEMM rows = (tap, s2d channel) in four-channel pieces (one ds_read_b64_tr_b16 each): 16 taps x 3 real pieces = 48 pieces
     // = 12 row tiles; the padding piece (channels 12-15) of a pixel record is never read
     constexpr int NPC = 3, MT = KS * KS * NPC / 4, MW = (MT + 3) / 4;
@@ -680,12 +684,21 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             const f32x4_t v0 = __builtin_bit_cast(f32x4_t, lr0[i]), v1 = __builtin_bit_cast(f32x4_t, lr1[i]);
-            bf16x4_t pa, pb;
-            pa[0] = (__bf16)v0[0]; pa[1] = (__bf16)v0[1]; pa[2] = (__bf16)v1[0]; pa[3] = (__bf16)v1[1];
-            pb[0] = (__bf16)v0[2]; pb[1] = (__bf16)v0[3]; pb[2] = (__bf16)v1[2]; pb[3] = (__bf16)v1[3];
+            const float fa[4] = {v0[0], v0[1], v1[0], v1[1]}, fb[4] = {v0[2], v0[3], v1[2], v1[3]};
+            bf16x4_t pa, pb, qa, qb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pa[j] = (__bf16)fa[j]; pb[j] = (__bf16)fb[j];
+                if constexpr (X3) { qa[j] = (__bf16)(fa[j] - (float)pa[j]); qb[j] = (__bf16)(fb[j] - (float)pb[j]); }
+            }
             const int d0 = l_lds[i] & 0xFFFFF;
+            const int d1 = (l_lds[i] >> 20) ? a.lds_dump_off : d0 + PIXB;
             *reinterpret_cast<bf16x4_t*>(ldsX + d0) = pa;
-            *reinterpret_cast<bf16x4_t*>(ldsX + ((l_lds[i] >> 20) ? a.lds_dump_off : d0 + PIXB)) = pb;
+            *reinterpret_cast<bf16x4_t*>(ldsX + d1) = pb;
+            if constexpr (X3) {                              // lo plane 32 bytes behind the hi plane (the dump slot has room for both)
+                *reinterpret_cast<bf16x4_t*>(ldsX + d0 + 32) = qa;
+                *reinterpret_cast<bf16x4_t*>(ldsX + d1 + 32) = qb;
+            }
         }
     };
     // pooled-window pieces: item = window*3 + j; gradient piece = 16 B (8 channels), winner piece = 8 B
@@ -703,7 +716,7 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
             w_lds[i] = win * COUTP + j * 8;
         }
     }
-    auto fetch_win = [&](u32x4_t (&rg)[NPW], u32x2_t (&ri)[NPW], const TileOrigin& o) {
+    auto fetch_win = [&](u32x4_t (&rg)[NPW], u32x4_t (&rg2)[X3 ? NPW : 1], u32x2_t (&ri)[NPW], const TileOrigin& o) {
         const int py0 = o.oy0 >> 1, px0 = o.ox0 >> 1;
         const int base = (o.img0 * a.Hp + py0) * a.Wp + px0;
         const int ylim = a.Hp - py0, xlim = a.Wp - px0, ilim = g.n_img - o.img0;
@@ -712,10 +725,16 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
             const int p = w_pos[i];
             const bool ok = p >= 0 && (p >> 20) < ilim && ((p >> 10) & 1023) < ylim && (p & 1023) < xlim;
             const int pix = base + (w_rel[i] >> 2), j = w_rel[i] & 3;
+            if constexpr (X3) {                               // eight fp32 channels = two 16-byte loads
+                const unsigned goff = ok ? (unsigned)(pix * 96 + j * 32) : MIL_OOB;
+                rg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, goff, 0, 0);
+                rg2[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, ok ? goff + 16 : MIL_OOB, 0, 0);
+            } else {
             const unsigned goff = ok ? (unsigned)(pix * a.gpx + j * 16) : MIL_OOB;
             const u32x2_t lo = __builtin_amdgcn_raw_buffer_load_b64(rs_g, goff, 0, 0);
             const u32x2_t hi = __builtin_amdgcn_raw_buffer_load_b64(rs_g, (a.gpx != 48 && j == 2) ? MIL_OOB : goff + 8, 0, 0);      // dense: channels 20-23 do not exist
             rg[i] = u32x4_t{lo[0], lo[1], hi[0], hi[1]};
+            }
             ri[i] = __builtin_amdgcn_raw_buffer_load_b64(rs_i, ok ? (unsigned)(pix * COUTP + j * 8) : MIL_OOB, 0, 0);
         }
     };
@@ -751,11 +770,11 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
     const int bid = mil_xcd_block_id();
     cur.init(g, bid, gridDim.x);
     nxt = cur; nxt.advance();
-    u32x4_t rx[NPX], rgp[NPW];
+    u32x4_t rx[FROM_X ? 1 : NPX], rgp[NPW], rgp2[X3 ? NPW : 1];
     u32x2_t rwi[NPW];
     if (bid < a.ntiles) {
         if constexpr (FROM_X) fetch_x(cur.origin(g)); else mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, cur.origin(g));
-        fetch_win(rgp, rwi, cur.origin(g));
+        fetch_win(rgp, rgp2, rwi, cur.origin(g));
     }
     for (int tile = bid; tile < a.ntiles; tile += gridDim.x) {
         __syncthreads();                         // previous tile's MFMA loop is done with ldsX / ldsZ
@@ -763,14 +782,19 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             if (w_pos[i] >= 0) {
-                *reinterpret_cast<u32x4_t*>(ldsG + w_lds[i] * 2) = rgp[i];
+                if constexpr (X3) {
+                    *reinterpret_cast<u32x4_t*>(ldsG + w_lds[i] * 4) = rgp[i];
+                    *reinterpret_cast<u32x4_t*>(ldsG + w_lds[i] * 4 + 16) = rgp2[i];
+                } else {
+                    *reinterpret_cast<u32x4_t*>(ldsG + w_lds[i] * 2) = rgp[i];
+                }
                 *reinterpret_cast<u32x2_t*>(ldsI + w_lds[i]) = rwi[i];
             }
         }
         __syncthreads();
         if (tile + (int)gridDim.x < a.ntiles) {
             if constexpr (FROM_X) fetch_x(nxt.origin(g)); else mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, nxt.origin(g));
-            fetch_win(rgp, rwi, nxt.origin(g));
+            fetch_win(rgp, rgp2, rwi, nxt.origin(g));
         }
         cur = nxt; nxt.advance();
 
@@ -793,13 +817,16 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
                 for (int wx = 0; wx < 2; ++wx) {
                     const int win = (b_ti * WH + b_y + wy) * WW + b_x + wx;
                     const unsigned short* wi = reinterpret_cast<const unsigned short*>(ldsI + win * COUTP + bc6 * 6);
-                    const unsigned* gp = reinterpret_cast<const unsigned*>(ldsG + win * PIXZ + bc6 * 12);
+                    const unsigned* gp = reinterpret_cast<const unsigned*>(ldsG + win * PIXG + bc6 * (X3 ? 24 : 12));
                     const unsigned wpk[3] = {wi[0], wi[1], wi[2]};
-                    const unsigned gpk[3] = {gp[0], gp[1], gp[2]};
+                    unsigned gpk[X3 ? 6 : 3];
+#pragma unroll
+                    for (int k = 0; k < (X3 ? 6 : 3); ++k) gpk[k] = gp[k];
 #pragma unroll
                     for (int j = 0; j < 6; ++j) {
                         const unsigned wb = (wpk[j >> 1] >> (8 * (j & 1))) & 0xffu;
-                        const float gj = __uint_as_float((j & 1) ? (gpk[j >> 1] & 0xffff0000u) : (gpk[j >> 1] << 16));
+                        const float gj = X3 ? __uint_as_float(gpk[X3 ? j : 0])
+                                            : __uint_as_float((j & 1) ? (gpk[j >> 1] & 0xffff0000u) : (gpk[j >> 1] << 16));
                         const float gm = (wb & 16u) ? gj * a.slope : gj;
                         const unsigned t = wb & 15u;
 #pragma unroll
@@ -828,7 +855,14 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
                         bf16x2_t pr;
                         pr[0] = (__bf16)gsum[dy][dx][2 * k]; pr[1] = (__bf16)gsum[dy][dx][2 * k + 1];
                         dst[k] = __builtin_bit_cast(unsigned, pr);
+                        if constexpr (X3) {                      // lo plane of the dz record; the bias sums take the fp32 values themselves
+                            bf16x2_t lo;
+                            lo[0] = (__bf16)(gsum[dy][dx][2 * k] - (float)pr[0]); lo[1] = (__bf16)(gsum[dy][dx][2 * k + 1] - (float)pr[1]);
+                            dst[12 + k] = __builtin_bit_cast(unsigned, lo);
+                            bsum[2 * k] += gsum[dy][dx][2 * k]; bsum[2 * k + 1] += gsum[dy][dx][2 * k + 1];
+                        } else {
                         bsum[2 * k] += (float)pr[0]; bsum[2 * k + 1] += (float)pr[1];      // the rounded values, as the MFMA loop sees them
+                        }
                     }
                 }
         }
@@ -844,36 +878,42 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
 #if MIL_STEM_BWD_PIPE
         {
             static_assert(MT == 4 * MW, "every wave owns MW full row tiles");
-            bf16x8_t bc[NT], ac[MW], bn[NT], an[MW];
-            {
-                const int kb = mil_pix_base<PIXB>(g, 0, 1);
-                const char* z0 = ldsZ + (8 * gq + q4) * PIXZ + p4 * 8;
+            constexpr int NL2 = X3 ? 2 : 1;                  // operand planes: hi (+ lo)
+            bf16x8_t bc[NL2][NT], ac[NL2][MW], bn[NL2][NT], an[NL2][MW];
+            auto load = [&](int k32, bf16x8_t (&bf)[NL2][NT], bf16x8_t (&af)[NL2][MW]) {
+                const int kb = mil_pix_base<PIXB>(g, k32, 1);
+                const char* z0 = ldsZ + (k32 + 8 * gq + q4) * PIXZ + p4 * 8;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bc[nt] = mil_tr_pair(z0 + nt * 32, z0 + 4 * PIXZ + nt * 32);
+                for (int pl = 0; pl < NL2; ++pl) {
 #pragma unroll
-                for (int i = 0; i < MW; ++i) ac[i] = mil_tr_pair(ldsX + kb + wpl0 + toff[i], ldsX + kb + wpl1 + toff[i]);
-            }
+                    for (int nt = 0; nt < NT; ++nt) bf[pl][nt] = mil_tr_pair(z0 + pl * 48 + nt * 32, z0 + pl * 48 + 4 * PIXZ + nt * 32);
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) af[pl][i] = mil_tr_pair(ldsX + kb + wpl0 + toff[i] + pl * 32, ldsX + kb + wpl1 + toff[i] + pl * 32);
+                }
+            };
+            load(0, bc, ac);
 #pragma unroll
             for (int k32 = 0; k32 < 256; k32 += 32) {
-                if (k32 + 32 < 256) {
-                    const int kb = mil_pix_base<PIXB>(g, k32 + 32, 1);
-                    const char* z0 = ldsZ + (k32 + 32 + 8 * gq + q4) * PIXZ + p4 * 8;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bn[nt] = mil_tr_pair(z0 + nt * 32, z0 + 4 * PIXZ + nt * 32);
-#pragma unroll
-                    for (int i = 0; i < MW; ++i) an[i] = mil_tr_pair(ldsX + kb + wpl0 + toff[i], ldsX + kb + wpl1 + toff[i]);
-                }
+                if (k32 + 32 < 256) load(k32 + 32, bn, an);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < MW; ++i)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[i], bc[nt], acc[i][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if constexpr (X3) {
+                            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[1][i], bc[0][nt], acc[i][nt], 0, 0, 0);
+                            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[0][i], bc[1][nt], acc[i][nt], 0, 0, 0);
+                        }
+                        acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[0][i], bc[0][nt], acc[i][nt], 0, 0, 0);
+                    }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bc[nt] = bn[nt];
+                for (int pl = 0; pl < NL2; ++pl) {
 #pragma unroll
-                for (int i = 0; i < MW; ++i) ac[i] = an[i];
+                    for (int nt = 0; nt < NT; ++nt) bc[pl][nt] = bn[pl][nt];
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) ac[pl][i] = an[pl][i];
+                }
             }
         }
 #else
@@ -933,11 +973,12 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
 static int stem_bwd_entry(const void* xs, const float* x, const void* gp, const uint8_t* widx, float* dw, float* db, void* ws,
                           size_t ws_bytes, int n, int H2, int W2, float slope, int accumulate, int dtype, bool from_x, bool query,
                           size_t* need, void* stream) {
-    if (dtype != MIL_DT_BF16 && dtype != MIL_DT_BF16_DGRAD) return MIL_ERR_UNSUPPORTED;
-    const int gpx = dtype == MIL_DT_BF16_DGRAD ? 40 : 48;   // g_pool [n,Hp,Wp,20] dense or [n,Hp,Wp,24]
+    const bool x3 = dtype == MIL_DT_F32S;                   // fp32 g_pool [n,Hp,Wp,24], split-precision products: from the fp32 tiles only
+    if (dtype != MIL_DT_BF16 && dtype != MIL_DT_BF16_DGRAD && !(x3 && from_x)) return MIL_ERR_UNSUPPORTED;
+    const int gpx = x3 ? 96 : dtype == MIL_DT_BF16_DGRAD ? 40 : 48;   // g_pool [n,Hp,Wp,20] dense or [n,Hp,Wp,24]
     if (n <= 0 || H2 <= 0 || W2 <= 0) return MIL_ERR_ARG;
     if (from_x && (W2 & 1)) return MIL_ERR_UNSUPPORTED;      // 16-byte input pieces: W % 4 == 0
-    constexpr int PIXB = mil_pix_pitch(16, 2), PIXZ = mil_pix_pitch(24, 2);
+    const int PIXB = mil_pix_pitch(16, x3 ? 4 : 2), PIXZ = mil_pix_pitch(24, x3 ? 4 : 2), PIXG = x3 ? 96 : PIXZ;
     constexpr int MT = 12;                                  // 16 taps x 3 four-channel row pieces / 4 (see the kernel)
     StemBwdArgs a{};
     ConvGeom& g = a.g;
@@ -955,11 +996,11 @@ static int stem_bwd_entry(const void* xs, const float* x, const void* gp, const 
     int chunk = mil_imgs_under_2g(in_img > gp_img ? in_img : gp_img);
     if (chunk >= (1 << g.ti_log2)) chunk &= ~((1 << g.ti_log2) - 1); else return MIL_ERR_UNSUPPORTED;
     if (chunk > n) chunk = n;
-    const int xb = (halo_px * PIXB + 15) & ~15, zb = 256 * PIXZ, gb = (nwin * PIXZ + 15) & ~15, ib = (nwin * 24 + 15) & ~15;
-    const int lds = xb + zb + gb + ib + 16;                 // + dump slot (FROM_X: second pixel of a pair behind an odd-width halo)
+    const int xb = (halo_px * PIXB + 15) & ~15, zb = 256 * PIXZ, gb = (nwin * PIXG + 15) & ~15, ib = (nwin * 24 + 15) & ~15;
+    const int lds = xb + zb + gb + ib + 48;                 // + dump slot (FROM_X: second pixel of a pair behind an odd-width halo; hi + lo)
     const int groups = (chunk + (1 << g.ti_log2) - 1) >> g.ti_log2;
     const int ntiles_max = groups * g.tiles_y * g.tiles_x;
-    auto kern = from_x ? stem_bwd_fused_kernel<true> : stem_bwd_fused_kernel<false>;
+    auto kern = x3 ? stem_bwd_fused_kernel<true, true> : from_x ? stem_bwd_fused_kernel<true> : stem_bwd_fused_kernel<false>;
     int grid = mil_num_cus() * mil_resident_per_cu(kern, lds, 4) * 2;          // two rounds of the resident set
     if (grid > ntiles_max) grid = ntiles_max;
     const size_t slab_elems = (size_t)(MT + 1) * 16 * 32;

@@ -13,6 +13,7 @@
 // each XCD walks its own contiguous range of tiles so that neighbouring tiles (which share halo rows/columns)
 // are in flight on the same L2.
 #include "pf_common.cuh"
+#include <type_traits>
 
 #ifndef MIL_STEM_FWD_LOOKAHEAD
 #define MIL_STEM_FWD_LOOKAHEAD 2      // pixel fragments read this many (k-step, row tile) steps ahead of their MFMAs; 0 = compiler order
@@ -20,10 +21,10 @@
 
 struct StemFwdArgs {
     const float* x;            // [n,3,H,W]
-    const __bf16* w;           // MIL_PACK_STEM fragments [8][NT][64][8]
+    const void* w;             // MIL_PACK_STEM fragments [8][NT][64][8] (bf16; MIL_DT_F32S: [hi | lo] pairs)
     const float* bias;         // [NT*16]
-    __bf16* xs;                // [n,H2,W2,16]
-    __bf16* pool;              // [n,Ho,Wo,COUTP]
+    __bf16* xs;                // [n,H2,W2,16] (bf16 path only; may be null)
+    void* pool;                // [n,Ho,Wo,COUTP] bf16, or fp32 (MIL_DT_F32S)
     uint8_t* widx;             // [n,Ho,Wo,COUTP]
     int n_img, H, W, H2, W2, Ho, Wo, tiles_x, tiles_y, ntiles;
     float slope;
@@ -31,24 +32,31 @@ struct StemFwdArgs {
 
 constexpr int SF_SH = 17, SF_SW = 33;               // stem tile
 constexpr int SF_XH = 20, SF_XW = 38, SF_NPAIR = 19;  // s2d tile; a "pair" = 2 s2d pixels = 4 input columns
-constexpr int SF_XPIX = 48;                         // 16 ch bf16 = 32 B at an odd 16-B slot pitch
-constexpr int SF_XBYTES = SF_XH * SF_XW * SF_XPIX;  // 36480
+// s2d pixel record in LDS: 16 ch bf16 = 32 B at an odd 16-B slot pitch (48); split precision (X3): [hi 32 B][lo 32 B] at pitch 80
+__host__ __device__ constexpr int sf_xpix(bool x3) { return x3 ? 80 : 48; }
+__host__ __device__ constexpr int sf_xbytes(bool x3) { return SF_XH * SF_XW * sf_xpix(x3); }  // 36480 / 60800
 constexpr int SF_NITEM = SF_XH * SF_NPAIR * 3;      // (row, pair, colour) load items
 constexpr int SF_NSTEM = SF_SH * SF_SW;             // 561
 constexpr int SF_MTILES = 36;                       // 16-pixel row tiles of the stem tile (36*16 = 576 >= 561)
 
-template <int NT>
+template <int NT, bool X3 = false>
 __host__ __device__ constexpr int sf_lds_bytes() {
-    return SF_XBYTES + ((SF_NSTEM * mil_pix_pitch(mil_nt_to_cp(NT), 2) + 15) & ~15) + 8 * NT * 64 * 16 + 256;   // + dump slot
+    return sf_xbytes(X3) + ((SF_NSTEM * mil_pix_pitch(mil_nt_to_cp(NT), X3 ? 4 : 2) + 15) & ~15) + 8 * NT * 64 * (X3 ? 32 : 16) + 256;   // + dump slot
 }
 
 // NW = waves per workgroup.  The kernel is VALU-bound (pool compare/select, activation, conversions) and at 4 waves per
 // workgroup its 238 VGPRs leave two waves per SIMD, which keep the vector pipe only half busy; with 8 waves every
 // per-wave quantity halves (5 row tiles, 3 load items, 2 pool items) and four waves per SIMD fit on the same LDS tiles.
-template <int NT, int NW>
-__global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 2 : 1)) void stem_fwd_fused_kernel(StemFwdArgs a) {
+// X3 (MIL_DT_F32S: fp32 tensors, bf16x3 split products): the s2d tile holds hi and lo bf16 planes, every (filter, pixel)
+// fragment pair costs three MFMAs, the stem tile and the pooled output are fp32.  156 KB of LDS: one 8-wave workgroup per CU.
+template <int NT, int NW, bool X3 = false>
+__global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 2 : 1)) void stem_fwd_fused_kernel(StemFwdArgs a) {
+    using T = typename std::conditional<X3, F32S, BF16>::type;
+    constexpr int SF_XPIX = sf_xpix(X3), SF_XBYTES = sf_xbytes(X3);
+    constexpr int OESZ = X3 ? 4 : 2;                          // bytes per element of the stem tile / pooled output
+    constexpr int FRAGB = X3 ? 32 : 16;
     constexpr int COUTP = mil_nt_to_cp(NT);
-    constexpr int SPIX = mil_pix_pitch(COUTP, 2);
+    constexpr int SPIX = mil_pix_pitch(COUTP, OESZ);
     constexpr int KSTEPS = 8;
     constexpr int NG4 = COUTP / 4;
     constexpr int NTHR = 64 * NW;
@@ -64,19 +72,19 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 
     char* ldsW = ldsS + ((SF_NSTEM * SPIX + 15) & ~15);
     // LDS writes of unused slots (the last partial rounds of the tables below) go to a dump area instead of being
     // branched around: a divergent branch per store costs more than the store.
-    const int dump = sf_lds_bytes<NT>() - 256;
+    const int dump = sf_lds_bytes<NT, X3>() - 256;
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, gq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     {
-        mil_stage_filter(ldsW, a.w, KSTEPS * NT * 64 * 16, tid, NTHR);
+        mil_stage_filter(ldsW, a.w, KSTEPS * NT * 64 * FRAGB, tid, NTHR);
         for (int i = tid * 16; i < SF_XBYTES; i += NTHR * 16)          // channels 12..15 of every s2d pixel stay zero
             *reinterpret_cast<uint4*>(ldsX + i) = make_uint4(0, 0, 0, 0);
     }
     const int H = a.H, W = a.W, H2 = a.H2, W2 = a.W2, Ho = a.Ho, Wo = a.Wo;
     const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, (unsigned)((size_t)a.n_img * 3 * H * W * 4));
     const __amdgpu_buffer_rsrc_t rs_xs = mil_rsrc(a.xs, (unsigned)((size_t)a.n_img * H2 * W2 * 32));
-    const __amdgpu_buffer_rsrc_t rs_p = mil_rsrc(a.pool, (unsigned)((size_t)a.n_img * Ho * Wo * COUTP * 2));
+    const __amdgpu_buffer_rsrc_t rs_p = mil_rsrc(a.pool, (unsigned)((size_t)a.n_img * Ho * Wo * COUTP * OESZ));
     const __amdgpu_buffer_rsrc_t rs_i = mil_rsrc(a.widx, (unsigned)((size_t)a.n_img * Ho * Wo * COUTP));
 
     // ---- tile-invariant tables --------------------------------------------------------------------
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 
         // k-group q = 4*step + gq is tap 2*step + (gq>>1), channel group gq&1: the lane-dependent part of the tap offset
         // ((gq>>1) pixels + (gq&1) pieces) is folded in here, the step-dependent part is a compile-time immediate below
         pixbase[m] = (ok ? (sy * SF_XW + sx + 1) * SF_XPIX : 0) + (gq >> 1) * SF_XPIX + (gq & 1) * 16;
-        sdst[m] = (ok ? SF_XBYTES + tp * SPIX : dump) + gq * 8;
+        sdst[m] = (ok ? SF_XBYTES + tp * SPIX : dump) + gq * 4 * OESZ;
     }
     int p_lds[NPOOL], p_rel[NPOOL];          // pooled pixels x 4-channel groups; p_lds = LDS offset | py << 20 | px << 24 (py 15 = unused)
 #pragma unroll
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 
         p_lds[i] = 15 << 20; p_rel[i] = 0;
         if (id < 128 * NG4) {
             const int c4 = id % NG4, pp = id / NG4, py = pp >> 4, px = pp & 15;
-            p_lds[i] = (((2 * py) * SF_SW + 2 * px) * SPIX + c4 * 8) | (py << 20) | (px << 24);
+            p_lds[i] = (((2 * py) * SF_SW + 2 * px) * SPIX + c4 * 4 * OESZ) | (py << 20) | (px << 24);
             p_rel[i] = (py * Wo + px) * COUTP + c4 * 4;
         }
     }
@@ -153,17 +161,25 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 
 #pragma unroll
         for (int i = 0; i < SF_NLOAD; ++i) {
             const f32x4_t v0 = __builtin_bit_cast(f32x4_t, r0[i]), v1 = __builtin_bit_cast(f32x4_t, r1[i]);
-            bf16x4_t pa, pb;
-            pa[0] = (__bf16)v0[0]; pa[1] = (__bf16)v0[1]; pa[2] = (__bf16)v1[0]; pa[3] = (__bf16)v1[1];
-            pb[0] = (__bf16)v0[2]; pb[1] = (__bf16)v0[3]; pb[2] = (__bf16)v1[2]; pb[3] = (__bf16)v1[3];
+            const float fa[4] = {v0[0], v0[1], v1[0], v1[1]}, fb[4] = {v0[2], v0[3], v1[2], v1[3]};
+            bf16x4_t pa, pb, qa, qb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pa[j] = (__bf16)fa[j]; pb[j] = (__bf16)fb[j];
+                if constexpr (X3) { qa[j] = (__bf16)(fa[j] - (float)pa[j]); qb[j] = (__bf16)(fb[j] - (float)pb[j]); }
+            }
             char* dst = smem + (l_lds[i] & 0x3FFFF);
             *reinterpret_cast<bf16x4_t*>(dst) = pa;
             *reinterpret_cast<bf16x4_t*>(dst + SF_XPIX) = pb;
+            if constexpr (X3) {                                  // lo plane: 32 bytes behind the hi plane of the same pixel
+                *reinterpret_cast<bf16x4_t*>(dst + 32) = qa;
+                *reinterpret_cast<bf16x4_t*>(dst + SF_XPIX + 32) = qb;
+            }
         }
         __syncthreads();
         if (tile + G8 < t_end) fetch(tile + G8);
         // ---- the tile's own 16x32 s2d pixels go to the xs tensor (when the caller keeps one) ------------
-        if (a.xs) {
+        if (!X3 && a.xs) {
             const int xbase = ((img * H2 + 16 * ty) * W2 + 32 * tx) * 32;
             const int ylim = H2 - 16 * ty, xlim = W2 - 32 * tx;
 #pragma unroll
@@ -188,22 +204,22 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 
             // ahead, and scheduling fences keep that order.  Left alone, hipcc reads each fragment right in front of its
             // MFMA pair behind an lgkmcnt(0): 72 LDS round trips per tile and wave, two thirds of this kernel's time.
             constexpr int TOT = KSTEPS * SF_MT, LA = MIL_STEM_FWD_LOOKAHEAD, R = LA + 1;
-            Frag8<BF16> ring[R], wq[2][NT];
+            Frag8<T> ring[R], wq[2][NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wq[0][nt] = lds_frag<BF16>(ldsW + (nt * 64 + lane) * 16);
+            for (int nt = 0; nt < NT; ++nt) wq[0][nt] = lds_frag<T>(ldsW + (nt * 64 + lane) * FRAGB);
 #pragma unroll
             for (int j = 0; j < LA; ++j)
-                ring[j % R] = lds_frag<BF16>(ldsX + pixbase[j % SF_MT] + (((j / SF_MT) >> 1) * SF_XW + 2 * ((j / SF_MT) & 1)) * SF_XPIX);
+                ring[j % R] = lds_pix_frag<T, 32>(ldsX + pixbase[j % SF_MT] + (((j / SF_MT) >> 1) * SF_XW + 2 * ((j / SF_MT) & 1)) * SF_XPIX);
 #pragma unroll
             for (int j = 0; j < TOT; ++j) {
                 const int sl = j / SF_MT, m = j % SF_MT;
                 if (j + LA < TOT) {
                     const int jn = j + LA, sn = jn / SF_MT;
-                    ring[jn % R] = lds_frag<BF16>(ldsX + pixbase[jn % SF_MT] + ((sn >> 1) * SF_XW + 2 * (sn & 1)) * SF_XPIX);
+                    ring[jn % R] = lds_pix_frag<T, 32>(ldsX + pixbase[jn % SF_MT] + ((sn >> 1) * SF_XW + 2 * (sn & 1)) * SF_XPIX);
                 }
                 if (m == 0 && sl + 1 < KSTEPS) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) wq[(sl + 1) & 1][nt] = lds_frag<BF16>(ldsW + (((sl + 1) * NT + nt) * 64 + lane) * 16);
+                    for (int nt = 0; nt < NT; ++nt) wq[(sl + 1) & 1][nt] = lds_frag<T>(ldsW + (((sl + 1) * NT + nt) * 64 + lane) * FRAGB);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -214,12 +230,12 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 
 #else
 #pragma unroll
         for (int sl = 0; sl < KSTEPS; ++sl) {
-            Frag8<BF16> wf[NT];
+            Frag8<T> wf[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<BF16>(ldsW + ((sl * NT + nt) * 64 + lane) * 16);
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag<T>(ldsW + ((sl * NT + nt) * 64 + lane) * FRAGB);
 #pragma unroll
             for (int m = 0; m < SF_MT; ++m) {
-                const Frag8<BF16> xf = lds_frag<BF16>(ldsX + pixbase[m] + ((sl >> 1) * SF_XW + 2 * (sl & 1)) * SF_XPIX);
+                const Frag8<T> xf = lds_pix_frag<T, 32>(ldsX + pixbase[m] + ((sl >> 1) * SF_XW + 2 * (sl & 1)) * SF_XPIX);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wf[nt], xf, acc[m][nt]);
             }
@@ -239,12 +255,24 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if (LAST_PARTIAL && nt == NT - 1 && gq >= 2) continue;        // channels COUTP.. do not exist
+                if constexpr (X3) {
+                    f32x4_t o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const float v = acc[m][nt][i]; o[i] = fmaxf(v, v * a.slope); }
+                    u32x4_t ou = __builtin_bit_cast(u32x4_t, o);
+                    if (border) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ou[i] = inside ? ou[i] : 0xFF800000u;      // -inf
+                    }
+                    *reinterpret_cast<u32x4_t*>(smem + sdst[m] + nt * 64) = ou;
+                } else {
                 bf16x4_t o;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { const float v = acc[m][nt][i]; o[i] = (__bf16)fmaxf(v, v * a.slope); }
                 u32x2_t ou = __builtin_bit_cast(u32x2_t, o);
                 if (border) { ou[0] = inside ? ou[0] : 0xFF80FF80u; ou[1] = inside ? ou[1] : 0xFF80FF80u; }
                 *reinterpret_cast<u32x2_t*>(smem + sdst[m] + nt * 32) = ou;
+                }
             }
         }
         __syncthreads();
@@ -257,13 +285,25 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 
             for (int it = 0; it < NPOOL; ++it) {
                 const int py = (p_lds[it] >> 20) & 15, px = p_lds[it] >> 24;
                 const char* src = ldsS + (p_lds[it] & 0xFFFFF);
-                u32x2_t t[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) t[k] = *reinterpret_cast<const u32x2_t*>(src + ((k / 3) * SF_SW + (k % 3)) * SPIX);
                 float best[4];
                 unsigned bi[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+                if constexpr (X3) {
+                    f32x4_t t[9];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) t[k] = *reinterpret_cast<const f32x4_t*>(src + ((k / 3) * SF_SW + (k % 3)) * SPIX);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (t[k][j] > best[j]) { best[j] = t[k][j]; bi[j] = k; }
+                        }
+                    }
+                } else {
+                u32x2_t t[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) t[k] = *reinterpret_cast<const u32x2_t*>(src + ((k / 3) * SF_SW + (k % 3)) * SPIX);
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
 #pragma unroll
@@ -273,15 +313,21 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 
                         if (v > best[j]) { best[j] = v; bi[j] = k; }
                     }
                 }
+                }
                 const bool ok = py < ylim && px < xlim;                 // py 15 (unused slot) is never inside: ylim <= 8
-                u32x2_t ov;
-                ov[0] = (__float_as_uint(best[0]) >> 16) | (__float_as_uint(best[1]) & 0xFFFF0000u);
-                ov[1] = (__float_as_uint(best[2]) >> 16) | (__float_as_uint(best[3]) & 0xFFFF0000u);
+                const unsigned eoff = (unsigned)(obase + p_rel[it]);
+                if constexpr (X3) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4_t{best[0], best[1], best[2], best[3]}), rs_p,
+                                                           ok ? eoff * 4u : MIL_OOB, 0, 0);
+                } else {
+                    u32x2_t ov;
+                    ov[0] = (__float_as_uint(best[0]) >> 16) | (__float_as_uint(best[1]) & 0xFFFF0000u);
+                    ov[1] = (__float_as_uint(best[2]) >> 16) | (__float_as_uint(best[3]) & 0xFFFF0000u);
+                    __builtin_amdgcn_raw_buffer_store_b64(ov, rs_p, ok ? eoff * 2u : MIL_OOB, 0, 0);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bi[j] |= (best[j] > 0.f) ? 0u : 16u;
                 const unsigned rec = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
-                const unsigned eoff = (unsigned)(obase + p_rel[it]);
-                __builtin_amdgcn_raw_buffer_store_b64(ov, rs_p, ok ? eoff * 2u : MIL_OOB, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(rec, rs_i, ok ? eoff : MIL_OOB, 0, 0);
             }
         }
@@ -289,19 +335,21 @@ __global__ __launch_bounds__(64 * NW, (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 
     }
 }
 
-template <int NT>
+template <int NT, bool X3 = false>
 static int launch_stem_fwd(StemFwdArgs a, hipStream_t st) {
     constexpr int COUTP = mil_nt_to_cp(NT);
-    const int lds = sf_lds_bytes<NT>();
-    // measured (24 channels): 1120 us with 4 waves per workgroup at 238 VGPRs, 1428 us with 8 waves squeezed into 128
-    // VGPRs (15 spilled): the 8-wave form is kept as a template option only
-    constexpr int NW = 4;
-    auto kern = stem_fwd_fused_kernel<NT, NW>;
+    constexpr int OESZ = X3 ? 4 : 2;
+    const int lds = sf_lds_bytes<NT, X3>();
+    // measured (24 channels, bf16): 1120 us with 4 waves per workgroup at 238 VGPRs, 1428 us with 8 waves squeezed into 128
+    // VGPRs (15 spilled): the 8-wave form serves the split-precision kernel, whose 156 KB of LDS leave one workgroup per CU
+    // (two waves per SIMD at up to 256 VGPRs)
+    constexpr int NW = X3 ? 8 : 4;
+    auto kern = stem_fwd_fused_kernel<NT, NW, X3>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MIL_ERR_LAUNCH;
     // every tensor is addressed with 32-bit offsets below 2 GiB: split the launch by images
     size_t per_img = (size_t)3 * a.H * a.W * 4;
-    const size_t xs_img = (size_t)a.H2 * a.W2 * 32, p_img = (size_t)a.Ho * a.Wo * COUTP * 2;
+    const size_t xs_img = X3 ? 0 : (size_t)a.H2 * a.W2 * 32, p_img = (size_t)a.Ho * a.Wo * COUTP * OESZ;
     if (xs_img > per_img) per_img = xs_img;
     if (p_img > per_img) per_img = p_img;
     const int chunk = mil_imgs_under_2g(per_img);
@@ -311,11 +359,11 @@ static int launch_stem_fwd(StemFwdArgs a, hipStream_t st) {
         b.n_img = n_total - i0 < chunk ? n_total - i0 : chunk;
         b.x = a.x + (size_t)i0 * 3 * a.H * a.W;
         b.xs = a.xs ? a.xs + (size_t)i0 * a.H2 * a.W2 * 16 : nullptr;
-        b.pool = a.pool + (size_t)i0 * a.Ho * a.Wo * COUTP;
+        b.pool = static_cast<char*>(a.pool) + (size_t)i0 * a.Ho * a.Wo * COUTP * OESZ;
         b.widx = a.widx + (size_t)i0 * a.Ho * a.Wo * COUTP;
         b.ntiles = b.n_img * a.tiles_y * a.tiles_x;
         int grid = (b.ntiles + 7) & ~7;
-        const int cap = mil_num_cus() * (NT <= 2 ? 2 : 1);
+        const int cap = mil_num_cus() * ((NT <= 2 && !X3) ? 2 : 1);
         if (grid > cap) grid = cap;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, st, b);
         MIL_CHECK_LAUNCH();
@@ -330,16 +378,18 @@ static int launch_stem_fwd(StemFwdArgs a, hipStream_t st) {
 extern "C" int mil_stem_fwd_fused(const float* x_nchw, const void* wpack, const float* bias_pad, void* xs, void* pool,
                                   uint8_t* widx, int n_img, int H, int W, int cout_p, float slope, int dtype, void* stream) {
     if (!x_nchw || !wpack || !pool || !widx || n_img < 0 || H <= 0 || W <= 0) return MIL_ERR_ARG;
-    if (dtype != MIL_DT_BF16 || (H & 1) || (W & 3) || (reinterpret_cast<uintptr_t>(x_nchw) & 15) || slope < 0.f || slope >= 1.f)
+    if ((dtype != MIL_DT_BF16 && dtype != MIL_DT_F32S) || (H & 1) || (W & 3) || (reinterpret_cast<uintptr_t>(x_nchw) & 15) || slope < 0.f || slope >= 1.f)
         return MIL_ERR_UNSUPPORTED;
     if (cout_p != 24 && cout_p != 64) return MIL_ERR_UNSUPPORTED;
+    if (dtype == MIL_DT_F32S && (cout_p != 24 || xs)) return MIL_ERR_UNSUPPORTED;      // split precision: no s2d copy (the backward reads x), 20-channel stem
     if (n_img == 0) return MIL_OK;
     StemFwdArgs a{};
-    a.x = x_nchw; a.w = (const __bf16*)wpack; a.bias = bias_pad; a.xs = (__bf16*)xs; a.pool = (__bf16*)pool; a.widx = widx;
+    a.x = x_nchw; a.w = wpack; a.bias = bias_pad; a.xs = (__bf16*)xs; a.pool = pool; a.widx = widx;
     a.n_img = n_img; a.H = H; a.W = W; a.H2 = H / 2; a.W2 = W / 2;
     a.Ho = (a.H2 - 1) / 2 + 1; a.Wo = (a.W2 - 1) / 2 + 1;
     a.tiles_y = (a.Ho + 7) / 8; a.tiles_x = (a.Wo + 15) / 16;
     a.slope = slope;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIL_DT_F32S) return launch_stem_fwd<2, true>(a, st);
     return cout_p == 24 ? launch_stem_fwd<2>(a, st) : launch_stem_fwd<4>(a, st);
 }

@@ -205,8 +205,9 @@ def encoder_forward(net, x, dtype):
     wp, bp = net._packed("stem", net.conv1.weight, net.conv1.bias, L.PACK_STEM, dtype)
     stem_hooked = hk is not None and hooks.any_hooked((net.conv1, net.relu, net.maxpool))
     # no space-to-depth copy is kept (keep_s2d False): the fused stem backward rebuilds its tiles from x itself
+    split = dtype == torch.float32 and L.dt_code(dtype, mma=True) == L.MIL_DT_F32S       # bf16x3: never an s2d copy
     fused = ops.stem_fwd_fused(x, wp, bp, ops.cpad(STEM_WIDTH), dtype=dtype,
-                               keep_s2d=net.keep_s2d or not net.fuse_backward) if (net.fuse_stem_forward and not stem_hooked) else None
+                               keep_s2d=(net.keep_s2d or not net.fuse_backward) and not split) if (net.fuse_stem_forward and not stem_hooked) else None
     if fused is not None:
         xs, pool, widx = fused
         stem_hw = (x.shape[2] // 2, x.shape[3] // 2)

@@ -423,7 +423,13 @@ def stem_fwd_fused(x, wpack, bias_pad, cout_p, *, slope=LEAK, dtype=torch.bfloat
         raise ValueError(f"expected a CUDA fp32 [N,3,H,W] tile stack, got {tuple(x.shape)} {x.dtype} on {x.device}")
     x = x.contiguous()
     n, c, h, w = x.shape
-    if dtype != torch.bfloat16 or h % 2 or w % 4 or cout_p not in (24, 64) or x.data_ptr() % 16:
+    code = L.dt_code(dtype, mma=True)
+    if code == L.MIL_DT_F32S:               # split precision: fp32 pooled map, never an s2d copy (the backward reads x)
+        if keep_s2d or cout_p != 24:
+            return None
+    elif dtype != torch.bfloat16:
+        return None
+    if h % 2 or w % 4 or cout_p not in (24, 64) or x.data_ptr() % 16:
         return None
     h2, w2 = h // 2, w // 2
     hp, wp = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
@@ -432,7 +438,7 @@ def stem_fwd_fused(x, wpack, bias_pad, cout_p, *, slope=LEAK, dtype=torch.bfloat
     widx = torch.empty((n, hp, wp, cout_p), dtype=torch.uint8, device=x.device)
     end = TIMER.bracket(("stem_fwd", cout_p, n, h, w)) if TIMER else None
     rc = L.lib().mil_stem_fwd_fused(x.data_ptr(), wpack.data_ptr(), L.ptr(bias_pad), L.ptr(xs), pool.data_ptr(),
-                                    widx.data_ptr(), n, h, w, cout_p, slope, L.dt_code(dtype), L.stream_ptr())
+                                    widx.data_ptr(), n, h, w, cout_p, slope, code, L.stream_ptr())
     if rc == 2:
         return None
     L.check(rc, "mil_stem_fwd_fused")
@@ -481,7 +487,7 @@ def stem_bwd_fused_nchw(x, g_pool, widx, *, workspace=None, out=None, slope=LEAK
     n, _, h, w = x.shape
     dense = g_pool.shape[-1] == 20            # dense gradient layout (MIL_DT_BF16_DGRAD)
     need = ctypes.c_size_t(0)
-    rc = L.lib().mil_stem_bwd_fused_nchw_workspace(ctypes.byref(need), n, h, w, L.dt_code(g_pool.dtype, dense))
+    rc = L.lib().mil_stem_bwd_fused_nchw_workspace(ctypes.byref(need), n, h, w, L.dt_code(g_pool.dtype, dense, mma=True))
     if rc == 2 or x.data_ptr() % 16:
         return None
     L.check(rc, "mil_stem_bwd_fused_nchw_workspace")
@@ -503,7 +509,7 @@ def stem_bwd_fused_nchw(x, g_pool, widx, *, workspace=None, out=None, slope=LEAK
     end = TIMER.bracket(("stem_bwd", n, h, w)) if TIMER else None
     rc = L.lib().mil_stem_bwd_fused_nchw(x.data_ptr(), g_pool.data_ptr(), widx.data_ptr(), dw.data_ptr(), db.data_ptr(),
                                          workspace.data_ptr(), workspace.numel() * workspace.element_size(), n, h, w,
-                                         slope, 0 if out is None else 1, L.dt_code(g_pool.dtype, dense), L.stream_ptr())
+                                         slope, 0 if out is None else 1, L.dt_code(g_pool.dtype, dense, mma=True), L.stream_ptr())
     if rc == 2:
         return None
     L.check(rc, "mil_stem_bwd_fused_nchw")

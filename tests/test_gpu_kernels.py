@@ -344,6 +344,43 @@ def test_wide_conv_forward_dgrad_wgrad(ops, dtype, case):
     assert torch.equal(dw, dw2)
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 16), (3, 32, 32), (2, 25, 34), (5, 128, 128)])
+def test_stem_backward_fused_split_precision(ops, shape):
+    """mil_stem_bwd_fused_nchw on fp32 tensors with bf16x3 split products (MIL_DT_F32S) against autograd of conv7x7/s2 ->
+    LeakyReLU -> MaxPool(3,2,1) taken at the winners the HIP forward recorded (the fused split-precision forward), and
+    against the un-fused device sequence pool-backward + stem weight gradient."""
+    L = _lib()
+    n, h, w = shape                                   # stem-output dims: the image is (2h, 2w)
+    g = torch.Generator().manual_seed(41 + h)
+    x = torch.randn(n, 3, 2 * h, 2 * w, generator=g).clamp_(-1, 1)
+    wt = (torch.randn(20, 3, 7, 7, generator=g) / 147 ** 0.5).requires_grad_(True)
+    b = (torch.randn(20, generator=g) * 0.1).requires_grad_(True)
+    stem = F.leaky_relu(F.conv2d(x, wt, b, stride=2, padding=3), LEAK)
+    pooled = F.max_pool2d(stem, 3, 2, 1)
+    gp = torch.randn(pooled.shape, generator=g)
+    pooled.backward(gp)
+    with L.f32_mma(L.MIL_DT_F32S):
+        wp, bp = ops.pack_weights(wt.detach().cuda(), b.detach().cuda(), L.PACK_STEM, torch.float32)
+        fwd = ops.stem_fwd_fused(x.cuda(), wp, bp, 24, dtype=torch.float32, keep_s2d=False)
+        assert fwd is not None
+        _xs, _pool, widx = fwd
+        gpg = to_nhwc(gp, torch.float32)
+        out = ops.stem_bwd_fused_nchw(x.cuda(), gpg, widx)
+        assert out is not None, "the split-precision fused stem backward must exist for these tile sizes"
+        dw, db = out
+        dstem = ops.maxpool_bwd(gpg, widx, (h, w))
+        xs = ops.stem_s2d(x.cuda(), torch.float32)
+        dw2, db2 = ops.conv_wgrad(xs, dstem, 3, 20, ks=4, stride=1, pad=2, stem=True)
+    assert rel_err(dw.cpu(), dw2.cpu()) < 5e-5 and rel_err(db.cpu(), db2.cpu()) < 1e-5
+    # vs autograd: a near-tie in a pooling window / a stem value within 1e-5 of zero takes the other branch here and there
+    # (measured 7.6e-3 on the 5 x 128 x 128 case); the device-side comparison above is the tight one
+    assert rel_err(dw.cpu(), wt.grad) < 2e-2 and rel_err(db.cpu(), b.grad) < 2e-2
+    # bitwise reproducible
+    with L.f32_mma(L.MIL_DT_F32S):
+        dw3, db3 = ops.stem_bwd_fused_nchw(x.cuda(), gpg, widx)
+    assert torch.equal(dw, dw3) and torch.equal(db, db3)
+
+
 STEM_FUSED_CASES = [
     # n, H, W, cout, slope
     (3, 64, 64, 20, LEAK),
@@ -383,6 +420,42 @@ def test_stem_forward_fused_is_bit_identical_to_the_three_kernels(ops, case):
     # without the space-to-depth copy (what the encoder runs): same pooled map and winner records
     xs2, pool2, widx2 = ops.stem_fwd_fused(x, wp, bp, cp, slope=slope, dtype=dt, keep_s2d=False)
     assert xs2 is None and torch.equal(pool1.view(torch.int16), pool2.view(torch.int16)) and torch.equal(widx1, widx2)
+
+
+@pytest.mark.parametrize("case", STEM_FUSED_CASES[:4])
+def test_stem_forward_fused_split_precision(ops, case):
+    """The same one-pass stem on fp32 tensors with bf16x3 split products (MIL_DT_F32S): pooled map against torch's fp32
+    conv / LeakyReLU / max-pool (un-rounded operands: 16 significant bits per operand), and winner records that select the
+    maximum of their window (a near-tie may pick the other candidate: its value must then equal the maximum within the
+    kernel's own error)."""
+    L = _lib()
+    n, h, w, cout, slope = case
+    g = torch.Generator().manual_seed(19 + h + w)
+    x = torch.randn(n, 3, h, w, generator=g)
+    wt = torch.randn(cout, 3, 7, 7, generator=g) * 0.1
+    b = torch.randn(cout, generator=g) * 0.1
+    cp = cpad(cout)
+    with L.f32_mma(L.MIL_DT_F32S):
+        wp, bp = ops.pack_weights(wt.cuda(), b.cuda(), L.PACK_STEM, torch.float32)
+        fused = ops.stem_fwd_fused(x.cuda(), wp, bp, cp, slope=slope, dtype=torch.float32, keep_s2d=False)
+        assert fused is not None
+        assert ops.stem_fwd_fused(x.cuda(), wp, bp, cp, slope=slope, dtype=torch.float32, keep_s2d=True) is None
+    xs, pool, widx = fused
+    assert xs is None and pool.dtype == torch.float32
+    stem = F.leaky_relu(F.conv2d(x, wt, b, stride=2, padding=3), slope)
+    ref, idx = F.max_pool2d(stem, 3, 2, 1, return_indices=True)
+    assert rel_err(from_nhwc(pool, cout), ref) < TOL[X3]
+    assert float(pool[..., cout:].abs().max()) == 0.0
+    # winner records: value at the recorded tap == the window maximum (within the kernel's error), sign bit == (max <= 0)
+    hp, wp_ = ref.shape[2:]
+    rec = widx[..., :cout].permute(0, 3, 1, 2).cpu()
+    tap = (rec & 15).long()
+    win = F.unfold(F.pad(stem, (1, 1, 1, 1), value=float("-inf")), 3, stride=2).view(n, cout, 9, hp, wp_)
+    picked = win.gather(2, tap.unsqueeze(2)).squeeze(2)
+    scale = float(ref.abs().max())
+    assert float((picked - ref).abs().max()) < 1e-4 * scale
+    clear = ref.abs() > 1e-4 * scale
+    assert bool((((rec >> 4) & 1).bool() == (ref <= 0))[clear].all())
 
 
 def test_stem_forward_fused_declines_unsupported_shapes(ops):
