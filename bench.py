@@ -133,7 +133,9 @@ def path_record(args, mode, w, x_all, sizes, labels, dev, copy_gbps):
       "f32"     exact-f32 MFMA (v_mfma_f32_16x16x4_f32) — the bit-level parity path; 3 timed steps."""
     import mil_amd
     from mil_amd import ops
-    cdt = mil_amd.BF16X3 if mode == "bf16x3" else torch.float32
+    cdt = {"bf16x3": mil_amd.BF16X3, "f32": torch.float32, "s2d": torch.bfloat16}[mode]
+    if mode == "s2d":       # the headline path fed by the bf16 space-to-depth tiles TilePreprocessor(out="s2d") hands over
+        x_all = mil_amd.S2dTiles(ops.stem_s2d(x_all, torch.bfloat16))
     net = mil_amd.Attention(3, compute_dtype=cdt, device=dev).eval()
     net.load_state_dict({k: torch.tensor(w[k]) for k in w.keys()})
     flat = mil_amd.FlatParams(net)
@@ -146,11 +148,11 @@ def path_record(args, mode, w, x_all, sizes, labels, dev, copy_gbps):
         opt.step()
         return outs
 
-    steps, warm = (max(10, args.steps), 2) if mode == "bf16x3" else (3, 1)
+    steps, warm = (max(10, args.steps), 2) if mode in ("bf16x3", "s2d") else (3, 1)
     for _ in range(warm):
         step()
     timer = None
-    if mode == "bf16x3" and not args.no_kernel_timer:
+    if mode in ("bf16x3", "s2d") and not args.no_kernel_timer:
         timer = ops.KernelTimer(timer_wants)
         ops.TIMER = timer
     elapsed, outs = timed_steps(step, steps, 0, torch.cuda.synchronize)
@@ -169,6 +171,12 @@ def path_record(args, mode, w, x_all, sizes, labels, dev, copy_gbps):
         rec["note"] = ("same workload and step as `value`; fp32 tensors, every conv / weight gradient as bf16x3 split products "
                        "(hi*hi + lo*hi + hi*lo, fp32 accumulate): logits within 2.5e-4 of the fp32 CPU reference, attention "
                        "weights within 3e-6 (tests/test_gpu_configs.py asserts 1e-3 on Mterm / Aterm / y_pred / loss)")
+    elif mode == "s2d":
+        rec["dtype"] = "bf16"
+        rec["roofline"] = roofline_record("bf16", timer.durations_ms(), MFMA_PEAK_BF16_TFLOPS, copy_gbps, tfl, profile_tag="bf16") if timer else None
+        rec["note"] = ("the headline path with the tiles handed over as mil_amd.S2dTiles (bf16 space-to-depth records, what "
+                       "TilePreprocessor(out='s2d') writes): the fp32 [T,3,H,W] stack never exists; outputs and gradients are "
+                       "bit-identical to the fp32-tensor API (tests/test_gpu_preprocess.py)")
     else:
         rec["frac_of_f32_mfma_peak"] = tfl / MFMA_PEAK_F32_TFLOPS
         rec["note"] = "same workload and step as `value`, exact-fp32 kernels (bit-level parity path: Mterm within 2e-6)"
@@ -252,6 +260,11 @@ def _family_cost(label, esz):
         h2, w2 = h // 2, w // 2
         hp, wp = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
         return 2.0 * 147 * 20 * n * h2 * w2, n * 3 * h * w * 4 + n * hp * wp * 20 * (esz + 1), (n, h, w)
+    if fam in ("stem_fwd_xs", "stem_bwd_xs"):   # bf16 space-to-depth feed: 12 real channels x 2 B per 2x2 pixel block in
+        n, h, w = label[-3], label[-2], label[-1]
+        h2, w2 = h // 2, w // 2
+        hp, wp = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
+        return 2.0 * 147 * 20 * n * h2 * w2, n * h2 * w2 * 24 + n * hp * wp * 20 * (esz + 1), (n, h, w)
     if fam == "stem_bwd":                     # ("stem_bwd", n, H, W): fp32 tiles + pooled gradient + winner bytes in
         _f, n, h, w = label
         h2, w2 = h // 2, w // 2
@@ -267,6 +280,8 @@ _FAMILY_KERNEL = {
     "wgrad": ("wgrad_kernel<..3,24,2,..> (weight+bias gradient of the 3x3 s1 conv, 20->20 ch", ("wgrad_kernel<F32S, 3, 24, 2", "wgrad_kernel<BF16, 3, 24, 2")),
     "stem_fwd": ("stem_fwd_fused_kernel (fp32 tiles -> s2d -> 7x7/s2 conv + bias + LeakyReLU -> 3x3/s2 max-pool, one pass", ("stem_fwd_fused_kernel<",)),
     "stem_bwd": ("stem_bwd_fused_kernel<FROM_X> (max-pool backward + LeakyReLU backward + 7x7 weight gradient, one pass", ("stem_bwd_fused_kernel<",)),
+    "stem_fwd_xs": ("stem_fwd_fused_kernel<..FROM_XS> (bf16 s2d tiles -> 7x7/s2 conv + bias + LeakyReLU -> 3x3/s2 max-pool, one pass", ("stem_fwd_fused_kernel<",)),
+    "stem_bwd_xs": ("stem_bwd_fused_kernel (bf16 s2d tiles: max-pool backward + LeakyReLU backward + 7x7 weight gradient, one pass", ("stem_bwd_fused_kernel<",)),
 }
 
 
@@ -274,7 +289,7 @@ def timer_wants(label):
     """Launches bench.py brackets with HIP events: the layer-1 kernel families (64x64 maps, 20 -> 20 channels: 47 % of the
     FLOPs) and the stem pair."""
     fam = label[0]
-    if fam in ("stem_fwd", "stem_bwd"):
+    if fam in ("stem_fwd", "stem_bwd", "stem_fwd_xs", "stem_bwd_xs"):
         return True
     if fam == "block_fwd":
         return label[1] == 24
@@ -564,6 +579,7 @@ def main():
             line["model_tflops"] = achieved_model_tflops
         extra = world == 1 and not args.infer and not args.no_extra_paths
         if extra and args.dtype == "bf16":
+            line["s2d_feed_path"] = path_record(args, "s2d", w, x_all, sizes, labels, dev, copy_gbps)
             line["bf16x3_path"] = path_record(args, "bf16x3", w, x_all, sizes, labels, dev, copy_gbps)
             line["fp32_path"] = path_record(args, "f32", w, x_all, sizes, labels, dev, copy_gbps)
         del x_all

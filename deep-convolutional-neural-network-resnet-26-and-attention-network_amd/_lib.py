@@ -58,6 +58,8 @@ _SIGS = {
     "mil_resize_plan": ([_i, _i, _c.POINTER(_i)], _i),
     "mil_resize_coeffs": ([_i, _i, _vp, _vp], _i),
     "mil_tile_preprocess": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "mil_tile_preprocess_s2d": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "mil_stem_fwd_fused_xs": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp], _i),
     "mil_conv_block_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp], _i),
     "mil_conv_chain": ([_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp], _i),
     "mil_conv_pair": ([_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _i, _vp], _i),

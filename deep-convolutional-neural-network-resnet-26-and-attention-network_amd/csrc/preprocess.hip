@@ -23,7 +23,8 @@ struct PrepArgs {
     const int* params;          // [T,4] = top, left, hflip, vflip (train chain) or null (flat chain: no pad/crop/flip)
     const int* bounds;          // [R,2] first source index, count
     const int* kk;              // [R,ksize]
-    float* out;                 // [T,3,R,R]
+    float* out;                 // [T,3,R,R] fp32 NCHW, or null when xs is given
+    __bf16* xs;                 // [T,R/2,R/2,16] bf16 space-to-depth NHWC (channel = c*4 + dy*2 + dx, 12 real), or null
     int T, S, pad, R, ksize;
     int margin, row_pitch;      // bytes: zero margin in front of a staged row (>= 3*pad, 4-aligned); pitch of a staged row
     int lds_h_off, lds_k_off, lds_b_off;
@@ -132,6 +133,51 @@ __global__ __launch_bounds__(256) void tile_preprocess_kernel(PrepArgs a) {
         __syncthreads();
     }
     // ---- vertical pass of the strip, ToTensor + Normalize, flips at the store ---------------------------------------
+    if (a.xs) {
+        // space-to-depth bf16 output: what the stem kernels consume (the 7x7/s2 conv as a 4x4/s1 conv over 2x2 pixel blocks).
+        // A thread owns one 2x2 block of the band = ONE 32-byte record [c0: 00 01 10 11 | c1 .. | c2 .. | 0 0 0 0]; a flip
+        // sends a block to the mirrored block and swaps the pixels inside it.  R is even, bands start on even rows.
+        const int R2 = R >> 1;
+        for (int it = tid; it < ((r1 - r0) >> 1) * R2; it += 256) {
+            const int by = it / R2, bx = it - by * R2;
+            __bf16 rec[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) rec[j] = (__bf16)0.0f;
+            int oby = 0, obx = 0;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int yr = r0 + 2 * by + dy, xr = 2 * bx + dx;
+                    const int ymin = bds[2 * yr], cnt = bds[2 * yr + 1];
+                    const unsigned char* p = hres + ((ymin - y_lo) * R + xr) * 3;
+                    const int* w = kks + yr * ksize;
+                    int s0 = 1 << (PREP_BITS - 1), s1 = s0, s2 = s0;
+                    for (int k = 0; k < cnt; ++k) {
+                        const int wk = w[k];
+                        s0 += (int)p[k * R * 3] * wk; s1 += (int)p[k * R * 3 + 1] * wk; s2 += (int)p[k * R * 3 + 2] * wk;
+                    }
+                    const int yo = vflip ? R - 1 - yr : yr, xo = hflip ? R - 1 - xr : xr;
+                    oby = yo >> 1; obx = xo >> 1;                       // the same block for all four pixels
+                    const int q = (yo & 1) * 2 + (xo & 1);
+                    const float v0 = ((float)prep_clip8(s0) / 255.0f - 0.5f) / 0.5f, v1 = ((float)prep_clip8(s1) / 255.0f - 0.5f) / 0.5f,
+                                v2 = ((float)prep_clip8(s2) / 255.0f - 0.5f) / 0.5f;
+                    // (compile-time register indices: select on q)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        if (q == qq) { rec[qq] = (__bf16)v0; rec[4 + qq] = (__bf16)v1; rec[8 + qq] = (__bf16)v2; }
+                    }
+                }
+            }
+            bf16x8_t lo8, hi8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { lo8[j] = rec[j]; hi8[j] = rec[8 + j]; }
+            __bf16* o = a.xs + (((size_t)t * R2 + oby) * R2 + obx) * 16;
+            *reinterpret_cast<bf16x8_t*>(o) = lo8;
+            *reinterpret_cast<bf16x8_t*>(o + 8) = hi8;
+        }
+        return;
+    }
     for (int it = tid; it < (r1 - r0) * R; it += 256) {
         const int yy = it / R, xr = it - yy * R, yr = r0 + yy;
         const int ymin = bds[2 * yr], cnt = bds[2 * yr + 1];
@@ -200,12 +246,13 @@ extern "C" int mil_resize_coeffs(int in_size, int out_size, int32_t* bounds, int
 // out [T,3,R,R] fp32 in [-1,1] from uint8 ROIs [T,S,S,3].  params [T,4] (top, left, hflip, vflip with top/left in
 // [0, 2*pad]) selects the train chain, null the flat chain.  bounds_host is the host copy of the table (the launcher
 // sizes the LDS strip from it); bounds_dev / kk_dev are its device copies (mil_resize_coeffs(S, R)).
-extern "C" int mil_tile_preprocess(const uint8_t* rois, const int32_t* params, const int32_t* bounds_host, const int32_t* bounds_dev,
-                                   const int32_t* kk_dev, float* out, int T, int S, int pad, int R, void* stream) {
-    if (!rois || !bounds_host || !bounds_dev || !kk_dev || !out || T < 0 || S <= 0 || R <= 0 || pad < 0) return MIL_ERR_ARG;
+static int prep_entry(const uint8_t* rois, const int32_t* params, const int32_t* bounds_host, const int32_t* bounds_dev,
+                      const int32_t* kk_dev, float* out, void* xs, int T, int S, int pad, int R, void* stream) {
+    if (!rois || !bounds_host || !bounds_dev || !kk_dev || (!out && !xs) || T < 0 || S <= 0 || R <= 0 || pad < 0) return MIL_ERR_ARG;
+    if (xs && ((R & 1) || (reinterpret_cast<uintptr_t>(xs) & 15))) return MIL_ERR_UNSUPPORTED;      // 2x2 blocks, 16-byte records
     if (T == 0) return MIL_OK;
     PrepArgs a{};
-    a.rois = rois; a.params = params; a.bounds = bounds_dev; a.kk = kk_dev; a.out = out;
+    a.rois = rois; a.params = params; a.bounds = bounds_dev; a.kk = kk_dev; a.out = out; a.xs = static_cast<__bf16*>(xs);
     a.T = T; a.S = S; a.pad = params ? pad : 0; a.R = R; a.ksize = prep_ksize(S, R);
     int nri_max = 0;
     for (int r0 = 0; r0 < R; r0 += PREP_BAND) {
@@ -227,4 +274,19 @@ extern "C" int mil_tile_preprocess(const uint8_t* rois, const int32_t* params, c
     hipLaunchKernelGGL(kern, dim3((R + PREP_BAND - 1) / PREP_BAND, T), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
+}
+
+extern "C" int mil_tile_preprocess(const uint8_t* rois, const int32_t* params, const int32_t* bounds_host, const int32_t* bounds_dev,
+                                   const int32_t* kk_dev, float* out, int T, int S, int pad, int R, void* stream) {
+    if (!out) return MIL_ERR_ARG;
+    return prep_entry(rois, params, bounds_host, bounds_dev, kk_dev, out, nullptr, T, S, pad, R, stream);
+}
+
+// The same chain with the output written as the bf16 space-to-depth NHWC tensor xs [T,R/2,R/2,16] the stem kernels read
+// (mil_stem_fwd_fused_xs / mil_stem_bwd_fused): a pre-processed bag then never exists as fp32 — the values are the bf16
+// roundings of mil_tile_preprocess's, i.e. exactly what the stem's own fp32 -> bf16 conversion produces.  R must be even.
+extern "C" int mil_tile_preprocess_s2d(const uint8_t* rois, const int32_t* params, const int32_t* bounds_host, const int32_t* bounds_dev,
+                                       const int32_t* kk_dev, void* xs, int T, int S, int pad, int R, void* stream) {
+    if (!xs) return MIL_ERR_ARG;
+    return prep_entry(rois, params, bounds_host, bounds_dev, kk_dev, nullptr, xs, T, S, pad, R, stream);
 }

@@ -20,7 +20,8 @@
 #endif
 
 struct StemFwdArgs {
-    const float* x;            // [n,3,H,W]
+    const float* x;            // [n,3,H,W] (FROM_XS: null)
+    const __bf16* xs_in;       // FROM_XS: the input already as bf16 space-to-depth NHWC [n,H2,W2,16] (mil_tile_preprocess_s2d)
     const void* w;             // MIL_PACK_STEM fragments [8][NT][64][8] (bf16; MIL_DT_F32S: [hi | lo] pairs)
     const float* bias;         // [NT*16]
     __bf16* xs;                // [n,H2,W2,16] (bf16 path only; may be null)
@@ -49,8 +50,12 @@ __host__ __device__ constexpr int sf_lds_bytes() {
 // per-wave quantity halves (5 row tiles, 3 load items, 2 pool items) and four waves per SIMD fit on the same LDS tiles.
 // X3 (MIL_DT_F32S: fp32 tensors, bf16x3 split products): the s2d tile holds hi and lo bf16 planes, every (filter, pixel)
 // fragment pair costs three MFMAs, the stem tile and the pooled output are fp32.  156 KB of LDS: one 8-wave workgroup per CU.
-template <int NT, int NW, bool X3 = false>
+// FROM_XS (bf16 only): the tiles arrive as the bf16 space-to-depth tensor itself — the s2d tile is a plain halo copy in
+// 16-byte pieces (1.07 GB read per 2048 tiles of 256x256 instead of 1.6 GB of fp32 in 304-byte plane segments), everything
+// behind it is the same code on the same LDS bytes: bit-identical pooled map and winner records.
+template <int NT, int NW, bool X3 = false, bool FROM_XS = false>
 __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 2 : 1)) void stem_fwd_fused_kernel(StemFwdArgs a) {
+    static_assert(!(X3 && FROM_XS), "the space-to-depth feed is bf16");
     using T = typename std::conditional<X3, F32S, BF16>::type;
     constexpr int SF_XPIX = sf_xpix(X3), SF_XBYTES = sf_xbytes(X3);
     constexpr int OESZ = X3 ? 4 : 2;                          // bytes per element of the stem tile / pooled output
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? 2 : 1) * (NW == 8 && N
     constexpr int KSTEPS = 8;
     constexpr int NG4 = COUTP / 4;
     constexpr int NTHR = 64 * NW;
-    constexpr int SF_NLOAD = (SF_NITEM + NTHR - 1) / NTHR;
+    constexpr int SF_NLOAD = ((FROM_XS ? SF_XH * SF_XW * 2 : SF_NITEM) + NTHR - 1) / NTHR;      // FROM_XS: items = 16-byte halves of the tile's s2d records
     constexpr int SF_MT = (SF_MTILES + NW - 1) / NW;          // row tiles per wave
     constexpr int NXS = 1024 / NTHR;                          // 16-byte pieces of the tile's own 16x32 s2d pixels per thread
     constexpr int NPOOL = (128 * NG4 + NTHR - 1) / NTHR;      // (pooled pixel, 4-channel group) items per thread
@@ -82,7 +87,8 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? 2 : 1) * (NW == 8 && N
             *reinterpret_cast<uint4*>(ldsX + i) = make_uint4(0, 0, 0, 0);
     }
     const int H = a.H, W = a.W, H2 = a.H2, W2 = a.W2, Ho = a.Ho, Wo = a.Wo;
-    const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, (unsigned)((size_t)a.n_img * 3 * H * W * 4));
+    const __amdgpu_buffer_rsrc_t rs_x = FROM_XS ? mil_rsrc(a.xs_in, (unsigned)((size_t)a.n_img * H2 * W2 * 32))
+                                                : mil_rsrc(a.x, (unsigned)((size_t)a.n_img * 3 * H * W * 4));
     const __amdgpu_buffer_rsrc_t rs_xs = mil_rsrc(a.xs, (unsigned)((size_t)a.n_img * H2 * W2 * 32));
     const __amdgpu_buffer_rsrc_t rs_p = mil_rsrc(a.pool, (unsigned)((size_t)a.n_img * Ho * Wo * COUTP * OESZ));
     const __amdgpu_buffer_rsrc_t rs_i = mil_rsrc(a.widx, (unsigned)((size_t)a.n_img * Ho * Wo * COUTP));
@@ -93,6 +99,13 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? 2 : 1) * (NW == 8 && N
     for (int i = 0; i < SF_NLOAD; ++i) {
         const int idx = tid + NTHR * i;
         l_lds[i] = dump | (31 << 18); l_rel[i] = 0;
+        if constexpr (FROM_XS) {             // (row, s2d column, half): "pair" field = the column
+            if (idx < SF_XH * SF_XW * 2) {
+                const int half = idx & 1, col = (idx >> 1) % SF_XW, row = (idx >> 1) / SF_XW;
+                l_lds[i] = ((row * SF_XW + col) * SF_XPIX + half * 16) | (row << 18) | (col << 24);
+                l_rel[i] = (row * W2 + col) * 32 + half * 16;
+            }
+        } else
         if (idx < SF_NITEM) {
             const int pair = idx % SF_NPAIR, t = idx / SF_NPAIR;
             const int c = t % 3, row = t / 3;
@@ -138,10 +151,21 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? 2 : 1) * (NW == 8 && N
     const int t_end = min(t_begin + per, a.ntiles);
     int tile = t_begin + (blockIdx.x >> 3);
 
-    u32x4_t r0[SF_NLOAD], r1[SF_NLOAD];
+    u32x4_t r0[SF_NLOAD], r1[FROM_XS ? 1 : SF_NLOAD];
     auto fetch = [&](int t) {
         const int tx = t % a.tiles_x, q = t / a.tiles_x, ty = q % a.tiles_y, img = q / a.tiles_y;
         const int y0 = 16 * ty - 3, c0 = 64 * tx - 8;            // first s2d row / first input column of the tile
+        if constexpr (FROM_XS) {
+            const int x0 = 32 * tx - 4;                          // first s2d column of the tile
+            const int base = ((img * H2 + y0) * W2 + x0) * 32;
+#pragma unroll
+            for (int i = 0; i < SF_NLOAD; ++i) {
+                const int row = (l_lds[i] >> 18) & 31, col = l_lds[i] >> 24;
+                const bool ok = (unsigned)(y0 + row) < (unsigned)H2 && (unsigned)(x0 + col) < (unsigned)W2;
+                r0[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (unsigned)(base + l_rel[i]) : MIL_OOB, 0, 0);
+            }
+            return;
+        }
         const int base = (((img * 3) * H + 2 * y0) * W + c0) * 4;
 #pragma unroll
         for (int i = 0; i < SF_NLOAD; ++i) {
@@ -158,6 +182,10 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? 2 : 1) * (NW == 8 && N
     for (; tile < t_end; tile += G8) {
         const int tx = tile % a.tiles_x, tq = tile / a.tiles_x, ty = tq % a.tiles_y, img = tq / a.tiles_y;
         // ---- s2d tile: fp32 -> bf16, channel = c*4 + dy*2 + dx --------------------------------------
+        if constexpr (FROM_XS) {
+#pragma unroll
+            for (int i = 0; i < SF_NLOAD; ++i) *reinterpret_cast<u32x4_t*>(smem + (l_lds[i] & 0x3FFFF)) = r0[i];
+        } else
 #pragma unroll
         for (int i = 0; i < SF_NLOAD; ++i) {
             const f32x4_t v0 = __builtin_bit_cast(f32x4_t, r0[i]), v1 = __builtin_bit_cast(f32x4_t, r1[i]);
@@ -179,7 +207,7 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? 2 : 1) * (NW == 8 && N
         __syncthreads();
         if (tile + G8 < t_end) fetch(tile + G8);
         // ---- the tile's own 16x32 s2d pixels go to the xs tensor (when the caller keeps one) ------------
-        if (!X3 && a.xs) {
+        if (!X3 && !FROM_XS && a.xs) {
             const int xbase = ((img * H2 + 16 * ty) * W2 + 32 * tx) * 32;
             const int ylim = H2 - 16 * ty, xlim = W2 - 32 * tx;
 #pragma unroll
@@ -335,7 +363,7 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? 2 : 1) * (NW == 8 && N
     }
 }
 
-template <int NT, bool X3 = false>
+template <int NT, bool X3 = false, bool FROM_XS = false>
 static int launch_stem_fwd(StemFwdArgs a, hipStream_t st) {
     constexpr int COUTP = mil_nt_to_cp(NT);
     constexpr int OESZ = X3 ? 4 : 2;
@@ -344,11 +372,11 @@ static int launch_stem_fwd(StemFwdArgs a, hipStream_t st) {
     // VGPRs (15 spilled): the 8-wave form serves the split-precision kernel, whose 156 KB of LDS leave one workgroup per CU
     // (two waves per SIMD at up to 256 VGPRs)
     constexpr int NW = X3 ? 8 : 4;
-    auto kern = stem_fwd_fused_kernel<NT, NW, X3>;
+    auto kern = stem_fwd_fused_kernel<NT, NW, X3, FROM_XS>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MIL_ERR_LAUNCH;
     // every tensor is addressed with 32-bit offsets below 2 GiB: split the launch by images
-    size_t per_img = (size_t)3 * a.H * a.W * 4;
+    size_t per_img = FROM_XS ? 0 : (size_t)3 * a.H * a.W * 4;
     const size_t xs_img = X3 ? 0 : (size_t)a.H2 * a.W2 * 32, p_img = (size_t)a.Ho * a.Wo * COUTP * OESZ;
     if (xs_img > per_img) per_img = xs_img;
     if (p_img > per_img) per_img = p_img;
@@ -357,7 +385,8 @@ static int launch_stem_fwd(StemFwdArgs a, hipStream_t st) {
     for (int i0 = 0; i0 < n_total; i0 += chunk) {
         StemFwdArgs b = a;
         b.n_img = n_total - i0 < chunk ? n_total - i0 : chunk;
-        b.x = a.x + (size_t)i0 * 3 * a.H * a.W;
+        b.x = a.x ? a.x + (size_t)i0 * 3 * a.H * a.W : nullptr;
+        b.xs_in = a.xs_in ? a.xs_in + (size_t)i0 * a.H2 * a.W2 * 16 : nullptr;
         b.xs = a.xs ? a.xs + (size_t)i0 * a.H2 * a.W2 * 16 : nullptr;
         b.pool = static_cast<char*>(a.pool) + (size_t)i0 * a.Ho * a.Wo * COUTP * OESZ;
         b.widx = a.widx + (size_t)i0 * a.Ho * a.Wo * COUTP;
@@ -392,4 +421,22 @@ extern "C" int mil_stem_fwd_fused(const float* x_nchw, const void* wpack, const 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MIL_DT_F32S) return launch_stem_fwd<2, true>(a, st);
     return cout_p == 24 ? launch_stem_fwd<2>(a, st) : launch_stem_fwd<4>(a, st);
+}
+
+// The same pass fed by the bf16 space-to-depth tensor xs [n,H2,W2,16] (mil_tile_preprocess_s2d's output, or mil_stem_s2d's):
+// pool / widx are bit-identical to mil_stem_fwd_fused on the fp32 tiles xs was made from.  bf16 only; H2, W2 = dims of xs.
+extern "C" int mil_stem_fwd_fused_xs(const void* xs, const void* wpack, const float* bias_pad, void* pool, uint8_t* widx,
+                                     int n_img, int H2, int W2, int cout_p, float slope, int dtype, void* stream) {
+    if (!xs || !wpack || !pool || !widx || n_img < 0 || H2 <= 0 || W2 <= 0) return MIL_ERR_ARG;
+    if (dtype != MIL_DT_BF16 || (reinterpret_cast<uintptr_t>(xs) & 15) || slope < 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
+    if (cout_p != 24 && cout_p != 64) return MIL_ERR_UNSUPPORTED;
+    if (n_img == 0) return MIL_OK;
+    StemFwdArgs a{};
+    a.xs_in = (const __bf16*)xs; a.w = wpack; a.bias = bias_pad; a.pool = pool; a.widx = widx;
+    a.n_img = n_img; a.H = 2 * H2; a.W = 2 * W2; a.H2 = H2; a.W2 = W2;
+    a.Ho = (H2 - 1) / 2 + 1; a.Wo = (W2 - 1) / 2 + 1;
+    a.tiles_y = (a.Ho + 7) / 8; a.tiles_x = (a.Wo + 15) / 16;
+    a.slope = slope;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return cout_p == 24 ? launch_stem_fwd<2, false, true>(a, st) : launch_stem_fwd<4, false, true>(a, st);
 }

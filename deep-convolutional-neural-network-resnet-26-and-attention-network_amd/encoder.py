@@ -194,6 +194,11 @@ class ResNet(nn.Module):
                 hooks.fire(stage, hooks.nchw(stage_in, stage[0].conv1.in_channels), hooks.nchw(out, cout))
 
     def forward(self, x):
+        """x: fp32 [T,3,H,W] tiles (the reference's tensor), or `preprocess.S2dTiles` — the same tiles as the bf16
+        space-to-depth tensor the stem kernels read (bf16 compute mode only)."""
+        from .preprocess import S2dTiles
+        if isinstance(x, S2dTiles):
+            x = x.xs
         return _EncoderFn.apply(self, x, *self.encoder_params())
 
 
@@ -204,15 +209,32 @@ def encoder_forward(net, x, dtype):
     hk = net.child_hooks()              # None unless a forward hook sits on a child module (then views are built for it)
     wp, bp = net._packed("stem", net.conv1.weight, net.conv1.bias, L.PACK_STEM, dtype)
     stem_hooked = hk is not None and hooks.any_hooked((net.conv1, net.relu, net.maxpool))
+    if x.dtype == torch.bfloat16:       # the tiles arrive as the bf16 space-to-depth tensor [T,H/2,W/2,16] (preprocess.S2dTiles)
+        if x.dim() != 4 or x.shape[3] != 16:
+            raise ValueError(f"a bf16 input must be the space-to-depth tensor [T,H/2,W/2,16], got {tuple(x.shape)}")
+        if dtype != torch.bfloat16:
+            raise ValueError("space-to-depth bf16 tiles feed the bf16 compute mode only (the fp32 modes take fp32 [T,3,H,W] tiles)")
+        return _encoder_forward_from(net, x, dtype, hk, stem_hooked, wp, bp, xs_in=x)
+    return _encoder_forward_from(net, x, dtype, hk, stem_hooked, wp, bp, xs_in=None)
+
+
+def _encoder_forward_from(net, x, dtype, hk, stem_hooked, wp, bp, xs_in):
     # no space-to-depth copy is kept (keep_s2d False): the fused stem backward rebuilds its tiles from x itself
     split = dtype == torch.float32 and L.dt_code(dtype, mma=True) == L.MIL_DT_F32S       # bf16x3: never an s2d copy
-    fused = ops.stem_fwd_fused(x, wp, bp, ops.cpad(STEM_WIDTH), dtype=dtype,
-                               keep_s2d=(net.keep_s2d or not net.fuse_backward) and not split) if (net.fuse_stem_forward and not stem_hooked) else None
+    fused = None
+    if xs_in is None:
+        fused = ops.stem_fwd_fused(x, wp, bp, ops.cpad(STEM_WIDTH), dtype=dtype,
+                                   keep_s2d=(net.keep_s2d or not net.fuse_backward) and not split) if (net.fuse_stem_forward and not stem_hooked) else None
+    else:                               # no fp32 stack exists: the fused stem reads the s2d records themselves
+        fused = ops.stem_fwd_fused_xs(xs_in, wp, bp, ops.cpad(STEM_WIDTH)) if (net.fuse_stem_forward and not stem_hooked) else None
+        if fused is not None:
+            fused = (xs_in,) + fused
+        x = hooks.s2d_to_nchw(xs_in) if stem_hooked else None          # a hooked stem sees the reference's tensor
     if fused is not None:
         xs, pool, widx = fused
-        stem_hw = (x.shape[2] // 2, x.shape[3] // 2)
+        stem_hw = (xs_in.shape[1], xs_in.shape[2]) if xs_in is not None else (x.shape[2] // 2, x.shape[3] // 2)
     else:
-        xs = ops.stem_s2d(x, dtype)
+        xs = xs_in if xs_in is not None else ops.stem_s2d(x, dtype)
         stem = ops.conv(xs, wp, bp, ops.cpad(STEM_WIDTH), ks=4, stride=1, pad=2, lrelu=True)
         pool, widx = ops.maxpool_fwd(stem)
         stem_hw = tuple(stem.shape[1:3])
@@ -226,7 +248,9 @@ def encoder_forward(net, x, dtype):
     # the stem output itself is not kept.  Without an s2d copy the backward rebuilds its tiles from the INPUT tensor: its
     # version counter is recorded so that an in-place change between forward and backward raises instead of silently
     # giving a wrong conv1 gradient (keep_s2d=True keeps a library-owned copy where the caller cannot promise that)
-    saved = {"xs": xs, "x": x if xs is None else None, "x_version": x._version, "stem_hw": stem_hw, "widx": widx, "blocks": []}
+    src = xs_in if xs_in is not None else x             # the caller's tensor the backward re-reads
+    saved = {"xs": xs, "x": x if xs is None else None, "x_src": src if (xs is None or xs_in is not None) else None,
+             "x_version": src._version, "stem_hw": stem_hw, "widx": widx, "blocks": []}
     t = pool
     stage_in = pool
     all_blocks = list(net.blocks())
@@ -309,7 +333,7 @@ def encoder_backward(net, saved, dfeats, dtype):
     the reference, gbm/model.py:194-196, so no data-gradient is produced for the tiles)."""
     blocks = list(net.blocks())
     grads = {}
-    if saved["x"] is not None and saved["x"]._version != saved["x_version"]:
+    if saved["x_src"] is not None and saved["x_src"]._version != saved["x_version"]:
         raise RuntimeError("the input tiles were modified in place between the encoder's forward and backward: conv1's gradient is "
                            "computed from them (no space-to-depth copy is kept).  Keep the tensor untouched until backward, or set "
                            "`net.cnn.module.keep_s2d = True` (MIL_KEEP_S2D=1) to have the forward keep its own copy")

@@ -57,3 +57,9 @@ def refuse(owner, names):
         if hooked(child):
             raise RuntimeError(f"a forward hook is registered on '{name}', whose output the fused HIP kernels never "
                                "materialise (it lives in registers/LDS only); hook the enclosing block or stage instead")
+
+
+def s2d_to_nchw(xs):
+    """bf16 space-to-depth tiles [T,H/2,W/2,16] (channel = c*4 + dy*2 + dx) -> the fp32 [T,3,H,W] stack they stand for."""
+    t, h2, w2, _ = xs.shape
+    return xs[..., :12].float().view(t, h2, w2, 3, 2, 2).permute(0, 3, 1, 4, 2, 5).reshape(t, 3, 2 * h2, 2 * w2).contiguous()

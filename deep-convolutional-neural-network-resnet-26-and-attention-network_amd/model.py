@@ -15,6 +15,7 @@ from . import hooks
 from . import ops
 from .encoder import BasicResBlock, ResNet
 from .head import DROP_P, SMOOTHING, BagLayout, head_apply
+from .preprocess import S2dTiles
 
 SUBSAMPLE = 0.2     # gbm/model.py:193
 
@@ -180,14 +181,17 @@ class Attention(nn.Module):
             if x_cat.shape[0] != sum(cat_sizes):
                 raise ValueError("bag sizes do not add up to the number of tiles")
             if self.training:      # per-bag subsampling needs the bags separately
-                bags = list(torch.split(x_cat, list(cat_sizes), dim=0))
+                if isinstance(x_cat, S2dTiles):
+                    bags = [S2dTiles(t) for t in torch.split(x_cat.xs, list(cat_sizes), dim=0)]
+                else:
+                    bags = list(torch.split(x_cat, list(cat_sizes), dim=0))
             else:
                 bags = None
         tiles, sizes, keep = [], [], None
         if bags is None:
             if x_cat.dim() != 4 or x_cat.shape[1] != 3:
                 raise ValueError(f"expected [N,3,H,W], got {tuple(x_cat.shape)}")
-            tiles, sizes, bags = [x_cat.detach().to(dev, torch.float32)], list(cat_sizes), []
+            tiles, sizes, bags = [x_cat.detach() if isinstance(x_cat, S2dTiles) else x_cat.detach().to(dev, torch.float32)], list(cat_sizes), []
         for b, x in enumerate(bags):
             x = x.detach()
             if x.dim() != 4 or x.shape[1] != 3:
@@ -198,10 +202,17 @@ class Attention(nn.Module):
                 else:
                     idx = torch.randperm(x.shape[0])[: int(x.shape[0] * SUBSAMPLE)]
                 x = x[idx.to(x.device)]
-            tiles.append(x.to(dev, torch.float32))
+            tiles.append(x if isinstance(x, S2dTiles) else x.to(dev, torch.float32))
             sizes.append(x.shape[0])
         layout = BagLayout.cached(sizes, dev)
-        x_all = tiles[0] if len(tiles) == 1 else torch.cat(tiles, dim=0)
+        if any(isinstance(t, S2dTiles) for t in tiles):
+            if not all(isinstance(t, S2dTiles) for t in tiles):
+                raise ValueError("bags of one call must all be fp32 tile stacks or all S2dTiles")
+            if any(t.device != dev for t in tiles):
+                raise ValueError("S2dTiles must live on the module's device")
+            x_all = tiles[0] if len(tiles) == 1 else S2dTiles.cat(tiles)
+        else:
+            x_all = tiles[0] if len(tiles) == 1 else torch.cat(tiles, dim=0)
         if self.training:
             if self.rng_override is not None and "keep_mask" in self.rng_override:
                 keep = self.rng_override["keep_mask"].to(dev, torch.uint8).contiguous()

@@ -447,6 +447,28 @@ def stem_fwd_fused(x, wpack, bias_pad, cout_p, *, slope=LEAK, dtype=torch.bfloat
     return xs, pool, widx
 
 
+def stem_fwd_fused_xs(xs, wpack, bias_pad, cout_p, *, slope=LEAK):
+    """(pool, widx) of the whole stem in one pass over the bf16 space-to-depth tiles xs [n,H2,W2,16] (see
+    mil_stem_fwd_fused_xs), or None when the shape has no fused kernel."""
+    if xs.dim() != 4 or xs.shape[3] != 16 or xs.dtype != torch.bfloat16 or not xs.is_cuda or not xs.is_contiguous():
+        raise ValueError(f"expected a contiguous CUDA bf16 [N,H/2,W/2,16] tensor, got {tuple(xs.shape)} {xs.dtype}")
+    n, h2, w2, _ = xs.shape
+    if cout_p not in (24, 64) or xs.data_ptr() % 16:
+        return None
+    hp, wp = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1
+    pool = torch.empty((n, hp, wp, cout_p), dtype=torch.bfloat16, device=xs.device)
+    widx = torch.empty((n, hp, wp, cout_p), dtype=torch.uint8, device=xs.device)
+    end = TIMER.bracket(("stem_fwd_xs", cout_p, n, 2 * h2, 2 * w2)) if TIMER else None
+    rc = L.lib().mil_stem_fwd_fused_xs(xs.data_ptr(), wpack.data_ptr(), L.ptr(bias_pad), pool.data_ptr(), widx.data_ptr(), n, h2, w2,
+                                       cout_p, slope, L.MIL_DT_BF16, L.stream_ptr())
+    if rc == 2:
+        return None
+    L.check(rc, "mil_stem_fwd_fused_xs")
+    if end is not None:
+        end.record()
+    return pool, widx
+
+
 def stem_bwd_fused(xs, g_pool, widx, *, workspace=None, out=None, slope=LEAK, ws_alloc=None):
     """(dW [20,3,7,7], db [20]) of the stem from the pooled-output gradient in one pass (see mil_stem_bwd_fused),
     or None when the shape/dtype has no fused kernel."""
@@ -472,10 +494,13 @@ def stem_bwd_fused(xs, g_pool, widx, *, workspace=None, out=None, slope=LEAK, ws
         dw, db = out
         _need(dw, (20, 3, 7, 7), torch.float32, "dw")
         _need(db, (20,), torch.float32, "db")
+    end = TIMER.bracket(("stem_bwd_xs", n, 2 * h2, 2 * w2)) if TIMER else None
     L.check(L.lib().mil_stem_bwd_fused(xs.data_ptr(), g_pool.data_ptr(), widx.data_ptr(), dw.data_ptr(), db.data_ptr(),
                                        workspace.data_ptr(), workspace.numel() * workspace.element_size(), n, h2, w2,
                                        slope, 0 if out is None else 1, L.dt_code(xs.dtype, dense), L.stream_ptr()),
             "mil_stem_bwd_fused")
+    if end is not None:
+        end.record()
     return dw, db
 
 

@@ -148,6 +148,10 @@ int mil_resize_plan(int in_size, int out_size, int* ksize);
 int mil_resize_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* kk);
 int mil_tile_preprocess(const uint8_t* rois, const int32_t* params, const int32_t* bounds_host, const int32_t* bounds_dev,
                         const int32_t* kk_dev, float* out, int T, int S, int pad, int R, void* stream);
+/* Same chain, output as the bf16 space-to-depth NHWC tensor xs [T,R/2,R/2,16] (channel = c*4 + dy*2 + dx, 12 real, 4 zero)
+ * that mil_stem_fwd_fused_xs / mil_stem_bwd_fused read: values = the bf16 roundings of mil_tile_preprocess's.  R even. */
+int mil_tile_preprocess_s2d(const uint8_t* rois, const int32_t* params, const int32_t* bounds_host, const int32_t* bounds_dev,
+                            const int32_t* kk_dev, void* xs, int T, int S, int pad, int R, void* stream);
 
 /* Forward of a whole identity-shortcut residual block in one pass (bf16 path; nnBlocks.py:175-189 with
  * downsample=None): o1 = lrelu(conv3x3(x)+b1) — written because the backward needs it — and
@@ -224,6 +228,12 @@ int mil_conv_dgrad_s2(const void* dz1, const void* dz2, const void* wpack, const
  * otherwise MIL_ERR_UNSUPPORTED (the caller then uses the three calls). */
 int mil_stem_fwd_fused(const float* x_nchw, const void* wpack, const float* bias_pad, void* xs, void* pool,
                        uint8_t* widx, int n_img, int H, int W, int cout_p, float slope, int dtype, void* stream);
+/* The same pass fed by the bf16 space-to-depth tensor xs [n,H2,W2,16] itself (mil_tile_preprocess_s2d's output): a
+ * pre-processed tile then never exists as fp32 (RoiBuilder.py:193-210 -> gbm/model.py:24,51 without the fp32 stack in
+ * between).  pool / widx are bit-identical to mil_stem_fwd_fused on the fp32 tiles xs is the bf16 rounding of; the
+ * backward is mil_stem_bwd_fused(xs, ...).  bf16 only. */
+int mil_stem_fwd_fused_xs(const void* xs, const void* wpack, const float* bias_pad, void* pool, uint8_t* widx, int n_img,
+                          int H2, int W2, int cout_p, float slope, int dtype, void* stream);
 
 /* Fused backward of the whole stem (bf16 path): max-pool backward + LeakyReLU backward + the 7x7 conv's weight
  * and bias gradient in one pass over xs [n,H2,W2,16] (mil_stem_s2d output), g_pool [n,Hp,Wp,24] (gradient of
