@@ -176,7 +176,12 @@ template <typename T> struct Epi8;          // 8 consecutive channels of one pix
 template <> struct Epi8<BF16> { u32x4_t v[1]; };
 template <> struct Epi8<F32S> { u32x4_t v[2]; };
 
-template <typename T, int CINP, int NT, int KS, int MTW, int FLAGS = -1, int NW = 4>
+// NTALL > NT: OUTPUT-COLUMN SPLIT.  The workgroups of grid row blockIdx.y compute only the NT column tiles
+// [blockIdx.y*NT, +NT) of the layer's NTALL and keep only that slice of the filter resident — for the filters that do not
+// fit LDS whole (split precision, 64 channels: 147 KB of [hi | lo] fragments; a half is 74 KB next to a 128-pixel halo tile).
+// Every grid row walks all tiles, so the input is read once per row (the second read mostly from L2 / Infinity Cache: the
+// rows run side by side), the output once.
+template <typename T, int CINP, int NT, int KS, int MTW, int FLAGS = -1, int NW = 4, int NTALL = NT>
 __global__ __launch_bounds__(64 * NW, T::SPLIT ? (NW == 8 ? 2 : (CINP <= 24 ? 2 : 1)) : (NW == 8 ? (CINP <= 40 ? 4 : 2) : ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 24 && FLAGS >= 0 && FLAGS != 3) ? MIL_PF_WAVES_24 : (CINP <= 40 ? 2 : 1))))
 void conv_igemm_pf_kernel(ConvArgs<T> a, int ntiles, unsigned x_bytes, unsigned y_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -186,11 +191,13 @@ void conv_igemm_pf_kernel(ConvArgs<T> a, int ntiles, unsigned x_bytes, unsigned 
     constexpr bool PIPE = !T::SPLIT && MIL_PF_PIPE(CINP, NT, MTW, NW);
     constexpr int PIXB = mil_pix_pitch(CINP, ESZ);
     constexpr int CG = CINP / 8;
-    constexpr int COUTP = mil_nt_to_cp(NT);
+    constexpr int COUTP = mil_nt_to_cp(NTALL);
     constexpr int NTHR = 64 * NW;
     constexpr int NPX = (mil_halo_px_max(NW * MTW == 16 ? 4 : 2) * (CINP * ESZ / 16) + NTHR - 1) / NTHR;
     constexpr int KSTEPS = (KS * KS * CG + 3) / 4;
     constexpr bool LAST_PARTIAL = (COUTP % 16) != 0;        // the last column tile holds only 8 channels
+    static_assert(NTALL % NT == 0 && (NTALL == NT || !LAST_PARTIAL), "column split: whole 16-channel tiles only");
+    const int nt0 = NTALL == NT ? 0 : (int)blockIdx.y * NT; // first column tile of this grid row
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -201,7 +208,16 @@ void conv_igemm_pf_kernel(ConvArgs<T> a, int ntiles, unsigned x_bytes, unsigned 
     const bool has_act = FLAGS < 0 ? (a.act != nullptr) : (FLAGS & 2) != 0;
     const bool do_lrelu = FLAGS < 0 ? (a.apply_lrelu != 0) : (FLAGS & 4) != 0;
 
-    mil_stage_filter(ldsW, a.w, KSTEPS * NT * 64 * FRAGB, tid, NTHR);
+    if constexpr (NTALL == NT) {
+        mil_stage_filter(ldsW, a.w, KSTEPS * NT * 64 * FRAGB, tid, NTHR);
+    } else {                                 // this row's NT column tiles of every k-step: KSTEPS runs of NT*64*FRAGB bytes
+        constexpr int RUN = NT * 64 * FRAGB;
+        const char* src = reinterpret_cast<const char*>(a.w) + (size_t)nt0 * 64 * FRAGB;
+        for (int i = tid * 16; i < KSTEPS * RUN; i += NTHR * 16) {
+            const int ks = i / RUN, r_ = i - ks * RUN;
+            *reinterpret_cast<u32x4_t*>(ldsW + i) = *reinterpret_cast<const u32x4_t*>(src + (size_t)ks * (NTALL * 64 * FRAGB) + r_);
+        }
+    }
     const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, x_bytes);
     const __amdgpu_buffer_rsrc_t rs_res = mil_rsrc(a.res, a.res ? y_bytes : 0);
     const __amdgpu_buffer_rsrc_t rs_act = mil_rsrc(a.act, a.act ? y_bytes : 0);
@@ -242,7 +258,7 @@ void conv_igemm_pf_kernel(ConvArgs<T> a, int ntiles, unsigned x_bytes, unsigned 
     for (int p = 0; p < NPAIR; ++p) {
         const int tp = PAIRED ? (wave * MTW + 2 * p + (gq & 1)) * 16 + r : wave * 16 + r;
         const int tx = tp & (TW - 1), ty = (tp >> g.tw_log2) & (TH - 1), ti = tp >> (g.tw_log2 + g.th_log2);
-        o_rel[p] = ((ti * g.Ho + ty) * g.Wo + tx) * (COUTP * ESZ) + (PAIRED ? (gq >> 1) * 8 : gq * 4) * ESZ;
+        o_rel[p] = ((ti * g.Ho + ty) * g.Wo + tx) * (COUTP * ESZ) + (PAIRED ? (gq >> 1) * 8 : gq * 4) * ESZ + nt0 * 16 * ESZ;
         o_pos[p] = (ti << 20) | (ty << 10) | tx;
     }
     // channels of the last column tile this lane owns exist
@@ -251,7 +267,7 @@ void conv_igemm_pf_kernel(ConvArgs<T> a, int ntiles, unsigned x_bytes, unsigned 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bias_r[nt][i] = a.bias ? a.bias[nt * 16 + gq * 4 + i] : 0.f;
+        for (int i = 0; i < 4; ++i) bias_r[nt][i] = a.bias ? a.bias[(nt0 + nt) * 16 + gq * 4 + i] : 0.f;
 
     TileWalker cur, nxt;
     const int bid = mil_xcd_block_id();
@@ -576,15 +592,15 @@ static int mil_pf_waves64() {
 #ifndef MIL_PF_MTW_24
 #define MIL_PF_MTW_24 4
 #endif
-template <typename T, int CINP, int NT, int KS, int MTW, int FLAGS, int NW = 4>
-static auto conv_pf_variant() { return conv_igemm_pf_kernel<T, CINP, NT, KS, MTW, FLAGS, NW>; }
+template <typename T, int CINP, int NT, int KS, int MTW, int FLAGS, int NW = 4, int NTALL = NT>
+static auto conv_pf_variant() { return conv_igemm_pf_kernel<T, CINP, NT, KS, MTW, FLAGS, NW, NTALL>; }
 
-template <typename T, int CINP, int NT, int KS, int MTW = 4, int NW = 4>
+template <typename T, int CINP, int NT, int KS, int MTW = 4, int NW = 4, int NTALL = NT>
 static int launch_conv_pf_ks(const ConvArgs<T>& a0, hipStream_t stream, bool* taken) {
     ConvArgs<T> a = a0;
     constexpr int ESZ = T::ESZ;
     constexpr int PIXB = mil_pix_pitch(CINP, ESZ);
-    constexpr int COUTP = mil_nt_to_cp(NT);
+    constexpr int COUTP = mil_nt_to_cp(NTALL);
     constexpr int DUMPB = T::SPLIT ? CINP * 2 + 16 : 16;        // spare bytes behind a halo buffer for the branch-free commit (split: hi + lo)
     *taken = false;
     mil_geom_tiles(a.g, NW * MTW == 16 ? 8 : 7);
@@ -602,14 +618,14 @@ static int launch_conv_pf_ks(const ConvArgs<T>& a0, hipStream_t stream, bool* ta
     a.lds_w_off = (dbuf ? 2 : 1) * a_bytes;
     a.lds_a2_off = dbuf ? a_bytes : 0;
     a.lds_dump_rel = a_bytes - DUMPB;
-    auto kern = conv_igemm_pf_kernel<T, CINP, NT, KS, MTW, -1, NW>;
+    auto kern = conv_igemm_pf_kernel<T, CINP, NT, KS, MTW, -1, NW, NTALL>;
     // the hot square 3x3 layers get the epilogue options as compile-time constants
-    if constexpr (KS == 3 && ((CINP == 24 && NT == 2) || (CINP == 40 && NT == 3) || (CINP == 64 && NT == 4) || (CINP == 80 && NT == 5))) {
+    if constexpr (KS == 3 && ((CINP == 24 && NTALL == 2) || (CINP == 40 && NTALL == 3) || (CINP == 64 && NTALL == 4) || (CINP == 80 && NTALL == 5))) {
         const int fl = (a.res ? 1 : 0) | (a.act ? 2 : 0) | (a.apply_lrelu ? 4 : 0);
-        if (fl == 4) kern = conv_pf_variant<T, CINP, NT, KS, MTW, 4, NW>();
-        else if (fl == 5) kern = conv_pf_variant<T, CINP, NT, KS, MTW, 5, NW>();
-        else if (fl == 2) kern = conv_pf_variant<T, CINP, NT, KS, MTW, 2, NW>();
-        else if (fl == 3) kern = conv_pf_variant<T, CINP, NT, KS, MTW, 3, NW>();
+        if (fl == 4) kern = conv_pf_variant<T, CINP, NT, KS, MTW, 4, NW, NTALL>();
+        else if (fl == 5) kern = conv_pf_variant<T, CINP, NT, KS, MTW, 5, NW, NTALL>();
+        else if (fl == 2) kern = conv_pf_variant<T, CINP, NT, KS, MTW, 2, NW, NTALL>();
+        else if (fl == 3) kern = conv_pf_variant<T, CINP, NT, KS, MTW, 3, NW, NTALL>();
     }
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -631,9 +647,10 @@ static int launch_conv_pf_ks(const ConvArgs<T>& a0, hipStream_t stream, bool* ta
         if (a.res) c.res = a.res + (size_t)i0 * (y_img / ESZ);
         if (a.act) c.act = a.act + (size_t)i0 * (y_img / ESZ);
         const int ntiles = c.g.n_groups * c.g.tiles_y * c.g.tiles_x;
-        int grid = mil_num_cus() * per_cu;
+        int grid = mil_num_cus() * per_cu / (NTALL / NT);      // the column rows share the resident set
+        if (grid < 1) grid = 1;
         if (grid > ntiles) grid = ntiles;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, c, ntiles, (unsigned)(x_img * n), (unsigned)(y_img * n));
+        hipLaunchKernelGGL(kern, dim3(grid, NTALL / NT), dim3(64 * NW), lds, stream, c, ntiles, (unsigned)(x_img * n), (unsigned)(y_img * n));
         MIL_CHECK_LAUNCH();
     }
     *taken = true;
@@ -656,6 +673,9 @@ static int launch_conv_pf(const ConvArgs<T>& a, hipStream_t stream, bool* taken)
         if (a.g.ks == 1) return launch_conv_pf_ks<T, 40, 2, 1>(a, stream, taken);
     }
     if constexpr (CINP == 64 && NT == 4) {
+        // split precision: the 147 KB filter does not fit — two grid rows of 32 output channels each on 128-pixel tiles
+        if constexpr (T::SPLIT) { if (a.g.ks == 3) return launch_conv_pf_ks<T, 64, 2, 3, 1, 8, 4>(a, stream, taken); }
+        else
         if (a.g.ks == 3) return mil_pf_waves64() == 8 ? launch_conv_pf_ks<T, 64, 4, 3, 2, 8>(a, stream, taken) : launch_conv_pf_ks<T, 64, 4, 3>(a, stream, taken);
     }
     if constexpr (CINP == 64 && NT == 3) {
