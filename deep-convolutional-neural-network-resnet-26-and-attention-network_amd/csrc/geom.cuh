@@ -17,6 +17,8 @@ struct ConvGeom {
 };
 
 __host__ inline void mil_geom_set(ConvGeom& g, int tw, int th, int ti);
+#include <cstdlib>
+__host__ inline bool mil_geom_wide() { const char* e = getenv("MIL_GEOM_WIDE"); return e && e[0] == '1'; }
 __host__ inline void mil_geom_tiles(ConvGeom& g, int tile_px_log2) {
     // choose TW x TH x TI = 2^tile_px_log2 output pixels
     int tw, th;
@@ -31,6 +33,9 @@ __host__ inline void mil_geom_tiles(ConvGeom& g, int tile_px_log2) {
 #define MIL_GEOM_KS_MAX 3
 #endif
             if (c8 < c16 && g.stride == 1 && !g.zins && g.ks <= MIL_GEOM_KS_MAX) { tw = 3; th = 3; } else { tw = 4; th = 4; }
+            // experiment (MIL_GEOM_WIDE=1): 64-pixel-wide maps as 4 rows x 64 columns — a tile's rows are then ONE contiguous
+            // run of the NHWC tensor (24 KB of a 24-channel fp32 map instead of sixteen 1.5 KB segments)
+            if (g.Wo == 64 && g.stride == 1 && !g.zins && g.ks == 3 && mil_geom_wide()) { tw = 6; th = 2; }
         }
         else if (g.Wo > 4 || g.Ho > 4) { tw = 3; th = 3; }
         else { tw = 2; th = 2; }

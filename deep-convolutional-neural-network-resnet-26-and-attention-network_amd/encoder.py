@@ -21,6 +21,15 @@ WEIGHT_EPOCH = [0]                     # bumped by optimizers that update weight
 STEM_WIDTH = 20                        # gbm/model.py:20
 
 
+def invalidate_packed_weights():
+    """Call after changing conv weights in a way autograd's version counters do not see — `conv.weight.data.normal_()` (as the
+    reference itself does, nnBlocks.py:375), EMA / clipping code writing through `.data`, raw-pointer updates: the encoders
+    keep MFMA-fragment-order copies of every filter, re-packed only when a parameter's `_version`, its storage or this
+    epoch changes.  (`FlatAdam.step` bumps the epoch itself; `load_state_dict` and in-place ops on the Parameter bump
+    `_version`.)"""
+    WEIGHT_EPOCH[0] += 1
+
+
 class BasicResBlock(nn.Module):
     """Parameter container with the reference block's layout (nnBlocks.py:157-173): conv1 (3x3,
     stride s, bias), conv2 (3x3, bias), optional `downsample` = Sequential(1x1 stride-s conv, no bias).

@@ -86,6 +86,7 @@ class _HeadFn(torch.autograd.Function):
                                  wrois.data_ptr(), bterm.data_ptr(), kld.data_ptr(), rec.data_ptr(), ntot, nbags,
                                  ops.LEAK, DROP_P, SMOOTHING, BN_EPS, L.stream_ptr()), "mil_head_fwd")
         ctx.layout, ctx.keep_mask, ctx.ws, ctx.work = layout, keep_mask, ws, work
+        ctx.params = weights               # the Parameters themselves: their .grad may be one flat bucket (dist.FlatParams)
         if internals is not None:          # forward hooks on head children read the kernels' own intermediates
             o = nbags * 2 * N_FEATS
             internals["stats"] = work[:o].view(nbags, 2, N_FEATS)                      # per bag: mean, 1/sqrt(var+eps)
@@ -115,11 +116,36 @@ class _HeadFn(torch.autograd.Function):
                                  arr, ctx.work.data_ptr(), bterm.data_ptr(), rec.data_ptr(), g_loss.data_ptr(),
                                  L.ptr(g_l2), dH.data_ptr(), grads.data_ptr(), layout.ntot, layout.nbags, ops.LEAK,
                                  DROP_P, L.stream_ptr()), "mil_head_bwd")
-        out, o = [], 0
-        for w in ctx.ws:
-            out.append(grads[o:o + w.numel()].view(w.shape))
+        # Parameters whose .grad tensors sit back to back in one buffer, in this order (dist.FlatParams: the ten tensors from
+        # context.bn.weight to buffer.classifier.bias): ONE add of the kernel's gradient block into that run instead of one
+        # autograd accumulation (a torch add launch) per parameter — the kernel writes its gradients in the same order.
+        out, o, run = [], 0, _contiguous_grad_run(ctx.params)
+        if run is not None:
+            first, count, total = run
+            g0 = ctx.params[first].grad
+            off0 = sum(w.numel() for w in ctx.ws[:first])
+            torch.empty(0, dtype=torch.float32, device=dev).set_(g0.untyped_storage(), g0.storage_offset(), (total,)).add_(grads[off0:off0 + total])
+        for i, w in enumerate(ctx.ws):
+            direct = run is not None and run[0] <= i < run[0] + run[1]
+            out.append(None if direct else grads[o:o + w.numel()].view(w.shape))
             o += w.numel()
         return (dH, None, None, None, None, None, *out)
+
+
+def _contiguous_grad_run(params):
+    """(first index, count, total elements) of the longest prefix run of `params` (from index 0) whose existing fp32 .grad
+    tensors are contiguous and adjacent in memory, or None when fewer than two qualify."""
+    run, nxt, total = 0, None, 0
+    for p in params:
+        g = getattr(p, "grad", None)
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or not p.requires_grad:
+            break
+        if nxt is not None and g.data_ptr() != nxt:
+            break
+        nxt = g.data_ptr() + g.numel() * 4
+        total += g.numel()
+        run += 1
+    return (0, run, total) if run >= 2 else None
 
 
 def head_apply(H, layout, labels, keep_mask, class_weights, weights, internals=None):

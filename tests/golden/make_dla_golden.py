@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Golden `.dla` files for the attention-map export (gbm/classify.py:207-225).
 
-The reference's `write_map` cannot be imported (gbm/classify.py pulls in modules that are not in the repository and
-writes into a module-global directory), so this script executes the reference's own formatting statements — the
-`plt.Normalize()(attn.data)` call on matplotlib itself and the four f-string writes — on seeded tensors, and stores
-the resulting files (data) next to the inputs.  Run in the build container; the fixtures are committed.
+The reference module cannot be imported (gbm/classify.py pulls in modules that are not in the repository), but its
+`write_map` is self-contained: this script parses the reference file with `ast`, compiles ONLY the `write_map` function
+definition, and runs it — the reference's own code, matplotlib's own `plt.Normalize` — on seeded tensors with the
+module-global `output_dir` it writes into pointed at tests/golden/dla.  The resulting files (data) are committed; the
+reference source is read at generation time only and never stored.  Runs in the build container (needs /root/reference):
 
     python tests/golden/make_dla_golden.py
 """
@@ -23,15 +24,23 @@ import torch  # noqa: E402
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dla")
 
 
+REFERENCE = "/root/reference/gbm/classify.py"
+
+
+def reference_write_map(output_dir):
+    """The reference's own `write_map(meta, epoch, raster, attn, activations)` (gbm/classify.py:207-225), compiled from its
+    source file: only that FunctionDef is executed, in a namespace holding what it refers to (`plt`, `output_dir`)."""
+    import ast
+    tree = ast.parse(open(REFERENCE).read(), filename=REFERENCE)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "write_map"]
+    assert len(fn) == 1, "write_map not found in the reference"
+    ns = {"plt": plt, "output_dir": output_dir}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), REFERENCE, "exec"), ns)
+    return ns["write_map"]
+
+
 def reference_statements(output_dir, name, raster, attn, activations):
-    # the statements of gbm/classify.py:208-225, verbatim in effect (output_dir passed instead of a global)
-    att_weights_real = plt.Normalize()(attn.data)
-    for tag, col in (("ATTN", None), ("ACTF1", 0), ("ACTF2", 1), ("ACTF3", 2)):
-        f = open(f'{output_dir}/prediction-AGMIL-{tag}.{name}.dla', "w+")
-        for i, coord in enumerate(raster):
-            v = att_weights_real[i, 0] if col is None else activations[i, col]
-            f.write(f'{coord[1]} {coord[0]} {v}\n')
-        f.close()
+    reference_write_map(output_dir)({"basename": name}, 0, raster, attn, activations)
 
 
 def main():

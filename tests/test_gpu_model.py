@@ -442,3 +442,22 @@ def test_input_modified_between_forward_and_backward_raises(golden_dir):
     x.mul_(0.5)
     out["loss"].backward()
     assert float(net.cnn.module.conv1.weight.grad.abs().max()) > 0
+
+
+def test_weight_update_through_data_needs_invalidate_packed_weights(golden_dir):
+    """The encoder keeps MFMA-order copies of its filters, refreshed on parameter version / storage / epoch changes.  A write
+    through `.data` (the reference does this at nnBlocks.py:375) bumps none of them: `mil_amd.invalidate_packed_weights()` is
+    the documented hook, after which the next forward sees the new weights; an in-place op on the Parameter needs nothing."""
+    import mil_amd
+    net = _model(golden_dir, torch.bfloat16).eval()
+    x = torch.randn(6, 3, 64, 64, generator=torch.Generator().manual_seed(4)).clamp_(-1, 1).cuda()
+    with torch.no_grad():
+        f0 = net.cnn(x).clone()
+        net.cnn.module.layer1[0].conv1.weight.data.mul_(0.5)
+        stale = net.cnn(x).clone()                      # packed copy not refreshed: documented behaviour
+        mil_amd.invalidate_packed_weights()
+        f1 = net.cnn(x).clone()
+        net.cnn.module.layer1[0].conv1.weight.mul_(2.0)   # in-place on the Parameter: version counter moves
+        f2 = net.cnn(x).clone()
+    assert torch.equal(stale, f0) and not torch.equal(f1, f0)
+    assert float((f2 - f0).abs().max()) <= 2e-2 * float(f0.abs().max())

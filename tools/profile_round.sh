@@ -12,7 +12,7 @@ OUT=gpurun_out/prof_$ROUND
 mkdir -p $OUT profiles
 BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-extra-paths"
 
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths --no-kernel-timer > $OUT/stats.log 2>&1
 cp "$(ls $OUT/stats/*/*kernel_stats.csv | head -n 1)" profiles/${ROUND}_bench_kernel_stats.csv
 echo "stats done"
 
@@ -31,7 +31,7 @@ python3 profiles/summarise_sq_counters.py $OUT/sq1 $OUT/sq2 profiles/sq_counters
 cp profiles/sq_counters.json profiles/${ROUND}_sq_counters.json
 # the same passes for the split-precision path (fp32 tensors, bf16x3 products): kernel stats + HBM traffic + SQ counters
 X3="python3 bench.py --dtype bf16x3 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-extra-paths"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/x3_stats -- python3 bench.py --dtype bf16x3 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths > $OUT/x3_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/x3_stats -- python3 bench.py --dtype bf16x3 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths --no-kernel-timer > $OUT/x3_stats.log 2>&1
 cp "$(ls $OUT/x3_stats/*/*kernel_stats.csv | head -n 1)" profiles/${ROUND}_bf16x3_kernel_stats.csv
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/x3_fetch -- $X3 > $OUT/x3_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/x3_write -- $X3 > $OUT/x3_write.log 2>&1
