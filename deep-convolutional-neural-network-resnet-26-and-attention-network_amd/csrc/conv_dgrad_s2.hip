@@ -11,12 +11,13 @@
 // of the persistent conv kernel then stores two horizontally adjacent output pixels per lane pair.
 #include "pf_common.cuh"
 
+template <typename T>
 struct DgradS2Args {
-    const __bf16* dz1;      // [n,h,w,CZ]   gradient of the 3x3/s2 conv's output
-    const __bf16* dz2;      // [n,h,w,CZ]   gradient of the block output (input of the projection's transposed conv), or null
-    const __bf16* w;        // MIL_PACK_DGRAD_S2 fragments [mil_s2_nsteps][NT][64][8]
-    const __bf16* act;      // [n,H,W,CXP]  block input (lrelu' mask), or null
-    __bf16* y;              // [n,H,W,CXP]
+    const typename T::elem* dz1;      // [n,h,w,CZ]   gradient of the 3x3/s2 conv's output
+    const typename T::elem* dz2;      // [n,h,w,CZ]   gradient of the block output (input of the projection's transposed conv), or null
+    const typename T::elem* w;        // MIL_PACK_DGRAD_S2 fragments [mil_s2_nsteps][NT][64][8] (F32S: [hi | lo] pairs)
+    const typename T::elem* act;      // [n,H,W,CXP]  block input (lrelu' mask), or null
+    typename T::elem* y;              // [n,H,W,CXP]
     ConvGeom g;             // output tiling: Ho=H, Wo=W (dx), H=h, W=w (dz)
     int ch, cw;             // compact halo extent per image: TH/2+1, TW/2+1
     int lds_z2_off, lds_w_off;
@@ -25,15 +26,20 @@ struct DgradS2Args {
     unsigned act_bytes;
 };
 
-template <int CZ, int NT>
-__global__ __launch_bounds__(256, CZ <= 40 ? 2 : 1) void conv_dgrad_s2_kernel(DgradS2Args a, int ntiles, unsigned z_bytes, unsigned y_bytes) {
+// T = BF16, or F32S (MIL_DT_F32S: fp32 tensors, bf16x3 split products — the compact tiles hold [hi | lo] planes, three MFMAs per
+// fragment pair, fp32 mask / output; the 40 -> 24 channel entry only: the larger filters do not fit LDS beside two compact tiles).
+template <typename T, int CZ, int NT>
+__global__ __launch_bounds__(256, (CZ <= 40 && !T::SPLIT) ? 2 : 1) void conv_dgrad_s2_kernel(DgradS2Args<T> a, int ntiles, unsigned z_bytes, unsigned y_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MIL_POISON(smem);
+    constexpr int ESZ = T::ESZ, FRAGB = 8 * ESZ;
     constexpr int CG = CZ / 8;
-    constexpr int PIXZ = mil_pix_pitch(CZ, 2);
+    constexpr int N16 = CZ * ESZ / 16;                       // 16-byte pieces per dz pixel
+    constexpr int JB = T::SPLIT ? 8 : 16;
+    constexpr int PIXZ = mil_pix_pitch(CZ, ESZ);
     constexpr int CXP = mil_nt_to_cp(NT);
     constexpr int NS = mil_s2_nsteps(CG);
-    constexpr int NPZ = (144 * CG + 255) / 256;              // <= 144 compact halo pixels (16 images of 3x3)
+    constexpr int NPZ = (144 * N16 + 255) / 256;             // <= 144 compact halo pixels (16 images of 3x3)
     constexpr bool LAST_PARTIAL = (CXP % 16) != 0;
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -41,7 +47,7 @@ __global__ __launch_bounds__(256, CZ <= 40 ? 2 : 1) void conv_dgrad_s2_kernel(Dg
     const int r = lane & 15, gq = lane >> 4;
     char* ldsZ = smem;
     char* ldsW = smem + a.lds_w_off;
-    mil_stage_filter(ldsW, a.w, NS * NT * 64 * 16, tid, 256);
+    mil_stage_filter(ldsW, a.w, NS * NT * 64 * FRAGB, tid, 256);
     const __amdgpu_buffer_rsrc_t rs_z1 = mil_rsrc(a.dz1, z_bytes);
     const __amdgpu_buffer_rsrc_t rs_z2 = mil_rsrc(a.dz2, a.dz2 ? z_bytes : 0);
     const __amdgpu_buffer_rsrc_t rs_act = mil_rsrc(a.act, a.act ? a.act_bytes : 0);
@@ -52,17 +58,17 @@ __global__ __launch_bounds__(256, CZ <= 40 ? 2 : 1) void conv_dgrad_s2_kernel(Dg
     // ---- tile-invariant tables ---------------------------------------------------------------------
     int z_pos[NPZ], z_lds[NPZ], z_rel[NPZ];                  // compact halo pieces (same for both sources)
     {
-        const int total = ((CH * CW) << g.ti_log2) * CG;
+        const int total = ((CH * CW) << g.ti_log2) * N16;
 #pragma unroll
         for (int i = 0; i < NPZ; ++i) {
             const int idx = tid + 256 * i;
             z_pos[i] = -1; z_lds[i] = 0; z_rel[i] = 0;
             if (idx < total) {
-                const int p = idx / CG, j = idx - p * CG;
+                const int p = idx / N16, j = idx - p * N16;
                 const int cx = p % CW, t = p / CW, cy = t % CH, ti = t / CH;
                 z_pos[i] = (ti << 20) | (cy << 10) | cx;
-                z_lds[i] = p * PIXZ + j * 16;
-                z_rel[i] = ((ti * h + cy) * w + cx) * (CZ * 2) + j * 16;
+                z_lds[i] = p * PIXZ + j * JB;
+                z_rel[i] = ((ti * h + cy) * w + cx) * (CZ * ESZ) + j * 16;
             }
         }
     }
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(256, CZ <= 40 ? 2 : 1) void conv_dgrad_s2_kernel(Dg
     nxt = cur; nxt.advance();
     auto fetch_z = [&](u32x4_t (&r1)[NPZ], u32x4_t (&r2)[NPZ], const TileOrigin& o) {
         const int i0 = o.oy0 >> 1, j0 = o.ox0 >> 1;
-        const int base = ((o.img0 * h + i0) * w + j0) * (CZ * 2);
+        const int base = ((o.img0 * h + i0) * w + j0) * (CZ * ESZ);
         const int ylim = h - i0, xlim = w - j0, ilim = g.n_img - o.img0;
 #pragma unroll
         for (int i = 0; i < NPZ; ++i) {
@@ -110,26 +116,30 @@ __global__ __launch_bounds__(256, CZ <= 40 ? 2 : 1) void conv_dgrad_s2_kernel(Dg
             r2[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_z2, off, 0, 0);
         }
     };
-    auto fetch_epi = [&](const TileOrigin& o, unsigned (&ooff)[2], u32x4_t (&ract)[2][NT]) {
+    constexpr int NE = T::SPLIT ? 2 : 1;                     // 16-byte loads per 8 channels of the mask operand
+    auto fetch_epi = [&](const TileOrigin& o, unsigned (&ooff)[2], u32x4_t (&ract)[2][NT][NE]) {
         const int obase = (o.img0 * H + o.oy0) * W + o.ox0;
         const int ylim = H - o.oy0, xlim = W - o.ox0, ilim = g.n_img - o.img0;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const bool ok = (o_pos[p] >> 20) < ilim && ((o_pos[p] >> 10) & 1023) < ylim && (o_pos[p] & 1023) < xlim;
             const int opix = obase + o_rel[p];
-            ooff[p] = ok ? (unsigned)(opix * a.ypx + (gq >> 1) * 16) : MIL_OOB;
-            const unsigned aoff = ok ? (unsigned)(opix * (CXP * 2) + (gq >> 1) * 16) : MIL_OOB;
+            ooff[p] = ok ? (unsigned)(opix * a.ypx + (gq >> 1) * 8 * ESZ) : MIL_OOB;
+            const unsigned aoff = ok ? (unsigned)(opix * (CXP * ESZ) + (gq >> 1) * 8 * ESZ) : MIL_OOB;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : aoff + nt * 32;
-                if (a.act) ract[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, off, 0, 0);
+                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : aoff + nt * 16 * ESZ;
+                if (a.act) {
+                    ract[p][nt][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, off, 0, 0);
+                    if constexpr (T::SPLIT) ract[p][nt][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, off == MIL_OOB ? MIL_OOB : off + 16, 0, 0);
+                }
             }
         }
     };
 
     u32x4_t rz1[NPZ], rz2[NPZ];
     unsigned ooff_n[2];
-    u32x4_t ract_n[2][NT];
+    u32x4_t ract_n[2][NT][NE];
     if (bid < ntiles) {
         fetch_z(rz1, rz2, cur.origin(g));
         fetch_epi(cur.origin(g), ooff_n, ract_n);
@@ -140,17 +150,19 @@ __global__ __launch_bounds__(256, CZ <= 40 ? 2 : 1) void conv_dgrad_s2_kernel(Dg
 #pragma unroll
         for (int i = 0; i < NPZ; ++i) {
             if (z_pos[i] >= 0) {
-                *reinterpret_cast<u32x4_t*>(ldsZ + z_lds[i]) = rz1[i];
-                *reinterpret_cast<u32x4_t*>(ldsZ + a.lds_z2_off + z_lds[i]) = rz2[i];
+                mil_commit_piece<T, CZ * 2>(ldsZ + z_lds[i], rz1[i]);
+                mil_commit_piece<T, CZ * 2>(ldsZ + a.lds_z2_off + z_lds[i], rz2[i]);
             }
         }
         unsigned ooff[2];
-        u32x4_t ract[2][NT];
+        u32x4_t ract[2][NT][NE];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             ooff[p] = ooff_n[p];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) ract[p][nt] = ract_n[p][nt];
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int e = 0; e < NE; ++e) ract[p][nt][e] = ract_n[p][nt][e];
         }
         __syncthreads();
         if (tile + G < ntiles) {
@@ -169,16 +181,16 @@ __global__ __launch_bounds__(256, CZ <= 40 ? 2 : 1) void conv_dgrad_s2_kernel(Dg
             // one k-step ahead (the steps of the four parity classes flattened into one sequence): the fragments of step
             // s+1 are read before the MFMAs of step s and scheduling fences keep that order (see mil_conv_ring)
             auto cls = [](int st) { int c = 0; while (st >= mil_s2_steps(c, CG)) { st -= mil_s2_steps(c, CG); ++c; } return c; };
-            Frag8<BF16> xq[2], wq[2][NT];
-            xq[0] = lds_frag<BF16>(ldsZ + pixbase + toff[0]);
+            Frag8<T> xq[2], wq[2][NT];
+            xq[0] = lds_pix_frag<T, CZ * 2>(ldsZ + pixbase + toff[0]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wq[0][nt] = lds_frag<BF16>(ldsW + (nt * 64 + lane) * 16);
+            for (int nt = 0; nt < NT; ++nt) wq[0][nt] = lds_frag<T>(ldsW + (nt * 64 + lane) * FRAGB);
 #pragma unroll
             for (int st = 0; st < NS; ++st) {
                 if (st + 1 < NS) {
-                    xq[(st + 1) & 1] = lds_frag<BF16>(ldsZ + pixbase + toff[st + 1 < NS ? st + 1 : st]);
+                    xq[(st + 1) & 1] = lds_pix_frag<T, CZ * 2>(ldsZ + pixbase + toff[st + 1 < NS ? st + 1 : st]);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) wq[(st + 1) & 1][nt] = lds_frag<BF16>(ldsW + (((st + 1) * NT + nt) * 64 + lane) * 16);
+                    for (int nt = 0; nt < NT; ++nt) wq[(st + 1) & 1][nt] = lds_frag<T>(ldsW + (((st + 1) * NT + nt) * 64 + lane) * FRAGB);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -193,10 +205,10 @@ __global__ __launch_bounds__(256, CZ <= 40 ? 2 : 1) void conv_dgrad_s2_kernel(Dg
             for (int c = 0; c < 4; ++c) {
 #pragma unroll
                 for (int sl = 0; sl < mil_s2_steps(c, CG); ++sl, ++s) {
-                    const Frag8<BF16> xf = lds_frag<BF16>(ldsZ + pixbase + toff[s]);
+                    const Frag8<T> xf = lds_pix_frag<T, CZ * 2>(ldsZ + pixbase + toff[s]);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        const Frag8<BF16> wf = lds_frag<BF16>(ldsW + ((s * NT + nt) * 64 + lane) * 16);
+                        const Frag8<T> wf = lds_frag<T>(ldsW + ((s * NT + nt) * 64 + lane) * FRAGB);
                         acc[c][nt] = mma8(wf, xf, acc[c][nt]);          // D[channel][pixel]
                     }
                 }
@@ -215,54 +227,68 @@ __global__ __launch_bounds__(256, CZ <= 40 ? 2 : 1) void conv_dgrad_s2_kernel(Dg
                     v[i] = lo;
                     v[4 + i] = hi;
                 }
+                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 16 * ESZ;
+                if constexpr (T::SPLIT) {
+                    if (a.act) {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const f32x4_t t = __builtin_bit_cast(f32x4_t, ract[p][nt][e]);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[4 * e + i] *= (t[i] > 0.f ? 1.f : a.slope);
+                        }
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4_t{v[0], v[1], v[2], v[3]}), rs_y, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4_t{v[4], v[5], v[6], v[7]}), rs_y, off == MIL_OOB ? MIL_OOB : off + 16, 0, 0);
+                } else {
                 if (a.act) {
-                    const bf16x8_t t = __builtin_bit_cast(bf16x8_t, ract[p][nt]);
+                    const bf16x8_t t = __builtin_bit_cast(bf16x8_t, ract[p][nt][0]);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] *= ((float)t[i] > 0.f ? 1.f : a.slope);
                 }
                 bf16x8_t ov;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) ov[i] = (__bf16)v[i];
-                const unsigned off = (LAST_PARTIAL && nt == NT - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 32;
                 const u32x4_t ou = __builtin_bit_cast(u32x4_t, ov);
                 if (LAST_PARTIAL && nt == NT - 1 && a.ypx != CXP * 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{ou[0], ou[1]}, rs_y, off, 0, 0);      // dense: channels 16-19 only
                 else __builtin_amdgcn_raw_buffer_store_b128(ou, rs_y, off, 0, 0);
+                }
             }
         }
     }
 }
 
-template <int CZ, int NT>
-static int launch_dgrad_s2(DgradS2Args a, hipStream_t st) {
-    constexpr int CG = CZ / 8, PIXZ = mil_pix_pitch(CZ, 2), CXP = mil_nt_to_cp(NT);
+template <typename T, int CZ, int NT>
+static int launch_dgrad_s2(DgradS2Args<T> a, hipStream_t st) {
+    constexpr int ESZ = T::ESZ;
+    constexpr int CG = CZ / 8, PIXZ = mil_pix_pitch(CZ, ESZ), CXP = mil_nt_to_cp(NT);
     mil_geom_tiles(a.g, 8);
     if (a.g.tw_log2 < 1 || a.g.th_log2 < 1) return MIL_ERR_UNSUPPORTED;
     a.ch = (1 << a.g.th_log2) / 2 + 1; a.cw = (1 << a.g.tw_log2) / 2 + 1;
     const int npx = (a.ch * a.cw) << a.g.ti_log2;
     if (npx > 144) return MIL_ERR_UNSUPPORTED;
     const int z_bytes = (npx * PIXZ + 15) & ~15;
-    const int w_bytes = mil_s2_nsteps(CG) * NT * 64 * 16;
+    const int w_bytes = mil_s2_nsteps(CG) * NT * 64 * 8 * ESZ;
     a.lds_z2_off = z_bytes; a.lds_w_off = 2 * z_bytes;
     const int lds = 2 * z_bytes + w_bytes;
     if (lds > 160 * 1024) return MIL_ERR_UNSUPPORTED;
-    auto kern = conv_dgrad_s2_kernel<CZ, NT>;
+    auto kern = conv_dgrad_s2_kernel<T, CZ, NT>;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MIL_ERR_LAUNCH;
     const int per_cu = mil_resident_per_cu(kern, lds, 4);      // by registers AND LDS (see conv_s2_entry.hip)
-    const size_t z_img = (size_t)a.g.H * a.g.W * CZ * 2, act_img = (size_t)a.g.Ho * a.g.Wo * CXP * 2, y_img = (size_t)a.g.Ho * a.g.Wo * a.ypx;
+    const size_t z_img = (size_t)a.g.H * a.g.W * CZ * ESZ, act_img = (size_t)a.g.Ho * a.g.Wo * CXP * ESZ, y_img = (size_t)a.g.Ho * a.g.Wo * a.ypx;
     int chunk = mil_imgs_under_2g(z_img > act_img ? z_img : act_img);
     if (chunk >= 16) chunk &= ~15;
     const int n_total = a.g.n_img;
     for (int i0 = 0; i0 < n_total; i0 += chunk) {
         const int n = (n_total - i0 < chunk) ? n_total - i0 : chunk;
-        DgradS2Args c = a;
+        DgradS2Args<T> c = a;
         c.g.n_img = n;
         c.g.n_groups = (n + (1 << c.g.ti_log2) - 1) >> c.g.ti_log2;
-        c.dz1 = a.dz1 + (size_t)i0 * (z_img / 2);
-        if (a.dz2) c.dz2 = a.dz2 + (size_t)i0 * (z_img / 2);
-        if (a.act) c.act = a.act + (size_t)i0 * (act_img / 2);
+        c.dz1 = a.dz1 + (size_t)i0 * (z_img / ESZ);
+        if (a.dz2) c.dz2 = a.dz2 + (size_t)i0 * (z_img / ESZ);
+        if (a.act) c.act = a.act + (size_t)i0 * (act_img / ESZ);
         c.act_bytes = (unsigned)(act_img * n);
-        c.y = a.y + (size_t)i0 * (y_img / 2);
+        c.y = a.y + (size_t)i0 * (y_img / ESZ);
         const int ntiles = c.g.n_groups * c.g.tiles_y * c.g.tiles_x;
         int grid = mil_num_cus() * per_cu;
         if (grid > ntiles) grid = ntiles;
@@ -279,9 +305,17 @@ static int launch_dgrad_s2(DgradS2Args a, hipStream_t st) {
 extern "C" int mil_conv_dgrad_s2(const void* dz1, const void* dz2, const void* wpack, const void* act, void* y, int n_img,
                                  int h, int w, int cz_p, int H, int W, int cx_p, float slope, int dtype, void* stream) {
     if (!dz1 || !wpack || !y || n_img < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return MIL_ERR_ARG;
-    if ((dtype != MIL_DT_BF16 && dtype != MIL_DT_BF16_DGRAD) || h != (H - 1) / 2 + 1 || w != (W - 1) / 2 + 1 || slope < 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
+    if ((dtype != MIL_DT_BF16 && dtype != MIL_DT_BF16_DGRAD && dtype != MIL_DT_F32S) || h != (H - 1) / 2 + 1 || w != (W - 1) / 2 + 1 || slope < 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
     if (n_img == 0) return MIL_OK;
-    DgradS2Args a{};
+    if (dtype == MIL_DT_F32S) {                  // fp32 tensors, bf16x3 products: the 40 -> 24 channel entry (the only filter that fits)
+        if (cz_p != 40 || cx_p != 24) return MIL_ERR_UNSUPPORTED;
+        DgradS2Args<F32S> b{};
+        b.dz1 = (const float*)dz1; b.dz2 = (const float*)dz2; b.w = (const float*)wpack; b.act = (const float*)act; b.y = (float*)y;
+        b.g.n_img = n_img; b.g.H = h; b.g.W = w; b.g.Ho = H; b.g.Wo = W; b.g.ks = 3; b.g.stride = 1; b.g.pad = 1; b.g.zins = 1;
+        b.slope = slope; b.ypx = cx_p * 4;
+        return launch_dgrad_s2<F32S, 40, 2>(b, reinterpret_cast<hipStream_t>(stream));
+    }
+    DgradS2Args<BF16> a{};
     a.dz1 = (const __bf16*)dz1; a.dz2 = (const __bf16*)dz2; a.w = (const __bf16*)wpack; a.act = (const __bf16*)act; a.y = (__bf16*)y;
     a.g.n_img = n_img; a.g.H = h; a.g.W = w; a.g.Ho = H; a.g.Wo = W; a.g.ks = 3; a.g.stride = 1; a.g.pad = 1; a.g.zins = 1;
     a.slope = slope;
@@ -291,8 +325,8 @@ extern "C" int mil_conv_dgrad_s2(const void* dz1, const void* dz2, const void* w
         if (cz_p != 40 || cx_p != 24) return MIL_ERR_UNSUPPORTED;
         a.ypx = 40;
     }
-    if (cz_p == 40 && cx_p == 24) return launch_dgrad_s2<40, 2>(a, st);
-    if (cz_p == 64 && cx_p == 40) return launch_dgrad_s2<64, 3>(a, st);
-    if (cz_p == 80 && cx_p == 64) return launch_dgrad_s2<80, 4>(a, st);
+    if (cz_p == 40 && cx_p == 24) return launch_dgrad_s2<BF16, 40, 2>(a, st);
+    if (cz_p == 64 && cx_p == 40) return launch_dgrad_s2<BF16, 64, 3>(a, st);
+    if (cz_p == 80 && cx_p == 64) return launch_dgrad_s2<BF16, 80, 4>(a, st);
     return MIL_ERR_UNSUPPORTED;
 }

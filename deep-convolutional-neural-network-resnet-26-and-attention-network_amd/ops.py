@@ -397,16 +397,16 @@ def conv_dgrad_s2(dz1, dz2, wpack, cx_p, out_hw, *, act=None, slope=LEAK, dense_
     layout, MIL_DT_BF16_DGRAD); act keeps its padded channels."""
     n, h, w, cz_p = dz1.shape
     hh, ww = out_hw
-    if dz1.dtype != torch.bfloat16:
-        return None
     dense = dense_cx is not None
+    if dz1.dtype != torch.bfloat16 and (dense or L.dt_code(dz1.dtype, mma=True) != L.MIL_DT_F32S):
+        return None               # bf16, or fp32 tensors with split-precision products (the 40 -> 24 channel entry)
     _need(dz1, dz1.shape, dz1.dtype, "dz1")
     _need(dz2, dz1.shape, dz1.dtype, "dz2")
     y = torch.empty((n, hh, ww, dense_cx if dense else cx_p), dtype=dz1.dtype, device=dz1.device)
     _need(act, (n, hh, ww, cx_p), dz1.dtype, "act")
     end = TIMER.bracket(("dgrad_s2", cz_p, cx_p, n, hh, ww)) if TIMER else None
     rc = L.lib().mil_conv_dgrad_s2(dz1.data_ptr(), L.ptr(dz2), wpack.data_ptr(), L.ptr(act), y.data_ptr(), n, h, w, cz_p,
-                                   hh, ww, cx_p, slope, L.dt_code(dz1.dtype, dense), L.stream_ptr())
+                                   hh, ww, cx_p, slope, L.dt_code(dz1.dtype, dense, mma=True), L.stream_ptr())
     if rc == 2:
         return None
     L.check(rc, "mil_conv_dgrad_s2")

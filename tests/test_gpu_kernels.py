@@ -478,6 +478,36 @@ DGRAD_S2_CASES = [
 
 
 @pytest.mark.parametrize("with_proj", [True, False])
+@pytest.mark.parametrize("case", DGRAD_S2_CASES[:3])
+def test_stage_entry_data_gradient_one_pass_split_precision(ops, case, with_proj):
+    """The parity-class stage-entry data gradient on fp32 tensors with bf16x3 products (MIL_DT_F32S; the 40 -> 20 channel
+    entry) vs autograd on un-rounded operands; the larger entries decline (their filters do not fit beside two compact tiles)."""
+    L = _lib()
+    cin, cout, n, h, w = case
+    g = torch.Generator().manual_seed(103 + cin + h)
+    x = torch.randn(n, cin, h, w, generator=g).requires_grad_(True)
+    w1 = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    wp = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    y1 = F.conv2d(x, w1, None, stride=2, padding=1)
+    y2 = F.conv2d(x, wp, None, stride=2)
+    dz1, dz2 = torch.randn(y1.shape, generator=g), torch.randn(y2.shape, generator=g)
+    ((y1 * dz1).sum() + ((y2 * dz2).sum() if with_proj else 0.0)).backward()
+    act = torch.randn(x.shape, generator=g)
+    want = x.grad * torch.where(act > 0, 1.0, LEAK)
+    with L.f32_mma(L.MIL_DT_F32S):
+        ws2, _ = ops.pack_weights(w1.cuda(), wp.cuda() if with_proj else None, L.PACK_DGRAD_S2, torch.float32)
+        got = ops.conv_dgrad_s2(to_nhwc(dz1, torch.float32), to_nhwc(dz2, torch.float32) if with_proj else None, ws2, cpad(cin), (h, w),
+                                act=to_nhwc(act, torch.float32))
+        assert got is not None and got.dtype == torch.float32
+        assert rel_err(from_nhwc(got, cin), want) < TOL[X3]
+        assert float(got[..., cin:].abs().max()) == 0.0
+        big = torch.zeros((2, 4, 4, 64), device="cuda")
+        wbig, _ = ops.pack_weights(torch.randn(60, 40, 3, 3).cuda(), None, L.PACK_DGRAD_S2, torch.float32)
+        assert ops.conv_dgrad_s2(big, None, wbig, 40, (8, 8)) is None
+    assert ops.conv_dgrad_s2(to_nhwc(dz1, torch.float32), None, ws2, cpad(cin), (h, w)) is None      # exact-fp32 mode: no such kernel
+
+
+@pytest.mark.parametrize("with_proj", [True, False])
 @pytest.mark.parametrize("case", DGRAD_S2_CASES)
 def test_stage_entry_data_gradient_one_pass(ops, case, with_proj):
     """mask * (conv3x3_s2^T(dz1) + conv1x1_s2^T(dz2)) by output parity class vs autograd, and vs the two zero-insert

@@ -90,6 +90,32 @@ def test_fp32_outputs_match_reference_golden(golden_dir, name):
 
 
 @pytest.mark.parametrize("name", CASES)
+def test_bf16x3_outputs_match_reference_golden(golden_dir, name):
+    """The split-precision path (fp32 tensors, bf16x3 products) on every reference golden case — eval and train mode (recorded
+    subsample indices and dropout mask), class weights, 50x70 tiles (W % 4 != 0: the un-fused stem), the two-tile bag: same
+    output dict, and the north-star gate, 1e-3 absolute, on logits / attention weights / probabilities / loss."""
+    from gpu_util import X3
+    net, g, out = _run_case(golden_dir, name, X3)
+    assert list(out.keys()) == OUT_KEYS
+    for k in OUT_KEYS:
+        ref, got = g["out." + k], out[k].detach().cpu().numpy()
+        assert got.shape == ref.shape and got.dtype == ref.dtype, k
+    assert np.array_equal(out["y_pred_hat"].cpu().numpy(), g["out.y_pred_hat"])
+    err = {k: _maxabs(out[k].detach().cpu().numpy(), g["out." + k]) for k in ("Mterm", "Aterm", "y_pred", "loss", "wROIs", "Bterm")}
+    print(f"bf16x3 golden {name}: {err}")
+    for k, e in err.items():
+        assert e < 1e-3, (k, e)
+    assert _rel(out["Fterm"].detach().cpu().numpy(), g["out.Fterm"]) < 5e-5
+    assert abs(float(out["Aterm"].sum(1).sub(1).abs().max())) < 1e-5
+    params = dict(net.named_parameters())
+    worst = 0.0
+    for k, n_ref in zip(list(g["gradnorm.names"]), g["gradnorm.l2"]):
+        worst = max(worst, abs(float(params[k].grad.double().norm()) - n_ref) / max(n_ref, 1e-3))
+    print(f"bf16x3 golden {name}: worst gradient-norm deviation {worst:.2e}")
+    assert worst < (0.2 if name == "eval_n2_256" else 5e-2)      # branch flips (DESIGN.md §1); N=2: ill-conditioned BN backward
+
+
+@pytest.mark.parametrize("name", CASES)
 def test_fp32_gradients_match_reference_golden(golden_dir, name):
     net, g, out = _run_case(golden_dir, name, torch.float32)
     params = dict(net.named_parameters())
