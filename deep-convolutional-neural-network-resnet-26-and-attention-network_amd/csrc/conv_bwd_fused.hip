@@ -57,18 +57,24 @@ struct BwdFusedArgs {
 #ifndef MIL_BWD_PIPE_MAXC
 #define MIL_BWD_PIPE_MAXC 40      // explicit one-step-ahead operand prefetch for layers up to this many channels (the 64-channel
 #endif                            // instantiation already sits at 256 VGPRs: the second operand set would spill)
-template <int CZ, int NTX, int KS, bool ADD, bool MASK, int NW = 4>
-__global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES) void conv_bwd_fused_kernel(BwdFusedArgs a) {
+// T = BF16, or F32S (round 3: MIL_DT_F32S — fp32 dz / x / addend / dx, bf16x3 split products).  The pointers of BwdFusedArgs
+// are then float tensors behind their __bf16 type; the dz halo and the x centre tile hold [hi | lo] planes per pixel record,
+// both MFMA loops take three products per fragment pair, the epilogue adds / masks / stores fp32.  24 channels only (one
+// 8-wave workgroup per CU on 94 KB of LDS): the 40-channel filter, halo and x tile do not fit together.
+template <typename T, int CZ, int NTX, int KS, bool ADD, bool MASK, int NW = 4>
+__global__ __launch_bounds__(64 * NW, T::SPLIT ? 2 : ((NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)) void conv_bwd_fused_kernel(BwdFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MIL_POISON(smem);
-    constexpr bool PIPE = CZ <= MIL_BWD_PIPE_MAXC;
-    constexpr int PIXB = mil_pix_pitch(CZ, 2);            // dz halo pixel pitch
+    constexpr int ESZ = T::ESZ, FRAGB = 8 * ESZ;
+    constexpr int NE = T::SPLIT ? 2 : 1;                  // 16-byte registers per 8 channels of an epilogue operand
+    constexpr bool PIPE = !T::SPLIT && CZ <= MIL_BWD_PIPE_MAXC;
+    constexpr int PIXB = mil_pix_pitch(CZ, ESZ);          // dz halo pixel pitch
     constexpr int CG = CZ / 8;
     constexpr int CX = mil_nt_to_cp(NTX);
-    constexpr int PIXX = mil_pix_pitch(CX, 2);            // x centre tile pixel pitch
+    constexpr int PIXX = mil_pix_pitch(CX, ESZ);          // x centre tile pixel pitch
     constexpr int NTHR = 64 * NW;
     constexpr int MTW = 16 / NW;                          // data-gradient row tiles per wave (256-pixel tile)
-    constexpr int NPX = (400 * (CZ * 2 / 16) + NTHR - 1) / NTHR;
+    constexpr int NPX = (400 * (CZ * ESZ / 16) + NTHR - 1) / NTHR;
     constexpr int KSTEPS = (KS * KS * CG + 3) / 4;
     constexpr int RG = KS * KS * CG;                       // wgrad row groups (tap', 8 dz channels)
     constexpr int MT = (RG + 1) / 2;
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
     char* ldsW = smem + a.lds_w_off;
     char* ldsX = smem + a.lds_x_off;
 
-    mil_stage_filter(ldsW, a.w, KSTEPS * NTX * 64 * 16, tid, NTHR);
+    mil_stage_filter(ldsW, a.w, KSTEPS * NTX * 64 * FRAGB, tid, NTHR);
     const int TW = 1 << g.tw_log2, TH = 1 << g.th_log2;
 
     const __amdgpu_buffer_rsrc_t rs_z = mil_rsrc(a.dz, a.z_bytes);
@@ -93,9 +99,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
     const __amdgpu_buffer_rsrc_t rs_dx = mil_rsrc(a.dx, a.x_bytes);
 
     // ---- tile-invariant tables (see conv_igemm_pf_kernel) -------------------------------------------
+    constexpr int DUMPB = T::SPLIT ? CZ * 2 + 16 : 16;    // spare bytes behind each halo buffer (split: a hi and a lo piece)
     HaloTables<NPX> ht;
-    mil_build_halo_tables<CZ, NPX, NTHR>(ht, g, tid);
-    mil_halo_tables_use_dump<NPX>(ht, a.lds_w_off - 16 - a.lds_a2_off);     // 16 spare bytes behind each halo buffer
+    mil_build_halo_tables<CZ, NPX, NTHR, T>(ht, g, tid);
+    mil_halo_tables_use_dump<NPX>(ht, a.lds_w_off - DUMPB - a.lds_a2_off);
     int toff[KSTEPS];
 #pragma unroll
     for (int sl = 0; sl < KSTEPS; ++sl) {
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
     for (int p = 0; p < NPAIR; ++p) {
         const int tp = (wave * MTW + 2 * p + (gq & 1)) * 16 + r;
         const int tx = tp & (TW - 1), ty = (tp >> g.tw_log2) & (TH - 1), ti = tp >> (g.tw_log2 + g.th_log2);
-        o_rel[p] = ((ti * g.Ho + ty) * g.Wo + tx) * (CX * 2) + (gq >> 1) * 16;
+        o_rel[p] = ((ti * g.Ho + ty) * g.Wo + tx) * (CX * ESZ) + (gq >> 1) * 8 * ESZ;
         o_pos[p] = (ti << 20) | (ty << 10) | tx;
         x_lds[p] = tp * PIXX + (gq >> 1) * 16;
     }
@@ -161,14 +168,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
     cur.init(g, bid, gridDim.x);
     nxt = cur; nxt.advance();
     u32x4_t rx[NPX];
-    if (bid < a.ntiles) mil_fetch_halo<CZ, NPX>(rx, rs_z, ht, g, cur.origin(g));
+    if (bid < a.ntiles) mil_fetch_halo<CZ, NPX, T>(rx, rs_z, ht, g, cur.origin(g));
     // The tile's x (mask + wgrad operand) and addend are needed only after the data-gradient MFMA loop; their loads are
     // issued a phase early — behind the previous tile's last barrier, under its weight-gradient loop — into the registers
     // that tile has just finished with, so the ~2 us round trip is no longer waited for in the middle of the tile.
     unsigned ooff[NPAIR];
-    u32x4_t rxc[NPAIR][NTX], radd[NPAIR][NTX];
+    u32x4_t rxc[NPAIR][NTX][NE], radd[NPAIR][NTX][NE];
     auto fetch_xa = [&](const TileOrigin& o) {
-        const int obase = ((o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (CX * 2);
+        const int obase = ((o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (CX * ESZ);
         const int ylim = g.Ho - o.oy0, xlim = g.Wo - o.ox0, ilim = g.n_img - o.img0;
 #pragma unroll
         for (int p = 0; p < NPAIR; ++p) {
@@ -176,9 +183,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
             ooff[p] = ok ? (unsigned)(obase + o_rel[p]) : MIL_OOB;
 #pragma unroll
             for (int nt = 0; nt < NTX; ++nt) {
-                const unsigned off = (LAST_PARTIAL && nt == NTX - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 32;
-                rxc[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
-                if constexpr (ADD) radd[p][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, off, 0, 0);
+                const unsigned off = (LAST_PARTIAL && nt == NTX - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 16 * ESZ;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const unsigned oe = (e == 0 || off == MIL_OOB) ? off : off + 16;
+                    rxc[p][nt][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, oe, 0, 0);
+                    if constexpr (ADD) radd[p][nt][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, oe, 0, 0);
+                }
             }
         }
     };
@@ -196,13 +207,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
         if (buf_step == 0) __syncthreads();    // single buffer: previous tile's reads of ldsA are done
         char* ldsA_t = ldsA + buf;
         buf = buf_step - buf;
-        mil_commit_halo_all<NPX>(rx, ldsA_t, ht);
+        mil_commit_halo_all<NPX, T, CZ>(rx, ldsA_t, ht);
         MIL_ST_MARK(0)                         // halo commit (incl. the wait for the prefetched loads)
 
         __syncthreads();                       // dz halo visible
         MIL_ST_MARK(1)                         // barrier 1
         const bool more = tile + (int)gridDim.x < a.ntiles;
-        if (more) mil_fetch_halo<CZ, NPX>(rx, rs_z, ht, g, nxt.origin(g));
+        if (more) mil_fetch_halo<CZ, NPX, T>(rx, rs_z, ht, g, nxt.origin(g));
         const TileOrigin o_next = nxt.origin(g);
         cur = nxt; nxt.advance();
 
@@ -243,12 +254,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
         } else {
 #pragma unroll
         for (int sl = 0; sl < KSTEPS; ++sl) {
-            Frag8<BF16> wf[NTX];
+            Frag8<T> wf[NTX];
 #pragma unroll
-            for (int nt = 0; nt < NTX; ++nt) wf[nt] = lds_frag<BF16>(ldsW + ((sl * NTX + nt) * 64 + lane) * 16);
+            for (int nt = 0; nt < NTX; ++nt) wf[nt] = lds_frag<T>(ldsW + ((sl * NTX + nt) * 64 + lane) * FRAGB);
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
-                const Frag8<BF16> zf = lds_frag<BF16>(ldsA_t + pixbase[m] + toff[sl]);
+                const Frag8<T> zf = lds_pix_frag<T, CZ * 2>(ldsA_t + pixbase[m] + toff[sl]);
 #pragma unroll
                 for (int nt = 0; nt < NTX; ++nt) acc[m][nt] = mma8(wf[nt], zf, acc[m][nt]);
             }
@@ -264,7 +275,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
             {
                 // lanes whose channels of the last column tile do not exist write to the dump slot instead of branching
                 const int dst = (LAST_PARTIAL && nt == NTX - 1 && !last_ok) ? a.lds_dump_off : a.lds_x_off + x_lds[p] + nt * 32;
-                *reinterpret_cast<u32x4_t*>(smem + dst) = rxc[p][nt];
+                if constexpr (T::SPLIT) {       // eight fp32 channels -> 16 bytes of the record's hi plane + 16 bytes of its lo plane
+                    const f32x4_t v0 = __builtin_bit_cast(f32x4_t, rxc[p][nt][0]), v1 = __builtin_bit_cast(f32x4_t, rxc[p][nt][1]);
+                    const float f8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    bf16x8_t hi, lo;
+                    mil_split8(f8, hi, lo);
+                    *reinterpret_cast<bf16x8_t*>(smem + dst) = hi;
+                    *reinterpret_cast<bf16x8_t*>(smem + dst + CX * 2) = lo;
+                } else {
+                    *reinterpret_cast<u32x4_t*>(smem + dst) = rxc[p][nt][0];
+                }
             }
 
         // ---- data-gradient epilogue from registers, 8 channels per lane --------------------------------
@@ -280,21 +300,39 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
                     v[i] = lo;
                     v[4 + i] = hi;
                 }
+                const unsigned off = (LAST_PARTIAL && nt == NTX - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 16 * ESZ;
+                if constexpr (T::SPLIT) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        if constexpr (ADD) {
+                            const f32x4_t t = __builtin_bit_cast(f32x4_t, radd[p][nt][e]);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[4 * e + i] += t[i];
+                        }
+                        if constexpr (MASK) {
+                            const f32x4_t t = __builtin_bit_cast(f32x4_t, rxc[p][nt][e]);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[4 * e + i] *= (t[i] > 0.f ? 1.f : a.slope);
+                        }
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4_t{v[0], v[1], v[2], v[3]}), rs_dx, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4_t{v[4], v[5], v[6], v[7]}), rs_dx, off == MIL_OOB ? MIL_OOB : off + 16, 0, 0);
+                } else {
                 if constexpr (ADD) {
-                    const bf16x8_t t = __builtin_bit_cast(bf16x8_t, radd[p][nt]);
+                    const bf16x8_t t = __builtin_bit_cast(bf16x8_t, radd[p][nt][0]);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] += (float)t[i];
                 }
                 if constexpr (MASK) {
-                    const bf16x8_t t = __builtin_bit_cast(bf16x8_t, rxc[p][nt]);
+                    const bf16x8_t t = __builtin_bit_cast(bf16x8_t, rxc[p][nt][0]);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] *= ((float)t[i] > 0.f ? 1.f : a.slope);
                 }
                 bf16x8_t ov;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) ov[i] = (__bf16)v[i];
-                const unsigned off = (LAST_PARTIAL && nt == NTX - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 32;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), rs_dx, off, 0, 0);
+                }
             }
         }
         MIL_ST_MARK(3)                         // x tile write + epilogue + dx stores
@@ -350,6 +388,29 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)
             bf16x8_t xf[NTX];
 #pragma unroll
             for (int nt = 0; nt < NTX; ++nt) xf[nt] = mil_tr_pair(x0 + nt * 32, x1 + nt * 32);
+            if constexpr (T::SPLIT) {            // dW' += dz_lo*x_hi + dz_hi*x_lo + dz_hi*x_hi from the hi / lo planes of both tiles
+                bf16x8_t xl[NTX];
+#pragma unroll
+                for (int nt = 0; nt < NTX; ++nt) xl[nt] = mil_tr_pair(x0 + CX * 2 + nt * 32, x1 + CX * 2 + nt * 32);
+#pragma unroll
+                for (int i = 0; i < MW; ++i) {
+                    if (mvalid[i]) {
+                        const bf16x8_t zf = mil_tr_pair(ldsA_t + pb0 + wtoff[i], ldsA_t + pb1 + wtoff[i]);
+                        const bf16x8_t zl = mil_tr_pair(ldsA_t + pb0 + CZ * 2 + wtoff[i], ldsA_t + pb1 + CZ * 2 + wtoff[i]);
+#pragma unroll
+                        for (int nt = 0; nt < NTX; ++nt) {
+                            wacc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zl, xf[nt], wacc[i][nt], 0, 0, 0);
+                            wacc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf, xl[nt], wacc[i][nt], 0, 0, 0);
+                            wacc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf, xf[nt], wacc[i][nt], 0, 0, 0);
+                        }
+                        if (i == bias_i) {
+                            bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zl, ones, bacc, 0, 0, 0);
+                            bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf, ones, bacc, 0, 0, 0);
+                        }
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < MW; ++i) {
                 if (mvalid[i]) {
@@ -761,12 +822,14 @@ static bool mil_bwd16_enabled() {
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int CZ, int NTX, int KS, int NW = 4>
+template <typename T, int CZ, int NTX, int KS, int NW = 4>
 static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t ws_bytes, int cout, int cin, int accumulate, bool query,
                          size_t* need, hipStream_t stream, bool dense_grads = false) {
-    constexpr int PIXB = mil_pix_pitch(CZ, 2);
+    constexpr int ESZ = T::ESZ, EM = ESZ / 2;               // EM: BwdFusedArgs pointers are typed __bf16 — fp32 tensors advance two per element
+    constexpr int PIXB = mil_pix_pitch(CZ, ESZ);
     constexpr int CX = mil_nt_to_cp(NTX);
-    constexpr int PIXX = mil_pix_pitch(CX, 2);
+    constexpr int PIXX = mil_pix_pitch(CX, ESZ);
+    constexpr int DUMPA = T::SPLIT ? CZ * 2 + 16 : 16, DUMPX = T::SPLIT ? CX * 2 + 16 : 16;      // dump slots (split: a hi and a lo piece)
     constexpr int KSTEPS = (KS * KS * (CZ / 8) + 3) / 4;
     constexpr int RG = KS * KS * (CZ / 8);
     constexpr int MT = (RG + 1) / 2;
@@ -774,34 +837,34 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
     {   // the 8x8-tiles-of-four-images shape stages 400 halo pixels; where that (plus filter and x tile) does not fit in
         // LDS but the 16x16 shape's 324 pixels would, take 16x16
         const int px = (a.g.hh * a.g.hw) << a.g.ti_log2;
-        const int need = ((px * PIXB + 15) & ~15) + 16 + KSTEPS * NTX * 64 * 16 + 256 * PIXX + 16;
+        const int need = ((px * PIXB + 15) & ~15) + DUMPA + KSTEPS * NTX * 64 * 8 * ESZ + 256 * PIXX + DUMPX;
         if (need > 160 * 1024 && a.g.tw_log2 == 3 && a.g.ti_log2 == 2 && (a.g.Wo > 8 || a.g.Ho > 8)) mil_geom_set(a.g, 4, 4, 0);
     }
     const int halo_px = (a.g.hh * a.g.hw) << a.g.ti_log2;
     if (halo_px > 400 || a.g.hh >= 1024 || a.g.hw >= 1024) return MIL_ERR_UNSUPPORTED;
     // buffer descriptors address < 2 GiB: larger launches are split by images, later chunks accumulating into dW/db
-    const size_t img_bytes = (size_t)a.g.H * a.g.W * (CZ > CX ? CZ : CX) * 2;
+    const size_t img_bytes = (size_t)a.g.H * a.g.W * (CZ > CX ? CZ : CX) * ESZ;
     int chunk = mil_imgs_under_2g(img_bytes);
     if (chunk >= 16) chunk &= ~15;
     const int n_total = a.g.n_img;
     if (chunk < n_total) { a.g.n_img = chunk; a.g.n_groups = (chunk + (1 << a.g.ti_log2) - 1) >> a.g.ti_log2; }
-    const int a_bytes = ((halo_px * PIXB + 15) & ~15) + 16;   // + dump slot behind the halo for the branch-free commit
-    const int w_bytes = KSTEPS * NTX * 64 * 16;
+    const int a_bytes = ((halo_px * PIXB + 15) & ~15) + DUMPA;   // + dump slot behind the halo for the branch-free commit
+    const int w_bytes = KSTEPS * NTX * 64 * 8 * ESZ;
     const int x_bytes = 256 * PIXX;
-    const bool dbuf = 2 * (2 * a_bytes + w_bytes + x_bytes + 16) <= 160 * 1024;      // second halo buffer if two workgroups still fit
+    const bool dbuf = 2 * (2 * a_bytes + w_bytes + x_bytes + DUMPX) <= 160 * 1024;      // second halo buffer if two workgroups still fit
     // 24-channel layers on 16x16 tiles of one image: the compile-time-geometry, software-pipelined, one-barrier form
     // (two halo buffers AND two x-tile buffers: 70 KB, two workgroups per CU)
     bool t16 = false;
-    if constexpr (CZ == 24 && NTX == 2 && KS == 3 && NW == 8)
+    if constexpr (CZ == 24 && NTX == 2 && KS == 3 && NW == 8 && !T::SPLIT)
         t16 = mil_bwd16_enabled() && dbuf && a.g.tw_log2 == 4 && a.g.th_log2 == 4 && a.g.ti_log2 == 0 && a.g.H < 1024 && a.g.W < 1024 &&
               cout == 20;      // the K20 order (and the packed filter's second section) exists for 20 dz channels
     if (dense_grads && !t16) return MIL_ERR_UNSUPPORTED;      // only the 16x16-tile kernel reads the dense gradient layout
-    const int lds = (dbuf ? 2 : 1) * a_bytes + w_bytes + (t16 ? 2 : 1) * x_bytes + 16;          // + dump slot for the x-tile writes
+    const int lds = (dbuf ? 2 : 1) * a_bytes + w_bytes + (t16 ? 2 : 1) * x_bytes + DUMPX;          // + dump slot for the x-tile writes
     if (lds > 160 * 1024) return MIL_ERR_UNSUPPORTED;
     const int ntiles = a.g.n_groups * a.g.tiles_y * a.g.tiles_x;
-    auto kern = a.addend ? (a.apply_mask ? conv_bwd_fused_kernel<CZ, NTX, KS, true, true, NW> : conv_bwd_fused_kernel<CZ, NTX, KS, true, false, NW>)
-                         : (a.apply_mask ? conv_bwd_fused_kernel<CZ, NTX, KS, false, true, NW> : conv_bwd_fused_kernel<CZ, NTX, KS, false, false, NW>);
-    if constexpr (CZ == 24 && NTX == 2 && KS == 3 && NW == 8) {
+    auto kern = a.addend ? (a.apply_mask ? conv_bwd_fused_kernel<T, CZ, NTX, KS, true, true, NW> : conv_bwd_fused_kernel<T, CZ, NTX, KS, true, false, NW>)
+                         : (a.apply_mask ? conv_bwd_fused_kernel<T, CZ, NTX, KS, false, true, NW> : conv_bwd_fused_kernel<T, CZ, NTX, KS, false, false, NW>);
+    if constexpr (CZ == 24 && NTX == 2 && KS == 3 && NW == 8 && !T::SPLIT) {
         if (t16) kern = a.addend ? (a.apply_mask ? conv_bwd_fused16_kernel<true, true> : conv_bwd_fused16_kernel<true, false>)
                                  : (a.apply_mask ? conv_bwd_fused16_kernel<false, true> : conv_bwd_fused16_kernel<false, false>);
     }
@@ -813,10 +876,10 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
     // on the ADD/MASK variant's few registers, but take the minimum over the variants to be safe
     int per_cu = 3;
     {
-        int o1 = mil_resident_per_cu(conv_bwd_fused_kernel<CZ, NTX, KS, true, true, NW>, lds, 3, 64 * NW);
-        int o2 = mil_resident_per_cu(conv_bwd_fused_kernel<CZ, NTX, KS, false, true, NW>, lds, 3, 64 * NW);
-        int o3 = mil_resident_per_cu(conv_bwd_fused_kernel<CZ, NTX, KS, true, false, NW>, lds, 3, 64 * NW);
-        if constexpr (CZ == 24 && NTX == 2 && KS == 3 && NW == 8) {
+        int o1 = mil_resident_per_cu(conv_bwd_fused_kernel<T, CZ, NTX, KS, true, true, NW>, lds, 3, 64 * NW);
+        int o2 = mil_resident_per_cu(conv_bwd_fused_kernel<T, CZ, NTX, KS, false, true, NW>, lds, 3, 64 * NW);
+        int o3 = mil_resident_per_cu(conv_bwd_fused_kernel<T, CZ, NTX, KS, true, false, NW>, lds, 3, 64 * NW);
+        if constexpr (CZ == 24 && NTX == 2 && KS == 3 && NW == 8 && !T::SPLIT) {
             if (t16) {
                 o1 = mil_resident_per_cu(conv_bwd_fused16_kernel<true, true>, lds, 3, 512);
                 o2 = mil_resident_per_cu(conv_bwd_fused16_kernel<false, true>, lds, 3, 512);
@@ -853,11 +916,11 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
         c.ntiles = c.g.n_groups * c.g.tiles_y * c.g.tiles_x;
         const int gz = dense_grads ? 20 : CZ, gx = dense_grads ? 20 : CX;      // channels per pixel of the gradient tensors
         const size_t zo = (size_t)i0 * a.g.H * a.g.W * gz, xo = (size_t)i0 * a.g.H * a.g.W * CX, go = (size_t)i0 * a.g.H * a.g.W * gx;
-        c.dz = a0.dz + zo; c.x = a0.x + xo; c.dx = a0.dx + go;
-        if (a0.addend) c.addend = a0.addend + go;
-        c.z_bytes = (unsigned)((size_t)n * a.g.H * a.g.W * gz * 2);
-        c.x_bytes = (unsigned)((size_t)n * a.g.H * a.g.W * CX * 2);
-        c.g_bytes = (unsigned)((size_t)n * a.g.H * a.g.W * gx * 2);
+        c.dz = a0.dz + zo * EM; c.x = a0.x + xo * EM; c.dx = a0.dx + go * EM;
+        if (a0.addend) c.addend = a0.addend + go * EM;
+        c.z_bytes = (unsigned)((size_t)n * a.g.H * a.g.W * gz * ESZ);
+        c.x_bytes = (unsigned)((size_t)n * a.g.H * a.g.W * CX * ESZ);
+        c.g_bytes = (unsigned)((size_t)n * a.g.H * a.g.W * gx * ESZ);
         c.gpx = gz * 2;
         int gr = grid < c.ntiles ? grid : c.ntiles;
         hipLaunchKernelGGL(kern, dim3(gr), dim3(64 * NW), lds, stream, c);
@@ -882,7 +945,7 @@ static int bwd_fused_entry(const void* dz, const void* wpack, const void* x, con
                            float* db, void* ws, size_t ws_bytes, int n_img, int H, int W, int cout, int cin, int ks,
                            int pad, int apply_mask, int accumulate, float slope, int dtype, bool query, size_t* need, void* stream) {
     const bool dense_grads = dtype == MIL_DT_BF16_DGRAD;
-    if ((dtype != MIL_DT_BF16 && !dense_grads) || ks != 3 || pad != 1) return MIL_ERR_UNSUPPORTED;
+    if ((dtype != MIL_DT_BF16 && !dense_grads && dtype != MIL_DT_F32S) || ks != 3 || pad != 1) return MIL_ERR_UNSUPPORTED;
     if (n_img <= 0 || H <= 0 || W <= 0) return MIL_ERR_ARG;
     if (slope <= 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
     BwdFusedArgs a{};
@@ -894,10 +957,14 @@ static int bwd_fused_entry(const void* dz, const void* wpack, const void* x, con
 #ifndef MIL_BWD24_WAVES
 #define MIL_BWD24_WAVES 8       // measured in the model: 397/428/401 us per launch with 4 waves per workgroup (two per SIMD), 356/397/371 us with 8 (four per SIMD, 122-128 VGPRs)
 #endif
-    if (czp == 24 && cxp == 24) return run_bwd_fused<24, 2, 3, MIL_BWD24_WAVES>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st, dense_grads);
+    if (dtype == MIL_DT_F32S) {                  // fp32 tensors, bf16x3 products: the 24-channel layers (one 8-wave workgroup per CU)
+        if (czp == 24 && cxp == 24) return run_bwd_fused<F32S, 24, 2, 3, 8>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st);
+        return MIL_ERR_UNSUPPORTED;
+    }
+    if (czp == 24 && cxp == 24) return run_bwd_fused<BF16, 24, 2, 3, MIL_BWD24_WAVES>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st, dense_grads);
     if (dense_grads) return MIL_ERR_UNSUPPORTED;
-    if (czp == 40 && cxp == 40) return run_bwd_fused<40, 3, 3, 8>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st);
-    if (czp == 64 && cxp == 64) return run_bwd_fused<64, 4, 3, 8>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st);
+    if (czp == 40 && cxp == 40) return run_bwd_fused<BF16, 40, 3, 3, 8>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st);
+    if (czp == 64 && cxp == 64) return run_bwd_fused<BF16, 64, 4, 3, 8>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st);
     return MIL_ERR_UNSUPPORTED;
 }
 

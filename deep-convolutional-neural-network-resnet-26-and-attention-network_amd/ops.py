@@ -190,7 +190,7 @@ def conv_wgrad(x, dz, cin, cout, *, ks, stride, pad, stem=False, want_bias=True,
 def bwd_fused_workspace_bytes(n, h, w, cout, cin, ks, pad, dtype, dense=False):
     """Slab bytes the fused backward needs, or None when this shape (and gradient layout) has no fused kernel."""
     need = ctypes.c_size_t(0)
-    rc = L.lib().mil_conv_bwd_fused_workspace(ctypes.byref(need), n, h, w, cout, cin, ks, pad, L.dt_code(dtype, dense))
+    rc = L.lib().mil_conv_bwd_fused_workspace(ctypes.byref(need), n, h, w, cout, cin, ks, pad, L.dt_code(dtype, dense, mma=True))
     if rc == 2:
         return None
     L.check(rc, "mil_conv_bwd_fused_workspace")
@@ -224,7 +224,7 @@ def conv_bwd_fused(dz, wpack_dgrad, x, cin, cout, *, addend=None, mask=True, ks=
     L.check(L.lib().mil_conv_bwd_fused(dz.data_ptr(), wpack_dgrad.data_ptr(), x.data_ptr(), L.ptr(addend), dx.data_ptr(),
                                        dw.data_ptr(), db.data_ptr(), workspace.data_ptr(),
                                        workspace.numel() * workspace.element_size(), n, h, w, cout, cin, ks, pad,
-                                       1 if mask else 0, 0 if out is None else 1, slope, L.dt_code(dz.dtype, dense), L.stream_ptr()),
+                                       1 if mask else 0, 0 if out is None else 1, slope, L.dt_code(dz.dtype, dense, mma=True), L.stream_ptr()),
             "mil_conv_bwd_fused")
     if end is not None:
         end.record()

@@ -202,6 +202,36 @@ def test_avgpool_fc(ops, dtype, shape):
     assert rel_err(dwfc.cpu(), wfc.grad) < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(3, 16, 16, 20), (2, 19, 23, 20), (5, 8, 8, 20), (2, 64, 64, 20), (36, 64, 64, 20)])
+@pytest.mark.parametrize("with_addend,mask", [(True, True), (False, True), (True, False)])
+def test_fused_backward_split_precision(ops, shape, with_addend, mask):
+    """mil_conv_bwd_fused on fp32 tensors with bf16x3 products (MIL_DT_F32S, the 20-channel layers): dx, dW, db in one pass
+    against autograd of F.conv2d on un-rounded operands, and bit-reproducible."""
+    L = _lib()
+    n, h, w, cin = shape
+    cout = cin
+    g = torch.Generator().manual_seed(23 + h)
+    x = torch.randn(n, cin, h, w, generator=g).requires_grad_(True)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).requires_grad_(True)
+    b = torch.zeros(cout, requires_grad=True)
+    dz = torch.randn(n, cout, h, w, generator=g)
+    F.conv2d(x, wt, b, padding=1).backward(dz)
+    addend = torch.randn(x.shape, generator=g)
+    want = (x.grad + (addend if with_addend else 0.0)) * (torch.where(x.detach() > 0, 1.0, LEAK) if mask else 1.0)
+    with L.f32_mma(L.MIL_DT_F32S):
+        wd, _ = ops.pack_weights(wt.detach().cuda(), None, L.PACK_DGRAD, torch.float32)
+        xg, dzg = to_nhwc(x.detach(), torch.float32), to_nhwc(dz, torch.float32)
+        out = ops.conv_bwd_fused(dzg, wd, xg, cin, cout, addend=to_nhwc(addend, torch.float32) if with_addend else None, mask=mask)
+        assert out is not None
+        out2 = ops.conv_bwd_fused(dzg, wd, xg, cin, cout, addend=to_nhwc(addend, torch.float32) if with_addend else None, mask=mask)
+    dx, dw, db = out
+    assert dx.dtype == torch.float32 and rel_err(from_nhwc(dx, cin), want) < TOL[X3]
+    assert float(dx[..., cin:].abs().max()) == 0.0
+    assert rel_err(dw.cpu(), wt.grad) < WTOL[X3] and rel_err(db.cpu(), b.grad) < WTOL[X3]
+    assert all(torch.equal(p, q) for p, q in zip(out, out2))
+    assert ops.conv_bwd_fused(dzg, wd, xg, cin, cout) is None          # exact-fp32 mode: no fused kernel
+
+
 @pytest.mark.parametrize("shape", [(3, 16, 16, 20), (2, 19, 23, 20), (5, 8, 8, 20), (2, 64, 64, 20),
                                    (36, 64, 64, 20),                    # 576 tiles > the resident workgroups: both LDS tile buffers in use
                                    (3, 32, 32, 40), (2, 19, 23, 40), (9, 8, 8, 40),            # 8-wave workgroups
