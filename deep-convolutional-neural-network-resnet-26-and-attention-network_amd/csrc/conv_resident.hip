@@ -259,6 +259,12 @@ static int launch_resident(ResArgs a, hipStream_t st) {
     // one workgroup per CU is resident (137-138 KB of LDS): groups beyond that are walked by the same workgroups
     int grid = mil_num_cus();
     if (grid > a.ngroups) grid = a.ngroups;
+    {   // MIL_RES_GRID_CAP (tests): fewer workgroups than image groups, so that a workgroup walks several groups — the
+        // persistent loop (re-copy behind a barrier, partial last group) otherwise needs more than 2048 images to run at all
+        const char* e = getenv("MIL_RES_GRID_CAP");
+        const int cap = e ? atoi(e) : 0;
+        if (cap > 0 && grid > cap) grid = cap;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G::TILE, st, a);
     MIL_CHECK_LAUNCH();
     return MIL_OK;

@@ -618,8 +618,19 @@ def test_stage_entry_forward_pair_one_pass(ops, case):
         assert float(y1[..., cout:].float().abs().max()) == 0.0 and float(y2[..., cout:].float().abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("shape", [(80, 8, 3), (80, 8, 8), (80, 8, 21), (60, 16, 2), (60, 16, 3), (60, 16, 10)])
-def test_conv_pair_equals_two_launches(ops, shape):
+@pytest.fixture(params=[0, 1, 2], ids=["grid=resident", "grid=1", "grid=2"])
+def resident_grid_cap(request, monkeypatch):
+    """The pixel-resident kernels are persistent over groups of images, but a workgroup only walks a second group when there
+    are more groups than CUs (> 2048 images at 80 channels): MIL_RES_GRID_CAP caps the grid so that ONE or TWO workgroups
+    walk all groups of a small launch — the re-copy behind the barrier, the barrier-free wave-is-image path on its second
+    group, and a ragged last group — for the pair, the data-gradient chain and the five-conv chain alike."""
+    if request.param:
+        monkeypatch.setenv("MIL_RES_GRID_CAP", str(request.param))
+    return request.param
+
+
+@pytest.mark.parametrize("shape", [(80, 8, 3), (80, 8, 8), (80, 8, 21), (80, 8, 29), (60, 16, 2), (60, 16, 3), (60, 16, 10)])
+def test_conv_pair_equals_two_launches(ops, shape, resident_grid_cap):
     """mil_conv_pair (two 3x3 convs back to back on LDS-resident whole images: 80 channels on 8x8 maps, 64 on 16x16) in both
     of its roles — a whole identity block forward and a block's data-gradient chain — against two mil_conv_igemm calls
     and against torch.  On the 80-channel shape mil_conv_igemm runs the same kernel one conv at a time: bit-identical; on the

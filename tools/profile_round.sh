@@ -42,6 +42,10 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACT
 python3 profiles/summarise_sq_counters.py $OUT/x3_sq1 $OUT/x3_sq2 profiles/sq_counters_bf16x3.json "$ROUND: $X3" > profiles/${ROUND}_sq_counters_bf16x3.txt
 cp profiles/sq_counters_bf16x3.json profiles/${ROUND}_sq_counters_bf16x3.json
 echo "bf16x3 passes done"
+# the second encoder configuration (alt_resnet.py widths, 256 tiles @256x256 fwd+bwd: the bench's alt_resnet_path step)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/alt_stats -- python3 tools/prof_alt.py 4 > $OUT/alt_stats.log 2>&1
+cp "$(ls $OUT/alt_stats/*/*kernel_stats.csv | head -n 1)" profiles/${ROUND}_alt_kernel_stats.csv
+echo "alt_resnet stats done"
 # the bench lines last: their roofline.traffic / sq_counters fields read the PMC summaries written just above
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench.err
 tail -n 1 $OUT/bench_line.json > profiles/${ROUND}_bench_line.json
@@ -49,6 +53,9 @@ echo "bench done"
 # the other single-GPU configurations of BASELINE.json (512x512 tiles; one 4096-tile bag, forward only)
 python3 bench.py --size 512 --tiles 128 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_cfg3_512.json
 python3 bench.py --infer --bags 1 --tiles 4096 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_cfg5_infer4096.json
+# the split-precision path at the other single-GPU configurations
+python3 bench.py --dtype bf16x3 --size 512 --tiles 128 --steps 5 --warmup 2 --no-cpu-baseline --no-extra-paths 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_bf16x3_cfg3_512.json
+python3 bench.py --dtype bf16x3 --infer --bags 1 --tiles 4096 --steps 5 --warmup 2 --no-cpu-baseline --no-extra-paths 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_bf16x3_cfg5_infer4096.json
 echo "cfg3 / cfg5 lines done"
 
 echo "all profiles written"
