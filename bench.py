@@ -273,16 +273,25 @@ def _family_cost(label, esz):
     return None
 
 
-_FAMILY_KERNEL = {
-    "block_fwd": ("conv_block_fwd_kernel<24,..> (whole identity block forward: conv-lrelu-conv-add-lrelu, 20 ch", ("conv_block_fwd_kernel<24,",)),
-    "conv": ("conv_igemm_pf_kernel<..24,2,3,4> (3x3 s1 conv, forward or data gradient, 20->20 ch", ("conv_igemm_pf_kernel<24, 2, 3, 4", "conv_igemm_pf_kernel<F32S, 24, 2, 3, 4")),
-    "bwd_fused": ("conv_bwd_fused16_kernel<ADD,MASK> (fused data+weight gradient of the 3x3 s1 conv, 16x16 tiles, 20->20 ch", ("conv_bwd_fused16_kernel<", "conv_bwd_fused_kernel<24, 2, 3")),
-    "wgrad": ("wgrad_kernel<..3,24,2,..> (weight+bias gradient of the 3x3 s1 conv, 20->20 ch", ("wgrad_kernel<F32S, 3, 24, 2", "wgrad_kernel<BF16, 3, 24, 2")),
-    "stem_fwd": ("stem_fwd_fused_kernel (fp32 tiles -> s2d -> 7x7/s2 conv + bias + LeakyReLU -> 3x3/s2 max-pool, one pass", ("stem_fwd_fused_kernel<",)),
-    "stem_bwd": ("stem_bwd_fused_kernel<FROM_X> (max-pool backward + LeakyReLU backward + 7x7 weight gradient, one pass", ("stem_bwd_fused_kernel<",)),
-    "stem_fwd_xs": ("stem_fwd_fused_kernel<..FROM_XS> (bf16 s2d tiles -> 7x7/s2 conv + bias + LeakyReLU -> 3x3/s2 max-pool, one pass", ("stem_fwd_fused_kernel<",)),
-    "stem_bwd_xs": ("stem_bwd_fused_kernel (bf16 s2d tiles: max-pool backward + LeakyReLU backward + 7x7 weight gradient, one pass", ("stem_bwd_fused_kernel<",)),
-}
+def _family_kernel(fam, dtype_name):
+    """(description, kernel-name keys into the rocprofv3 summaries) of a bracketed family, per compute mode."""
+    x3 = dtype_name == "bf16x3"
+    table = {
+        "block_fwd": ("conv_block_fwd_kernel<24,..> (whole identity block forward: conv-lrelu-conv-add-lrelu, 20 ch", ("conv_block_fwd_kernel<24,",)),
+        "conv": (("conv_igemm_pf_kernel<F32S,24,2,3,4,..>" if x3 else "conv_igemm_pf_kernel<BF16,24,2,3,4,..>") +
+                 " (3x3 s1 conv, forward or data gradient, 20->20 ch",
+                 ("conv_igemm_pf_kernel<F32S, 24, 2, 3, 4",) if x3 else ("conv_igemm_pf_kernel<BF16, 24, 2, 3, 4", "conv_igemm_pf_kernel<24, 2, 3, 4")),
+        "bwd_fused": (("conv_bwd_fused_kernel<F32S,24,2,3,ADD,MASK,8> (fused data+weight gradient of the 3x3 s1 conv, split precision, 20->20 ch",
+                       ("conv_bwd_fused_kernel<F32S, 24, 2, 3",)) if x3 else
+                      ("conv_bwd_fused16_kernel<ADD,MASK> (fused data+weight gradient of the 3x3 s1 conv, 16x16 tiles, 20->20 ch",
+                       ("conv_bwd_fused16_kernel<", "conv_bwd_fused_kernel<BF16, 24, 2, 3", "conv_bwd_fused_kernel<24, 2, 3"))),
+        "wgrad": ("wgrad_kernel<..3,24,2,..> (weight+bias gradient of the 3x3 s1 conv, 20->20 ch", ("wgrad_kernel<F32S, 3, 24, 2", "wgrad_kernel<BF16, 3, 24, 2")),
+        "stem_fwd": ("stem_fwd_fused_kernel (fp32 tiles -> s2d -> 7x7/s2 conv + bias + LeakyReLU -> 3x3/s2 max-pool, one pass", ("stem_fwd_fused_kernel<",)),
+        "stem_bwd": ("stem_bwd_fused_kernel<FROM_X> (max-pool backward + LeakyReLU backward + 7x7 weight gradient, one pass", ("stem_bwd_fused_kernel<",)),
+        "stem_fwd_xs": ("stem_fwd_fused_kernel<..FROM_XS> (bf16 s2d tiles -> 7x7/s2 conv + bias + LeakyReLU -> 3x3/s2 max-pool, one pass", ("stem_fwd_fused_kernel<",)),
+        "stem_bwd_xs": ("stem_bwd_fused_kernel (bf16 s2d tiles: max-pool backward + LeakyReLU backward + 7x7 weight gradient, one pass", ("stem_bwd_fused_kernel<",)),
+    }
+    return table[fam]
 
 
 def timer_wants(label):
@@ -323,8 +332,8 @@ def roofline_record(dtype_name, spans, peak, copy_gbps, achieved_model_tflops, p
 
     flops, alg_bytes, avg_ms, n_l, shape = fam_stats(fam)
     n_img = shape[0]
-    kname = _FAMILY_KERNEL[fam][0] + f", {shape[1]}x{shape[2]} maps, {n_img} tiles/launch)"
-    pmc_keys = _FAMILY_KERNEL[fam][1]
+    kname = _family_kernel(fam, dtype_name)[0] + f", {shape[1]}x{shape[2]} maps, {n_img} tiles/launch)"
+    pmc_keys = _family_kernel(fam, dtype_name)[1]
     traffic = traffic_source = None
     suffix = "" if profile_tag in (None, "bf16") else "_" + profile_tag
     pmc = _profile_json(f"pmc_traffic{suffix}.json")                   # rocprofv3 PMC passes of this same command (tools/profile_round.sh)
