@@ -67,7 +67,11 @@ __global__ __launch_bounds__(64 * NW, T::SPLIT ? 2 : ((NW == 8 && CZ <= 24) ? 4 
     MIL_POISON(smem);
     constexpr int ESZ = T::ESZ, FRAGB = 8 * ESZ;
     constexpr int NE = T::SPLIT ? 2 : 1;                  // 16-byte registers per 8 channels of an epilogue operand
-    constexpr bool PIPE = !T::SPLIT && CZ <= MIL_BWD_PIPE_MAXC;
+#ifndef MIL_BWD_X3_PIPE
+#define MIL_BWD_X3_PIPE 1         // split precision: the same one-step-ahead operand sets (hi and lo planes)
+#endif
+    constexpr bool PIPE = (T::SPLIT ? MIL_BWD_X3_PIPE != 0 : true) && CZ <= MIL_BWD_PIPE_MAXC;
+    constexpr int NL2 = T::SPLIT ? 2 : 1;                 // operand planes of the weight-gradient loop: hi (+ lo)
     constexpr int PIXB = mil_pix_pitch(CZ, ESZ);          // dz halo pixel pitch
     constexpr int CG = CZ / 8;
     constexpr int CX = mil_nt_to_cp(NTX);
@@ -227,18 +231,18 @@ __global__ __launch_bounds__(64 * NW, T::SPLIT ? 2 : ((NW == 8 && CZ <= 24) ? 4 
             // one k-step ahead: the fragment reads of step sl+1 are issued before the MFMAs of step sl, and scheduling
             // fences keep that order (left alone, hipcc issues each read right in front of its MFMAs and waits
             // lgkmcnt(0) per group: with two waves per SIMD the loop is then paced by LDS latency)
-            Frag8<BF16> wc[NTX], zc[MTW], wn[NTX], zn[MTW];
+            Frag8<T> wc[NTX], zc[MTW], wn[NTX], zn[MTW];
 #pragma unroll
-            for (int nt = 0; nt < NTX; ++nt) wc[nt] = lds_frag<BF16>(ldsW + (nt * 64 + lane) * 16);
+            for (int nt = 0; nt < NTX; ++nt) wc[nt] = lds_frag<T>(ldsW + (nt * 64 + lane) * FRAGB);
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) zc[m] = lds_frag<BF16>(ldsA_t + pixbase[m] + toff[0]);
+            for (int m = 0; m < MTW; ++m) zc[m] = lds_pix_frag<T, CZ * 2>(ldsA_t + pixbase[m] + toff[0]);
 #pragma unroll
             for (int sl = 0; sl < KSTEPS; ++sl) {
                 if (sl + 1 < KSTEPS) {
 #pragma unroll
-                    for (int nt = 0; nt < NTX; ++nt) wn[nt] = lds_frag<BF16>(ldsW + (((sl + 1) * NTX + nt) * 64 + lane) * 16);
+                    for (int nt = 0; nt < NTX; ++nt) wn[nt] = lds_frag<T>(ldsW + (((sl + 1) * NTX + nt) * 64 + lane) * FRAGB);
 #pragma unroll
-                    for (int m = 0; m < MTW; ++m) zn[m] = lds_frag<BF16>(ldsA_t + pixbase[m] + toff[sl + 1 < KSTEPS ? sl + 1 : sl]);
+                    for (int m = 0; m < MTW; ++m) zn[m] = lds_pix_frag<T, CZ * 2>(ldsA_t + pixbase[m] + toff[sl + 1 < KSTEPS ? sl + 1 : sl]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -344,37 +348,46 @@ __global__ __launch_bounds__(64 * NW, T::SPLIT ? 2 : ((NW == 8 && CZ <= 24) ? 4 
         if constexpr (PIPE) {
             // same, one 32-pixel k-step ahead and without branches on the wave's row-tile validity (a row tile that
             // does not exist computes on row group 0 and is never stored); only the bias MFMA sits under a scalar branch
-            bf16x8_t xc[NTX], zc[MW], xn[NTX], zn[MW];
-            {
-                const int kb = mil_pix_base<PIXB>(g, 0, 1);
+            bf16x8_t xc[NL2][NTX], zc[NL2][MW], xn[NL2][NTX], zn[NL2][MW];
+            auto loadw = [&](int k32, bf16x8_t (&xf)[NL2][NTX], bf16x8_t (&zf)[NL2][MW]) {
+                const int kb = mil_pix_base<PIXB>(g, k32, 1);
+                const char* x0 = ldsX + k32 * PIXX + wxl0;
 #pragma unroll
-                for (int nt = 0; nt < NTX; ++nt) xc[nt] = mil_tr_pair(ldsX + wxl0 + nt * 32, ldsX + wxl0 + 4 * PIXX + nt * 32);
+                for (int pl = 0; pl < NL2; ++pl) {
 #pragma unroll
-                for (int i = 0; i < MW; ++i) zc[i] = mil_tr_pair(ldsA_t + kb + wpl0 + wtoff[i], ldsA_t + kb + wpl1 + wtoff[i]);
-            }
+                    for (int nt = 0; nt < NTX; ++nt) xf[pl][nt] = mil_tr_pair(x0 + pl * (CX * 2) + nt * 32, x0 + pl * (CX * 2) + 4 * PIXX + nt * 32);
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) zf[pl][i] = mil_tr_pair(ldsA_t + kb + wpl0 + wtoff[i] + pl * (CZ * 2), ldsA_t + kb + wpl1 + wtoff[i] + pl * (CZ * 2));
+                }
+            };
+            loadw(0, xc, zc);
 #pragma unroll
             for (int k32 = 0; k32 < 256; k32 += 32) {
-                if (k32 + 32 < 256) {
-                    const int kb = mil_pix_base<PIXB>(g, k32 + 32, 1);
-                    const char* x0 = ldsX + (k32 + 32) * PIXX + wxl0;
-#pragma unroll
-                    for (int nt = 0; nt < NTX; ++nt) xn[nt] = mil_tr_pair(x0 + nt * 32, x0 + 4 * PIXX + nt * 32);
-#pragma unroll
-                    for (int i = 0; i < MW; ++i) zn[i] = mil_tr_pair(ldsA_t + kb + wpl0 + wtoff[i], ldsA_t + kb + wpl1 + wtoff[i]);
-                }
+                if (k32 + 32 < 256) loadw(k32 + 32, xn, zn);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < MW; ++i) {
 #pragma unroll
-                    for (int nt = 0; nt < NTX; ++nt)
-                        wacc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zc[i], xc[nt], wacc[i][nt], 0, 0, 0);
-                    if (i == bias_i) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zc[i], ones, bacc, 0, 0, 0);
+                    for (int nt = 0; nt < NTX; ++nt) {
+                        if constexpr (T::SPLIT) {
+                            wacc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zc[1][i], xc[0][nt], wacc[i][nt], 0, 0, 0);
+                            wacc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zc[0][i], xc[1][nt], wacc[i][nt], 0, 0, 0);
+                        }
+                        wacc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zc[0][i], xc[0][nt], wacc[i][nt], 0, 0, 0);
+                    }
+                    if (i == bias_i) {
+                        if constexpr (T::SPLIT) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zc[1][i], ones, bacc, 0, 0, 0);
+                        bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zc[0][i], ones, bacc, 0, 0, 0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int nt = 0; nt < NTX; ++nt) xc[nt] = xn[nt];
+                for (int pl = 0; pl < NL2; ++pl) {
 #pragma unroll
-                for (int i = 0; i < MW; ++i) zc[i] = zn[i];
+                    for (int nt = 0; nt < NTX; ++nt) xc[pl][nt] = xn[pl][nt];
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) zc[pl][i] = zn[pl][i];
+                }
             }
         } else {
 #pragma unroll 2

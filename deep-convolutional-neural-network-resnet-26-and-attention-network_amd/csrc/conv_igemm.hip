@@ -188,7 +188,13 @@ void conv_igemm_pf_kernel(ConvArgs<T> a, int ntiles, unsigned x_bytes, unsigned 
     MIL_POISON(smem);
     constexpr int ESZ = T::ESZ;
     constexpr int FRAGB = 8 * ESZ;              // bytes of one packed filter fragment per lane
-    constexpr bool PIPE = !T::SPLIT && MIL_PF_PIPE(CINP, NT, MTW, NW);
+#ifndef MIL_PF_PIPE_X3
+// split precision: the one-step-ahead operand sets where they fit the 256-VGPR budget of two waves per SIMD
+// (measured with everything on: 24 channels spill 47-145 VGPRs, the 40-channel res+mask variant 64; the 40-channel 8-wave forms
+// with one epilogue operand fit at 230-252, the 64-channel column-split form at 178-194)
+#define MIL_PF_PIPE_X3(CINP, NT, MTW, NW, FLAGS) ((CINP) == 64 || ((CINP) == 40 && (NW) == 8 && (FLAGS) >= 0 && (FLAGS) != 3))
+#endif
+    constexpr bool PIPE = T::SPLIT ? MIL_PF_PIPE_X3(CINP, NT, MTW, NW, FLAGS) : MIL_PF_PIPE(CINP, NT, MTW, NW);
     constexpr int PIXB = mil_pix_pitch(CINP, ESZ);
     constexpr int CG = CINP / 8;
     constexpr int COUTP = mil_nt_to_cp(NTALL);
@@ -377,16 +383,16 @@ void conv_igemm_pf_kernel(ConvArgs<T> a, int ntiles, unsigned x_bytes, unsigned 
             // keep that order (left alone, hipcc issues every read right in front of its MFMAs behind an lgkmcnt(0))
             Frag8<T> wc[NT], xc[MTW], wn[NT], xn[MTW];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wc[nt] = lds_frag<T>(ldsW + (nt * 64 + lane) * 16);
+            for (int nt = 0; nt < NT; ++nt) wc[nt] = lds_frag<T>(ldsW + (nt * 64 + lane) * FRAGB);
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) xc[m] = lds_frag<T>(ldsA_t + pixbase[m] + toff[0]);
+            for (int m = 0; m < MTW; ++m) xc[m] = lds_pix_frag<T, CINP * 2>(ldsA_t + pixbase[m] + toff[0]);
 #pragma unroll
             for (int sl = 0; sl < KSTEPS; ++sl) {
                 if (sl + 1 < KSTEPS) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) wn[nt] = lds_frag<T>(ldsW + (((sl + 1) * NT + nt) * 64 + lane) * 16);
+                    for (int nt = 0; nt < NT; ++nt) wn[nt] = lds_frag<T>(ldsW + (((sl + 1) * NT + nt) * 64 + lane) * FRAGB);
 #pragma unroll
-                    for (int m = 0; m < MTW; ++m) xn[m] = lds_frag<T>(ldsA_t + pixbase[m] + toff[sl + 1 < KSTEPS ? sl + 1 : sl]);
+                    for (int m = 0; m < MTW; ++m) xn[m] = lds_pix_frag<T, CINP * 2>(ldsA_t + pixbase[m] + toff[sl + 1 < KSTEPS ? sl + 1 : sl]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
