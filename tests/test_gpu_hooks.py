@@ -26,10 +26,12 @@ def _model(golden_dir, dtype):
     return net.eval(), w
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("name", ["eval_n8_64", "eval_n5_50x70"])
-def test_encoder_child_hooks_see_reference_activations(golden_dir, name):
+def test_encoder_child_hooks_see_reference_activations(golden_dir, name, mode):
+    import mil_amd
     g = np.load(os.path.join(golden_dir, name + ".npz"))
-    net, _w = _model(golden_dir, torch.float32)
+    net, _w = _model(golden_dir, torch.float32 if mode == "fp32" else mil_amd.BF16X3)     # split precision: the same fp32 tensors
     cnn = net.cnn.module
     x, y = torch.tensor(g["x"]).cuda(), torch.tensor(g["y"]).cuda()
     plain = net(x, y)
@@ -54,19 +56,21 @@ def test_encoder_child_hooks_see_reference_activations(golden_dir, name):
     out = net(x, y)
     for k in ("stem", "pool", "layer1", "layer2", "layer3", "layer4"):
         assert seen[k][1].shape == g["act." + k].shape and seen[k][1].dtype == np.float32, k
-        assert _rel(seen[k][1], g["act." + k]) < 2e-5, k
+        assert _rel(seen[k][1], g["act." + k]) < (2e-5 if mode == "fp32" else 1e-4), k
     assert np.array_equal(seen["pool"][0], seen["stem"][1])                 # max-pool's input is the stem activation
     assert np.array_equal(seen["layer1"][0], seen["pool"][1])               # stage input = previous stage output
     assert np.array_equal(seen["layer2"][0], seen["layer1"][1]) and np.array_equal(seen["layer2.0"][0], seen["layer1"][1])
     assert seen["layer2.0"][1].shape == seen["layer2"][1].shape
     assert seen["avgpool"][1].shape == (x.shape[0], 80, 1, 1) and np.array_equal(seen["avgpool"][0], seen["layer4"][1])
-    assert _rel(seen["fc"][1], g["out.Fterm"]) < 5e-5 and np.array_equal(seen["cnn"][1], seen["fc"][1])
+    assert _rel(seen["fc"][1], g["out.Fterm"]) < (5e-5 if mode == "fp32" else 2e-4) and np.array_equal(seen["cnn"][1], seen["fc"][1])
     assert relu_calls == [seen["layer1"][1].shape] * 2                      # the block's LeakyReLU runs twice (nnBlocks.py:180,187)
     assert calls.index("stem") < calls.index("pool") < calls.index("layer1") < calls.index("layer2.0") < calls.index("layer2") \
         < calls.index("layer4") < calls.index("avgpool") < calls.index("fc") < calls.index("cnn")
     # hooks observe; they change nothing (same kernels for the blocks; the stem ran un-fused, fp32: identical arithmetic)
+    # (split precision: the hooked run takes the un-fused stem — another product order, 16 significant bits per operand)
+    rt, at = (1e-6, 1e-8) if mode == "fp32" else (1e-3, 1e-3)
     for k in ("Aterm", "Mterm", "loss", "Fterm"):
-        assert torch.allclose(out[k], plain[k], rtol=1e-6, atol=1e-8), k
+        assert torch.allclose(out[k], plain[k], rtol=rt, atol=at), k
     for h in handles:
         h.remove()
     calls.clear()
