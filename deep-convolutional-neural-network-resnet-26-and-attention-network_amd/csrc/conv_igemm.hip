@@ -192,7 +192,9 @@ void conv_igemm_pf_kernel(ConvArgs<T> a, int ntiles, unsigned x_bytes, unsigned 
 // split precision: the one-step-ahead operand sets where they fit the 256-VGPR budget of two waves per SIMD
 // (measured with everything on: 24 channels spill 47-145 VGPRs, the 40-channel res+mask variant 64; the 40-channel 8-wave forms
 // with one epilogue operand fit at 230-252, the 64-channel column-split form at 178-194)
-#define MIL_PF_PIPE_X3(CINP, NT, MTW, NW, FLAGS) ((CINP) == 64 || ((CINP) == 40 && (NW) == 8 && (FLAGS) >= 0 && (FLAGS) != 3))
+// Only the 8-wave forms: the 4-wave 64-channel 1x1 zero-insert form (256 VGPRs + 216 AGPRs either way) went from 0.21 to
+// 0.53 ms with it.
+#define MIL_PF_PIPE_X3(CINP, NT, MTW, NW, FLAGS) ((NW) == 8 && ((CINP) == 64 || ((CINP) == 40 && (FLAGS) >= 0 && (FLAGS) != 3)))
 #endif
     constexpr bool PIPE = T::SPLIT ? MIL_PF_PIPE_X3(CINP, NT, MTW, NW, FLAGS) : MIL_PF_PIPE(CINP, NT, MTW, NW);
     constexpr int PIXB = mil_pix_pitch(CINP, ESZ);
@@ -202,8 +204,10 @@ void conv_igemm_pf_kernel(ConvArgs<T> a, int ntiles, unsigned x_bytes, unsigned 
     constexpr int NPX = (mil_halo_px_max(NW * MTW == 16 ? 4 : 2) * (CINP * ESZ / 16) + NTHR - 1) / NTHR;
     constexpr int KSTEPS = (KS * KS * CG + 3) / 4;
     constexpr bool LAST_PARTIAL = (COUTP % 16) != 0;        // the last column tile holds only 8 channels
-    static_assert(NTALL % NT == 0 && (NTALL == NT || !LAST_PARTIAL), "column split: whole 16-channel tiles only");
+    static_assert(NTALL % NT == 0, "column split: equal grid rows");
     const int nt0 = NTALL == NT ? 0 : (int)blockIdx.y * NT; // first column tile of this grid row
+    // the layer's LAST column tile (8 channels when COUTP % 16 != 0) is the last tile of the last grid row
+    const bool last_row = NTALL == NT || nt0 + NT == NTALL;
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -268,7 +272,7 @@ void conv_igemm_pf_kernel(ConvArgs<T> a, int ntiles, unsigned x_bytes, unsigned 
         o_pos[p] = (ti << 20) | (ty << 10) | tx;
     }
     // channels of the last column tile this lane owns exist
-    const bool last_ok = !LAST_PARTIAL || (PAIRED ? (gq >> 1) == 0 : gq * 4 < COUTP - (NT - 1) * 16);
+    const bool last_ok = !LAST_PARTIAL || !last_row || (PAIRED ? (gq >> 1) == 0 : gq * 4 < COUTP - (NTALL - 1) * 16);
     f32x4_t bias_r[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -685,12 +689,19 @@ static int launch_conv_pf(const ConvArgs<T>& a, hipStream_t stream, bool* taken)
         if (a.g.ks == 3) return mil_pf_waves64() == 8 ? launch_conv_pf_ks<T, 64, 4, 3, 2, 8>(a, stream, taken) : launch_conv_pf_ks<T, 64, 4, 3>(a, stream, taken);
     }
     if constexpr (CINP == 64 && NT == 3) {
+        // split precision (the 64 -> 40 channel stage-entry data gradient, zero-insert): three grid rows of one column tile
+        if constexpr (T::SPLIT) { if (a.g.ks == 3) return launch_conv_pf_ks<T, 64, 1, 3, 2, 8, 3>(a, stream, taken); }
+        else
         if (a.g.ks == 3) return launch_conv_pf_ks<T, 64, 3, 3>(a, stream, taken);
         if (a.g.ks == 1) return launch_conv_pf_ks<T, 64, 3, 1>(a, stream, taken);
     }
     // 80-channel layers: the whole filter (115 KB) stays resident, so the tile shrinks to 128 px
     // (eight waves with one row tile each by default: one workgroup per CU either way, but two waves per SIMD)
     if constexpr (CINP == 80 && NT == 5) {
+        // (split precision: five grid rows of one 16-channel column tile each — 46 KB of [hi | lo] fragments per row on
+        // 128-pixel tiles — measured 124 us per conv against 103 us on the K-chunked generic kernel: not dispatched)
+        if constexpr (T::SPLIT) { return MIL_OK; }
+        else
         if (a.g.ks == 3) return mil_pf_waves64() == 8 ? launch_conv_pf_ks<T, 80, 5, 3, 1, 8>(a, stream, taken) : launch_conv_pf_ks<T, 80, 5, 3, 2>(a, stream, taken);
     }
     if constexpr (CINP == 80 && NT == 4) {
