@@ -260,3 +260,94 @@ def test_checkpoint_roundtrip_in_reference_format(tmp_path):
     for k, v in model3.state_dict().items():
         moved = "cnn" in k and "conv" in k
         assert torch.equal(v, ckpt["classifier"][k]) if moved else torch.equal(v, before[k]), k
+
+
+# ---- round 3 host logic -----------------------------------------------------------------------------------------------
+def test_compute_mode_plumbing():
+    """`compute_dtype=mil_amd.BF16X3` = fp32 tensors whose convolution entry points get MIL_DT_F32S; the pointwise entry points
+    keep MIL_DT_F32; the mode is scoped (context manager) and restored on exceptions."""
+    import mil_amd
+    from mil_amd import _lib as L
+    assert L.storage_dtype(mil_amd.BF16X3) == torch.float32 and L.storage_dtype(torch.bfloat16) == torch.bfloat16
+    assert L.mma_code(mil_amd.BF16X3) == L.MIL_DT_F32S == 3 and L.mma_code(torch.float32) == L.MIL_DT_F32 == 0
+    assert L.dt_code(torch.float32) == L.MIL_DT_F32 and L.dt_code(torch.float32, mma=True) == L.MIL_DT_F32
+    with L.f32_mma(L.MIL_DT_F32S):
+        assert L.dt_code(torch.float32, mma=True) == L.MIL_DT_F32S
+        assert L.dt_code(torch.float32) == L.MIL_DT_F32                 # pooling / s2d / head: plain fp32 entry points
+        assert L.dt_code(torch.bfloat16, mma=True) == L.MIL_DT_BF16
+    with pytest.raises(RuntimeError):
+        with L.f32_mma(L.MIL_DT_F32S):
+            raise RuntimeError("x")
+    assert L.dt_code(torch.float32, mma=True) == L.MIL_DT_F32
+    with pytest.raises(ValueError):
+        L.dt_code(torch.float32, dense_grads=True)
+    net = mil_amd.Attention(3, compute_dtype=mil_amd.BF16X3, device="cpu")
+    assert net.compute_dtype == mil_amd.BF16X3
+
+
+def test_split_precision_queries_need_no_gpu():
+    """MIL_DT_F32S is accepted by the workspace queries of the kernels that have a split-precision form and refused by the rest."""
+    import mil_amd
+    lib = mil_amd.lib()
+    n = ctypes.c_size_t(0)
+    assert lib.mil_conv_wgrad_workspace(ctypes.byref(n), 8, 64, 64, 20, 64, 64, 20, 3, 1, 1, 0, 3) == 0 and n.value > 0
+    # (the fused kernels' queries raise their LDS limit through the HIP runtime and need a device: covered by -m gpu)
+    assert lib.mil_conv_bwd_fused_workspace(ctypes.byref(n), 8, 32, 32, 40, 40, 3, 1, 3) == 2                     # 40 channels: does not fit LDS
+    assert lib.mil_conv_bwd_fused_workspace(ctypes.byref(n), 8, 64, 64, 20, 20, 3, 1, 0) == 2                     # exact fp32: no fused kernel
+    assert lib.mil_stem_bwd_fused_workspace(ctypes.byref(n), 8, 128, 128, 3) == 2                                 # the s2d feed is bf16
+    assert lib.mil_stream_copy(None, None, 16, None) == 1
+
+
+def test_s2d_tiles_handle():
+    import mil_amd
+    xs = torch.zeros((5, 8, 6, 16), dtype=torch.bfloat16)
+    t = mil_amd.S2dTiles(xs)
+    assert tuple(t.shape) == (5, 3, 16, 12) and t.dim() == 4 and len(t) == 5
+    assert tuple(t[torch.tensor([0, 3])].shape) == (2, 3, 16, 12) and tuple(t[1:4].shape) == (3, 3, 16, 12)
+    assert tuple(mil_amd.S2dTiles.cat([t, t[:2]]).shape) == (7, 3, 16, 12)
+    with pytest.raises(ValueError):
+        mil_amd.S2dTiles(torch.zeros((5, 8, 6, 16)))            # fp32: not the bf16 record tensor
+    with pytest.raises(ValueError):
+        mil_amd.S2dTiles(torch.zeros((5, 8, 6, 12), dtype=torch.bfloat16))
+
+
+def test_head_gradient_run_detection():
+    """The head adds its gradient block into the flat bucket with ONE add when the parameters' .grad tensors sit back to back
+    (FlatParams); otherwise autograd accumulates per parameter as before."""
+    import mil_amd
+    from mil_amd.head import _contiguous_grad_run
+    net = mil_amd.Attention(3, device="cpu")
+    ws = net.head_weights()
+    assert _contiguous_grad_run(ws) is None                       # no .grad yet
+    flat = mil_amd.FlatParams(net)
+    first, count, total = _contiguous_grad_run(ws)
+    assert first == 0 and count == 10 and total == 6807 - 3       # context.bn.weight .. buffer.classifier.bias; weight_mask sits elsewhere
+    ws[3].grad = torch.zeros_like(ws[3])                          # a foreign .grad tensor breaks the run there
+    assert _contiguous_grad_run(ws) == (0, 3, 80 + 80 + 40 * 80)
+    flat.zero_grad()                                              # re-attaches
+    assert _contiguous_grad_run(ws)[1] == 10
+
+
+def test_bench_roofline_accounting():
+    """bench.py's per-family algorithmic cost (what `roofline.achieved` is computed from) and the launch filter."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    px = 2048 * 64 * 64
+    fl, by, shape = bench._family_cost(("bwd_fused", 24, 24, 3, 1, False, 2048, 64, 64, True), 2)
+    assert fl == 2 * 2.0 * 9 * 20 * 20 * px and by == 4 * px * 20 * 2 and shape == (2048, 64, 64)
+    fl, by, _ = bench._family_cost(("bwd_fused", 24, 24, 3, 1, False, 2048, 64, 64, False), 4)
+    assert by == 3 * px * 20 * 4
+    fl, by, _ = bench._family_cost(("stem_fwd", 24, 2048, 256, 256), 2)
+    assert fl == 2.0 * 147 * 20 * 2048 * 128 * 128 and by == 2048 * 3 * 256 * 256 * 4 + 2048 * 64 * 64 * 20 * 3
+    fl, by, _ = bench._family_cost(("stem_fwd_xs", 24, 2048, 256, 256), 2)
+    assert by == 2048 * 128 * 128 * 24 + 2048 * 64 * 64 * 20 * 3
+    assert bench.timer_wants(("conv", 24, 24, 3, 1, False, 2048, 64, 64)) and not bench.timer_wants(("conv", 40, 40, 3, 1, False, 2048, 32, 32))
+    assert bench.timer_wants(("stem_bwd", 2048, 256, 256)) and bench.timer_wants(("wgrad", 24, 24, 3, 1, 2048, 64, 64))
+    assert not bench.timer_wants(("wgrad", 16, 24, 4, 1, 2048, 128, 128)) and not bench.timer_wants(("chain", 80, 2048, 8, 8, 5))
+    for mode in ("bf16", "bf16x3"):
+        for fam in ("block_fwd", "conv", "bwd_fused", "wgrad", "stem_fwd", "stem_bwd", "stem_fwd_xs", "stem_bwd_xs"):
+            name, keys = bench._family_kernel(fam, mode)
+            assert isinstance(name, str) and len(keys) >= 1
+    assert "F32S" in bench._family_kernel("bwd_fused", "bf16x3")[0] and "fused16" in bench._family_kernel("bwd_fused", "bf16")[0]
