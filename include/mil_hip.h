@@ -20,7 +20,12 @@
  *                          lo*hi + hi*lo + hi*hi with fp32 accumulation.  16 significant bits per operand: meets the 1e-3
  *                          gate on logits / attention weights (2.5e-4 measured) at 3/16 of the exact path's matrix time.
  *                          Accepted by mil_pack_conv_weights / mil_pack_job_fill (fragments [hi | lo], the byte count of
- *                          MIL_DT_F32), mil_conv_igemm and mil_conv_wgrad(_workspace); everything else takes MIL_DT_F32.
+ *                          MIL_DT_F32), mil_conv_igemm, mil_conv_wgrad(_workspace), and — fused forms, where the shape has
+ *                          one (MIL_ERR_UNSUPPORTED otherwise: the caller falls back to the un-fused calls) —
+ *                          mil_conv_bwd_fused(_workspace) (20-channel layers), mil_conv_dgrad_s2 (the 40 -> 20 channel entry),
+ *                          mil_stem_fwd_fused (xs must be null: no space-to-depth copy) and
+ *                          mil_stem_bwd_fused_nchw(_workspace); every pointwise entry point takes MIL_DT_F32 for the same
+ *                          tensors.
  *   - master weights, biases, all gradients of parameters, and the whole MIL head are fp32.
  */
 #ifndef MIL_HIP_H
