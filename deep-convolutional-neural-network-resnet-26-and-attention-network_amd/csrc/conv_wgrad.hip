@@ -61,7 +61,7 @@ template <typename T, int KS, int CINP, int NT, int MSPLIT, bool PF, int NW = 4,
 #ifndef MIL_WGRAD_X3_WAVES
 #define MIL_WGRAD_X3_WAVES 4        // split precision, 8-wave workgroups: waves per SIMD the register budget is held to
 #endif
-__global__ __launch_bounds__(64 * NW, NW == 8 ? ((T::SPLIT && CINP <= 24) ? MIL_WGRAD_X3_WAVES : 2) : ((PF && CINP > 40) ? 1 : 0)) void wgrad_kernel(WgradArgs<T> a) {
+__global__ __launch_bounds__(64 * NW, NW == 8 ? ((T::SPLIT && CINP <= 24 && NT <= 2) ? MIL_WGRAD_X3_WAVES : 2) : ((PF && CINP > 40) ? 1 : 0)) void wgrad_kernel(WgradArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MIL_POISON(smem);
     constexpr int ESZ = T::ESZ;
@@ -474,7 +474,9 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     // 8-wave workgroups where the 4-wave form holds a single wave per SIMD (persistent bf16 form, >= 64 input channels)
     // (split precision: eight waves too — the fragment reads of its three-product loop are not software-pipelined, and twice
     // the waves per SIMD hide their latency instead)
-    constexpr int NW = (PF_OK && (CINP >= 64 || (T::SPLIT && CINP <= 24 && NT <= 2))) ? 8 : 4;      // (40 channels / 40 columns: 240-390 spilled VGPRs at four waves per SIMD)
+    // (24 channels / 24 columns at four waves per SIMD; 40 channels or columns at two — 240-390 VGPRs would spill at four —, where
+    // the 4-wave form's 397 registers leave ONE wave per SIMD)
+    constexpr int NW = (PF_OK && (CINP >= 64 || T::SPLIT)) ? 8 : 4;
     const int nthr = pf ? 64 * NW : 256;
     if (PROJ && !pf) return MIL_ERR_UNSUPPORTED;                 // the paired form exists for the persistent bf16 kernel only
     auto kern = pf ? wgrad_kernel<T, KS, CINP, NT, MSPLIT, PF_OK, NW, PROJ && PF_OK> : wgrad_kernel<T, KS, CINP, NT, MSPLIT, false>;
