@@ -79,6 +79,10 @@ _SIGS = {
     "mil_wide_conv": ([_vp] * 6 + [_i] * 12 + [_f, _i, _vp], _i),
     "mil_wide_wgrad_workspace": ([_c.POINTER(_sz)] + [_i] * 11, _i),
     "mil_wide_wgrad": ([_vp, _vp, _vp, _vp, _sz] + [_i] * 12 + [_vp], _i),
+    "mil_gconv_supported": ([_i, _i, _i, _i], _i),
+    "mil_gconv_packed_elems": ([_c.POINTER(_sz), _i, _i, _i, _i], _i),
+    "mil_gconv_pack_weights": ([_vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "mil_gconv": ([_vp] * 5 + [_i] * 12 + [_f, _vp], _i),
     "mil_fc_wgrad_workspace": ([_c.POINTER(_sz), _i, _i, _i], _i),
     "mil_fc_wgrad": ([_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp], _i),
     "mil_adam_step": ([_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _vp], _i),

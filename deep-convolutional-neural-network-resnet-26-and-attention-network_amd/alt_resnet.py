@@ -16,6 +16,7 @@ from . import _lib as L
 from . import ops
 
 WIDTHS = (64, 128, 256, 512)          # alt_resnet.py:86-89
+GATHER_GEMM = [True]                  # A/B switch: False keeps every wide conv on the channel-blocked kernels of conv_wide.hip
 
 
 class BasicBlock(nn.Module):
@@ -48,14 +49,21 @@ class _Conv:
         self.w, self.cout, self.cin, self.ks = w, w.shape[0], w.shape[1], w.shape[2]
         self.stride, self.pad = conv.stride[0], conv.padding[0]
         self.wide = self.cout > 80 or self.cin > 80
+        # bf16 wide layers whose channel counts fit its 64-channel K-steps / 128-channel output blocks run the gather-GEMM
+        # kernel (csrc/conv_gather.hip); the 128 -> 64 channel gradient of the stage-2 entry does not and stays on conv_wide
+        bf = dtype == torch.bfloat16 and self.wide and GATHER_GEMM[0]
+        self.g_fwd = bf and ops.gconv_supported(self.cin, self.cout, self.ks, self.stride)
+        self.g_bwd = bf and ops.gconv_supported(self.cout, self.cin, self.ks, self.stride)
         if self.wide:
-            self.fwd_w = ops.wide_pack_weights(w, L.PACK_FWD, dtype)
-            self.bwd_w = ops.wide_pack_weights(w, L.PACK_DGRAD, dtype)
+            self.fwd_w = ops.gconv_pack_weights(w, L.PACK_FWD) if self.g_fwd else ops.wide_pack_weights(w, L.PACK_FWD, dtype)
+            self.bwd_w = ops.gconv_pack_weights(w, L.PACK_DGRAD) if self.g_bwd else ops.wide_pack_weights(w, L.PACK_DGRAD, dtype)
         else:
             self.fwd_w, self.fwd_b = ops.pack_weights(w, None, L.PACK_FWD, dtype)
             self.bwd_w, _ = ops.pack_weights(w, None, L.PACK_DGRAD, dtype)
 
     def forward(self, x, res=None, relu=True):
+        if self.g_fwd:
+            return ops.gconv(x, self.fwd_w, self.cout, ks=self.ks, stride=self.stride, pad=self.pad, res=res, relu=relu)
         if self.wide:
             return ops.wide_conv(x, self.fwd_w, self.cout, ks=self.ks, stride=self.stride, pad=self.pad, res=res, relu=relu)
         return ops.conv(x, self.fwd_w, None, self.cout, ks=self.ks, stride=self.stride, pad=self.pad, res=res, lrelu=relu,
@@ -63,6 +71,9 @@ class _Conv:
 
     def dgrad(self, dz, in_hw, addend=None, act=None):
         zi = self.stride == 2
+        if self.g_bwd:
+            return ops.gconv(dz, self.bwd_w, self.cin, ks=self.ks, stride=self.stride, pad=self.pad, transposed=True, out_hw=in_hw,
+                             res=addend, act=act)
         if self.wide:
             return ops.wide_conv(dz, self.bwd_w, self.cin, ks=self.ks, stride=1, pad=self.pad, res=addend, act=act,
                                  zero_insert=zi, out_hw=in_hw)

@@ -1,0 +1,471 @@
+// Gather-GEMM convolution for the wide layers (alt_resnet.py widths 128/256/512: alt_resnet.py:24-33,35-66), bf16.
+//
+//   D[m][n] = sum over taps t, channels c of  Src[pix(m) + off(t)][c] * W[t][c][n]
+//
+// as ONE deep-pipelined GEMM per workgroup: 256 output pixels (m) x 128 output channels (n), K-step = one tap x 64 input
+// channels.  Each K-step's two operand images — 256 pixel rows x 128 B gathered straight from the NHWC tensor at the tap's
+// offset, and 128 filter rows x 128 B — are copied HBM/L2 -> LDS by LDS-DMA (`buffer_load ... lds`, 16 B per lane, no
+// registers, no ds_write pass) into a ring of three stage buffers; the copies of the next two K-steps stay in flight across
+// the one barrier per K-step (counted `s_waitcnt vmcnt`, raw `s_barrier`).  Out-of-image pixels are out-of-range buffer
+// offsets: the DMA writes zeros (the conv's zero padding).  The channel-blocked kernels of conv_wide.hip (128-pixel x
+// 64-channel tiles, two workgroups per CU, register prefetch + a barrier pair per 32-channel chunk) sit at the 0.7-0.9
+// PFLOP/s that structure tops out at; this one exists to get past it.
+//
+// The tap list is data: (dy, dx, filter tap) triples with a source stride and an output stride/offset, so the same kernel
+// runs the stride-1 forward conv and data gradient, the stride-2 forward conv (source stride 2), and the stride-2 data
+// gradient as four parity classes of output pixels, each with only the taps that reach it (1, 2, 2 and 4 of 9: no
+// multiply-by-inserted-zero work).
+//
+// LDS images are [row][64 ch] bf16 with the 16-byte slot index XOR-ed by (row >> 1) & 7: the sixteen lanes of a
+// ds_read_b128 group then fall on sixteen different 16-byte slots of the 256-byte bank row.  LDS-DMA writes lanes linearly,
+// so the swizzle is applied to the SOURCE address (pixel rows) or baked into the packed filter images.
+#include "pf_common.cuh"
+#include <cstdlib>
+
+#define GC_BM 256
+#define GC_BN 128
+#define GC_BK 64
+#define GC_STAGES 3
+#define GC_A_BYTES (GC_BM * GC_BK * 2)         // 32 KB
+#define GC_B_BYTES (GC_BN * GC_BK * 2)         // 16 KB
+#define GC_STAGE_BYTES (GC_A_BYTES + GC_B_BYTES)
+#define GC_LDS_BYTES (GC_STAGES * GC_STAGE_BYTES)      // 144 KB
+#define GC_MAX_TAPS 9
+
+struct GConvArgs {
+    const __bf16* x;            // source [n_img, Hs, Ws, cin]
+    const __bf16* w;            // filter images [cout/128][ktaps][cin/64][128 rows][64] (swizzled), mil_gconv_pack_weights
+    const __bf16* res;          // added before the activation, or null          [n_img, Hout, Wout, cout]
+    const __bf16* act;          // multiplies by lrelu'(act) after it, or null   [n_img, Hout, Wout, cout]
+    __bf16* y;                  // [n_img, Hout, Wout, cout]
+    int n_img, Hs, Ws, cin;
+    int Hout, Wout, cout;
+    int os;                     // output pixel of grid point (gy, gx) of class z = (gy*os + c_oy[z], gx*os + c_ox[z])
+    int ss;                     // source pixel of grid point (gy, gx), tap t = (gy*ss + dy[t], gx*ss + dx[t])
+    int tw_log2, th_log2, ti_log2, tiles_x, tiles_y;
+    int ktaps;                  // taps in the packed filter
+    // blockIdx.z = class of output pixels: the whole output (one class), or the four parities of a stride-2 data gradient,
+    // each with its own grid extent, output offset and tap list ((dy + 8) << 16 | (dx + 8) << 8 | filter tap)
+    int ncls;
+    int c_ntaps[4], c_hg[4], c_wg[4], c_oy[4], c_ox[4];
+    int c_tap[4][GC_MAX_TAPS];
+    int apply_relu;
+    float slope;
+    unsigned x_bytes, w_bytes, y_bytes;
+    int exp_flags;              // MIL_GCONV_EXP (ablation runs): 1 = no pixel-row traffic, 2 = no filter traffic, 4 = no MFMA loop
+};
+
+template <int N>
+__device__ __forceinline__ void gc_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void gc_wait_vm_n(int n) {       // n = 0..6, wave-uniform
+    if (n <= 0) gc_wait_vm<0>(); else if (n == 1) gc_wait_vm<1>(); else if (n == 2) gc_wait_vm<2>(); else if (n == 3) gc_wait_vm<3>();
+    else if (n == 4) gc_wait_vm<4>(); else if (n == 5) gc_wait_vm<5>(); else gc_wait_vm<6>();
+}
+
+#define GC_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// HD = 0: every K-step copies its own 256 gathered pixel rows (any tap list, any source stride): 6 copies per wave and K-step
+//         into a ring of three 48 KB stages.
+// HD > 0: the canonical 3x3 stride-1 tap list.  The K-steps run chunk-major (nine taps of one 64-channel chunk after another)
+//         on ONE halo image per chunk — (th+2) x (tw+2) pixel rows per image of the tile, copied once (HD 64-row pieces per
+//         wave) and read at nine row offsets — double-buffered: the next chunk's halo arrives one piece per wave during the
+//         first HD K-steps of the current chunk.  Per K-step the copy traffic falls from 48 KB to 16 KB of filter + 4.6 KB of
+//         halo.  HD = 6 (16x16-pixel tiles) leaves room for a ring of four filter images (filter image s+3 is requested during
+//         K-step s: two K-steps to land), HD = 7 (8x8 pixels of four images) for three.
+// The loop bodies are branch-free — copies that would run past the end get an out-of-range offset and land as zeros in a slot
+// nobody reads again — so that reads, copies and MFMAs of a K-step sit in ONE basic block and can be interleaved.
+template <int HD>
+__global__ __launch_bounds__(512, 1) void gconv_kernel(GConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    MIL_POISON(smem);
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, gq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;                 // wave grid: 4 (pixels) x 2 (channels); wave tile 64 x 64
+    const int nb = blockIdx.y, cls = blockIdx.z;
+    const int nchunks = a.cin / GC_BK;
+    const int ntaps = a.c_ntaps[cls], Hg = a.c_hg[cls], Wg = a.c_wg[cls], oy_off = a.c_oy[cls], ox_off = a.c_ox[cls];
+    const int KT = ntaps * nchunks;
+
+    // ---- tile origin ------------------------------------------------------------------------------------------
+    int tile = blockIdx.x;
+    const int tx0 = tile % a.tiles_x; tile /= a.tiles_x;
+    const int ty0 = tile % a.tiles_y; const int grp = tile / a.tiles_y;
+    const int img0 = grp << a.ti_log2, gy0 = ty0 << a.th_log2, gx0 = tx0 << a.tw_log2;
+    const int tw_mask = (1 << a.tw_log2) - 1, th_mask = (1 << a.th_log2) - 1;
+
+    const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rs_w = mil_rsrc(a.w, a.w_bytes);
+    const int row_bytes = a.cin * 2;
+    const int b_voff = lane * 16;
+
+    f32x4_t acc[4][4];                                       // [channel tile][pixel tile]: D rows = channels, columns = pixels
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // ---- K-step schedule --------------------------------------------------------------------------------------------------
+    // Two fragment sets (the k32 halves of a K-step).  While the 16 MFMAs of one half run, the 8 fragment reads of the next
+    // half — the second half of this K-step, then the first half of the NEXT one, whose stage landed a K-step early — are
+    // issued between them, one read per two MFMAs (sched_group_barrier pins that interleave: a read in an MFMA's shadow costs
+    // the wave a few cycles, eight reads in a row in front of the MFMAs cost both waves of the SIMD the whole burst, because
+    // the barrier keeps them in the same phase).  The K-step's copies go out the same way.
+    struct Half { bf16x8_t w[4], x[4]; };
+    const int swq = gq ^ (r >> 1);                               // filter rows: (row >> 1) & 7 == r >> 1
+    auto read_w = [&](Half& h, const char* lb, int k32) {
+        const char* wb = lb + (wn * 64 + r) * 128 + ((swq ^ (k32 * 4)) * 16);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) h.w[nt] = *reinterpret_cast<const bf16x8_t*>(wb + nt * 2048);
+    };
+    auto mfma16 = [&](const Half& h) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h.w[nt], h.x[mt], acc[nt][mt], 0, 0, 0);
+    };
+    // the schedule of one half: nv copies and 8 reads spread over 16 MFMAs
+    auto pin_half = [&](int nv) {
+#ifndef GC_NO_PIN
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);       // 2 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // 1 DS read
+            if (i < nv) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read (LDS-DMA copy)
+        }
+#endif
+    };
+    Half f0, f1;
+
+    if constexpr (HD == 0) {
+        // ---- this lane's four pixel rows of every A image: row = wave*32 + i*8 + lane/8, slot = lane%8 -------------
+        int a_base[4], a_pos[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = wave * 32 + i * 8 + (lane >> 3);
+            const int gx = gx0 + (m & tw_mask), gy = gy0 + ((m >> a.tw_log2) & th_mask), img = img0 + (m >> (a.tw_log2 + a.th_log2));
+            const bool ok = img < a.n_img && gy < Hg && gx < Wg;
+            const int sy = gy * a.ss, sx = gx * a.ss;
+            const int slot = (lane & 7) ^ ((m >> 1) & 7);        // logical 16-byte piece of the 128-byte row that lands in physical slot lane%8
+            a_pos[i] = ok ? (sy << 16) | sx : (0x4000 << 16);    // an invalid row fails every bounds test below
+            a_base[i] = ((img * a.Hs + sy) * a.Ws + sx) * row_bytes + slot * 16;
+        }
+        // the tap list lives in lanes 0..8 of one register (v_readlane by the wave-uniform tap index): a table look-up in memory
+        // would be a scalar load, whose counter the fragment reads share
+        const int tap_tab = a.c_tap[cls][lane < ntaps ? lane : 0];
+        // copies d0..d1-1 of the six of stage (tap t, chunk c) into ring buffer `buf`: four pixel-row pieces, two filter pieces;
+        // !live: out-of-range offsets (zeros land in a buffer nobody reads again)
+        auto issue = [&](int t, int c, bool live, int buf, int d0, int d1) {
+            const int tp = __builtin_amdgcn_readlane(tap_tab, t < ntaps ? t : 0);
+            const int dy = (tp >> 16) - 8, dx = ((tp >> 8) & 0xFF) - 8, tw = tp & 0xFF;
+            const int delta = (dy * a.Ws + dx) * row_bytes + c * (GC_BK * 2);
+            const int img_off = ((nb * a.ktaps + tw) * nchunks + c) * GC_B_BYTES + wave * 2048;
+#pragma unroll
+            for (int d = 0; d < 6; ++d) {
+                if (d < d0 || d >= d1) continue;
+                if (d < 4) {
+                    const int sy = (a_pos[d] >> 16) + dy, sx = (a_pos[d] & 0xFFFF) + dx;
+                    const bool ok = live && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, GC_LDS_PTR(smem + buf * GC_STAGE_BYTES + wave * 4096 + d * 1024), 16,
+                                                             ok ? (unsigned)(a_base[d] + delta) : MIL_OOB, 0, 0, 0);
+                } else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, GC_LDS_PTR(smem + buf * GC_STAGE_BYTES + GC_A_BYTES + wave * 2048 + (d - 4) * 1024), 16,
+                                                             live ? (unsigned)b_voff : MIL_OOB, live ? img_off + (d - 4) * 1024 : 0, 0, 0);
+            }
+        };
+        auto read_half = [&](Half& h, int buf, int k32) {
+            const char* stg = smem + buf * GC_STAGE_BYTES;
+            read_w(h, stg + GC_A_BYTES, k32);
+            const char* xb = stg + (wm * 64 + r) * 128 + ((swq ^ (k32 * 4)) * 16);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) h.x[mt] = *reinterpret_cast<const bf16x8_t*>(xb + mt * 2048);
+        };
+        // K-step s = tap s / nchunks, chunk s % nchunks; (ti, ci) walks two K-steps ahead
+        issue(0, 0, KT > 0, 0, 0, 6);
+        int ti = nchunks > 1 ? 0 : 1, ci = nchunks > 1 ? 1 : 0;
+        issue(ti, ci, KT > 1, 1, 0, 6);
+        if (++ci == nchunks) { ci = 0; ++ti; }
+        gc_wait_vm<6>();                                         // stage 0 landed
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        read_half(f0, 0, 0);
+        int buf = 0;
+        for (int s = 0; s < KT; ++s) {
+            gc_wait_vm<0>();                                     // stage s+1 (requested a K-step ago) has landed
+            __builtin_amdgcn_s_barrier();                        // ... everywhere; everyone is done reading stage s-1
+            __builtin_amdgcn_sched_barrier(0);
+            const int nxt = buf == 2 ? 0 : buf + 1, prv = buf == 0 ? 2 : buf - 1;
+            const bool live = s + 2 < KT;
+            issue(ti, ci, live, prv, 0, 3);
+            read_half(f1, buf, 1);
+            mfma16(f0);
+            pin_half(3);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(ti, ci, live, prv, 3, 6);
+            read_half(f0, nxt, 0);
+            mfma16(f1);
+            pin_half(3);
+            __builtin_amdgcn_sched_barrier(0);
+            buf = nxt;
+            if (++ci == nchunks) { ci = 0; ++ti; }
+        }
+        gc_wait_vm<0>();
+    } else {
+        // ---- halo images: [2][HD * 64 rows][128 B], then the filter ring [RS][16 KB] ----------------------------------
+        constexpr int RS = HD <= 6 ? 4 : 3;
+        constexpr int hbytes = HD * 8192;
+        char* ring = smem + 2 * hbytes;
+        const int hw = (1 << a.tw_log2) + 2, hh = (1 << a.th_log2) + 2;
+        // this lane's halo rows: piece j covers rows (j*8 + wave)*8 + lane/8
+        int h_off[HD];
+#pragma unroll
+        for (int j = 0; j < HD; ++j) {
+            const int hr = (j * 8 + wave) * 8 + (lane >> 3);
+            const int ti = hr / (hh * hw), rem = hr - ti * (hh * hw), hy = rem / hw, hx = rem - hy * hw;
+            const int img = img0 + ti, sy = gy0 - 1 + hy, sx = gx0 - 1 + hx;
+            const bool ok = (ti >> a.ti_log2) == 0 && img < a.n_img && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
+            const int slot = (lane & 7) ^ ((hr >> 1) & 7);
+            h_off[j] = ok ? ((img * a.Hs + sy) * a.Ws + sx) * row_bytes + slot * 16 : (int)MIL_OOB;
+        }
+        auto issue_halo = [&](int c, int j) {                    // piece j of chunk c's halo
+            int off = h_off[0];                                  // a select chain the optimiser may not turn into a scratch array (its loads
+#pragma unroll                                                  // would count on vmcnt)
+            for (int q = 1; q < HD; ++q) { off = j == q ? h_off[q] : off; asm volatile("" : "+v"(off)); }
+            const unsigned o = off == (int)MIL_OOB ? MIL_OOB : (unsigned)(off + c * (GC_BK * 2));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, GC_LDS_PTR(smem + (c & 1) * hbytes + (j * 8 + wave) * 1024), 16, o, 0, 0, 0);
+        };
+        // the canonical list: tap t = (t/3 - 1, t%3 - 1), filter tap t
+        auto issue_b = [&](int c, int t, int slot, int j) {      // half j of the filter image of chunk c, tap t; past the end: zeros
+            const bool live = c < nchunks;
+            const int img_off = ((nb * 9 + t) * nchunks + c) * GC_B_BYTES + wave * 2048 + j * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, GC_LDS_PTR(ring + slot * GC_B_BYTES + wave * 2048 + j * 1024), 16,
+                                                     live ? (unsigned)b_voff : MIL_OOB, live ? img_off : 0, 0, 0);
+        };
+        // pixel fragments: halo row of tile pixel m at tap (0,0) = ti*hh*hw + ty*hw + tx, + the tap's row offset; the slot
+        // swizzle follows the row
+        int prow[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = wm * 64 + mt * 16 + r;
+            prow[mt] = (m >> (a.tw_log2 + a.th_log2)) * (hh * hw) + ((m >> a.tw_log2) & th_mask) * hw + (m & tw_mask);
+        }
+        auto read_half = [&](Half& h, int c, int toff, int slot, int k32) {
+            read_w(h, ring + slot * GC_B_BYTES, k32);
+            const char* halo = smem + (c & 1) * hbytes;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int row = prow[mt] + toff;
+                h.x[mt] = *reinterpret_cast<const bf16x8_t*>(halo + row * 128 + ((((row >> 1) & 7) ^ gq ^ (k32 * 4)) * 16));
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < HD; ++j) issue_halo(0, j);
+#pragma unroll
+        for (int st = 0; st < RS - 1; ++st) { issue_b(0, st, st, 0); issue_b(0, st, st, 1); }      // nine taps per chunk >= RS - 1
+        gc_wait_vm<2 * (RS - 2)>();                              // filter image 0 and, older, the first halo have landed
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        read_half(f0, 0, 0, 0, 0);
+        int slot = 0, c = 0, t = 0, kx = 0, toff = 0;            // K-step s = 9c + t; toff = (t/3)*hw + t%3
+        int cb = 0, tb = RS - 1;                                 // filter image s + RS - 1
+        bool prev_h = false;
+        for (int s = 0; s < KT; ++s) {
+            // Filter image s+1 has landed (and, older than it, the next chunk's halo when s+1 starts a chunk): the copies
+            // requested after it — the previous K-step's halo piece and, RS == 4, filter image s+2 — may still be in flight
+            if constexpr (RS == 4) { if (prev_h) gc_wait_vm<3>(); else gc_wait_vm<2>(); }
+            else gc_wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            int nslot = slot + 1; if (nslot == RS) nslot = 0;
+            int islot = slot - 1; if (islot < 0) islot = RS - 1;        // the slot K-step s-1 read
+            // the next K-step: tap, row offset, chunk
+            int tn = t + 1, kxn = kx + 1, toffn = toff + 1, cn = c;
+            if (kxn == 3) { kxn = 0; toffn += hw - 3; }
+            if (tn == 9) { tn = 0; toffn = 0; ++cn; }
+            prev_h = t < HD && c + 1 < nchunks;
+            if (prev_h) issue_halo(c + 1, t);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_b(cb, tb, islot, 0);
+            read_half(f1, c, toff, slot, 1);
+            mfma16(f0);
+            pin_half(1);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_b(cb, tb, islot, 1);
+            read_half(f0, cn, toffn, nslot, 0);
+            mfma16(f1);
+            pin_half(1);
+            __builtin_amdgcn_sched_barrier(0);
+            slot = nslot; t = tn; kx = kxn; toff = toffn; c = cn;
+            if (++tb == 9) { tb = 0; ++cb; }
+        }
+        gc_wait_vm<0>();
+    }
+
+    // ---- epilogue straight from the accumulators: lane = pixel column r of tile mt, 4 consecutive channels per tile --
+    const __amdgpu_buffer_rsrc_t rs_y = mil_rsrc(a.y, a.y_bytes);
+    const __amdgpu_buffer_rsrc_t rs_r = mil_rsrc(a.res, a.res ? a.y_bytes : 0);
+    const __amdgpu_buffer_rsrc_t rs_a = mil_rsrc(a.act, a.act ? a.y_bytes : 0);
+    const int cbase = (nb * GC_BN + wn * 64 + gq * 4) * 2;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = wm * 64 + mt * 16 + r;
+        const int gx = gx0 + (m & tw_mask), gy = gy0 + ((m >> a.tw_log2) & th_mask), img = img0 + (m >> (a.tw_log2 + a.th_log2));
+        const bool ok = img < a.n_img && gy < Hg && gx < Wg;
+        const unsigned poff = ok ? (unsigned)(((img * a.Hout + gy * a.os + oy_off) * a.Wout + gx * a.os + ox_off) * (a.cout * 2) + cbase) : MIL_OOB;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const unsigned off = ok ? poff + nt * 32 : MIL_OOB;
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = acc[nt][mt][i];
+            if (a.res) {
+                const u32x2_t rv = __builtin_amdgcn_raw_buffer_load_b64(rs_r, off, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] += __uint_as_float((i & 1) ? (rv[i >> 1] & 0xFFFF0000u) : (rv[i >> 1] << 16));
+            }
+            if (a.apply_relu) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = lrelu(v[i], a.slope);
+            }
+            if (a.act) {
+                const u32x2_t av = __builtin_amdgcn_raw_buffer_load_b64(rs_a, off, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] *= lrelu_grad(__uint_as_float((i & 1) ? (av[i >> 1] & 0xFFFF0000u) : (av[i >> 1] << 16)), a.slope);
+            }
+            bf16x4_t o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, o), rs_y, off, 0, 0);
+        }
+    }
+}
+
+// fp32 master [Cout][Cin][k][k] -> filter images [n block][tap][chunk][128 rows][64] with the slot swizzle.
+// mode 0: the conv as written (rows = Cout, k = Cin); mode 1: its data gradient (rows = Cin, k = Cout, taps flipped).
+__global__ void gconv_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int cout, int cin, int ks, int mode, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int kk = ks * ks;
+    const int cin_x = mode ? cout : cin;                       // contraction channels of the conv as executed
+    const int nchunks = cin_x / GC_BK;
+    const int e = idx & 7, pslot = (idx >> 3) & 7, row = (idx >> 6) & 127;
+    size_t t = idx >> 13;
+    const int c = (int)(t % nchunks); t /= nchunks;
+    const int tap = (int)(t % kk);
+    const int nb = (int)(t / kk);
+    const int slot = pslot ^ ((row >> 1) & 7);
+    const int kin = c * GC_BK + slot * 8 + e, nout = nb * GC_BN + row;
+    float val;
+    if (!mode) val = w[((size_t)nout * cin + kin) * kk + tap];
+    else val = w[((size_t)kin * cin + nout) * kk + (kk - 1 - tap)];
+    out[idx] = (__bf16)val;
+}
+
+extern "C" int mil_gconv_supported(int cin, int cout, int ks, int stride) {
+    return (cin % GC_BK == 0 && cout % GC_BN == 0 && (ks == 1 || ks == 3) && (stride == 1 || stride == 2)) ? 1 : 0;
+}
+
+extern "C" int mil_gconv_packed_elems(size_t* elems, int cout, int cin, int ks, int mode) {
+    if (!elems) return MIL_ERR_ARG;
+    const int k_x = mode ? cout : cin, n_x = mode ? cin : cout;
+    if (k_x % GC_BK || n_x % GC_BN || !(ks == 1 || ks == 3)) return MIL_ERR_UNSUPPORTED;
+    *elems = (size_t)n_x * k_x * ks * ks;
+    return MIL_OK;
+}
+
+extern "C" int mil_gconv_pack_weights(const float* w, void* wpack, int cout, int cin, int ks, int mode, void* stream) {
+    size_t total = 0;
+    if (!w || !wpack) return MIL_ERR_ARG;
+    const int rc = mil_gconv_packed_elems(&total, cout, cin, ks, mode);
+    if (rc != MIL_OK) return rc;
+    hipLaunchKernelGGL(gconv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w,
+                       (__bf16*)wpack, cout, cin, ks, mode, total);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+static int gconv_launch(GConvArgs a, hipStream_t st) {
+    int Hg = 0, Wg = 0;
+    for (int z = 0; z < a.ncls; ++z) { if (a.c_hg[z] > Hg) Hg = a.c_hg[z]; if (a.c_wg[z] > Wg) Wg = a.c_wg[z]; }
+    if (Hg <= 0 || Wg <= 0 || a.n_img <= 0) return MIL_OK;
+    // 256 grid points per workgroup: 16x16 of one image, or 8x8 of four (maps of 8 pixels and below: 4x4 of sixteen)
+    int tw, th;
+    if (Wg > 8 || Hg > 8) {
+        const long c16 = (long)((Wg + 15) >> 4) * ((Hg + 15) >> 4) * 4, c8 = (long)((Wg + 7) >> 3) * ((Hg + 7) >> 3);
+        tw = th = c8 < c16 ? 3 : 4;
+    } else if (Wg > 4 || Hg > 4) tw = th = 3;
+    else tw = th = 2;
+    a.tw_log2 = tw; a.th_log2 = th; a.ti_log2 = 8 - tw - th;
+    a.tiles_x = (Wg + (1 << tw) - 1) >> tw; a.tiles_y = (Hg + (1 << th) - 1) >> th;
+    const int groups = (a.n_img + (1 << a.ti_log2) - 1) >> a.ti_log2;
+    { static const int ef = [] { const char* e = getenv("MIL_GCONV_EXP"); return e ? atoi(e) : 0; }(); a.exp_flags = ef; }
+    // the canonical 3x3 stride-1 tap list runs on the halo-resident form when two halo images fit beside the filter ring
+    bool canon = a.ncls == 1 && a.ss == 1 && a.os == 1 && a.c_ntaps[0] == 9 && a.ktaps == 9 && !(a.exp_flags & 8);      // MIL_GCONV_EXP=8: A/B runs
+    for (int t = 0; t < 9 && canon; ++t) canon = a.c_tap[0][t] == (((t / 3 - 1 + 8) << 16) | ((t % 3 - 1 + 8) << 8) | t);
+    const int hrows = (((1 << tw) + 2) * ((1 << th) + 2)) << a.ti_log2;
+    const int hd = canon ? (hrows + 63) / 64 : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gconv_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, GC_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gconv_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gconv_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return MIL_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const dim3 grid(groups * a.tiles_y * a.tiles_x, a.cout / GC_BN, a.ncls);
+    if (hd > 0 && hd <= 6) hipLaunchKernelGGL(gconv_kernel<6>, grid, dim3(512), 2 * 6 * 8192 + 4 * GC_B_BYTES, st, a);
+    else if (hd == 7) hipLaunchKernelGGL(gconv_kernel<7>, grid, dim3(512), 2 * 7 * 8192 + 3 * GC_B_BYTES, st, a);
+    else hipLaunchKernelGGL(gconv_kernel<0>, grid, dim3(512), GC_LDS_BYTES, st, a);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
+// y = mask(relu?(conv(x) + res?)) on the gather-GEMM kernel, bf16 NHWC.  `wpack` = mil_gconv_pack_weights(mode 0) of the
+// conv's weight for transposed == 0 (y = conv(x): x [n,H,W,cin] -> y [n,Ho,Wo,cout]), mode 1 for transposed == 1 (the conv's
+// data gradient: x is dz [n,H,W,cin_x] on the conv's OUTPUT grid, y is dx [n,Ho,Wo,cout_x] on its input grid; `stride` is the
+// conv's stride, a stride-2 gradient runs as four parity-class launches).  cin/cout are the channel counts of x / y.
+extern "C" int mil_gconv(const void* x, const void* wpack, const void* res, const void* act, void* y, int n_img, int H, int W,
+                         int cin, int Ho, int Wo, int cout, int ks, int stride, int pad, int transposed, int apply_relu, float slope,
+                         void* stream) {
+    if (!x || !wpack || !y || n_img < 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return MIL_ERR_ARG;
+    if (!mil_gconv_supported(cin, cout, ks, stride) || pad != ks / 2) return MIL_ERR_UNSUPPORTED;
+    const size_t xb = (size_t)n_img * H * W * cin * 2, yb = (size_t)n_img * Ho * Wo * cout * 2;
+    const size_t wb = (size_t)cin * cout * ks * ks * 2;
+    if (xb >= ((size_t)1 << 31) || yb >= ((size_t)1 << 31) || H >= 0x4000 || W >= 0x4000) return MIL_ERR_UNSUPPORTED;
+    if (n_img == 0) return MIL_OK;
+    GConvArgs a{};
+    a.x = (const __bf16*)x; a.w = (const __bf16*)wpack; a.res = (const __bf16*)res; a.act = (const __bf16*)act; a.y = (__bf16*)y;
+    a.n_img = n_img; a.Hs = H; a.Ws = W; a.cin = cin; a.Hout = Ho; a.Wout = Wo; a.cout = cout;
+    a.ktaps = ks * ks; a.apply_relu = apply_relu; a.slope = slope;
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!transposed || stride == 1) {
+        // forward (source stride = the conv's stride) or stride-1 gradient (the flipped filter is in the packing)
+        if (!transposed && (Ho != (H + 2 * pad - ks) / stride + 1 || Wo != (W + 2 * pad - ks) / stride + 1)) return MIL_ERR_ARG;
+        if (transposed && (Ho != H || Wo != W)) return MIL_ERR_ARG;
+        a.ncls = 1; a.os = 1; a.ss = transposed ? 1 : stride;
+        a.c_hg[0] = Ho; a.c_wg[0] = Wo; a.c_oy[0] = a.c_ox[0] = 0; a.c_ntaps[0] = ks * ks;
+        for (int t = 0; t < ks * ks; ++t) a.c_tap[0][t] = ((t / ks - pad + 8) << 16) | ((t % ks - pad + 8) << 8) | t;
+        return gconv_launch(a, st);
+    }
+    // stride-2 data gradient: output pixel (2j + py, 2i + px) receives dz[(y + pad - ky) / 2] for the ky with y + pad - ky even:
+    // four classes of output pixels in one launch, each with the 1, 2, 2 or 4 taps (of 9) that reach it
+    if (H != (Ho + 2 * pad - ks) / 2 + 1 || W != (Wo + 2 * pad - ks) / 2 + 1) return MIL_ERR_ARG;
+    a.ncls = 4; a.os = 2; a.ss = 1;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            const int z = py * 2 + px;
+            a.c_hg[z] = (Ho - py + 1) / 2; a.c_wg[z] = (Wo - px + 1) / 2; a.c_oy[z] = py; a.c_ox[z] = px;
+            int n = 0;
+            for (int ky = 0; ky < ks; ++ky)
+                for (int kx = 0; kx < ks; ++kx) {
+                    const int ny = py + pad - ky, nx = px + pad - kx;        // even and >= -(ks - 1 - pad) when the tap reaches the class
+                    if ((ny & 1) || (nx & 1)) continue;
+                    // mode-1 packing stores forward tap q at index kk-1-q
+                    a.c_tap[z][n++] = ((ny / 2 + 8) << 16) | ((nx / 2 + 8) << 8) | (ks * ks - 1 - (ky * ks + kx));
+                }
+            a.c_ntaps[z] = n;
+        }
+    return gconv_launch(a, st);
+    return MIL_OK;
+}

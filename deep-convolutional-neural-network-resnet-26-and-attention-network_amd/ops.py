@@ -619,6 +619,37 @@ def wide_conv(x, wpack, cout, *, ks, stride, pad, out_hw=None, res=None, act=Non
     return y
 
 
+def gconv_supported(cin_x, cout_x, ks, stride):
+    """Whether the gather-GEMM kernel runs a conv that contracts `cin_x` channels into `cout_x` (bf16 only)."""
+    return bool(L.lib().mil_gconv_supported(cin_x, cout_x, ks, stride))
+
+
+def gconv_pack_weights(w, mode):
+    w = w.detach().contiguous()
+    cout, cin, ks, _ = w.shape
+    elems = ctypes.c_size_t(0)
+    L.check(L.lib().mil_gconv_packed_elems(ctypes.byref(elems), cout, cin, ks, mode), "mil_gconv_packed_elems")
+    packed = torch.empty(elems.value, dtype=torch.bfloat16, device=w.device)
+    L.check(L.lib().mil_gconv_pack_weights(w.data_ptr(), packed.data_ptr(), cout, cin, ks, mode, L.stream_ptr()),
+            "mil_gconv_pack_weights")
+    return packed
+
+
+def gconv(x, wpack, cout, *, ks, stride, pad, transposed=False, out_hw=None, res=None, act=None, relu=False, slope=0.0):
+    """y = mask(relu?(conv(x) + res?)) (transposed: the conv's data gradient, x = dz, out_hw = the conv's input extent)."""
+    n, h, w, cin = x.shape
+    if transposed:
+        ho, wo = out_hw if out_hw is not None else (h * stride, w * stride)
+    else:
+        ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+    y = torch.empty((n, ho, wo, cout), dtype=x.dtype, device=x.device)
+    _need(res, y.shape, x.dtype, "res")
+    _need(act, y.shape, x.dtype, "act")
+    L.check(L.lib().mil_gconv(x.data_ptr(), wpack.data_ptr(), L.ptr(res), L.ptr(act), y.data_ptr(), n, h, w, cin, ho, wo, cout,
+                              ks, stride, pad, 1 if transposed else 0, 1 if relu else 0, slope, L.stream_ptr()), "mil_gconv")
+    return y
+
+
 def wide_wgrad(x, dz, cin, cout, *, ks, stride, pad, workspace=None, out=None):
     n, h, w, _ = x.shape
     _, ho, wo, _ = dz.shape

@@ -317,6 +317,20 @@ int mil_wide_wgrad_workspace(size_t* bytes, int n_img, int H, int W, int cin, in
 int mil_wide_wgrad(const void* x, const void* dz, float* dw, void* workspace, size_t workspace_bytes, int n_img, int H, int W,
                    int cin, int Ho, int Wo, int cout, int ks, int stride, int pad, int accumulate, int dtype, void* stream);
 
+/* ---- wide layers, gather-GEMM form (bf16): one deep-pipelined GEMM per 256-pixel x 128-channel tile whose K-steps
+ * (one filter tap x 64 input channels) are copied to LDS by LDS-DMA, the next two in flight across the single barrier per
+ * K-step.  Same role as mil_wide_conv (conv3x3 / conv1x1 of alt_resnet.py:24-33 forward and data gradient; ReLU = slope 0)
+ * for channel counts with cin_x % 64 == 0 and cout_x % 128 == 0 (as executed: a data gradient contracts over the conv's
+ * Cout and produces its Cin).  transposed == 0: y = conv(x); transposed == 1: x is dz on the conv's output grid, y is the
+ * gradient on its input grid — a stride-2 gradient runs as four output-parity classes with only the taps that reach each.
+ * mil_gconv_pack_weights: fp32 [Cout][Cin][k][k] -> swizzled 128-row x 64-channel filter images, mode 0 forward /
+ * 1 data gradient. */
+int mil_gconv_supported(int cin_x, int cout_x, int ks, int stride);
+int mil_gconv_packed_elems(size_t* elems, int cout, int cin, int ks, int mode);
+int mil_gconv_pack_weights(const float* w, void* wpack, int cout, int cin, int ks, int mode, void* stream);
+int mil_gconv(const void* x, const void* wpack, const void* res, const void* act, void* y, int n_img, int H, int W, int cin_x,
+              int Ho, int Wo, int cout_x, int ks, int stride, int pad, int transposed, int apply_relu, float slope, void* stream);
+
 /* ---- training-step closure ---------------------------------------------------
  * mil_adam_step: torch.optim.Adam (gbm/classify_combined.py:519, stepped at :450-454) over the flat fp32
  * parameter / gradient buckets in ONE launch; `step` is the 1-based step count (bias correction),

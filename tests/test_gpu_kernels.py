@@ -374,6 +374,61 @@ def test_wide_conv_forward_dgrad_wgrad(ops, dtype, case):
     assert torch.equal(dw, dw2)
 
 
+GATHER_CASES = [
+    # cin, cout, ks, stride, n, H, W
+    (64, 128, 3, 2, 3, 16, 16),         # forward only: its gradient (128 -> 64 channels) is not a 128-channel output block
+    (64, 128, 1, 2, 2, 16, 16),
+    (128, 128, 3, 1, 2, 16, 16),        # halo-resident form, 16x16 tiles (two chunks)
+    (128, 128, 3, 1, 3, 9, 11),         # partial tiles
+    (128, 128, 3, 1, 5, 20, 33),        # several tiles per image, ragged edges
+    (128, 256, 3, 2, 2, 10, 10),
+    (128, 256, 3, 2, 3, 11, 9),         # odd extents: the four gradient classes have different grids
+    (256, 256, 3, 1, 5, 8, 8),          # halo-resident form, 8x8 tiles of four images (the last group partly empty)
+    (256, 128, 1, 1, 3, 8, 8),
+    (256, 512, 1, 2, 3, 8, 8),          # 1x1 stride 2: three of the four gradient classes receive no tap (zeros + addend)
+    (512, 512, 3, 1, 9, 4, 4),          # 4x4 maps: sixteen images per tile, per-K-step gather form
+    (512, 512, 3, 1, 70, 8, 8),         # eight chunks, many tiles
+]
+
+
+@pytest.mark.parametrize("case", GATHER_CASES)
+def test_gather_gemm_conv_forward_and_dgrad(ops, case):
+    """mil_gconv (bf16 gather-GEMM kernel of the wide layers) against F.conv2d + autograd: y = relu(conv(x) + res), and the data
+    gradient dx = (conv^T(dz) + addend) * [act > 0] — stride-2 gradients as four parity classes in one launch."""
+    L = _lib()
+    dtype = torch.bfloat16
+    cin, cout, ks, stride, n, h, w = case
+    g = torch.Generator().manual_seed(11 + cin + cout + ks + h)
+    pad = 1 if ks == 3 else 0
+    x = round_to(torch.randn(n, cin, h, w, generator=g), dtype).requires_grad_(True)
+    wt = round_to(torch.randn(cout, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5, dtype).requires_grad_(True)
+    lin = F.conv2d(x, wt, None, stride=stride, padding=pad)
+    res = round_to(torch.randn(lin.shape, generator=g), dtype)
+    xg = to_nhwc(x.detach(), dtype)
+    assert ops.gconv_supported(cin, cout, ks, stride)
+    wp = ops.gconv_pack_weights(wt.detach().cuda(), L.PACK_FWD)
+    y = ops.gconv(xg, wp, cout, ks=ks, stride=stride, pad=pad, res=to_nhwc(res, dtype), relu=True)
+    assert rel_err(from_nhwc(y, cout), F.relu(lin.detach() + res)) < TOL[dtype]
+    y0 = ops.gconv(xg, wp, cout, ks=ks, stride=stride, pad=pad)
+    assert rel_err(from_nhwc(y0, cout), lin.detach()) < TOL[dtype]
+    assert torch.equal(y0, ops.gconv(xg, wp, cout, ks=ks, stride=stride, pad=pad))
+    if not ops.gconv_supported(cout, cin, ks, stride):
+        with pytest.raises(Exception):
+            ops.gconv_pack_weights(wt.detach().cuda(), L.PACK_DGRAD)
+        return
+    dz = round_to(torch.randn(lin.shape, generator=g), dtype)
+    lin.backward(dz)
+    act = round_to(torch.randn(x.shape, generator=g), dtype)
+    addend = round_to(torch.randn(x.shape, generator=g), dtype)
+    wd = ops.gconv_pack_weights(wt.detach().cuda(), L.PACK_DGRAD)
+    dzg = to_nhwc(dz, dtype)
+    dx = ops.gconv(dzg, wd, cin, ks=ks, stride=stride, pad=pad, transposed=True, out_hw=(h, w), res=to_nhwc(addend, dtype),
+                   act=to_nhwc(act, dtype))
+    assert rel_err(from_nhwc(dx, cin), (x.grad + addend) * (act > 0)) < TOL[dtype]
+    dx0 = ops.gconv(dzg, wd, cin, ks=ks, stride=stride, pad=pad, transposed=True, out_hw=(h, w))
+    assert rel_err(from_nhwc(dx0, cin), x.grad) < TOL[dtype]
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 16), (3, 32, 32), (2, 25, 34), (5, 128, 128)])
 def test_stem_backward_fused_split_precision(ops, shape):
     """mil_stem_bwd_fused_nchw on fp32 tensors with bf16x3 split products (MIL_DT_F32S) against autograd of conv7x7/s2 ->
