@@ -719,7 +719,10 @@ static int run_wide_wgrad(const void* x, const void* dz, float* dw, void* ws, si
     if (xb + zb > 160 * 1024) return MIL_ERR_UNSUPPORTED;
     const int ntiles = g.n_groups * g.tiles_y * g.tiles_x;
     const int npairs = (cout / WIDE_NB) * (cin / WIDE_CK);
-    int gx = 2048 / npairs;
+    // one fp32 slab per workgroup: 512 workgroups (two per CU) keep the slab write + fixed-order reduce at 37 MB per launch —
+    // the 2048 of earlier rounds moved 151 MB for a 9 MB gradient (MIL_WIDE_WGRAD_WGS: A/B runs)
+    static const int wg_target = [] { const char* e = getenv("MIL_WIDE_WGRAD_WGS"); return e ? atoi(e) : 512; }();
+    int gx = wg_target / npairs;
     if (gx < 4) gx = 4;
     if (gx > 64) gx = 64;
     if (gx > ntiles) gx = ntiles;
@@ -733,7 +736,8 @@ static int run_wide_wgrad(const void* x, const void* dz, float* dw, void* ws, si
     bool done = false;
     if constexpr (T::DT == MIL_DT_BF16) {
         const size_t xbytes = (size_t)g.n_img * g.H * g.W * cin * 2, zbytes = (size_t)g.n_img * g.Ho * g.Wo * cout * 2;
-        if (mil_wide_pf_enabled() && g.stride == 1 && ((g.hh * g.hw) << g.ti_log2) <= 256 && g.hh < 1024 && g.hw < 1024 &&
+        const int halo_px = (g.hh * g.hw) << g.ti_log2;
+        if (mil_wide_pf_enabled() && g.stride == 1 && halo_px <= 256 && g.hh < 1024 && g.hw < 1024 &&
             xbytes < ((size_t)1 << 31) && zbytes < ((size_t)1 << 31)) {
             a.lds_z_off = xb + 16;                              // + dump slot for the unused halo piece slots
             auto kpf = wide_wgrad_pf_kernel<KS>;
