@@ -54,7 +54,7 @@ __host__ __device__ constexpr int sf_lds_bytes() {
 // 16-byte pieces (1.07 GB read per 2048 tiles of 256x256 instead of 1.6 GB of fp32 in 304-byte plane segments), everything
 // behind it is the same code on the same LDS bytes: bit-identical pooled map and winner records.
 template <int NT, int NW, bool X3 = false, bool FROM_XS = false>
-__global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? 2 : 1) * (NW == 8 && NT <= 2 ? 2 : 1)) void stem_fwd_fused_kernel(StemFwdArgs a) {
+__global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 6 ? 3 : 2)) : 1)) void stem_fwd_fused_kernel(StemFwdArgs a) {
     static_assert(!(X3 && FROM_XS), "the space-to-depth feed is bf16");
     using T = typename std::conditional<X3, F32S, BF16>::type;
     constexpr int SF_XPIX = sf_xpix(X3), SF_XBYTES = sf_xbytes(X3);
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? 2 : 1) * (NW == 8 && N
     constexpr int NTHR = 64 * NW;
     constexpr int SF_NLOAD = ((FROM_XS ? SF_XH * SF_XW * 2 : SF_NITEM) + NTHR - 1) / NTHR;      // FROM_XS: items = 16-byte halves of the tile's s2d records
     constexpr int SF_MT = (SF_MTILES + NW - 1) / NW;          // row tiles per wave
-    constexpr int NXS = 1024 / NTHR;                          // 16-byte pieces of the tile's own 16x32 s2d pixels per thread
+    constexpr int NXS = (1024 + NTHR - 1) / NTHR;             // 16-byte pieces of the tile's own 16x32 s2d pixels per thread
     constexpr int NPOOL = (128 * NG4 + NTHR - 1) / NTHR;      // (pooled pixel, 4-channel group) items per thread
     constexpr bool LAST_PARTIAL = (COUTP % 16) != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? 2 : 1) * (NW == 8 && N
 #pragma unroll
             for (int i = 0; i < NXS; ++i) {
                 constexpr int RPI = NTHR / 64;                   // rows covered per round
-                const bool ok = x_row0 + RPI * i < ylim && x_col < xlim;
+                const bool ok = x_row0 + RPI * i < (ylim < 16 ? ylim : 16) && x_col < xlim;
                 const u32x4_t v = *reinterpret_cast<const u32x4_t*>(ldsX + x_lds0 + i * (RPI * SF_XW * SF_XPIX));
                 __builtin_amdgcn_raw_buffer_store_b128(v, rs_xs, ok ? (unsigned)(xbase + x_rel0 + i * (RPI * W2 * 32)) : MIL_OOB, 0, 0);
             }
@@ -371,7 +371,10 @@ static int launch_stem_fwd(StemFwdArgs a, hipStream_t st) {
     // measured (24 channels, bf16): 1120 us with 4 waves per workgroup at 238 VGPRs, 1428 us with 8 waves squeezed into 128
     // VGPRs (15 spilled): the 8-wave form serves the split-precision kernel, whose 156 KB of LDS leave one workgroup per CU
     // (two waves per SIMD at up to 256 VGPRs)
-    constexpr int NW = X3 ? 8 : 4;
+#ifndef MIL_STEM_FWD_WAVES
+#define MIL_STEM_FWD_WAVES 4
+#endif
+    constexpr int NW = X3 ? 8 : (NT <= 2 ? MIL_STEM_FWD_WAVES : 4);
     auto kern = stem_fwd_fused_kernel<NT, NW, X3, FROM_XS>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MIL_ERR_LAUNCH;
