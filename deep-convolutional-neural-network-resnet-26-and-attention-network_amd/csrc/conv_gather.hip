@@ -469,3 +469,194 @@ extern "C" int mil_gconv(const void* x, const void* wpack, const void* res, cons
     return gconv_launch(a, st);
     return MIL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the wide layers in the same gather form:  dW[co][ci][tap] = sum over output pixels q of
+// dz[q][co] * x[src(q) + off(tap)][ci], a GEMM whose K dimension is the pixels.  One workgroup owns one (128 output
+// channels) x (64 input channels) x (all taps) block of dW — 36 accumulator tiles per wave — and a strided share of the
+// pixel stages; a stage is 32 consecutive output pixels: their dz rows (contiguous memory) and, per tap, their 32 gathered x
+// rows, copied by LDS-DMA into a ring of three.  Any stride and tap list (no halo): this is the form the stride-2 3x3 and the
+// 1x1 projection gradients run on, which the pipelined kernel of conv_wide.hip (stride 1 only) left on its synchronous
+// sibling.  Both MFMA operands are pixel-major in LDS and k (pixel)-major in the MFMA: ds_read_b64_tr_b16, with the 32-byte
+// chunk index XOR-ed by row bits so that the eight rows of a half-wave read fall on eight different bank spans.
+// Partial sums leave as one fp32 slab [tap][128][64] per workgroup; gwgrad_reduce_kernel adds them in fixed order.
+#define GW_P 32
+#define GW_Z_BYTES (GW_P * GC_BN * 2)          // 8 KB
+#define GW_X_BYTES (GW_P * GC_BK * 2)          // 4 KB per tap
+#define GW_STAGE_BYTES (GW_Z_BYTES + GC_MAX_TAPS * GW_X_BYTES)     // 44 KB
+
+struct GWgradArgs {
+    const __bf16* x;            // [n_img, H, W, cin]
+    const __bf16* dz;           // [n_img, Ho, Wo, cout]
+    float* slab;                // [pairs][gx][ntaps][128][64]
+    int n_img, H, W, cin, Ho, Wo, cout;
+    int stride, ntaps, nstages;
+    int tap[GC_MAX_TAPS];       // (dy + 8) << 8 | (dx + 8)
+    unsigned x_bytes, z_bytes;
+};
+
+__global__ __launch_bounds__(512, 1) void gwgrad_kernel(GWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    MIL_POISON(smem);
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, gq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave & 1, wc = wave >> 1;                 // wave grid: 2 (64 output channels) x 4 (16 input channels)
+    const int nchunks = a.cin / GC_BK;
+    const int cb = blockIdx.y / nchunks, ch = blockIdx.y - cb * nchunks;
+    const int ntaps = a.ntaps;
+    const int Q = a.n_img * a.Ho * a.Wo;
+    const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rs_z = mil_rsrc(a.dz, a.z_bytes);
+
+    // copies of this wave: one dz piece (rows 4*wave .. +3, 16 slots of 16 B each) and the x pieces j = wave + 8*i of the
+    // 4*ntaps (tap j/4, rows (j%4)*8 .. +7, 8 slots each): j%4 = wave%4 for every i, so a lane gathers ONE pixel per stage
+    const int zrow = wave * 4 + (lane >> 4);
+    const int zslot = (lane & 15) ^ ((((zrow & 3) | (((zrow >> 3) & 1) << 2))) << 1);
+    const int xrow = (wave & 3) * 8 + (lane >> 3);
+    const int xslot = (lane & 7) ^ (((((xrow >> 1) & 1) | (((xrow >> 3) & 1) << 1))) << 1);
+    const int nx = (4 * ntaps - wave + 7) / 8;               // x pieces of this wave: 4 or 5 for nine taps, 0 or 1 for one
+    const int tap_tab = a.tap[lane < ntaps ? lane : 0];
+
+    auto issue = [&](int st, int buf, bool live) {
+        char* stg = smem + buf * GW_STAGE_BYTES;
+        const int q0 = st * GW_P;
+        {
+            const int q = q0 + zrow;
+            const bool ok = live && q < Q;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_z, GC_LDS_PTR(stg + wave * 1024), 16,
+                                                     ok ? (unsigned)(q * (a.cout * 2) + cb * (GC_BN * 2) + zslot * 16) : MIL_OOB, 0, 0, 0);
+        }
+        const int q = q0 + xrow;
+        const int img = q / (a.Ho * a.Wo), rem = q - img * (a.Ho * a.Wo), oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        const bool qok = live && q < Q;
+        const int sy0 = oy * a.stride, sx0 = ox * a.stride;
+        const int base = ((img * a.H + sy0) * a.W + sx0) * (a.cin * 2) + ch * (GC_BK * 2) + xslot * 16;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            if (i < nx) {                                        // wave-uniform
+                const int j = wave + 8 * i;
+                const int tp = __builtin_amdgcn_readlane(tap_tab, j >> 2);
+                const int dy = (tp >> 8) - 8, dx = (tp & 0xFF) - 8;
+                const bool ok = qok && (unsigned)(sy0 + dy) < (unsigned)a.H && (unsigned)(sx0 + dx) < (unsigned)a.W;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, GC_LDS_PTR(stg + GW_Z_BYTES + j * 1024), 16,
+                                                         ok ? (unsigned)(base + (dy * a.W + dx) * (a.cin * 2)) : MIL_OOB, 0, 0, 0);
+            }
+        }
+    };
+    auto wait_stage = [&](bool one_in_flight) {                // this wave's copies of the oldest stage in flight have landed
+        const int n = one_in_flight ? 1 + nx : 0;
+        if (n == 0) gc_wait_vm<0>(); else if (n == 1) gc_wait_vm<1>(); else if (n == 2) gc_wait_vm<2>();
+        else if (n == 5) gc_wait_vm<5>(); else gc_wait_vm<6>();
+    };
+
+    f32x4_t acc[GC_MAX_TAPS][4];                             // [tap][output-channel tile]
+#pragma unroll
+    for (int t = 0; t < GC_MAX_TAPS; ++t)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[t][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // fragment addresses: pixel rows 8*gq + q4 (and + 4), 8 bytes at chunk (tile) of the row, chunk swizzled by row bits
+    const int q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int row0 = 8 * gq + q4, row1 = row0 + 4;
+    auto zoff = [&](int row, int ct) { return row * 256 + ((((wr * 4 + ct) ^ ((row & 3) | (((row >> 3) & 1) << 2))) * 32) + p4 * 8); };
+    auto xoff = [&](int row) { return row * 128 + (((wc ^ (((row >> 1) & 1) | (((row >> 3) & 1) << 1))) * 32) + p4 * 8); };
+    const int x0 = xoff(row0), x1 = xoff(row1);
+
+    // this workgroup's stages: blockIdx.x, blockIdx.x + gridDim.x, ...
+    const int G = gridDim.x;
+    int st = blockIdx.x;
+    const int mine = st < a.nstages ? (a.nstages - st + G - 1) / G : 0;
+    issue(st, 0, mine > 0);
+    issue(st + G, 1, mine > 1);
+    int buf = 0;
+    for (int i = 0; i < mine; ++i) {
+        wait_stage(i + 1 < mine);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        issue(st + 2 * G, buf == 0 ? 2 : buf - 1, i + 2 < mine);
+        const char* stg = smem + buf * GW_STAGE_BYTES;
+        bf16x8_t zf[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) zf[ct] = mil_tr_pair(stg + zoff(row0, ct), stg + zoff(row1, ct));
+#pragma unroll
+        for (int t = 0; t < GC_MAX_TAPS; ++t) {
+            if (t < ntaps) {                                     // wave-uniform
+                const char* xt = stg + GW_Z_BYTES + t * GW_X_BYTES;
+                const bf16x8_t xf = mil_tr_pair(xt + x0, xt + x1);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf[ct], xf, acc[t][ct], 0, 0, 0);
+            }
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+        st += G;
+    }
+    gc_wait_vm<0>();
+    // slab [tap][128 co][64 ci]: D rows = output channels (ct*16 + gq*4 + e), columns = input channels (r)
+    float* slab = a.slab + ((size_t)blockIdx.y * G + blockIdx.x) * ((size_t)ntaps * GC_BN * GC_BK);
+#pragma unroll
+    for (int t = 0; t < GC_MAX_TAPS; ++t) {
+        if (t < ntaps) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    slab[((size_t)t * GC_BN + wr * 64 + ct * 16 + gq * 4 + e) * GC_BK + wc * 16 + r] = acc[t][ct][e];
+        }
+    }
+}
+
+// dW[cb*128 + co][ch*64 + ci][tap] (+)= sum over the pair's slabs, fixed order
+__global__ void gwgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int npairs, int nchunks, int kk, float* __restrict__ dw,
+                                     int cin, int accumulate) {
+    const size_t per_pair = (size_t)kk * GC_BN * GC_BK;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= per_pair * npairs) return;
+    const int pair = (int)(idx / per_pair);
+    const int e = (int)(idx - (size_t)pair * per_pair);
+    const int ci = e & (GC_BK - 1), co = (e / GC_BK) & (GC_BN - 1), tap = e / (GC_BK * GC_BN);
+    const int cb = pair / nchunks, ch = pair - cb * nchunks;
+    const float* p = slab + (size_t)pair * nslab * per_pair + e;
+    float s = 0.f;
+    for (int i = 0; i < nslab; ++i) s += p[(size_t)i * per_pair];
+    float* q = dw + ((size_t)(cb * GC_BN + co) * cin + ch * GC_BK + ci) * kk + tap;
+    *q = accumulate ? *q + s : s;
+}
+
+// Internal entry (called from mil_wide_wgrad / mil_wide_wgrad_workspace in conv_wide.hip): bf16, cin % 64 == 0, cout % 128 == 0.
+// Returns MIL_ERR_UNSUPPORTED when the gather form does not take the shape (the caller then runs its own kernels).
+int mil_gwgrad(const void* x, const void* dz, float* dw, void* ws, size_t ws_bytes, int n_img, int H, int W, int cin, int Ho, int Wo,
+               int cout, int ks, int stride, int pad, int accumulate, bool query, size_t* need, hipStream_t st) {
+    if (cin % GC_BK || cout % GC_BN || !(ks == 1 || ks == 3) || !(stride == 1 || stride == 2) || pad != ks / 2) return MIL_ERR_UNSUPPORTED;
+    const size_t xb = (size_t)n_img * H * W * cin * 2, zb = (size_t)n_img * Ho * Wo * cout * 2;
+    if (xb >= ((size_t)1 << 31) || zb >= ((size_t)1 << 31)) return MIL_ERR_UNSUPPORTED;
+    const int kk = ks * ks, npairs = (cout / GC_BN) * (cin / GC_BK);
+    const long Q = (long)n_img * Ho * Wo;
+    const int nstages = (int)((Q + GW_P - 1) / GW_P);
+    // one workgroup per CU in all (each writes a slab of kk x 32 KB): the pixel stages of a pair are split over gx of them
+    int gx = mil_num_cus() / npairs;
+    if (gx < 1) gx = 1;
+    if (gx > nstages) gx = nstages;
+    const size_t bytes = (size_t)npairs * gx * kk * GC_BN * GC_BK * sizeof(float);
+    if (query) { *need = bytes; return MIL_OK; }
+    if (!ws || ws_bytes < bytes) return MIL_ERR_ARG;
+    if (Q == 0) return MIL_OK;
+    GWgradArgs a{};
+    a.x = (const __bf16*)x; a.dz = (const __bf16*)dz; a.slab = (float*)ws;
+    a.n_img = n_img; a.H = H; a.W = W; a.cin = cin; a.Ho = Ho; a.Wo = Wo; a.cout = cout;
+    a.stride = stride; a.ntaps = kk; a.nstages = nstages;
+    for (int t = 0; t < kk; ++t) a.tap[t] = ((t / ks - pad + 8) << 8) | (t % ks - pad + 8);
+    a.x_bytes = (unsigned)xb; a.z_bytes = (unsigned)zb;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gwgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * GW_STAGE_BYTES) != hipSuccess)
+            return MIL_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gwgrad_kernel, dim3(gx, npairs), dim3(512), 3 * GW_STAGE_BYTES, st, a);
+    MIL_CHECK_LAUNCH();
+    const size_t total = (size_t)kk * GC_BN * GC_BK * npairs;
+    hipLaunchKernelGGL(gwgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)ws, gx, npairs, cin / GC_BK, kk,
+                       dw, cin, accumulate);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}

@@ -764,6 +764,14 @@ static int run_wide_wgrad(const void* x, const void* dz, float* dw, void* ws, si
     return MIL_OK;
 }
 
+// conv_gather.hip: the gather form of the weight gradient (bf16; any stride / 1x1)
+int mil_gwgrad(const void* x, const void* dz, float* dw, void* ws, size_t ws_bytes, int n_img, int H, int W, int cin, int Ho, int Wo,
+               int cout, int ks, int stride, int pad, int accumulate, bool query, size_t* need, hipStream_t st);
+static int mil_gwgrad_mode() {           // MIL_GWGRAD: 0 = never, 1 = stride-2 and 1x1 launches (default), 2 = every eligible launch
+    static const int v = [] { const char* e = getenv("MIL_GWGRAD"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
 static int wide_wgrad_entry(const void* x, const void* dz, float* dw, void* ws, size_t ws_bytes, int n_img, int H, int W, int cin,
                             int Ho, int Wo, int cout, int ks, int stride, int pad, int accumulate, int dtype, bool query,
                             size_t* need, void* stream) {
@@ -772,6 +780,11 @@ static int wide_wgrad_entry(const void* x, const void* dz, float* dw, void* ws, 
     ConvGeom g{};
     g.n_img = n_img; g.H = H; g.W = W; g.Ho = Ho; g.Wo = Wo; g.ks = ks; g.stride = stride; g.pad = pad; g.zins = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MIL_DT_BF16 && (mil_gwgrad_mode() == 2 || (mil_gwgrad_mode() == 1 && (stride == 2 || ks == 1)))) {
+        // the stride-2 3x3 and the 1x1 gradients have no pipelined form here (wide_wgrad_pf_kernel is stride 1): gather form
+        const int rc = mil_gwgrad(x, dz, dw, ws, ws_bytes, n_img, H, W, cin, Ho, Wo, cout, ks, stride, pad, accumulate, query, need, st);
+        if (rc != MIL_ERR_UNSUPPORTED) return rc;
+    }
     if (dtype == MIL_DT_BF16) return ks == 3 ? run_wide_wgrad<BF16, 3>(x, dz, dw, ws, ws_bytes, g, cin, cout, accumulate, query, need, st)
                                              : run_wide_wgrad<BF16, 1>(x, dz, dw, ws, ws_bytes, g, cin, cout, accumulate, query, need, st);
     if (dtype == MIL_DT_F32) return ks == 3 ? run_wide_wgrad<F32, 3>(x, dz, dw, ws, ws_bytes, g, cin, cout, accumulate, query, need, st)
