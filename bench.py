@@ -203,16 +203,22 @@ def alt_resnet_record(dev):
         feats.backward(dfe)
         return feats
 
-    steps = 5
-    elapsed, feats = timed_steps(step, steps, 2, torch.cuda.synchronize)
+    steps, warm = 12, 3
+    elapsed, feats = timed_steps(step, steps, warm, torch.cuda.synchronize)
     if not bool(torch.isfinite(feats).all()):
         raise SystemExit("non-finite features on the alt_resnet path")
     value = tiles * steps / elapsed
     tfl = value * ALT_GFLOP_PER_TILE_FWD_BWD_256 / 1e3
-    return {"value": value, "unit": "tiles/s", "dtype": "bf16", "steps": steps, "warmup": 2, "tiles_per_step": tiles,
+    roof = {"bound": "mfma", "achieved": tfl, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_PEAK_BF16_TFLOPS}
+    sq = _profile_json("sq_counters_alt.json")               # tools/profile_round.sh: matrix-pipe utilisation of the wide conv kernels
+    if sq:
+        roof["sq_counters"] = {k.split("(")[0].replace("void ", ""): {"mfma_busy_frac_per_simd": v.get("mfma_busy_frac_per_simd"),
+                                                                      "launches": v.get("launches")}
+                               for k, v in sq.get("kernels", {}).items() if "gconv_kernel" in k or "wide_wgrad_pf" in k or "gwgrad_kernel" in k}
+        roof["sq_counters_library_match"] = sq.get("_library_sha16") == library_sha16()
+    return {"value": value, "unit": "tiles/s", "dtype": "bf16", "steps": steps, "warmup": warm, "tiles_per_step": tiles,
             "ms_per_step": elapsed / steps * 1e3, "model_tflops": tfl,
-            "roofline": {"bound": "mfma", "achieved": tfl, "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tfl / MFMA_PEAK_BF16_TFLOPS},
+            "roofline": roof,
             "workload": "alt_resnet.ResNet(BasicBlock,[3,3,3,3]) 64/128/256/512 ch, 256 tiles @256x256x3, fwd+bwd, "
                         "21.15 GFLOP/tile (SURVEY.md §8d)"}
 

@@ -2,19 +2,29 @@
 //
 //   D[m][n] = sum over taps t, channels c of  Src[pix(m) + off(t)][c] * W[t][c][n]
 //
-// as ONE deep-pipelined GEMM per workgroup: 256 output pixels (m) x 128 output channels (n), K-step = one tap x 64 input
-// channels.  Each K-step's two operand images — 256 pixel rows x 128 B gathered straight from the NHWC tensor at the tap's
-// offset, and 128 filter rows x 128 B — are copied HBM/L2 -> LDS by LDS-DMA (`buffer_load ... lds`, 16 B per lane, no
-// registers, no ds_write pass) into a ring of three stage buffers; the copies of the next two K-steps stay in flight across
-// the one barrier per K-step (counted `s_waitcnt vmcnt`, raw `s_barrier`).  Out-of-image pixels are out-of-range buffer
-// offsets: the DMA writes zeros (the conv's zero padding).  The channel-blocked kernels of conv_wide.hip (128-pixel x
-// 64-channel tiles, two workgroups per CU, register prefetch + a barrier pair per 32-channel chunk) sit at the 0.7-0.9
-// PFLOP/s that structure tops out at; this one exists to get past it.
+// as ONE pipelined GEMM per workgroup (eight waves, one workgroup per CU): 256 output pixels (m) x 128 output channels (n),
+// K-step = one tap x 64 input channels.  The operand images of a K-step are copied L2/HBM -> LDS by LDS-DMA (`buffer_load ...
+// lds`, 16 B per lane: no staging registers, no ds_write pass) into rings of stage buffers; the copies of the next one or two
+// K-steps stay in flight across the ONE barrier per K-step (counted `s_waitcnt vmcnt`, raw `s_barrier`).  Out-of-image pixels
+// are out-of-range buffer offsets: the DMA writes zeros (the conv's zero padding).
 //
-// The tap list is data: (dy, dx, filter tap) triples with a source stride and an output stride/offset, so the same kernel
-// runs the stride-1 forward conv and data gradient, the stride-2 forward conv (source stride 2), and the stride-2 data
-// gradient as four parity classes of output pixels, each with only the taps that reach it (1, 2, 2 and 4 of 9: no
-// multiply-by-inserted-zero work).
+// The tap list is data — (dy, dx, filter tap) triples with a source stride and an output stride/offset — so one kernel runs
+// the stride-1 forward conv and data gradient, the stride-2 forward conv (source stride 2: 156/140/222 us on the channel-
+// blocked kernel of conv_wide.hip -> 72/61/47 us), the 1x1 projections, and the stride-2 data gradient as four parity
+// classes of output pixels in one launch (blockIdx.z), each with only the 1, 2, 2 or 4 taps of 9 that reach it instead of
+// multiplying inserted zeros.
+//
+// What was measured on the way (256 tiles of 256x256, 3x3 stride 1, 128 ch @32x32 / 256 @16x16 / 512 @8x8; TFLOP/s forward):
+//   conv_wide.hip (128 px x 64 ch tiles, two workgroups per CU, register prefetch, barrier pair per chunk)      817 / 886 / 735
+//   this kernel, every K-step gathering its own 256 pixel rows (48 KB), copies issued in one burst               715 / 792 / 882
+//     ablations at 512 ch: MFMAs + barrier only 1250-1350 (the ceiling of 32 MFMAs per wave and barrier), with the 16
+//     fragment reads per K-step in two bursts 970, with the six copies per wave as well 850: an LDS-DMA instruction costs
+//     its wave 60-180 cycles of issue, and bursts cost BOTH waves of a SIMD because the barrier keeps them in phase
+//   + halo-resident form (one halo image per 64-channel chunk read at nine row offsets: 20.6 instead of 48 KB per K-step),
+//     fragment reads of the next half K-step and the copies interleaved between the MFMAs (sched_group_barrier)  766 / 902 / 921
+//   two wave groups staggered by one barrier, four barriers per K-step (reads of one group under the MFMAs of the other)
+//     559 / 605 / 654: slower — kept out
+// Data gradients 705/775/709 -> 740/855/888.  MFMA-busy cycles 0.36-0.40 of the CU-busy cycles (profiles/r03_sq_counters_alt).
 //
 // LDS images are [row][64 ch] bf16 with the 16-byte slot index XOR-ed by (row >> 1) & 7: the sixteen lanes of a
 // ds_read_b128 group then fall on sixteen different 16-byte slots of the 256-byte bank row.  LDS-DMA writes lanes linearly,
@@ -52,7 +62,6 @@ struct GConvArgs {
     int apply_relu;
     float slope;
     unsigned x_bytes, w_bytes, y_bytes;
-    int exp_flags;              // MIL_GCONV_EXP (ablation runs): 1 = no pixel-row traffic, 2 = no filter traffic, 4 = no MFMA loop
 };
 
 template <int N>
@@ -398,9 +407,9 @@ static int gconv_launch(GConvArgs a, hipStream_t st) {
     a.tw_log2 = tw; a.th_log2 = th; a.ti_log2 = 8 - tw - th;
     a.tiles_x = (Wg + (1 << tw) - 1) >> tw; a.tiles_y = (Hg + (1 << th) - 1) >> th;
     const int groups = (a.n_img + (1 << a.ti_log2) - 1) >> a.ti_log2;
-    { static const int ef = [] { const char* e = getenv("MIL_GCONV_EXP"); return e ? atoi(e) : 0; }(); a.exp_flags = ef; }
+    static const bool no_halo = [] { const char* e = getenv("MIL_GCONV_NO_HALO"); return e && e[0] == '1'; }();      // A/B runs: per-K-step gather everywhere
     // the canonical 3x3 stride-1 tap list runs on the halo-resident form when two halo images fit beside the filter ring
-    bool canon = a.ncls == 1 && a.ss == 1 && a.os == 1 && a.c_ntaps[0] == 9 && a.ktaps == 9 && !(a.exp_flags & 8);      // MIL_GCONV_EXP=8: A/B runs
+    bool canon = a.ncls == 1 && a.ss == 1 && a.os == 1 && a.c_ntaps[0] == 9 && a.ktaps == 9 && !no_halo;
     for (int t = 0; t < 9 && canon; ++t) canon = a.c_tap[0][t] == (((t / 3 - 1 + 8) << 16) | ((t % 3 - 1 + 8) << 8) | t);
     const int hrows = (((1 << tw) + 2) * ((1 << th) + 2)) << a.ti_log2;
     const int hd = canon ? (hrows + 63) / 64 : 0;

@@ -45,7 +45,12 @@ echo "bf16x3 passes done"
 # the second encoder configuration (alt_resnet.py widths, 256 tiles @256x256 fwd+bwd: the bench's alt_resnet_path step)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/alt_stats -- python3 tools/prof_alt.py 4 > $OUT/alt_stats.log 2>&1
 cp "$(ls $OUT/alt_stats/*/*kernel_stats.csv | head -n 1)" profiles/${ROUND}_alt_kernel_stats.csv
-echo "alt_resnet stats done"
+ALT="python3 tools/prof_alt.py 2"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d $OUT/alt_sq1 -- $ALT > $OUT/alt_sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM --output-format csv -d $OUT/alt_sq2 -- $ALT > $OUT/alt_sq2.log 2>&1
+python3 profiles/summarise_sq_counters.py $OUT/alt_sq1 $OUT/alt_sq2 profiles/sq_counters_alt.json "$ROUND: $ALT" > profiles/${ROUND}_sq_counters_alt.txt
+cp profiles/sq_counters_alt.json profiles/${ROUND}_sq_counters_alt.json
+echo "alt_resnet stats + SQ counters done"
 # the bench lines last: their roofline.traffic / sq_counters fields read the PMC summaries written just above
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench.err
 tail -n 1 $OUT/bench_line.json > profiles/${ROUND}_bench_line.json
