@@ -614,21 +614,31 @@ __global__ __launch_bounds__(512, 1) void gwgrad_kernel(GWgradArgs a) {
     }
 }
 
-// dW[cb*128 + co][ch*64 + ci][tap] (+)= sum over the pair's slabs, fixed order
+// dW[cb*128 + co][ch*64 + ci][tap] (+)= sum over the pair's slabs, fixed order.  One thread owns four consecutive input
+// channels (16-byte slab loads, eight slabs requested ahead of the adds that consume them in slab order).
 __global__ void gwgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int npairs, int nchunks, int kk, float* __restrict__ dw,
                                      int cin, int accumulate) {
     const size_t per_pair = (size_t)kk * GC_BN * GC_BK;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t idx = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (idx >= per_pair * npairs) return;
     const int pair = (int)(idx / per_pair);
     const int e = (int)(idx - (size_t)pair * per_pair);
     const int ci = e & (GC_BK - 1), co = (e / GC_BK) & (GC_BN - 1), tap = e / (GC_BK * GC_BN);
     const int cb = pair / nchunks, ch = pair - cb * nchunks;
     const float* p = slab + (size_t)pair * nslab * per_pair + e;
-    float s = 0.f;
-    for (int i = 0; i < nslab; ++i) s += p[(size_t)i * per_pair];
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+    int i = 0;
+    for (; i + 8 <= nslab; i += 8) {
+        f32x4_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x4_t*>(p + (size_t)(i + k) * per_pair);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; i < nslab; ++i) s += *reinterpret_cast<const f32x4_t*>(p + (size_t)i * per_pair);
     float* q = dw + ((size_t)(cb * GC_BN + co) * cin + ch * GC_BK + ci) * kk + tap;
-    *q = accumulate ? *q + s : s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[(size_t)k * kk] = accumulate ? q[(size_t)k * kk] + s[k] : s[k];
 }
 
 // Internal entry (called from mil_wide_wgrad / mil_wide_wgrad_workspace in conv_wide.hip): bf16, cin % 64 == 0, cout % 128 == 0.
@@ -664,7 +674,7 @@ int mil_gwgrad(const void* x, const void* dz, float* dw, void* ws, size_t ws_byt
     hipLaunchKernelGGL(gwgrad_kernel, dim3(gx, npairs), dim3(512), 3 * GW_STAGE_BYTES, st, a);
     MIL_CHECK_LAUNCH();
     const size_t total = (size_t)kk * GC_BN * GC_BK * npairs;
-    hipLaunchKernelGGL(gwgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)ws, gx, npairs, cin / GC_BK, kk,
+    hipLaunchKernelGGL(gwgrad_reduce_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, gx, npairs, cin / GC_BK, kk,
                        dw, cin, accumulate);
     MIL_CHECK_LAUNCH();
     return MIL_OK;

@@ -689,12 +689,13 @@ __global__ __launch_bounds__(256, 2) void wide_wgrad_pf_kernel(WideWgradArgs<BF1
     }
 }
 
-// dW[cb*64+col][ch*32+ci][tap] (+)= sum over the pair's slabs (fixed order); slab row = tap*32 + ci
+// dW[cb*64+col][ch*32+ci][tap] (+)= sum over the pair's slabs (fixed order); slab row = tap*32 + ci.  One thread owns four
+// consecutive output channels (16-byte slab loads, eight slabs requested ahead of the adds that consume them in slab order).
 __global__ void wide_wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int npairs, int nchunks, int ks,
                                          float* __restrict__ dw, int cout, int cin, int accumulate) {
     const int kk = ks * ks;
     const size_t per_pair = (size_t)kk * WIDE_CK * WIDE_NB;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t idx = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (idx >= per_pair * npairs) return;
     const int pair = (int)(idx / per_pair);
     const int e = (int)(idx - (size_t)pair * per_pair);
@@ -702,10 +703,20 @@ __global__ void wide_wgrad_reduce_kernel(const float* __restrict__ slab, int nsl
     const int tap = row / WIDE_CK, ci = row - tap * WIDE_CK;
     const int cb = pair / nchunks, ch = pair - cb * nchunks;
     const float* p = slab + (size_t)pair * nslab * per_pair + e;
-    float s = 0.f;
-    for (int i = 0; i < nslab; ++i) s += p[(size_t)i * per_pair];
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+    int i = 0;
+    for (; i + 8 <= nslab; i += 8) {
+        f32x4_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x4_t*>(p + (size_t)(i + k) * per_pair);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; i < nslab; ++i) s += *reinterpret_cast<const f32x4_t*>(p + (size_t)i * per_pair);
     float* q = dw + ((size_t)(cb * WIDE_NB + col) * cin + ch * WIDE_CK + ci) * kk + tap;
-    *q = accumulate ? *q + s : s;
+    const size_t cs = (size_t)cin * kk;                       // next output channel
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k * cs] = accumulate ? q[k * cs] + s[k] : s[k];
 }
 
 template <typename T, int KS>
@@ -758,7 +769,7 @@ static int run_wide_wgrad(const void* x, const void* dz, float* dw, void* ws, si
         MIL_CHECK_LAUNCH();
     }
     const size_t total = (size_t)KS * KS * WIDE_CK * WIDE_NB * npairs;
-    hipLaunchKernelGGL(wide_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)ws, gx, npairs,
+    hipLaunchKernelGGL(wide_wgrad_reduce_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, gx, npairs,
                        cin / WIDE_CK, KS, dw, cout, cin, accumulate);
     MIL_CHECK_LAUNCH();
     return MIL_OK;
