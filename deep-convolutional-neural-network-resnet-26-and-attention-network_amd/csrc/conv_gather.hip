@@ -83,13 +83,21 @@ __device__ __forceinline__ void gc_wait_vm_n(int n) {       // n = 0..6, wave-un
 //         K-step s: two K-steps to land), HD = 7 (8x8 pixels of four images) for three.
 // The loop bodies are branch-free — copies that would run past the end get an out-of-range offset and land as zeros in a slot
 // nobody reads again — so that reads, copies and MFMAs of a K-step sit in ONE basic block and can be interleaved.
-template <int HD>
-__global__ __launch_bounds__(512, 1) void gconv_kernel(GConvArgs a) {
+// NW = waves per workgroup (8 or 16; one workgroup per CU either way).  A bare loop of 16x16x32 bf16 MFMAs on random operands
+// with one barrier per 32 MFMAs per wave runs at 1.56 PFLOP/s with two waves per SIMD and at 1.83 with four (no barrier: 1.79 /
+// 1.81; one wave per SIMD: 1.13): with sixteen waves the wave tile is 64 pixels x 32 channels (16 MFMAs, 12 fragment reads and
+// at most 2 copies per wave and K-step) and the scheduler has four waves per SIMD to cover reads, copies and barriers with.
+// Measured in this kernel: 722/798/889 TFLOP/s forward with sixteen waves against 749/866/926 with eight (stride-2 shapes equal):
+// the barrier structure is not what holds it, eight stays the default (MIL_GCONV_WAVES=16 for A/B runs).
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void gconv_kernel(GConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MIL_POISON(smem);
+    constexpr int NTW = 32 / NW;                             // 16-channel tiles per wave: 4 (wave tile 64 x 64) or 2 (64 x 32)
+    constexpr int NBP = 16 / NW;                             // 1 KB pieces of a filter image per wave: 2 or 1
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, gq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 3, wn = wave >> 2;                 // wave grid: 4 (pixels) x 2 (channels); wave tile 64 x 64
+    const int wm = wave & 3, wn = wave >> 2;                 // wave grid: 4 (pixels) x NW/4 (channels)
     const int nb = blockIdx.y, cls = blockIdx.z;
     const int nchunks = a.cin / GC_BK;
     const int ntaps = a.c_ntaps[cls], Hg = a.c_hg[cls], Wg = a.c_wg[cls], oy_off = a.c_oy[cls], ox_off = a.c_ox[cls];
@@ -107,38 +115,39 @@ __global__ __launch_bounds__(512, 1) void gconv_kernel(GConvArgs a) {
     const int row_bytes = a.cin * 2;
     const int b_voff = lane * 16;
 
-    f32x4_t acc[4][4];                                       // [channel tile][pixel tile]: D rows = channels, columns = pixels
+    f32x4_t acc[NTW][4];                                     // [channel tile][pixel tile]: D rows = channels, columns = pixels
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // ---- K-step schedule --------------------------------------------------------------------------------------------------
-    // Two fragment sets (the k32 halves of a K-step).  While the 16 MFMAs of one half run, the 8 fragment reads of the next
-    // half — the second half of this K-step, then the first half of the NEXT one, whose stage landed a K-step early — are
-    // issued between them, one read per two MFMAs (sched_group_barrier pins that interleave: a read in an MFMA's shadow costs
-    // the wave a few cycles, eight reads in a row in front of the MFMAs cost both waves of the SIMD the whole burst, because
-    // the barrier keeps them in the same phase).  The K-step's copies go out the same way.
-    struct Half { bf16x8_t w[4], x[4]; };
+    // Two fragment sets (the k32 halves of a K-step).  While the MFMAs of one half run, the fragment reads of the next half —
+    // the second half of this K-step, then the first half of the NEXT one, whose stage landed a K-step early — are issued
+    // between them (sched_group_barrier pins that interleave: a read in an MFMA's shadow costs the wave a few cycles, a burst
+    // of reads in front of the MFMAs costs every wave of the SIMD the whole burst, because the barrier keeps them in the same
+    // phase).  The K-step's copies go out the same way.
+    struct Half { bf16x8_t w[NTW], x[4]; };
     const int swq = gq ^ (r >> 1);                               // filter rows: (row >> 1) & 7 == r >> 1
     auto read_w = [&](Half& h, const char* lb, int k32) {
-        const char* wb = lb + (wn * 64 + r) * 128 + ((swq ^ (k32 * 4)) * 16);
+        const char* wb = lb + (wn * (NTW * 16) + r) * 128 + ((swq ^ (k32 * 4)) * 16);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) h.w[nt] = *reinterpret_cast<const bf16x8_t*>(wb + nt * 2048);
+        for (int nt = 0; nt < NTW; ++nt) h.w[nt] = *reinterpret_cast<const bf16x8_t*>(wb + nt * 2048);
     };
-    auto mfma16 = [&](const Half& h) {
+    auto mfma_half = [&](const Half& h) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
                 acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h.w[nt], h.x[mt], acc[nt][mt], 0, 0, 0);
     };
-    // the schedule of one half: nv copies and 8 reads spread over 16 MFMAs
+    // the schedule of one half: nv copies and NTW + 4 reads spread over NTW * 4 MFMAs
     auto pin_half = [&](int nv) {
 #ifndef GC_NO_PIN
+        constexpr int NR = NTW + 4, MPR = (NTW * 4) / NR;       // reads, MFMAs per read: 8 / 2 or 6 / 1
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);       // 2 MFMA
+        for (int i = 0; i < NR; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);     // MFMA
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // 1 DS read
             if (i < nv) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read (LDS-DMA copy)
         }
@@ -147,11 +156,12 @@ __global__ __launch_bounds__(512, 1) void gconv_kernel(GConvArgs a) {
     Half f0, f1;
 
     if constexpr (HD == 0) {
-        // ---- this lane's four pixel rows of every A image: row = wave*32 + i*8 + lane/8, slot = lane%8 -------------
-        int a_base[4], a_pos[4];
+        // ---- this lane's pixel rows of every A image: piece q = wave*NAP + i covers rows q*8 .. q*8+7, slot = lane%8 -----------
+        constexpr int NAP = 32 / NW;                             // 1 KB pieces of the pixel image per wave: 4 or 2
+        int a_base[NAP], a_pos[NAP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = wave * 32 + i * 8 + (lane >> 3);
+        for (int i = 0; i < NAP; ++i) {
+            const int m = (wave * NAP + i) * 8 + (lane >> 3);
             const int gx = gx0 + (m & tw_mask), gy = gy0 + ((m >> a.tw_log2) & th_mask), img = img0 + (m >> (a.tw_log2 + a.th_log2));
             const bool ok = img < a.n_img && gy < Hg && gx < Wg;
             const int sy = gy * a.ss, sx = gx * a.ss;
@@ -162,24 +172,25 @@ __global__ __launch_bounds__(512, 1) void gconv_kernel(GConvArgs a) {
         // the tap list lives in lanes 0..8 of one register (v_readlane by the wave-uniform tap index): a table look-up in memory
         // would be a scalar load, whose counter the fragment reads share
         const int tap_tab = a.c_tap[cls][lane < ntaps ? lane : 0];
-        // copies d0..d1-1 of the six of stage (tap t, chunk c) into ring buffer `buf`: four pixel-row pieces, two filter pieces;
+        // copies d0..d1-1 of the NAP + NBP of stage (tap t, chunk c) into ring buffer `buf`: pixel-row pieces, then filter pieces;
         // !live: out-of-range offsets (zeros land in a buffer nobody reads again)
+        constexpr int ND = NAP + NBP;
         auto issue = [&](int t, int c, bool live, int buf, int d0, int d1) {
             const int tp = __builtin_amdgcn_readlane(tap_tab, t < ntaps ? t : 0);
             const int dy = (tp >> 16) - 8, dx = ((tp >> 8) & 0xFF) - 8, tw = tp & 0xFF;
             const int delta = (dy * a.Ws + dx) * row_bytes + c * (GC_BK * 2);
-            const int img_off = ((nb * a.ktaps + tw) * nchunks + c) * GC_B_BYTES + wave * 2048;
+            const int img_off = ((nb * a.ktaps + tw) * nchunks + c) * GC_B_BYTES + wave * (NBP * 1024);
 #pragma unroll
-            for (int d = 0; d < 6; ++d) {
+            for (int d = 0; d < ND; ++d) {
                 if (d < d0 || d >= d1) continue;
-                if (d < 4) {
+                if (d < NAP) {
                     const int sy = (a_pos[d] >> 16) + dy, sx = (a_pos[d] & 0xFFFF) + dx;
                     const bool ok = live && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, GC_LDS_PTR(smem + buf * GC_STAGE_BYTES + wave * 4096 + d * 1024), 16,
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, GC_LDS_PTR(smem + buf * GC_STAGE_BYTES + (wave * NAP + d) * 1024), 16,
                                                              ok ? (unsigned)(a_base[d] + delta) : MIL_OOB, 0, 0, 0);
                 } else
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, GC_LDS_PTR(smem + buf * GC_STAGE_BYTES + GC_A_BYTES + wave * 2048 + (d - 4) * 1024), 16,
-                                                             live ? (unsigned)b_voff : MIL_OOB, live ? img_off + (d - 4) * 1024 : 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, GC_LDS_PTR(smem + buf * GC_STAGE_BYTES + GC_A_BYTES + (wave * NBP + d - NAP) * 1024), 16,
+                                                             live ? (unsigned)b_voff : MIL_OOB, live ? img_off + (d - NAP) * 1024 : 0, 0, 0);
             }
         };
         auto read_half = [&](Half& h, int buf, int k32) {
@@ -190,11 +201,11 @@ __global__ __launch_bounds__(512, 1) void gconv_kernel(GConvArgs a) {
             for (int mt = 0; mt < 4; ++mt) h.x[mt] = *reinterpret_cast<const bf16x8_t*>(xb + mt * 2048);
         };
         // K-step s = tap s / nchunks, chunk s % nchunks; (ti, ci) walks two K-steps ahead
-        issue(0, 0, KT > 0, 0, 0, 6);
+        issue(0, 0, KT > 0, 0, 0, ND);
         int ti = nchunks > 1 ? 0 : 1, ci = nchunks > 1 ? 1 : 0;
-        issue(ti, ci, KT > 1, 1, 0, 6);
+        issue(ti, ci, KT > 1, 1, 0, ND);
         if (++ci == nchunks) { ci = 0; ++ti; }
-        gc_wait_vm<6>();                                         // stage 0 landed
+        gc_wait_vm<ND>();                                        // stage 0 landed
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         read_half(f0, 0, 0);
@@ -205,15 +216,15 @@ __global__ __launch_bounds__(512, 1) void gconv_kernel(GConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             const int nxt = buf == 2 ? 0 : buf + 1, prv = buf == 0 ? 2 : buf - 1;
             const bool live = s + 2 < KT;
-            issue(ti, ci, live, prv, 0, 3);
+            issue(ti, ci, live, prv, 0, ND / 2);
             read_half(f1, buf, 1);
-            mfma16(f0);
-            pin_half(3);
+            mfma_half(f0);
+            pin_half(ND / 2);
             __builtin_amdgcn_sched_barrier(0);
-            issue(ti, ci, live, prv, 3, 6);
+            issue(ti, ci, live, prv, ND / 2, ND);
             read_half(f0, nxt, 0);
-            mfma16(f1);
-            pin_half(3);
+            mfma_half(f1);
+            pin_half(ND - ND / 2);
             __builtin_amdgcn_sched_barrier(0);
             buf = nxt;
             if (++ci == nchunks) { ci = 0; ++ti; }
@@ -223,31 +234,33 @@ __global__ __launch_bounds__(512, 1) void gconv_kernel(GConvArgs a) {
         // ---- halo images: [2][HD * 64 rows][128 B], then the filter ring [RS][16 KB] ----------------------------------
         constexpr int RS = HD <= 6 ? 4 : 3;
         constexpr int hbytes = HD * 8192;
+        constexpr int HP = HD * 8;                               // 1 KB pieces (8 rows) of a halo image
+        constexpr int NHP = (HP + NW - 1) / NW;                  // ... per wave: piece j*NW + wave for j < NHP
         char* ring = smem + 2 * hbytes;
         const int hw = (1 << a.tw_log2) + 2, hh = (1 << a.th_log2) + 2;
-        // this lane's halo rows: piece j covers rows (j*8 + wave)*8 + lane/8
-        int h_off[HD];
+        int h_off[NHP];
 #pragma unroll
-        for (int j = 0; j < HD; ++j) {
-            const int hr = (j * 8 + wave) * 8 + (lane >> 3);
+        for (int j = 0; j < NHP; ++j) {
+            const int hr = (j * NW + wave) * 8 + (lane >> 3);
             const int ti = hr / (hh * hw), rem = hr - ti * (hh * hw), hy = rem / hw, hx = rem - hy * hw;
             const int img = img0 + ti, sy = gy0 - 1 + hy, sx = gx0 - 1 + hx;
             const bool ok = (ti >> a.ti_log2) == 0 && img < a.n_img && (unsigned)sy < (unsigned)a.Hs && (unsigned)sx < (unsigned)a.Ws;
             const int slot = (lane & 7) ^ ((hr >> 1) & 7);
             h_off[j] = ok ? ((img * a.Hs + sy) * a.Ws + sx) * row_bytes + slot * 16 : (int)MIL_OOB;
         }
-        auto issue_halo = [&](int c, int j) {                    // piece j of chunk c's halo
+        auto piece_exists = [&](int j) { return j * NW + wave < HP; };      // wave-uniform (HD 7, sixteen waves: the last round is half empty)
+        auto issue_halo = [&](int c, int j) {                    // piece j of this wave of chunk c's halo
             int off = h_off[0];                                  // a select chain the optimiser may not turn into a scratch array (its loads
 #pragma unroll                                                  // would count on vmcnt)
-            for (int q = 1; q < HD; ++q) { off = j == q ? h_off[q] : off; asm volatile("" : "+v"(off)); }
+            for (int q = 1; q < NHP; ++q) { off = j == q ? h_off[q] : off; asm volatile("" : "+v"(off)); }
             const unsigned o = off == (int)MIL_OOB ? MIL_OOB : (unsigned)(off + c * (GC_BK * 2));
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, GC_LDS_PTR(smem + (c & 1) * hbytes + (j * 8 + wave) * 1024), 16, o, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, GC_LDS_PTR(smem + (c & 1) * hbytes + (j * NW + wave) * 1024), 16, o, 0, 0, 0);
         };
         // the canonical list: tap t = (t/3 - 1, t%3 - 1), filter tap t
-        auto issue_b = [&](int c, int t, int slot, int j) {      // half j of the filter image of chunk c, tap t; past the end: zeros
+        auto issue_b = [&](int c, int t, int slot, int j) {      // piece j of this wave of the filter image of chunk c, tap t; past the end: zeros
             const bool live = c < nchunks;
-            const int img_off = ((nb * 9 + t) * nchunks + c) * GC_B_BYTES + wave * 2048 + j * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, GC_LDS_PTR(ring + slot * GC_B_BYTES + wave * 2048 + j * 1024), 16,
+            const int img_off = ((nb * 9 + t) * nchunks + c) * GC_B_BYTES + (wave * NBP + j) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, GC_LDS_PTR(ring + slot * GC_B_BYTES + (wave * NBP + j) * 1024), 16,
                                                      live ? (unsigned)b_voff : MIL_OOB, live ? img_off : 0, 0, 0);
         };
         // pixel fragments: halo row of tile pixel m at tap (0,0) = ti*hh*hw + ty*hw + tx, + the tap's row offset; the slot
@@ -268,10 +281,13 @@ __global__ __launch_bounds__(512, 1) void gconv_kernel(GConvArgs a) {
             }
         };
 #pragma unroll
-        for (int j = 0; j < HD; ++j) issue_halo(0, j);
+        for (int j = 0; j < NHP; ++j)
+            if (piece_exists(j)) issue_halo(0, j);
 #pragma unroll
-        for (int st = 0; st < RS - 1; ++st) { issue_b(0, st, st, 0); issue_b(0, st, st, 1); }      // nine taps per chunk >= RS - 1
-        gc_wait_vm<2 * (RS - 2)>();                              // filter image 0 and, older, the first halo have landed
+        for (int st = 0; st < RS - 1; ++st)
+#pragma unroll
+            for (int j = 0; j < NBP; ++j) issue_b(0, st, st, j);      // nine taps per chunk >= RS - 1
+        gc_wait_vm<NBP * (RS - 2)>();                            // filter image 0 and, older, the first halo have landed
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         read_half(f0, 0, 0, 0, 0);
@@ -281,7 +297,7 @@ __global__ __launch_bounds__(512, 1) void gconv_kernel(GConvArgs a) {
         for (int s = 0; s < KT; ++s) {
             // Filter image s+1 has landed (and, older than it, the next chunk's halo when s+1 starts a chunk): the copies
             // requested after it — the previous K-step's halo piece and, RS == 4, filter image s+2 — may still be in flight
-            if constexpr (RS == 4) { if (prev_h) gc_wait_vm<3>(); else gc_wait_vm<2>(); }
+            if constexpr (RS == 4) { if (prev_h) gc_wait_vm<NBP + 1>(); else gc_wait_vm<NBP>(); }
             else gc_wait_vm<0>();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -291,18 +307,18 @@ __global__ __launch_bounds__(512, 1) void gconv_kernel(GConvArgs a) {
             int tn = t + 1, kxn = kx + 1, toffn = toff + 1, cn = c;
             if (kxn == 3) { kxn = 0; toffn += hw - 3; }
             if (tn == 9) { tn = 0; toffn = 0; ++cn; }
-            prev_h = t < HD && c + 1 < nchunks;
+            prev_h = t < NHP && piece_exists(t) && c + 1 < nchunks;
             if (prev_h) issue_halo(c + 1, t);
             __builtin_amdgcn_sched_barrier(0);
             issue_b(cb, tb, islot, 0);
             read_half(f1, c, toff, slot, 1);
-            mfma16(f0);
+            mfma_half(f0);
             pin_half(1);
             __builtin_amdgcn_sched_barrier(0);
-            issue_b(cb, tb, islot, 1);
+            if constexpr (NBP == 2) issue_b(cb, tb, islot, 1);
             read_half(f0, cn, toffn, nslot, 0);
-            mfma16(f1);
-            pin_half(1);
+            mfma_half(f1);
+            pin_half(NBP == 2 ? 1 : 0);
             __builtin_amdgcn_sched_barrier(0);
             slot = nslot; t = tn; kx = kxn; toff = toffn; c = cn;
             if (++tb == 9) { tb = 0; ++cb; }
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(512, 1) void gconv_kernel(GConvArgs a) {
     const __amdgpu_buffer_rsrc_t rs_y = mil_rsrc(a.y, a.y_bytes);
     const __amdgpu_buffer_rsrc_t rs_r = mil_rsrc(a.res, a.res ? a.y_bytes : 0);
     const __amdgpu_buffer_rsrc_t rs_a = mil_rsrc(a.act, a.act ? a.y_bytes : 0);
-    const int cbase = (nb * GC_BN + wn * 64 + gq * 4) * 2;
+    const int cbase = (nb * GC_BN + wn * (NTW * 16) + gq * 4) * 2;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int m = wm * 64 + mt * 16 + r;
@@ -322,7 +338,7 @@ __global__ __launch_bounds__(512, 1) void gconv_kernel(GConvArgs a) {
         const bool ok = img < a.n_img && gy < Hg && gx < Wg;
         const unsigned poff = ok ? (unsigned)(((img * a.Hout + gy * a.os + oy_off) * a.Wout + gx * a.os + ox_off) * (a.cout * 2) + cbase) : MIL_OOB;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < NTW; ++nt) {
             const unsigned off = ok ? poff + nt * 32 : MIL_OOB;
             float v[4];
 #pragma unroll
@@ -413,18 +429,27 @@ static int gconv_launch(GConvArgs a, hipStream_t st) {
     for (int t = 0; t < 9 && canon; ++t) canon = a.c_tap[0][t] == (((t / 3 - 1 + 8) << 16) | ((t % 3 - 1 + 8) << 8) | t);
     const int hrows = (((1 << tw) + 2) * ((1 << th) + 2)) << a.ti_log2;
     const int hd = canon ? (hrows + 63) / 64 : 0;
+    static const int nw = [] { const char* e = getenv("MIL_GCONV_WAVES"); return e && atoi(e) == 16 ? 16 : 8; }();      // A/B runs
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gconv_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, GC_LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(gconv_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(gconv_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return MIL_ERR_LAUNCH;
+        const void* ks[6] = {reinterpret_cast<const void*>(gconv_kernel<0, 8>), reinterpret_cast<const void*>(gconv_kernel<6, 8>),
+                             reinterpret_cast<const void*>(gconv_kernel<7, 8>), reinterpret_cast<const void*>(gconv_kernel<0, 16>),
+                             reinterpret_cast<const void*>(gconv_kernel<6, 16>), reinterpret_cast<const void*>(gconv_kernel<7, 16>)};
+        for (const void* k : ks)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MIL_ERR_LAUNCH;
         attr_set = true;
     }
     const dim3 grid(groups * a.tiles_y * a.tiles_x, a.cout / GC_BN, a.ncls);
-    if (hd > 0 && hd <= 6) hipLaunchKernelGGL(gconv_kernel<6>, grid, dim3(512), 2 * 6 * 8192 + 4 * GC_B_BYTES, st, a);
-    else if (hd == 7) hipLaunchKernelGGL(gconv_kernel<7>, grid, dim3(512), 2 * 7 * 8192 + 3 * GC_B_BYTES, st, a);
-    else hipLaunchKernelGGL(gconv_kernel<0>, grid, dim3(512), GC_LDS_BYTES, st, a);
+    const int lds = hd > 0 && hd <= 6 ? 2 * 6 * 8192 + 4 * GC_B_BYTES : (hd == 7 ? 2 * 7 * 8192 + 3 * GC_B_BYTES : GC_LDS_BYTES);
+    if (nw == 16) {
+        if (hd > 0 && hd <= 6) hipLaunchKernelGGL((gconv_kernel<6, 16>), grid, dim3(1024), lds, st, a);
+        else if (hd == 7) hipLaunchKernelGGL((gconv_kernel<7, 16>), grid, dim3(1024), lds, st, a);
+        else hipLaunchKernelGGL((gconv_kernel<0, 16>), grid, dim3(1024), lds, st, a);
+    } else {
+        if (hd > 0 && hd <= 6) hipLaunchKernelGGL((gconv_kernel<6, 8>), grid, dim3(512), lds, st, a);
+        else if (hd == 7) hipLaunchKernelGGL((gconv_kernel<7, 8>), grid, dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((gconv_kernel<0, 8>), grid, dim3(512), lds, st, a);
+    }
     MIL_CHECK_LAUNCH();
     return MIL_OK;
 }
