@@ -1,4 +1,4 @@
-// scratch: bare MFMA loops, 8 waves per workgroup, one workgroup per CU: what does a barrier per N MFMAs cost?
+// Probe (not product code): bare 16x16x32 bf16 MFMA loops, one workgroup per CU, 4 / 8 / 16 waves: what does a workgroup barrier every N MFMAs cost?
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
