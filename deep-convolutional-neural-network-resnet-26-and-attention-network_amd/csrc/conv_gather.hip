@@ -31,6 +31,7 @@
 // so the swizzle is applied to the SOURCE address (pixel rows) or baked into the packed filter images.
 #include "pf_common.cuh"
 #include <cstdlib>
+#include <type_traits>
 
 #define GC_BM 256
 #define GC_BN 128
@@ -291,38 +292,97 @@ __global__ __launch_bounds__(64 * NW, 1) void gconv_kernel(GConvArgs a) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         read_half(f0, 0, 0, 0, 0);
+#ifndef GC_UNROLL_TAPS
+#define GC_UNROLL_TAPS 1
+#endif
+        if constexpr (NW == 8 && GC_UNROLL_TAPS) {
+            // The nine taps of a chunk unrolled, with the 36 swizzled fragment offsets of this lane (tap x pixel tile) computed
+            // once: the loop form spends ~45 of its ~65 vector instructions per K-step beside the 32 MFMAs on that arithmetic.
+            // Tap-dependent decisions (which K-steps carry a halo piece, the counted waits) become compile-time.
+            int xoff[9][4];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int row = prow[mt] + (t / 3) * hw + (t % 3);
+                    xoff[t][mt] = row * 128 + ((((row >> 1) & 7) ^ gq) * 16);
+                }
+            auto read_half_u = [&](Half& h, int hb, int t, int slot, int k32) {      // t: compile-time; hb: halo buffer offset
+                read_w(h, ring + slot * GC_B_BYTES, k32);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) h.x[mt] = *reinterpret_cast<const bf16x8_t*>(smem + hb + (xoff[t][mt] ^ (k32 * 64)));
+            };
+            auto issue_halo_u = [&](int c, int j) {                // j: compile-time; past the last chunk: zeros into the idle buffer
+                const unsigned o = (h_off[j] == (int)MIL_OOB || c >= nchunks) ? MIL_OOB : (unsigned)(h_off[j] + c * (GC_BK * 2));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, GC_LDS_PTR(smem + (c & 1) * hbytes + (j * NW + wave) * 1024), 16, o, 0, 0, 0);
+            };
+            // one chunk = nine K-steps; PAR = the chunk's halo buffer (compile-time, so the buffer offset folds into the
+            // ds_read immediates)
+            auto chunk = [&](int c, auto par) {
+                constexpr int PAR = decltype(par)::value;
+                constexpr int hb = PAR * hbytes, hbn = hbytes - hb;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    // K-step s = 9c + t in ring slot s % RS (9 = 1 mod 4, 0 mod 3)
+                    const int slot = RS == 4 ? ((c + t) & 3) : (t % 3);
+                    const int nslot = RS == 4 ? ((c + t + 1) & 3) : ((t + 1) % 3);
+                    const int islot = RS == 4 ? ((c + t + 3) & 3) : ((t + 2) % 3);      // the slot K-step s-1 read
+                    if constexpr (RS == 4) { if (t >= 1 && t - 1 < NHP) gc_wait_vm<NBP + 1>(); else gc_wait_vm<NBP>(); }
+                    else gc_wait_vm<0>();
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int tb = (t + RS - 1) % 9, cb = c + (t + RS - 1) / 9;         // filter image s + RS - 1
+                    if (t < NHP) issue_halo_u(c + 1, t);
+                    issue_b(cb, tb, islot, 0);
+                    read_half_u(f1, hb, t, slot, 1);
+                    mfma_half(f0);
+                    pin_half(t < NHP ? 2 : 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_b(cb, tb, islot, 1);
+                    read_half_u(f0, t == 8 ? hbn : hb, t == 8 ? 0 : t + 1, nslot, 0);
+                    mfma_half(f1);
+                    pin_half(1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            for (int c = 0; c < nchunks; c += 2) {
+                chunk(c, std::integral_constant<int, 0>{});
+                if (c + 1 < nchunks) chunk(c + 1, std::integral_constant<int, 1>{});
+            }
+        } else {
         int slot = 0, c = 0, t = 0, kx = 0, toff = 0;            // K-step s = 9c + t; toff = (t/3)*hw + t%3
-        int cb = 0, tb = RS - 1;                                 // filter image s + RS - 1
-        bool prev_h = false;
-        for (int s = 0; s < KT; ++s) {
-            // Filter image s+1 has landed (and, older than it, the next chunk's halo when s+1 starts a chunk): the copies
-            // requested after it — the previous K-step's halo piece and, RS == 4, filter image s+2 — may still be in flight
-            if constexpr (RS == 4) { if (prev_h) gc_wait_vm<NBP + 1>(); else gc_wait_vm<NBP>(); }
-            else gc_wait_vm<0>();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            int nslot = slot + 1; if (nslot == RS) nslot = 0;
-            int islot = slot - 1; if (islot < 0) islot = RS - 1;        // the slot K-step s-1 read
-            // the next K-step: tap, row offset, chunk
-            int tn = t + 1, kxn = kx + 1, toffn = toff + 1, cn = c;
-            if (kxn == 3) { kxn = 0; toffn += hw - 3; }
-            if (tn == 9) { tn = 0; toffn = 0; ++cn; }
-            prev_h = t < NHP && piece_exists(t) && c + 1 < nchunks;
-            if (prev_h) issue_halo(c + 1, t);
-            __builtin_amdgcn_sched_barrier(0);
-            issue_b(cb, tb, islot, 0);
-            read_half(f1, c, toff, slot, 1);
-            mfma_half(f0);
-            pin_half(1);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (NBP == 2) issue_b(cb, tb, islot, 1);
-            read_half(f0, cn, toffn, nslot, 0);
-            mfma_half(f1);
-            pin_half(NBP == 2 ? 1 : 0);
-            __builtin_amdgcn_sched_barrier(0);
-            slot = nslot; t = tn; kx = kxn; toff = toffn; c = cn;
-            if (++tb == 9) { tb = 0; ++cb; }
-        }
+            int cb = 0, tb = RS - 1;                                 // filter image s + RS - 1
+            bool prev_h = false;
+            for (int s = 0; s < KT; ++s) {
+                // Filter image s+1 has landed (and, older than it, the next chunk's halo when s+1 starts a chunk): the copies
+                // requested after it — the previous K-step's halo piece and, RS == 4, filter image s+2 — may still be in flight
+                if constexpr (RS == 4) { if (prev_h) gc_wait_vm<NBP + 1>(); else gc_wait_vm<NBP>(); }
+                else gc_wait_vm<0>();
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                int nslot = slot + 1; if (nslot == RS) nslot = 0;
+                int islot = slot - 1; if (islot < 0) islot = RS - 1;        // the slot K-step s-1 read
+                // the next K-step: tap, row offset, chunk
+                int tn = t + 1, kxn = kx + 1, toffn = toff + 1, cn = c;
+                if (kxn == 3) { kxn = 0; toffn += hw - 3; }
+                if (tn == 9) { tn = 0; toffn = 0; ++cn; }
+                prev_h = t < NHP && piece_exists(t) && c + 1 < nchunks;
+                if (prev_h) issue_halo(c + 1, t);
+                __builtin_amdgcn_sched_barrier(0);
+                issue_b(cb, tb, islot, 0);
+                read_half(f1, c, toff, slot, 1);
+                mfma_half(f0);
+                pin_half(1);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (NBP == 2) issue_b(cb, tb, islot, 1);
+                read_half(f0, cn, toffn, nslot, 0);
+                mfma_half(f1);
+                pin_half(NBP == 2 ? 1 : 0);
+                __builtin_amdgcn_sched_barrier(0);
+                slot = nslot; t = tn; kx = kxn; toff = toffn; c = cn;
+                if (++tb == 9) { tb = 0; ++cb; }
+            }
+    }
         gc_wait_vm<0>();
     }
 
