@@ -23,8 +23,11 @@
 //   + halo-resident form (one halo image per 64-channel chunk read at nine row offsets: 20.6 instead of 48 KB per K-step),
 //     fragment reads of the next half K-step and the copies interleaved between the MFMAs (sched_group_barrier)  766 / 902 / 921
 //   two wave groups staggered by one barrier, four barriers per K-step (reads of one group under the MFMAs of the other)
-//     559 / 605 / 654: slower — kept out
-// Data gradients 705/775/709 -> 740/855/888.  MFMA-busy cycles 0.36-0.40 of the CU-busy cycles (profiles/r03_sq_counters_alt).
+//     559 / 605 / 654: slower — kept out; sixteen waves per workgroup (64 x 32 wave tiles): 722 / 798 / 889 — kept as an A/B knob
+//   + the nine taps of a chunk unrolled, the 36 swizzled fragment offsets of a lane precomputed, chunk pairs unrolled so the
+//     halo buffer offset is a ds_read immediate (the loop form spent ~45 of its ~65 vector instructions per K-step beside
+//     the 32 MFMAs on that address arithmetic: the kernel was instruction-issue-bound)                               913 / 1061 / 1063
+// Data gradients 705/775/709 -> 845/1118/1112.  MFMA-busy cycles of the CU-busy cycles: profiles/r03_sq_counters_alt.txt.
 //
 // LDS images are [row][64 ch] bf16 with the 16-byte slot index XOR-ed by (row >> 1) & 7: the sixteen lanes of a
 // ds_read_b128 group then fall on sixteen different 16-byte slots of the 256-byte bank row.  LDS-DMA writes lanes linearly,
