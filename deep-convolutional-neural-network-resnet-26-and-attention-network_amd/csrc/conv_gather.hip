@@ -526,10 +526,23 @@ extern "C" int mil_gconv(const void* x, const void* wpack, const void* res, cons
                          void* stream) {
     if (!x || !wpack || !y || n_img < 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return MIL_ERR_ARG;
     if (!mil_gconv_supported(cin, cout, ks, stride) || pad != ks / 2) return MIL_ERR_UNSUPPORTED;
-    const size_t xb = (size_t)n_img * H * W * cin * 2, yb = (size_t)n_img * Ho * Wo * cout * 2;
+    const size_t x_img = (size_t)H * W * cin * 2, y_img = (size_t)Ho * Wo * cout * 2;
     const size_t wb = (size_t)cin * cout * ks * ks * 2;
-    if (xb >= ((size_t)1 << 31) || yb >= ((size_t)1 << 31) || H >= 0x4000 || W >= 0x4000) return MIL_ERR_UNSUPPORTED;
+    if (x_img >= mil_buffer_limit() || y_img >= mil_buffer_limit() || H >= 0x4000 || W >= 0x4000) return MIL_ERR_UNSUPPORTED;
     if (n_img == 0) return MIL_OK;
+    // every tensor is addressed with 32-bit offsets through a buffer descriptor: launches above its 2 GiB reach walk image chunks
+    const int chunk = mil_imgs_under_2g(x_img > y_img ? x_img : y_img);
+    if (n_img > chunk) {
+        for (int i0 = 0; i0 < n_img; i0 += chunk) {
+            const int n = n_img - i0 < chunk ? n_img - i0 : chunk;
+            const int rc = mil_gconv(static_cast<const char*>(x) + i0 * x_img, wpack, res ? static_cast<const char*>(res) + i0 * y_img : nullptr,
+                                     act ? static_cast<const char*>(act) + i0 * y_img : nullptr, static_cast<char*>(y) + i0 * y_img, n, H, W, cin, Ho,
+                                     Wo, cout, ks, stride, pad, transposed, apply_relu, slope, stream);
+            if (rc != MIL_OK) return rc;
+        }
+        return MIL_OK;
+    }
+    const size_t xb = n_img * x_img, yb = n_img * y_img;
     GConvArgs a{};
     a.x = (const __bf16*)x; a.w = (const __bf16*)wpack; a.res = (const __bf16*)res; a.act = (const __bf16*)act; a.y = (__bf16*)y;
     a.n_img = n_img; a.Hs = H; a.Ws = W; a.cin = cin; a.Hout = Ho; a.Wout = Wo; a.cout = cout;
@@ -735,7 +748,7 @@ int mil_gwgrad(const void* x, const void* dz, float* dw, void* ws, size_t ws_byt
                int cout, int ks, int stride, int pad, int accumulate, bool query, size_t* need, hipStream_t st) {
     if (cin % GC_BK || cout % GC_BN || !(ks == 1 || ks == 3) || !(stride == 1 || stride == 2) || pad != ks / 2) return MIL_ERR_UNSUPPORTED;
     const size_t xb = (size_t)n_img * H * W * cin * 2, zb = (size_t)n_img * Ho * Wo * cout * 2;
-    if (xb >= ((size_t)1 << 31) || zb >= ((size_t)1 << 31)) return MIL_ERR_UNSUPPORTED;
+    if (xb >= mil_buffer_limit() || zb >= mil_buffer_limit()) return MIL_ERR_UNSUPPORTED;      // the caller's kernels address with 64 bits
     const int kk = ks * ks, npairs = (cout / GC_BN) * (cin / GC_BK);
     const long Q = (long)n_img * Ho * Wo;
     const int nstages = (int)((Q + GW_P - 1) / GW_P);

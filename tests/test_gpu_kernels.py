@@ -374,6 +374,30 @@ def test_wide_conv_forward_dgrad_wgrad(ops, dtype, case):
     assert torch.equal(dw, dw2)
 
 
+def test_gather_gemm_launches_chunked_under_the_buffer_limit(ops, monkeypatch):
+    """mil_gconv addresses its tensors with 32-bit offsets: a launch above the 2 GiB reach of a buffer descriptor is walked in
+    image chunks (MIL_BUFFER_LIMIT_BYTES lowers the limit: 7 images as 3 + 3 + 1) and must give the bits of the single launch —
+    forward with residual, and the stride-2 data gradient; the gather-form weight gradient falls back to the 64-bit kernels."""
+    L = _lib()
+    dtype = torch.bfloat16
+    n, cin, cout, h, w = 7, 128, 256, 12, 12
+    g = torch.Generator().manual_seed(5)
+    x = to_nhwc(torch.randn(n, cin, h, w, generator=g), dtype)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).cuda()
+    res = to_nhwc(torch.randn(n, cout, h // 2, w // 2, generator=g), dtype)
+    dz = to_nhwc(torch.randn(n, cout, h // 2, w // 2, generator=g), dtype)
+    wp, wd = ops.gconv_pack_weights(wt, L.PACK_FWD), ops.gconv_pack_weights(wt, L.PACK_DGRAD)
+    y_one = ops.gconv(x, wp, cout, ks=3, stride=2, pad=1, res=res, relu=True)
+    dx_one = ops.gconv(dz, wd, cin, ks=3, stride=2, pad=1, transposed=True, out_hw=(h, w))
+    dw_one, _ = ops.wide_wgrad(x, dz, cin, cout, ks=3, stride=2, pad=1)
+    monkeypatch.setenv("MIL_BUFFER_LIMIT_BYTES", str(3 * h * w * cin * 2 + 64))
+    y_cut = ops.gconv(x, wp, cout, ks=3, stride=2, pad=1, res=res, relu=True)
+    dx_cut = ops.gconv(dz, wd, cin, ks=3, stride=2, pad=1, transposed=True, out_hw=(h, w))
+    dw_cut, _ = ops.wide_wgrad(x, dz, cin, cout, ks=3, stride=2, pad=1)
+    assert torch.equal(y_one, y_cut) and torch.equal(dx_one, dx_cut)
+    assert rel_err(dw_cut.cpu(), dw_one.cpu()) < 1e-5
+
+
 GATHER_CASES = [
     # cin, cout, ks, stride, n, H, W
     (64, 128, 3, 2, 3, 16, 16),         # forward only: its gradient (128 -> 64 channels) is not a 128-channel output block
