@@ -326,26 +326,54 @@ __global__ __launch_bounds__(64 * NW, 1) void gconv_kernel(GConvArgs a) {
                 constexpr int hb = PAR * hbytes, hbn = hbytes - hb;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    // K-step s = 9c + t in ring slot s % RS (9 = 1 mod 4, 0 mod 3)
+                    // K-step s = 9c + t in ring slot s % RS (9 = 1 mod 4, 0 mod 3).  Three ring slots: ONE barrier, in the middle of the
+                    // K-step:
+                    //   first half : request filter image s + RS - 1 into the slot K-step s-1 read (every wave finished those reads
+                    //                before the previous mid-step barrier) and, t < NHP, a piece of the next chunk's halo; read the
+                    //                second-half fragments of stage s; MFMAs of the first half
+                    //   middle     : this wave's pieces of filter image s+1 (and everything older) have landed — counted wait over the
+                    //                copies requested since — its fragment reads are back; barrier
+                    //   second half: read the first-half fragments of stage s+1; MFMAs of the second half
+                    // so a copy has a whole K-step (RS = 3) or two (RS = 4) to land; with the barrier at the top of the K-step the
+                    // second piece of a filter image had half a K-step at RS = 3 and the wait stalled every K-step.
                     const int slot = RS == 4 ? ((c + t) & 3) : (t % 3);
                     const int nslot = RS == 4 ? ((c + t + 1) & 3) : ((t + 1) % 3);
                     const int islot = RS == 4 ? ((c + t + 3) & 3) : ((t + 2) % 3);      // the slot K-step s-1 read
-                    if constexpr (RS == 4) { if (t >= 1 && t - 1 < NHP) gc_wait_vm<NBP + 1>(); else gc_wait_vm<NBP>(); }
-                    else gc_wait_vm<0>();
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
                     const int tb = (t + RS - 1) % 9, cb = c + (t + RS - 1) / 9;         // filter image s + RS - 1
-                    if (t < NHP) issue_halo_u(c + 1, t);
-                    issue_b(cb, tb, islot, 0);
-                    read_half_u(f1, hb, t, slot, 1);
-                    mfma_half(f0);
-                    pin_half(t < NHP ? 2 : 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    issue_b(cb, tb, islot, 1);
-                    read_half_u(f0, t == 8 ? hbn : hb, t == 8 ? 0 : t + 1, nslot, 0);
-                    mfma_half(f1);
-                    pin_half(1);
-                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (RS == 3) {
+                        if (t < NHP) issue_halo_u(c + 1, t);
+#pragma unroll
+                        for (int j = 0; j < NBP; ++j) issue_b(cb, tb, islot, j);
+                        read_half_u(f1, hb, t, slot, 1);
+                        mfma_half(f0);
+                        pin_half((t < NHP ? 1 : 0) + NBP);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (t < NHP) gc_wait_vm<NBP + 1>(); else gc_wait_vm<NBP>();      // younger: this K-step's halo piece and filter image s+2
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                        read_half_u(f0, t == 8 ? hbn : hb, t == 8 ? 0 : t + 1, nslot, 0);
+                        mfma_half(f1);
+                        pin_half(0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        // four ring slots: a filter image is requested two K-steps before its first read, the barrier at the top of
+                        // the K-step costs nothing in latency (the mid-step form measured 4-7 % slower here: its lgkmcnt(0))
+                        if (t >= 1 && t - 1 < NHP) gc_wait_vm<NBP + 1>(); else gc_wait_vm<NBP>();
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (t < NHP) issue_halo_u(c + 1, t);
+                        issue_b(cb, tb, islot, 0);
+                        read_half_u(f1, hb, t, slot, 1);
+                        mfma_half(f0);
+                        pin_half(t < NHP ? 2 : 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (NBP == 2) issue_b(cb, tb, islot, 1);
+                        read_half_u(f0, t == 8 ? hbn : hb, t == 8 ? 0 : t + 1, nslot, 0);
+                        mfma_half(f1);
+                        pin_half(NBP == 2 ? 1 : 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             };
             for (int c = 0; c < nchunks; c += 2) {
@@ -480,7 +508,8 @@ static int gconv_launch(GConvArgs a, hipStream_t st) {
     int tw, th;
     if (Wg > 8 || Hg > 8) {
         const long c16 = (long)((Wg + 15) >> 4) * ((Hg + 15) >> 4) * 4, c8 = (long)((Wg + 7) >> 3) * ((Hg + 7) >> 3);
-        tw = th = c8 < c16 ? 3 : 4;
+        static const bool tile8 = [] { const char* e = getenv("MIL_GCONV_TILE8"); return e && e[0] == '1'; }();      // A/B runs
+        tw = th = (c8 < c16 || (tile8 && c8 <= c16)) ? 3 : 4;
     } else if (Wg > 4 || Hg > 4) tw = th = 3;
     else tw = th = 2;
     a.tw_log2 = tw; a.th_log2 = th; a.ti_log2 = 8 - tw - th;
