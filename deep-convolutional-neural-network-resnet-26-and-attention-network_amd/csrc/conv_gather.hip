@@ -241,7 +241,9 @@ __global__ __launch_bounds__(64 * NW, 1) void gconv_kernel(GConvArgs a) {
         constexpr int HP = HD * 8;                               // 1 KB pieces (8 rows) of a halo image
         constexpr int NHP = (HP + NW - 1) / NW;                  // ... per wave: piece j*NW + wave for j < NHP
         char* ring = smem + 2 * hbytes;
-        const int hw = (1 << a.tw_log2) + 2, hh = (1 << a.th_log2) + 2;
+        // HD fixes the tile: 6 = 16x16 pixels of one image (18x18 halo), 7 = 8x8 pixels of four images (10x10 each): compile-time
+        // divisors for the halo tables
+        constexpr int hw = HD == 6 ? 18 : 10, hh = hw;
         int h_off[NHP];
 #pragma unroll
         for (int j = 0; j < NHP; ++j) {
@@ -519,8 +521,9 @@ static int gconv_launch(GConvArgs a, hipStream_t st) {
     // the canonical 3x3 stride-1 tap list runs on the halo-resident form when two halo images fit beside the filter ring
     bool canon = a.ncls == 1 && a.ss == 1 && a.os == 1 && a.c_ntaps[0] == 9 && a.ktaps == 9 && !no_halo;
     for (int t = 0; t < 9 && canon; ++t) canon = a.c_tap[0][t] == (((t / 3 - 1 + 8) << 16) | ((t % 3 - 1 + 8) << 8) | t);
-    const int hrows = (((1 << tw) + 2) * ((1 << th) + 2)) << a.ti_log2;
-    const int hd = canon ? (hrows + 63) / 64 : 0;
+    // halo-resident forms exist for the two tile shapes the choice above produces on maps of 8 pixels and more: 16x16 pixels of one
+    // image (324 halo rows: six 64-row pieces per wave-set) and 8x8 pixels of four images (400 rows: seven)
+    const int hd = canon ? (tw == 4 ? 6 : (tw == 3 ? 7 : 0)) : 0;
     static const int nw = [] { const char* e = getenv("MIL_GCONV_WAVES"); return e && atoi(e) == 16 ? 16 : 8; }();      // A/B runs
     static bool attr_set = false;
     if (!attr_set) {
@@ -532,13 +535,13 @@ static int gconv_launch(GConvArgs a, hipStream_t st) {
         attr_set = true;
     }
     const dim3 grid(groups * a.tiles_y * a.tiles_x, a.cout / GC_BN, a.ncls);
-    const int lds = hd > 0 && hd <= 6 ? 2 * 6 * 8192 + 4 * GC_B_BYTES : (hd == 7 ? 2 * 7 * 8192 + 3 * GC_B_BYTES : GC_LDS_BYTES);
+    const int lds = hd == 6 ? 2 * 6 * 8192 + 4 * GC_B_BYTES : (hd == 7 ? 2 * 7 * 8192 + 3 * GC_B_BYTES : GC_LDS_BYTES);
     if (nw == 16) {
-        if (hd > 0 && hd <= 6) hipLaunchKernelGGL((gconv_kernel<6, 16>), grid, dim3(1024), lds, st, a);
+        if (hd == 6) hipLaunchKernelGGL((gconv_kernel<6, 16>), grid, dim3(1024), lds, st, a);
         else if (hd == 7) hipLaunchKernelGGL((gconv_kernel<7, 16>), grid, dim3(1024), lds, st, a);
         else hipLaunchKernelGGL((gconv_kernel<0, 16>), grid, dim3(1024), lds, st, a);
     } else {
-        if (hd > 0 && hd <= 6) hipLaunchKernelGGL((gconv_kernel<6, 8>), grid, dim3(512), lds, st, a);
+        if (hd == 6) hipLaunchKernelGGL((gconv_kernel<6, 8>), grid, dim3(512), lds, st, a);
         else if (hd == 7) hipLaunchKernelGGL((gconv_kernel<7, 8>), grid, dim3(512), lds, st, a);
         else hipLaunchKernelGGL((gconv_kernel<0, 8>), grid, dim3(512), lds, st, a);
     }
