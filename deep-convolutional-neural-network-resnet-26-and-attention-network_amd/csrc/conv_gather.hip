@@ -27,7 +27,9 @@
 //   + the nine taps of a chunk unrolled, the 36 swizzled fragment offsets of a lane precomputed, chunk pairs unrolled so the
 //     halo buffer offset is a ds_read immediate (the loop form spent ~45 of its ~65 vector instructions per K-step beside
 //     the 32 MFMAs on that address arithmetic: the kernel was instruction-issue-bound)                               913 / 1061 / 1063
-// Data gradients 705/775/709 -> 845/1118/1112.  MFMA-busy cycles of the CU-busy cycles: profiles/r03_sq_counters_alt.txt.
+//   + three ring slots (8x8-pixel tiles): the barrier in the middle of the K-step, a filter image gets a whole K-step to land  896 / 1037 / 1223
+//   a persistent form (several tiles per workgroup, next tile's copies under the epilogue): 256 VGPRs + ~100 spilled — not kept
+// Data gradients 705/775/709 -> 811/1052/1253.  MFMA-busy cycles of the CU-busy cycles: profiles/r03_sq_counters_alt.txt.
 //
 // LDS images are [row][64 ch] bf16 with the 16-byte slot index XOR-ed by (row >> 1) & 7: the sixteen lanes of a
 // ds_read_b128 group then fall on sixteen different 16-byte slots of the 256-byte bank row.  LDS-DMA writes lanes linearly,
