@@ -72,10 +72,6 @@ struct GConvArgs {
 
 template <int N>
 __device__ __forceinline__ void gc_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void gc_wait_vm_n(int n) {       // n = 0..6, wave-uniform
-    if (n <= 0) gc_wait_vm<0>(); else if (n == 1) gc_wait_vm<1>(); else if (n == 2) gc_wait_vm<2>(); else if (n == 3) gc_wait_vm<3>();
-    else if (n == 4) gc_wait_vm<4>(); else if (n == 5) gc_wait_vm<5>(); else gc_wait_vm<6>();
-}
 
 #define GC_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
