@@ -430,6 +430,22 @@ def stream_copy_gbps(dev, seconds=0.5):
     return best
 
 
+def spawn_ranks(n):
+    """Re-launch this command under `python -m torch.distributed.run` with n ranks on this node (rendezvous on 127.0.0.1,
+    a free port) as a child process; returns the child's exit code.  stdout/stderr are inherited, so rank 0's JSON line is
+    the child's own print."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -448,7 +464,10 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     elif args.gpus != 1:
-        raise SystemExit("--gpus N>1 must be launched through torch.distributed.run (one process per GPU)")
+        # `python bench.py --gpus N` without a launcher: start the one-process-per-GPU job ourselves, as a CHILD process
+        # (never exec, and before anything here has touched the GPU: torch is imported, no torch.cuda call has run),
+        # relay its output — rank 0's JSON line — and leave with its exit code.
+        raise SystemExit(spawn_ranks(args.gpus))
     else:
         torch.cuda.set_device(0)
     if world != args.gpus:

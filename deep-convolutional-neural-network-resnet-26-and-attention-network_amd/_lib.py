@@ -6,6 +6,7 @@ import contextlib
 import ctypes
 import os
 import subprocess
+import threading
 
 import torch  # noqa: F401  (must be imported first: the HIP runtime torch loaded is the one we bind to)
 
@@ -134,19 +135,26 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-_F32_MMA = [MIL_DT_F32]
+class _MmaState(threading.local):
+    """Per THREAD: autograd runs backward on its own thread, and an exact-fp32 model and a BF16X3 model may be driven from
+    different threads of one process — a process-global code would let one read the other's (packed [hi|lo] filters
+    contracted as plain fp32, or the reverse)."""
+    code = MIL_DT_F32
+
+
+_F32_MMA = _MmaState()
 
 
 @contextlib.contextmanager
 def f32_mma(code):
-    """Inside the block, the convolution entry points run fp32 tensors with `code` (MIL_DT_F32: exact-f32 MFMA,
-    MIL_DT_F32S: bf16x3 split products)."""
-    prev = _F32_MMA[0]
-    _F32_MMA[0] = code
+    """Inside the block (on this thread), the convolution entry points run fp32 tensors with `code` (MIL_DT_F32: exact-f32
+    MFMA, MIL_DT_F32S: bf16x3 split products)."""
+    prev = _F32_MMA.code
+    _F32_MMA.code = code
     try:
         yield
     finally:
-        _F32_MMA[0] = prev
+        _F32_MMA.code = prev
 
 
 def storage_dtype(compute_dtype):
@@ -167,7 +175,7 @@ def dt_code(dtype, dense_grads=False, mma=False):
             raise ValueError("the dense gradient layout exists for bfloat16 only")
         return MIL_DT_BF16_DGRAD
     if dtype == torch.float32:
-        return _F32_MMA[0] if mma else MIL_DT_F32
+        return _F32_MMA.code if mma else MIL_DT_F32
     if dtype == torch.bfloat16:
         return MIL_DT_BF16
     raise ValueError(f"compute dtype must be torch.float32 or torch.bfloat16, got {dtype}")

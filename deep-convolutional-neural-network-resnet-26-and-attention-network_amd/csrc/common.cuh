@@ -191,4 +191,32 @@ __device__ __forceinline__ void mil_poison_lds(void* base) {
 #define MIL_POISON(base) ((void)0)
 #endif
 
+// A/B switches of the development builds.  The shipped library reads NO ambient environment for kernel selection: the
+// switches exist only in `make VARIANT=<name> EXTRA=-DMIL_AB_SWITCHES` builds (tools/README.md).  (Three TEST knobs stay in
+// every build, because the -m gpu tests drive small inputs through the large-launch paths with them: MIL_PF_MIN_TILES,
+// MIL_BUFFER_LIMIT_BYTES, MIL_RES_GRID_CAP; and MIL_LIB_PATH on the Python side selects which build is loaded.)
+#include <cstdlib>
+__host__ inline const char* mil_ab_env(const char* name) {
+#ifdef MIL_AB_SWITCHES
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
+// "Has this been done on the CURRENT device yet?" for per-device one-time set-up (hipFuncSetAttribute is a per-device
+// setting: a process-wide flag would leave a second GPU at the 64 KB default).  `done` is one bit per device ordinal;
+// two threads racing through the first call both do the (idempotent) set-up.
+#include <atomic>
+__host__ inline bool mil_device_needs(std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return true;
+    return !(done.load(std::memory_order_acquire) & (1ull << (dev & 63)));
+}
+__host__ inline void mil_device_done(std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) done.fetch_or(1ull << (dev & 63), std::memory_order_release);
+}
+
 #define MIL_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return MIL_ERR_LAUNCH; } while (0)

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64 * NW, (CP <= 24 ? 2 : 1) * (NW == 8 ? 2 : 1)) vo
 static int mil_block_waves() {
     // measured on the 64x64x24 maps: 434 us with 4 waves per workgroup, 446 us with 8 (16 resident waves per CU at 127
     // VGPRs) — more resident waves do not help: LDS operand bandwidth (~450 KB per tile) and the MFMA pipe set the pace
-    static const int v = [] { const char* e = getenv("MIL_BLOCK_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();
+    static const int v = [] { const char* e = mil_ab_env("MIL_BLOCK_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();
     return v;
 }
 

@@ -830,7 +830,7 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
 // MIL_BWD16=0 falls back to the generic kernel on 16x16 tiles too (A/B runs, bit-compatible results up to the bias
 // gradient's summation path)
 static bool mil_bwd16_enabled() {
-    static const bool v = [] { const char* e = getenv("MIL_BWD16"); return !(e && e[0] == '0'); }();
+    static const bool v = [] { const char* e = mil_ab_env("MIL_BWD16"); return !(e && e[0] == '0'); }();
     return v;
 }
 

@@ -508,29 +508,29 @@ static int gconv_launch(GConvArgs a, hipStream_t st) {
     int tw, th;
     if (Wg > 8 || Hg > 8) {
         const long c16 = (long)((Wg + 15) >> 4) * ((Hg + 15) >> 4) * 4, c8 = (long)((Wg + 7) >> 3) * ((Hg + 7) >> 3);
-        static const bool tile8 = [] { const char* e = getenv("MIL_GCONV_TILE8"); return e && e[0] == '1'; }();      // A/B runs
+        static const bool tile8 = [] { const char* e = mil_ab_env("MIL_GCONV_TILE8"); return e && e[0] == '1'; }();      // A/B runs
         tw = th = (c8 < c16 || (tile8 && c8 <= c16)) ? 3 : 4;
     } else if (Wg > 4 || Hg > 4) tw = th = 3;
     else tw = th = 2;
     a.tw_log2 = tw; a.th_log2 = th; a.ti_log2 = 8 - tw - th;
     a.tiles_x = (Wg + (1 << tw) - 1) >> tw; a.tiles_y = (Hg + (1 << th) - 1) >> th;
     const int groups = (a.n_img + (1 << a.ti_log2) - 1) >> a.ti_log2;
-    static const bool no_halo = [] { const char* e = getenv("MIL_GCONV_NO_HALO"); return e && e[0] == '1'; }();      // A/B runs: per-K-step gather everywhere
+    static const bool no_halo = [] { const char* e = mil_ab_env("MIL_GCONV_NO_HALO"); return e && e[0] == '1'; }();      // A/B runs: per-K-step gather everywhere
     // the canonical 3x3 stride-1 tap list runs on the halo-resident form when two halo images fit beside the filter ring
     bool canon = a.ncls == 1 && a.ss == 1 && a.os == 1 && a.c_ntaps[0] == 9 && a.ktaps == 9 && !no_halo;
     for (int t = 0; t < 9 && canon; ++t) canon = a.c_tap[0][t] == (((t / 3 - 1 + 8) << 16) | ((t % 3 - 1 + 8) << 8) | t);
     // halo-resident forms exist for the two tile shapes the choice above produces on maps of 8 pixels and more: 16x16 pixels of one
     // image (324 halo rows: six 64-row pieces per wave-set) and 8x8 pixels of four images (400 rows: seven)
     const int hd = canon ? (tw == 4 ? 6 : (tw == 3 ? 7 : 0)) : 0;
-    static const int nw = [] { const char* e = getenv("MIL_GCONV_WAVES"); return e && atoi(e) == 16 ? 16 : 8; }();      // A/B runs
-    static bool attr_set = false;
-    if (!attr_set) {
+    static const int nw = [] { const char* e = mil_ab_env("MIL_GCONV_WAVES"); return e && atoi(e) == 16 ? 16 : 8; }();      // A/B runs
+    static std::atomic<unsigned long long> attr_set{0};      // per device
+    if (mil_device_needs(attr_set)) {
         const void* ks[6] = {reinterpret_cast<const void*>(gconv_kernel<0, 8>), reinterpret_cast<const void*>(gconv_kernel<6, 8>),
                              reinterpret_cast<const void*>(gconv_kernel<7, 8>), reinterpret_cast<const void*>(gconv_kernel<0, 16>),
                              reinterpret_cast<const void*>(gconv_kernel<6, 16>), reinterpret_cast<const void*>(gconv_kernel<7, 16>)};
         for (const void* k : ks)
             if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MIL_ERR_LAUNCH;
-        attr_set = true;
+        mil_device_done(attr_set);
     }
     const dim3 grid(groups * a.tiles_y * a.tiles_x, a.cout / GC_BN, a.ncls);
     const int lds = hd == 6 ? 2 * 6 * 8192 + 4 * GC_B_BYTES : (hd == 7 ? 2 * 7 * 8192 + 3 * GC_B_BYTES : GC_LDS_BYTES);
@@ -796,11 +796,11 @@ int mil_gwgrad(const void* x, const void* dz, float* dw, void* ws, size_t ws_byt
     a.stride = stride; a.ntaps = kk; a.nstages = nstages;
     for (int t = 0; t < kk; ++t) a.tap[t] = ((t / ks - pad + 8) << 8) | (t % ks - pad + 8);
     a.x_bytes = (unsigned)xb; a.z_bytes = (unsigned)zb;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};      // per device
+    if (mil_device_needs(attr_set)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gwgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * GW_STAGE_BYTES) != hipSuccess)
             return MIL_ERR_LAUNCH;
-        attr_set = true;
+        mil_device_done(attr_set);
     }
     hipLaunchKernelGGL(gwgrad_kernel, dim3(gx, npairs), dim3(512), 3 * GW_STAGE_BYTES, st, a);
     MIL_CHECK_LAUNCH();

@@ -582,17 +582,17 @@ static int mil_pf_min_tiles() {
 }
 
 static int mil_pf_rounds() {
-    static const int r = [] { const char* e = getenv("MIL_PF_ROUNDS"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
+    static const int r = [] { const char* e = mil_ab_env("MIL_PF_ROUNDS"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
     return r;
 }
 
 static bool mil_pf_double_buffer() {
-    static const bool v = [] { const char* e = getenv("MIL_PF_DBUF"); return !(e && atoi(e) == 0); }();
+    static const bool v = [] { const char* e = mil_ab_env("MIL_PF_DBUF"); return !(e && atoi(e) == 0); }();
     return v;
 }
 
 static int mil_pf_waves64() {
-    static const int v = [] { const char* e = getenv("MIL_PF_WAVES64"); return (e && atoi(e) == 4) ? 4 : 8; }();
+    static const int v = [] { const char* e = mil_ab_env("MIL_PF_WAVES64"); return (e && atoi(e) == 4) ? 4 : 8; }();
     return v;
 }
 

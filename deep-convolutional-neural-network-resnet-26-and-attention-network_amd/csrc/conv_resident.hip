@@ -245,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void conv_resident_kernel(ResArgs a) {
 }
 
 static bool mil_resident_enabled() {
-    static const bool v = [] { const char* e = getenv("MIL_RESIDENT"); return !(e && e[0] == '0'); }();
+    static const bool v = [] { const char* e = mil_ab_env("MIL_RESIDENT"); return !(e && e[0] == '0'); }();
     return v;
 }
 

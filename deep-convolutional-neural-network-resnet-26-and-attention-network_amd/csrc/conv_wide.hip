@@ -362,7 +362,7 @@ extern "C" int mil_wide_pack_weights(const float* w, void* wpack, int cout, int 
 
 #include <cstdlib>
 static bool mil_wide_pf_enabled() {          // MIL_WIDE_PF=0: the plain kernel everywhere (A/B runs)
-    static const bool v = [] { const char* e = getenv("MIL_WIDE_PF"); return !(e && e[0] == '0'); }();
+    static const bool v = [] { const char* e = mil_ab_env("MIL_WIDE_PF"); return !(e && e[0] == '0'); }();
     return v;
 }
 
@@ -732,7 +732,7 @@ static int run_wide_wgrad(const void* x, const void* dz, float* dw, void* ws, si
     const int npairs = (cout / WIDE_NB) * (cin / WIDE_CK);
     // one fp32 slab per workgroup: 512 workgroups (two per CU) keep the slab write + fixed-order reduce at 37 MB per launch —
     // the 2048 of earlier rounds moved 151 MB for a 9 MB gradient (MIL_WIDE_WGRAD_WGS: A/B runs)
-    static const int wg_target = [] { const char* e = getenv("MIL_WIDE_WGRAD_WGS"); return e ? atoi(e) : 512; }();
+    static const int wg_target = [] { const char* e = mil_ab_env("MIL_WIDE_WGRAD_WGS"); return e ? atoi(e) : 512; }();
     int gx = wg_target / npairs;
     if (gx < 4) gx = 4;
     if (gx > 64) gx = 64;
@@ -779,7 +779,7 @@ static int run_wide_wgrad(const void* x, const void* dz, float* dw, void* ws, si
 int mil_gwgrad(const void* x, const void* dz, float* dw, void* ws, size_t ws_bytes, int n_img, int H, int W, int cin, int Ho, int Wo,
                int cout, int ks, int stride, int pad, int accumulate, bool query, size_t* need, hipStream_t st);
 static int mil_gwgrad_mode() {           // MIL_GWGRAD: 0 = never, 1 = stride-2 and 1x1 launches (default), 2 = every eligible launch
-    static const int v = [] { const char* e = getenv("MIL_GWGRAD"); return e ? atoi(e) : 1; }();
+    static const int v = [] { const char* e = mil_ab_env("MIL_GWGRAD"); return e ? atoi(e) : 1; }();
     return v;
 }
 

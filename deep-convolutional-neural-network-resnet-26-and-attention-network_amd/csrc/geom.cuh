@@ -18,7 +18,7 @@ struct ConvGeom {
 
 __host__ inline void mil_geom_set(ConvGeom& g, int tw, int th, int ti);
 #include <cstdlib>
-__host__ inline bool mil_geom_wide() { const char* e = getenv("MIL_GEOM_WIDE"); return e && e[0] == '1'; }
+__host__ inline bool mil_geom_wide() { const char* e = mil_ab_env("MIL_GEOM_WIDE"); return e && e[0] == '1'; }
 __host__ inline void mil_geom_tiles(ConvGeom& g, int tile_px_log2) {
     // choose TW x TH x TI = 2^tile_px_log2 output pixels
     int tw, th;

@@ -585,11 +585,11 @@ extern "C" int mil_head_bwd(const float* H, const int* bag_offsets, const int* i
     {
         const int nslices = (ntot + WGS - 1) / WGS;
         const int lds = WGS * R_STRIDE * 4;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static std::atomic<unsigned long long> attr_set{0};      // per device
+        if (mil_device_needs(attr_set)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(head_wgrad_partial_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
                 return MIL_ERR_LAUNCH;
-            attr_set = true;
+            mil_device_done(attr_set);
         }
         hipLaunchKernelGGL(head_wgrad_partial_kernel, dim3(nslices), dim3(1024), lds, st, H, inst_bag, ws.stats, keep_mask, w, ws.t,
                            ws.v, ws.du, ws.dv, ws.da, ws.dwm, ws.db, ws.dhz, ws.wpart, ntot, slope, ks);

@@ -75,12 +75,12 @@ class ResNet(nn.Module):
         self.n_side_streams = 1
         self.fuse_backward = True
         self.fuse_stem_forward = True
-        self.keep_s2d = os.environ.get("MIL_KEEP_S2D", "0") == "1"      # True: the fused stem forward also writes the bf16 space-to-depth copy of the input
+        self.keep_s2d = False           # True: the fused stem forward also writes the bf16 space-to-depth copy of the input (bf16 mode)
         self.fuse_stage_entry = True
         self.fuse_block_forward = True
         # gradient tensors of the 20-channel stage (produced and consumed only by the fused backward kernels) at 20 channels
         # per pixel instead of the padded 24: 17 % fewer bytes on three of the four tensor passes of its fused backward
-        self.dense_grads = os.environ.get("MIL_DENSE_GRADS", "1") != "0"
+        self.dense_grads = True
         # the 28 slab reductions of a backward pass recorded and run as ONE launch (ops.ReduceBatch) instead of one ~10 us
         # launch behind every weight-gradient kernel
         self.batch_reductions = True
@@ -230,6 +230,8 @@ def encoder_forward(net, x, dtype):
 def _encoder_forward_from(net, x, dtype, hk, stem_hooked, wp, bp, xs_in):
     # no space-to-depth copy is kept (keep_s2d False): the fused stem backward rebuilds its tiles from x itself
     split = dtype == torch.float32 and L.dt_code(dtype, mma=True) == L.MIL_DT_F32S       # bf16x3: never an s2d copy
+    if split and net.keep_s2d and xs_in is None:
+        x = x.clone()                   # this mode has no s2d form: `keep_s2d` keeps a library-owned fp32 copy for the backward instead
     fused = None
     if xs_in is None:
         fused = ops.stem_fwd_fused(x, wp, bp, ops.cpad(STEM_WIDTH), dtype=dtype,
@@ -337,7 +339,7 @@ def _encoder_forward_from(net, x, dtype, hk, stem_hooked, wp, bp, xs_in):
     return feats, saved
 
 
-def encoder_backward(net, saved, dfeats, dtype):
+def encoder_backward(net, saved, dfeats, dtype, allow_direct=True):
     """Gradients of every encoder parameter, in `encoder_params()` order (the input is detached in
     the reference, gbm/model.py:194-196, so no data-gradient is produced for the tiles)."""
     blocks = list(net.blocks())
@@ -345,11 +347,13 @@ def encoder_backward(net, saved, dfeats, dtype):
     if saved["x_src"] is not None and saved["x_src"]._version != saved["x_version"]:
         raise RuntimeError("the input tiles were modified in place between the encoder's forward and backward: conv1's gradient is "
                            "computed from them (no space-to-depth copy is kept).  Keep the tensor untouched until backward, or set "
-                           "`net.cnn.module.keep_s2d = True` (MIL_KEEP_S2D=1) to have the forward keep its own copy")
+                           "`net.cnn.module.keep_s2d = True` to have the forward keep its own copy (bf16: the space-to-depth records; "
+                           "bf16x3: an fp32 clone of the tiles)")
     last_out = saved["blocks"][-1][2]
     dz, dwfc = ops.avgpool_fc_bwd(dfeats.contiguous(), net.fc.weight.detach(), saved["pooled"], last_out,
                                   STAGE_WIDTHS[-1],
-                                  out=net.fc.weight.grad if (net.direct_grad and net.fc.weight.grad is not None) else None)
+                                  out=net.fc.weight.grad if (net.direct_grad and allow_direct and net.fc.weight.grad is not None and
+                                                             all(p.grad is not None and p.grad.is_contiguous() for p in net.encoder_params())) else None)
     # Weight gradients only consume (x, dz) and nothing downstream waits for them, so they run on side
     # streams (round-robin, one slab workspace each) beside the sequential dgrad chain: the small late-layer
     # and stride-2 launches do not fill 256 CUs alone.
@@ -359,7 +363,9 @@ def encoder_backward(net, saved, dfeats, dtype):
     ws = [None] * (len(sides) + 1)
     rr = [0]
 
-    direct = net.direct_grad and all(p.grad is not None and p.grad.is_contiguous() for p in net.encoder_params())
+    # in-place accumulation into the parameters' .grad: opt-in (dist.FlatParams sets direct_grad; plain loss.backward() only),
+    # and only when autograd wants a gradient for every encoder parameter (allow_direct, from ctx.needs_input_grad)
+    direct = net.direct_grad and allow_direct and all(p.grad is not None and p.grad.is_contiguous() for p in net.encoder_params())
     batch = None
     if net.batch_reductions and not use_side:
         if net._reduce_batch is None or net._reduce_batch.device != dfeats.device:
@@ -594,6 +600,6 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dfeats):
         with L.f32_mma(L.mma_code(ctx.mode)):
-            grads = encoder_backward(ctx.net, ctx.saved, dfeats, ctx.dtype)
+            grads = encoder_backward(ctx.net, ctx.saved, dfeats, ctx.dtype, allow_direct=all(ctx.needs_input_grad[2:]))
         ctx.saved = None
         return (None, None, *grads)

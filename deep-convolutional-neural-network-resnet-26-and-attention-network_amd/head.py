@@ -62,7 +62,7 @@ class _HeadFn(torch.autograd.Function):
     """(H, 11 head parameters) -> (loss [nbags], l2 []) with grad; a1/wrois/bterm/kld/rec without."""
 
     @staticmethod
-    def forward(ctx, H, layout, labels, keep_mask, class_weights, internals, *weights):
+    def forward(ctx, H, layout, labels, keep_mask, class_weights, internals, direct, *weights):
         lib = L.lib()
         H = H.contiguous()
         ws = [w.detach().contiguous() for w in weights]
@@ -87,6 +87,7 @@ class _HeadFn(torch.autograd.Function):
                                  ops.LEAK, DROP_P, SMOOTHING, BN_EPS, L.stream_ptr()), "mil_head_fwd")
         ctx.layout, ctx.keep_mask, ctx.ws, ctx.work = layout, keep_mask, ws, work
         ctx.params = weights               # the Parameters themselves: their .grad may be one flat bucket (dist.FlatParams)
+        ctx.direct = bool(direct)          # opt-in (FlatParams sets Attention.direct_grad): accumulate into that bucket in place
         if internals is not None:          # forward hooks on head children read the kernels' own intermediates
             o = nbags * 2 * N_FEATS
             internals["stats"] = work[:o].view(nbags, 2, N_FEATS)                      # per bag: mean, 1/sqrt(var+eps)
@@ -119,7 +120,12 @@ class _HeadFn(torch.autograd.Function):
         # Parameters whose .grad tensors sit back to back in one buffer, in this order (dist.FlatParams: the ten tensors from
         # context.bn.weight to buffer.classifier.bias): ONE add of the kernel's gradient block into that run instead of one
         # autograd accumulation (a torch add launch) per parameter — the kernel writes its gradients in the same order.
-        out, o, run = [], 0, _contiguous_grad_run(ctx.params)
+        # Only under the explicit opt-in (a FlatParams owns the gradients and the caller runs plain `loss.backward()`), and
+        # only for parameters autograd asked a gradient for; otherwise every gradient is RETURNED, so that
+        # torch.autograd.grad / backward(inputs=...) / gradient hooks see them and no .grad is touched behind their back.
+        n_fixed = 7                          # positional inputs in front of the weights
+        wanted = [bool(ctx.needs_input_grad[n_fixed + i]) for i in range(len(ctx.ws))]
+        out, o, run = [], 0, (_contiguous_grad_run(ctx.params, wanted) if ctx.direct else None)
         if run is not None:
             first, count, total = run
             g0 = ctx.params[first].grad
@@ -129,16 +135,19 @@ class _HeadFn(torch.autograd.Function):
             direct = run is not None and run[0] <= i < run[0] + run[1]
             out.append(None if direct else grads[o:o + w.numel()].view(w.shape))
             o += w.numel()
-        return (dH, None, None, None, None, None, *out)
+        return (dH, None, None, None, None, None, None, *out)
 
 
-def _contiguous_grad_run(params):
+def _contiguous_grad_run(params, wanted=None):
     """(first index, count, total elements) of the longest prefix run of `params` (from index 0) whose existing fp32 .grad
-    tensors are contiguous and adjacent in memory, or None when fewer than two qualify."""
+    tensors are contiguous and adjacent in memory — and for which autograd wants a gradient (`wanted[i]`, from
+    ctx.needs_input_grad) —, or None when fewer than two qualify."""
     run, nxt, total = 0, None, 0
-    for p in params:
+    for i, p in enumerate(params):
         g = getattr(p, "grad", None)
         if g is None or g.dtype != torch.float32 or not g.is_contiguous() or not p.requires_grad:
+            break
+        if wanted is not None and not wanted[i]:
             break
         if nxt is not None and g.data_ptr() != nxt:
             break
@@ -148,5 +157,8 @@ def _contiguous_grad_run(params):
     return (0, run, total) if run >= 2 else None
 
 
-def head_apply(H, layout, labels, keep_mask, class_weights, weights, internals=None):
-    return _HeadFn.apply(H, layout, labels, keep_mask, class_weights, internals, *weights)
+def head_apply(H, layout, labels, keep_mask, class_weights, weights, internals=None, direct=False):
+    """direct=True (set through `Attention.direct_grad` by dist.FlatParams): the backward adds the head gradients straight
+    into the parameters' existing .grad storage where that is one contiguous run and returns None for them — valid for plain
+    `loss.backward()` accumulation only; leave it False for torch.autograd.grad / backward(inputs=...) / gradient hooks."""
+    return _HeadFn.apply(H, layout, labels, keep_mask, class_weights, internals, direct, *weights)

@@ -86,6 +86,9 @@ class Attention(nn.Module):
         self.off_diag = 1 - torch.eye(3)
         self.reset_params()
         self.rng_override = None     # tests inject {"indices": LongTensor, "keep_mask": uint8 [n,80]}
+        # set by dist.FlatParams: the head backward may add its gradients in place into the flat gradient bucket (plain
+        # `loss.backward()` accumulation); False: every gradient is returned to autograd (autograd.grad, hooks)
+        self.direct_grad = False
         self.to(device)
 
     # ---- initialisation (gbm/model.py:161-187) -------------------------------------------------
@@ -231,7 +234,7 @@ class Attention(nn.Module):
         """Segmented head over the features of all bags + the per-bag output dicts (gbm/model.py:198-264)."""
         head_mods = self._hooked_head_modules()
         internals = {} if head_mods else None
-        loss, l2, a1, wrois, bterm, kld, rec = head_apply(H, layout, y, keep, cw, self.head_weights(), internals)
+        loss, l2, a1, wrois, bterm, kld, rec = head_apply(H, layout, y, keep, cw, self.head_weights(), internals, direct=self.direct_grad)
         Hd = H.detach()
         if head_mods:
             self._fire_head_hooks(Hd, layout, keep, bterm, internals)

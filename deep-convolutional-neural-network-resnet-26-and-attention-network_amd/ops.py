@@ -352,8 +352,7 @@ def conv_s2_entry(x, wpack3, bias_pad, wpack1, cout_p, *, slope=LEAK):
     return y1, y2
 
 
-import os as _os
-WGRAD_PAIR = _os.environ.get("MIL_WGRAD_PAIR", "1") != "0"      # experiment switch
+WGRAD_PAIR = True      # False (set from Python): the two stage-entry weight gradients as separate launches (A/B runs)
 
 
 def conv_wgrad_pair(x, dz1, dz2, cin, cout, *, workspace=None, out=None):

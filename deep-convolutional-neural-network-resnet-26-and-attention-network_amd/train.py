@@ -1,8 +1,9 @@
 """Host-side pieces adjacent to the hot path: the reference's learning-rate / mode schedule,
-gradient accumulation over bags with one optimizer step per group, and the attention-map text export.
+gradient accumulation over bags with one optimizer step per group, the attention-map text export and the tensors
+`visualize` derives from an output dict.
 
-Reference: `SetStage` (gbm/classify_combined.py:110-138), the 5-bag accumulation loop (:446-454) and `write_map`
-(gbm/classify.py:207-225).  Nothing here touches pixels: it drives `Attention`, `FlatParams` and `FlatAdam`.
+Reference: `SetStage` (gbm/classify_combined.py:110-138), the 5-bag accumulation loop (:446-454), `write_map`
+(gbm/classify.py:207-225) and `visualize` (gbm/classify_combined.py:142-167).  Nothing here touches pixels: it drives `Attention`, `FlatParams` and `FlatAdam`.
 """
 import torch
 
@@ -129,6 +130,30 @@ def write_attention_map(path, raster, weights, normalise=True):
     col = _minmax_f32(w) if normalise else w.numpy()
     with open(path, "w") as f:
         f.write(_dla_lines(raster, col))
+
+
+def visualize_terms(output):
+    """The tensors `visualize` (gbm/classify_combined.py:142-167) derives from one forward's output dict before it hands them
+    to its plotting helper, restated on CPU tensors exactly as written there:
+      angle  degrees(mean over the pairs i<j of arccos(M_i . M_j / (|M_i| |M_j| + 1e-5)))  (:156-160; M = Mterm [3,1])
+      A1     (wROIs - min) / (max - min) over the WHOLE [3,N] array                        (:162)
+      B1     Fterm viewed [N,8,10]                                                          (:163)
+      M1     |Mterm| viewed [3,1,1] and permuted to [1,1,3] (H, W, channel)                 (:164)
+    Returns {"angle": float, "A1", "B1", "M1"}.  A constant wROIs array gives NaNs in A1, as upstream (0/0)."""
+    import numpy as np
+    A = output["wROIs"].detach().float().cpu()
+    M = output["Mterm"].detach().float().cpu()
+    F = output["Fterm"].detach().float().cpu()
+    angles = []
+    for m_i, v1 in enumerate(M):
+        for m_j, v2 in enumerate(M):
+            if m_j > m_i:
+                angles.append(np.arccos(v1.dot(v2) / (v1.norm() * v2.norm() + 1e-5)).item())
+    angle = float(np.degrees(np.mean(angles)))
+    A1 = (A - A.min()) / (A.max() - A.min())
+    B1 = F.view(F.shape[0], 8, 10)
+    M1 = M.view(3, 1, 1).permute(1, 2, 0).abs()
+    return {"angle": angle, "A1": A1, "B1": B1, "M1": M1}
 
 
 def save_checkpoint(path, model, optimizer):

@@ -25,13 +25,21 @@ HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dla")
 
 
 REFERENCE = "/root/reference/gbm/classify.py"
+# sha256 of the reference file whose `write_map` was read (lines 207-225: four formatting statements, no imports, no default
+# arguments that evaluate code) before it was first executed here.  The function is executed only when the file still has this
+# digest: an upstream snapshot that differs must be re-read by a person first (it runs with this process's rights).
+REFERENCE_SHA256 = "595db461dd505c2de48b6dd8e61964cb28f3af970218029b69f8709d07ef5359"
 
 
 def reference_write_map(output_dir):
     """The reference's own `write_map(meta, epoch, raster, attn, activations)` (gbm/classify.py:207-225), compiled from its
     source file: only that FunctionDef is executed, in a namespace holding what it refers to (`plt`, `output_dir`)."""
     import ast
-    tree = ast.parse(open(REFERENCE).read(), filename=REFERENCE)
+    import hashlib
+    src = open(REFERENCE, "rb").read()
+    if hashlib.sha256(src).hexdigest() != REFERENCE_SHA256:
+        raise SystemExit(f"{REFERENCE} differs from the vetted snapshot (sha256 {REFERENCE_SHA256}): read write_map again, then update the digest")
+    tree = ast.parse(src.decode(), filename=REFERENCE)
     fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "write_map"]
     assert len(fn) == 1, "write_map not found in the reference"
     ns = {"plt": plt, "output_dir": output_dir}

@@ -304,6 +304,48 @@ def test_config3_512_tiles_fp32_vs_oracle(golden_dir, dtype):
         assert abs(float(p.grad.double().norm()) - nref) <= (2e-3 if dtype == torch.float32 else 2e-2) * max(nref, 1e-3), k
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, X3], ids=["bf16", "bf16x3"])
+def test_config2_full_size_properties(golden_dir, dtype):
+    """8 bags x 256 tiles @256x256 = 2048 tiles in ONE launch sequence — BASELINE configs[1], the headline workload, exactly as
+    bench.py steps it (grid sizes, 256 resident image groups, slab counts of the 2048-tile launches).  Size-independent
+    properties: finite everywhere, every attention map sums to 1, two runs bit-identical (no atomics, fixed-order slab
+    reductions), the first and last tiles' features equal their stand-alone encoding, and bag 0 of the 8-bag step equals the
+    same bag run alone: logits within 1e-3 on the split-precision path (fp32 storage: other tile shapes only regroup fp32
+    sums), within bf16 noise on the bf16 path."""
+    import mil_amd
+    net = _model(golden_dir, dtype)
+    flat = mil_amd.FlatParams(net)
+    x = torch.empty((2048, 3, 256, 256), dtype=torch.float32, device="cuda")
+    for b in range(8):
+        gen = torch.Generator(device="cuda").manual_seed(20260104 + b)
+        x[b * 256:(b + 1) * 256] = torch.randn((256, 3, 256, 256), generator=gen, device="cuda").clamp_(-1, 1)
+    sizes, labels = [256] * 8, torch.tensor([b % 3 for b in range(8)], device="cuda")
+    runs = []
+    for _ in range(2):
+        flat.zero_grad()
+        outs = net.forward_bags((x, sizes), labels)
+        outs.loss.sum().backward()
+        torch.cuda.synchronize()
+        runs.append((outs.loss.detach().clone(), torch.cat([o["Aterm"].reshape(-1) for o in outs]).clone(),
+                     flat.flat_grad.clone(), outs[7]["Fterm"][-4:].clone(), outs[0]["Mterm"].clone(), outs[0]["Aterm"].clone()))
+    for o in outs:
+        assert torch.isfinite(o["loss"]) and torch.isfinite(o["Fterm"]).all() and torch.isfinite(o["Aterm"]).all()
+        assert torch.allclose(o["Aterm"].sum(dim=1), torch.ones(3, device="cuda"), atol=1e-5)
+    assert torch.isfinite(runs[0][2]).all() and float(runs[0][2].abs().max()) > 0
+    assert all(torch.equal(a, b) for a, b in zip(runs[0], runs[1]))
+    ftol = 1e-4 if dtype == X3 else 3e-2
+    with torch.no_grad():
+        alone_first, alone_last = net.cnn(x[:4]), net.cnn(x[-4:])              # generic (non-persistent) kernels
+        bag0 = net(x[:256], labels[:1])                                       # the same bag as a 256-tile launch
+    for a, b in ((alone_first, outs[0]["Fterm"][:4]), (alone_last, runs[0][3])):
+        assert float((a - b).abs().max() / b.abs().max()) < ftol
+    m_err = float((bag0["Mterm"] - runs[0][4]).abs().max())
+    a_err = float((bag0["Aterm"] - runs[0][5]).abs().max())
+    print(f"cfg2-full[{dtype}]: bag 0 alone vs inside the 8-bag step: Mterm {m_err:.2e}  Aterm {a_err:.2e}")
+    assert a_err < 1e-3
+    assert m_err < (1e-3 if dtype == X3 else 0.2)
+
+
 def test_config3_full_size_bf16_properties(golden_dir):
     """8 bags x 128 tiles @512x512 in ONE launch sequence (BASELINE configs[2] as bench.py --size 512 --tiles 128 runs it):
     layer-1 tensors are 2.1 GiB here, so the kernels that address through 32-bit buffer offsets split their launches.

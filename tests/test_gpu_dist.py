@@ -128,6 +128,92 @@ def test_bench_two_ranks_training_and_tile_parallel_inference():
     assert "fwd-only" in line["metric"] and "split over 2 ranks" in line["config"]["workload"]
 
 
+def test_bench_gpus_n_without_a_launcher_spawns_the_ranks_itself():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (how a driver calls `--gpus 1`): bench.py starts torch.distributed.run as
+    a child process before touching the GPU and relays rank 0's line, with the collective's own time in it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MIL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "64",
+           "--bags", "2", "--tiles", "16", "--no-kernel-timer"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_bags"] == 4
+    assert line["allreduce_ms"] > 0 and line["step_ms_no_comm"] > 0
+
+
+def _real_shape_worker(rank, world, port, out):
+    """Bag-parallel step at the BENCHMARK's bag shape: one 256-tile bag @256x256 per rank, in the two fast compute modes."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import mil_amd
+        res = []
+        for mode in (torch.bfloat16, mil_amd.BF16X3):
+            bags = []
+            for b in range(world):
+                g = torch.Generator(device="cuda").manual_seed(20260104 + b)
+                bags.append(torch.randn((256, 3, 256, 256), generator=g, device="cuda").clamp_(-1.0, 1.0))
+            labels = torch.tensor([b % 3 for b in range(world)])
+            net = _net(mode)
+            flat = mil_amd.FlatParams(net)
+            flat.broadcast_params()
+            opt = mil_amd.FlatAdam(flat, lr=2e-4)
+            flat.zero_grad()
+            net.forward_bags([bags[rank]], labels[rank:rank + 1]).loss.sum().backward()
+            flat.allreduce_grads()
+            grad_dp = flat.flat_grad.clone()
+            opt.step()
+            lo, hi = flat.flat.clone(), flat.flat.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            replicas_equal = bool(torch.equal(lo, hi))
+            ref = _net(mode)
+            rflat = mil_amd.FlatParams(ref)
+            rflat.zero_grad()
+            ref.forward_bags(bags, labels).loss.sum().backward()
+            scale = float(rflat.flat_grad.abs().max())
+            # per parameter tensor: L2 error of the all-reduced gradient relative to the tensor's norm
+            worst, off = 0.0, 0
+            for p in rflat.params:
+                n = p.numel()
+                a, r_ = grad_dp[off:off + n], rflat.flat_grad[off:off + n]
+                worst = max(worst, float((a - r_).norm() / r_.norm().clamp_min(1e-30)))
+                off += n
+            res.append((str(mode), replicas_equal, worst, scale > 0))
+            del bags, net, ref, flat, rflat
+            torch.cuda.empty_cache()
+        out.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_at_the_benchmark_bag_shape_bf16_and_bf16x3():
+    """Each rank encodes ONE 256-tile bag @256x256 (the unit BASELINE configs[1]/[3] are made of): the all-reduced (SUM)
+    gradient equals what one process computes over both bags — same kernels on the same tiles, only the fp32 slab sums are
+    grouped differently (a 512-tile launch walks its tiles on other workgroups) — and the replicas are bit-equal after Adam.
+    gbm/model.py:132-135 is the strategy this replaces, gbm/classify_combined.py:446-454 the SUM semantics."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_real_shape_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=900)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    got = sorted(out.get(timeout=5) for _ in range(world))
+    for rank, res in got:
+        for mode, replicas_equal, worst, nonzero in res:
+            print(f"rank {rank} {mode}: worst per-tensor L2 error of the all-reduced gradient {worst:.2e}")
+            assert replicas_equal and nonzero, (rank, mode)
+            # bf16: a kernel that picks another K order for another launch size would show up as bf16 roundings (1e-3..1e-2)
+            assert worst < (1e-4 if "bf16x3" in mode else 2e-2), (rank, mode, worst)
+
+
 def _rccl_worker(port, out):
     """ONE rank over the real backend ("nccl" = RCCL on ROCm) with the `device_id=` eager-init path bench.py uses: proves that
     librccl loads on the box, that a communicator comes up, and that the three collectives of the data path run on the flat

@@ -411,6 +411,39 @@ def test_direct_gradient_accumulation_equals_autograd(golden_dir):
         assert _grad_close(k, p.grad.cpu().numpy(), q.grad.cpu().numpy(), 1e-5), k
 
 
+def test_autograd_grad_returns_gradients_and_never_touches_grad_storage(golden_dir):
+    """Without the FlatParams opt-in the in-place accumulation paths stay off even when the .grad tensors happen to be one
+    contiguous buffer: `torch.autograd.grad` gets every gradient back and that buffer is not written.  With the opt-in, a
+    call that asks for a SUBSET of the parameters (needs_input_grad false for the rest) gets returned gradients too."""
+    import mil_amd
+    g = np.load(os.path.join(golden_dir, "eval_n8_64.npz"))
+    x, y = torch.tensor(g["x"]).cuda(), torch.tensor(g["y"]).cuda()
+    ref = _model(golden_dir, torch.float32).eval()
+    ref(x, y)["loss"].backward()
+    want = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    net = _model(golden_dir, torch.float32).eval()
+    params = dict(net.named_parameters())
+    buf = torch.full((sum(p.numel() for p in params.values()),), 7.0, device="cuda")
+    off = 0
+    for p in params.values():                    # adjacent, contiguous .grad views — what FlatParams builds, minus the opt-in
+        p.grad = buf[off:off + p.numel()].view(p.shape)
+        off += p.numel()
+    assert not net.direct_grad and not net.cnn.module.direct_grad
+    got = torch.autograd.grad(net(x, y)["loss"], list(params.values()))
+    assert bool((buf == 7.0).all())              # nothing accumulated behind autograd's back
+    for (k, _p), gk in zip(params.items(), got):
+        assert gk is not None and _grad_close(k, gk.cpu().numpy(), want[k].cpu().numpy(), 1e-5), k
+    # opt-in active, but only the head's gradients are asked for
+    flat = mil_amd.FlatParams(net)
+    flat.zero_grad()
+    head = [(k, p) for k, p in net.named_parameters() if not k.startswith("cnn.")]
+    sub = [head[0], head[-1]]                     # a subset: the run test sees un-wanted members and keeps the fast path off
+    got = torch.autograd.grad(net(x, y)["loss"], [p for _k, p in sub])
+    assert float(flat.flat_grad.abs().max()) == 0.0
+    for (k, _p), gk in zip(sub, got):
+        assert gk is not None and _grad_close(k, gk.cpu().numpy(), want[k].cpu().numpy(), 1e-5), k
+
+
 def test_whole_step_is_bitwise_reproducible(golden_dir, monkeypatch):
     """Two passes from the same state give bit-identical outputs and gradients (no atomics, fixed reduction trees, no
     races in the double-buffered / early-load pipelines): large enough for the persistent kernels and several tiles per
@@ -457,17 +490,23 @@ def test_input_modified_between_forward_and_backward_raises(golden_dir):
     """Without a kept space-to-depth copy the fused stem backward re-reads the caller's input tiles: an in-place change between
     forward and backward must raise (the tensor's version counter is checked) instead of silently corrupting conv1's gradient;
     keep_s2d=True keeps a library-owned copy and is immune."""
-    net = _model(golden_dir, torch.bfloat16).eval()
-    x = torch.randn(8, 3, 64, 64, generator=torch.Generator().manual_seed(1)).clamp_(-1, 1).cuda()
-    out = net(x, torch.tensor([1]).cuda())
-    x.mul_(0.5)
-    with pytest.raises(RuntimeError, match="modified in place"):
+    import mil_amd
+    for mode in (torch.bfloat16, mil_amd.BF16X3):        # bf16x3 keeps an fp32 clone instead of s2d records (ADVICE r3)
+        net = _model(golden_dir, mode).eval()
+        x = torch.randn(8, 3, 64, 64, generator=torch.Generator().manual_seed(1)).clamp_(-1, 1).cuda()
+        out = net(x, torch.tensor([1]).cuda())
+        x.mul_(0.5)
+        with pytest.raises(RuntimeError, match="modified in place"):
+            out["loss"].backward()
+        net.cnn.module.keep_s2d = True
+        x0 = x.clone()
+        net(x0, torch.tensor([1]).cuda())["loss"].backward()
+        want = net.cnn.module.conv1.weight.grad.clone()
+        net.cnn.module.conv1.weight.grad = None
+        out = net(x, torch.tensor([1]).cuda())
+        x.mul_(0.5)
         out["loss"].backward()
-    net.cnn.module.keep_s2d = True
-    out = net(x, torch.tensor([1]).cuda())
-    x.mul_(0.5)
-    out["loss"].backward()
-    assert float(net.cnn.module.conv1.weight.grad.abs().max()) > 0
+        assert float(want.abs().max()) > 0 and torch.equal(net.cnn.module.conv1.weight.grad, want), mode
 
 
 def test_weight_update_through_data_needs_invalidate_packed_weights(golden_dir):
