@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MIL_LIB_PATH selects another build of the same library (the NaN-poisoned diagnostic build, `make -C csrc POISON=1`)
 LIB_PATH = os.environ.get("MIL_LIB_PATH") or os.path.join(_HERE, "libmil_hip.so")
 
-MIL_DT_F32, MIL_DT_BF16, MIL_DT_BF16_DGRAD, MIL_DT_F32S = 0, 1, 2, 3
+MIL_DT_F32, MIL_DT_BF16, MIL_DT_BF16_DGRAD, MIL_DT_F32S, MIL_DT_F32S_DGRAD = 0, 1, 2, 3, 4
 # compute_dtype value of the split-precision path: fp32 tensors (every pointwise kernel of the fp32 path), convolutions
 # as three bf16 MFMAs per k-step on hi/lo-split operands (MIL_DT_F32S in include/mil_hip.h)
 BF16X3 = "bf16x3"
@@ -167,13 +167,15 @@ def mma_code(compute_dtype):
 
 
 def dt_code(dtype, dense_grads=False, mma=False):
-    """MIL_DT_* code of a compute dtype; dense_grads selects MIL_DT_BF16_DGRAD (gradient tensors of the 20-channel layer
-    at 20 channels per pixel instead of 24; see include/mil_hip.h).  mma=True (the convolution entry points and the filter
+    """MIL_DT_* code of a compute dtype; dense_grads selects MIL_DT_BF16_DGRAD / MIL_DT_F32S_DGRAD (gradient tensors of the
+    20-channel layer at 20 channels per pixel instead of 24; see include/mil_hip.h).  mma=True (the convolution entry points and the filter
     packing): fp32 tensors get the code selected by `f32_mma` (exact or split products)."""
     if dense_grads:
-        if dtype != torch.bfloat16:
-            raise ValueError("the dense gradient layout exists for bfloat16 only")
-        return MIL_DT_BF16_DGRAD
+        if dtype == torch.bfloat16:
+            return MIL_DT_BF16_DGRAD
+        if dtype == torch.float32 and mma and _F32_MMA.code == MIL_DT_F32S:
+            return MIL_DT_F32S_DGRAD
+        raise ValueError("the dense gradient layout exists for bfloat16 and for the split-precision (bf16x3) mode only")
     if dtype == torch.float32:
         return _F32_MMA.code if mma else MIL_DT_F32
     if dtype == torch.bfloat16:

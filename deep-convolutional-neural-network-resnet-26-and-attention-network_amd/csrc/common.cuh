@@ -26,6 +26,10 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 // hi*hi + lo*hi + hi*lo with fp32 accumulation (the lo*lo term, 2^-18 relative, is dropped).  16 significant bits per
 // operand at 3/16 of the matrix-pipe time of the exact-f32 MFMA: the path that meets the 1e-3 gate on the logits at speed.
 #define MIL_DT_F32S 3
+// MIL_DT_F32S with the GRADIENT tensors of a 20-channel layer stored dense: 20 fp32 channels = 80 bytes = five 16-byte pieces
+// per pixel instead of 96 (the same chain of kernels as MIL_DT_BF16_DGRAD: mil_conv_dgrad_s2's output, mil_conv_bwd_fused,
+// mil_stem_bwd_fused_nchw).
+#define MIL_DT_F32S_DGRAD 4
 
 // Channel padding used by every NHWC activation tensor (multiple of 8 elements = one 16-B bf16 piece).
 __host__ __device__ constexpr int mil_cpad(int c) { return (c + 7) / 8 * 8; }

@@ -31,7 +31,8 @@ struct BwdFusedArgs {
     float slope;
     unsigned z_bytes, x_bytes;      // byte sizes of dz and of x/addend/dx (buffer descriptors)
     unsigned g_bytes;               // fused16 kernel: byte size of addend / dx (z_bytes there is dz at the gradient stride)
-    int gpx;                        // fused16 kernel: bytes per pixel of dz / addend / dx: 48 (padded) or 40 (MIL_DT_BF16_DGRAD)
+    int gpx;                        // fused16 kernels: bytes per pixel of dz / addend / dx: 48 (padded) or 40 (MIL_DT_BF16_DGRAD); split precision: 96 or 80
+    int xpx;                        // split-precision fused16 kernel: bytes per pixel of x (96)
     unsigned long long* stamp;      // MIL_STAMP diagnostic build only: [grid][NW][8] phase cycle sums (else null)
 };
 
@@ -825,6 +826,8 @@ __global__ __launch_bounds__(512, 4) void conv_bwd_fused16_kernel(BwdFusedArgs a
     }
 }
 
+#include "conv_bwd_fused16_x3.cuh"
+
 // (the slab reduction for this layout — rows tap'*CZ + co with tap' the flipped tap, cols ci — is kind 1 of reduce.cuh)
 
 // MIL_BWD16=0 falls back to the generic kernel on 16x16 tiles too (A/B runs, bit-compatible results up to the bias
@@ -954,10 +957,80 @@ static int run_bwd_fused(BwdFusedArgs a, float* dw, float* db, void* ws, size_t 
     return MIL_OK;
 }
 
+// Split precision on 16x16 tiles of one image (layer 1 at 256x256 and 512x512 tiles): conv_bwd_fused16x3_kernel.  Returns
+// MIL_ERR_UNSUPPORTED when the shape is not its own (the caller then takes the generic kernel, padded layout only).
+static int run_bwd_fused16_x3(BwdFusedArgs a, float* dw, float* db, void* ws, size_t ws_bytes, int cout, int cin, int accumulate, bool query,
+                              size_t* need, hipStream_t stream, bool dense_grads) {
+    constexpr int KS = 3, NTX = 2, MT_PITCH = 14;                  // slab pitch = the generic kernel's row-tile count (+1 bias tile)
+    if (cout != 20 || cin != 20) return MIL_ERR_UNSUPPORTED;
+    mil_geom_tiles(a.g, 8);
+    if (a.g.tw_log2 != 4 || a.g.th_log2 != 4 || a.g.ti_log2 != 0 || a.g.H >= 1024 || a.g.W >= 1024) return MIL_ERR_UNSUPPORTED;
+    constexpr int A_PLANE = 16 + 18 * 18 * 48, X_PLANE = 256 * 48, W_BYTES = MIL_K20_STEPS * NTX * 64 * 32;
+    constexpr int lds = 2 * A_PLANE + W_BYTES + 2 * X_PLANE + 64;
+    const int gpx = dense_grads ? 80 : 96, xpx = 96;
+    const size_t img_bytes = (size_t)a.g.H * a.g.W * 96;
+    int chunk = mil_imgs_under_2g(img_bytes);
+    if (chunk >= 16) chunk &= ~15;
+    const int n_total = a.g.n_img;
+    if (chunk < n_total) { a.g.n_img = chunk; a.g.n_groups = chunk; }
+    const int ntiles = a.g.n_groups * a.g.tiles_y * a.g.tiles_x;
+    auto pick = [](bool add, bool mask) {
+        return add ? (mask ? conv_bwd_fused16x3_kernel<true, true> : conv_bwd_fused16x3_kernel<true, false>)
+                   : (mask ? conv_bwd_fused16x3_kernel<false, true> : conv_bwd_fused16x3_kernel<false, false>);
+    };
+    auto kern = pick(a.addend != nullptr, a.apply_mask != 0);
+    static std::atomic<unsigned long long> attr_set{0};
+    if (mil_device_needs(attr_set)) {
+        for (int v = 0; v < 4; ++v)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(pick(v & 1, v & 2)), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+                return MIL_ERR_LAUNCH;
+        mil_device_done(attr_set);
+    }
+    int per_cu = 3;
+    for (int v = 0; v < 4; ++v) {          // the workspace query must size for the grid any ADD/MASK variant will use
+        const int o = mil_resident_per_cu(pick(v & 1, v & 2), lds, 3, 256);
+        per_cu = o < per_cu ? o : per_cu;
+    }
+    int grid = mil_num_cus() * per_cu;
+    if (grid > ntiles) grid = ntiles;
+    const size_t slab_elems = (size_t)(MT_PITCH + 1) * 16 * NTX * 16;
+    const size_t bytes = slab_elems * grid * sizeof(float);
+    if (query) { *need = bytes; return MIL_OK; }
+    if (!ws || ws_bytes < bytes) return MIL_ERR_ARG;
+    a.slab = (float*)ws;
+    a.lds_w_off = 2 * A_PLANE; a.lds_x_off = 2 * A_PLANE + W_BYTES; a.lds_dump_off = 2 * A_PLANE + W_BYTES + 2 * X_PLANE;
+    a.lds_a2_off = 0; a.lds_x2_off = 0;
+    if (grid <= 0) return MIL_OK;
+    const BwdFusedArgs a0 = a;
+    for (int i0 = 0; i0 < n_total; i0 += chunk) {
+        const int n = n_total - i0 < chunk ? n_total - i0 : chunk;
+        BwdFusedArgs c = a0;
+        c.g.n_img = n; c.g.n_groups = n;
+        c.ntiles = n * c.g.tiles_y * c.g.tiles_x;
+        const size_t px0 = (size_t)i0 * a.g.H * a.g.W, npx = (size_t)n * a.g.H * a.g.W;
+        // BwdFusedArgs pointers are typed __bf16: byte offsets / 2
+        c.dz = a0.dz + px0 * gpx / 2; c.x = a0.x + px0 * xpx / 2; c.dx = a0.dx + px0 * gpx / 2;
+        if (a0.addend) c.addend = a0.addend + px0 * gpx / 2;
+        c.z_bytes = (unsigned)(npx * gpx); c.g_bytes = (unsigned)(npx * gpx); c.x_bytes = (unsigned)(npx * xpx);
+        c.gpx = gpx; c.xpx = xpx;
+        const int gr = grid < c.ntiles ? grid : c.ntiles;
+        hipLaunchKernelGGL(kern, dim3(gr), dim3(256), lds, stream, c);
+        MIL_CHECK_LAUNCH();
+        MilReduceJob j{};
+        j.slab = (const float*)ws; j.nslab = gr; j.slab_elems = slab_elems; j.slab_cols = NTX * 16;
+        j.dw = dw; j.db = db; j.cout = cout; j.cin = cin; j.ks = KS; j.kind = 1;
+        j.cinp = 20; j.n_rows = KS * KS * 20; j.bias_off = (KS * KS / 2) * 20 * NTX * 16 + 23; j.bias_stride = NTX * 16;      // rows tap'*20 + co
+        j.accumulate = (i0 > 0) ? 1 : accumulate;
+        mil_reduce_or_defer(j, stream, /*may_defer=*/chunk >= n_total);
+        MIL_CHECK_LAUNCH();
+    }
+    return MIL_OK;
+}
+
 static int bwd_fused_entry(const void* dz, const void* wpack, const void* x, const void* addend, void* dx, float* dw,
                            float* db, void* ws, size_t ws_bytes, int n_img, int H, int W, int cout, int cin, int ks,
                            int pad, int apply_mask, int accumulate, float slope, int dtype, bool query, size_t* need, void* stream) {
-    const bool dense_grads = dtype == MIL_DT_BF16_DGRAD;
+    const bool dense_grads = dtype == MIL_DT_BF16_DGRAD || dtype == MIL_DT_F32S_DGRAD;
     if ((dtype != MIL_DT_BF16 && !dense_grads && dtype != MIL_DT_F32S) || ks != 3 || pad != 1) return MIL_ERR_UNSUPPORTED;
     if (n_img <= 0 || H <= 0 || W <= 0) return MIL_ERR_ARG;
     if (slope <= 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
@@ -970,9 +1043,12 @@ static int bwd_fused_entry(const void* dz, const void* wpack, const void* x, con
 #ifndef MIL_BWD24_WAVES
 #define MIL_BWD24_WAVES 8       // measured in the model: 397/428/401 us per launch with 4 waves per workgroup (two per SIMD), 356/397/371 us with 8 (four per SIMD, 122-128 VGPRs)
 #endif
-    if (dtype == MIL_DT_F32S) {                  // fp32 tensors, bf16x3 products: the 24-channel layers (one 8-wave workgroup per CU)
-        if (czp == 24 && cxp == 24) return run_bwd_fused<F32S, 24, 2, 3, 8>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st);
-        return MIL_ERR_UNSUPPORTED;
+    if (dtype == MIL_DT_F32S || dtype == MIL_DT_F32S_DGRAD) {      // fp32 tensors, bf16x3 products: the 24-channel layers
+        if (czp != 24 || cxp != 24) return MIL_ERR_UNSUPPORTED;
+        // 16x16 tiles of one image: the compile-time-geometry kernel (two 4-wave workgroups per CU; dense or padded gradients)
+        const int rc = run_bwd_fused16_x3(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st, dense_grads);
+        if (rc != MIL_ERR_UNSUPPORTED || dense_grads) return rc;          // only that kernel reads the dense layout
+        return run_bwd_fused<F32S, 24, 2, 3, 8>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st);
     }
     if (czp == 24 && cxp == 24) return run_bwd_fused<BF16, 24, 2, 3, MIL_BWD24_WAVES>(a, dw, db, ws, ws_bytes, cout, cin, accumulate, query, need, st, dense_grads);
     if (dense_grads) return MIL_ERR_UNSUPPORTED;

@@ -22,7 +22,7 @@ struct DgradS2Args {
     int ch, cw;             // compact halo extent per image: TH/2+1, TW/2+1
     int lds_z2_off, lds_w_off;
     float slope;
-    int ypx;                // bytes per pixel of y: CXP*2, or 40 when a 20-channel output is written dense (MIL_DT_BF16_DGRAD)
+    int ypx;                // bytes per pixel of y: CXP*ESZ, or 40 / 80 when a 20-channel output is written dense (MIL_DT_BF16_DGRAD / MIL_DT_F32S_DGRAD)
     unsigned act_bytes;
 };
 
@@ -238,7 +238,9 @@ __global__ __launch_bounds__(256, (CZ <= 40 && !T::SPLIT) ? 2 : 1) void conv_dgr
                         }
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4_t{v[0], v[1], v[2], v[3]}), rs_y, off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4_t{v[4], v[5], v[6], v[7]}), rs_y, off == MIL_OOB ? MIL_OOB : off + 16, 0, 0);
+                    // dense 20-channel output (a.ypx = 80): channels 20-23 of the last column tile do not exist
+                    const bool skip2 = off == MIL_OOB || (LAST_PARTIAL && nt == NT - 1 && a.ypx != CXP * ESZ);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4_t{v[4], v[5], v[6], v[7]}), rs_y, skip2 ? MIL_OOB : off + 16, 0, 0);
                 } else {
                 if (a.act) {
                     const bf16x8_t t = __builtin_bit_cast(bf16x8_t, ract[p][nt][0]);
@@ -305,14 +307,14 @@ static int launch_dgrad_s2(DgradS2Args<T> a, hipStream_t st) {
 extern "C" int mil_conv_dgrad_s2(const void* dz1, const void* dz2, const void* wpack, const void* act, void* y, int n_img,
                                  int h, int w, int cz_p, int H, int W, int cx_p, float slope, int dtype, void* stream) {
     if (!dz1 || !wpack || !y || n_img < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return MIL_ERR_ARG;
-    if ((dtype != MIL_DT_BF16 && dtype != MIL_DT_BF16_DGRAD && dtype != MIL_DT_F32S) || h != (H - 1) / 2 + 1 || w != (W - 1) / 2 + 1 || slope < 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
+    if ((dtype != MIL_DT_BF16 && dtype != MIL_DT_BF16_DGRAD && dtype != MIL_DT_F32S && dtype != MIL_DT_F32S_DGRAD) || h != (H - 1) / 2 + 1 || w != (W - 1) / 2 + 1 || slope < 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
     if (n_img == 0) return MIL_OK;
-    if (dtype == MIL_DT_F32S) {                  // fp32 tensors, bf16x3 products: the 40 -> 24 channel entry (the only filter that fits)
+    if (dtype == MIL_DT_F32S || dtype == MIL_DT_F32S_DGRAD) {      // fp32 tensors, bf16x3 products: the 40 -> 24 channel entry (the only filter that fits)
         if (cz_p != 40 || cx_p != 24) return MIL_ERR_UNSUPPORTED;
         DgradS2Args<F32S> b{};
         b.dz1 = (const float*)dz1; b.dz2 = (const float*)dz2; b.w = (const float*)wpack; b.act = (const float*)act; b.y = (float*)y;
         b.g.n_img = n_img; b.g.H = h; b.g.W = w; b.g.Ho = H; b.g.Wo = W; b.g.ks = 3; b.g.stride = 1; b.g.pad = 1; b.g.zins = 1;
-        b.slope = slope; b.ypx = cx_p * 4;
+        b.slope = slope; b.ypx = dtype == MIL_DT_F32S_DGRAD ? 80 : cx_p * 4;      // y [n,H,W,20] dense fp32, or padded
         return launch_dgrad_s2<F32S, 40, 2>(b, reinterpret_cast<hipStream_t>(stream));
     }
     DgradS2Args<BF16> a{};

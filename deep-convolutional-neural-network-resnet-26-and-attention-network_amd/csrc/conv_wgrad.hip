@@ -600,7 +600,7 @@ struct StemBwdArgs {
     unsigned x_bytes;
     int lds_dump_off;
     const __bf16* gp;        // [n,Hp,Wp,24] gradient of the pooled output ([n,Hp,Wp,20] when gpx == 40: MIL_DT_BF16_DGRAD; fp32 when gpx == 96: MIL_DT_F32S)
-    int gpx;                 // bytes per pixel of gp: 48, 40 or 96
+    int gpx;                 // bytes per pixel of gp: 48 / 40 (bf16 padded / dense) or 96 / 80 (fp32 padded / dense: MIL_DT_F32S_DGRAD)
     const uint8_t* widx;     // [n,Hp,Wp,24] winner tap (bits 0-3) + "winner <= 0" (bit 4)
     float* slab;
     ConvGeom g;              // geometry of the stem conv as executed (ks 4, stride 1, pad 2, Ho=H2, Wo=W2)
@@ -733,9 +733,9 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
             const bool ok = p >= 0 && (p >> 20) < ilim && ((p >> 10) & 1023) < ylim && (p & 1023) < xlim;
             const int pix = base + (w_rel[i] >> 2), j = w_rel[i] & 3;
             if constexpr (X3) {                               // eight fp32 channels = two 16-byte loads
-                const unsigned goff = ok ? (unsigned)(pix * 96 + j * 32) : MIL_OOB;
+                const unsigned goff = ok ? (unsigned)(pix * a.gpx + j * 32) : MIL_OOB;
                 rg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, goff, 0, 0);
-                rg2[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, ok ? goff + 16 : MIL_OOB, 0, 0);
+                rg2[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (ok && !(a.gpx != 96 && j == 2)) ? goff + 16 : MIL_OOB, 0, 0);      // dense: channels 20-23 do not exist
             } else {
             const unsigned goff = ok ? (unsigned)(pix * a.gpx + j * 16) : MIL_OOB;
             const u32x2_t lo = __builtin_amdgcn_raw_buffer_load_b64(rs_g, goff, 0, 0);
@@ -980,9 +980,9 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
 static int stem_bwd_entry(const void* xs, const float* x, const void* gp, const uint8_t* widx, float* dw, float* db, void* ws,
                           size_t ws_bytes, int n, int H2, int W2, float slope, int accumulate, int dtype, bool from_x, bool query,
                           size_t* need, void* stream) {
-    const bool x3 = dtype == MIL_DT_F32S;                   // fp32 g_pool [n,Hp,Wp,24], split-precision products: from the fp32 tiles only
+    const bool x3 = dtype == MIL_DT_F32S || dtype == MIL_DT_F32S_DGRAD;      // fp32 g_pool, split-precision products: from the fp32 tiles only
     if (dtype != MIL_DT_BF16 && dtype != MIL_DT_BF16_DGRAD && !(x3 && from_x)) return MIL_ERR_UNSUPPORTED;
-    const int gpx = x3 ? 96 : dtype == MIL_DT_BF16_DGRAD ? 40 : 48;   // g_pool [n,Hp,Wp,20] dense or [n,Hp,Wp,24]
+    const int gpx = x3 ? (dtype == MIL_DT_F32S_DGRAD ? 80 : 96) : dtype == MIL_DT_BF16_DGRAD ? 40 : 48;   // g_pool [n,Hp,Wp,20] dense or [n,Hp,Wp,24]
     if (n <= 0 || H2 <= 0 || W2 <= 0) return MIL_ERR_ARG;
     if (from_x && (W2 & 1)) return MIL_ERR_UNSUPPORTED;      // 16-byte input pieces: W % 4 == 0
     const int PIXB = mil_pix_pitch(16, x3 ? 4 : 2), PIXZ = mil_pix_pitch(24, x3 ? 4 : 2), PIXG = x3 ? 96 : PIXZ;

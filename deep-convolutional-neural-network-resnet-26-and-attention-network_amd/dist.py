@@ -19,7 +19,13 @@ def shard_bags(n_bags, rank, world):
 
 class FlatParams:
     """Re-points every parameter (and its .grad) of `module` into one contiguous fp32 buffer each, so the
-    gradient exchange is a single collective and an optimizer can sweep one array."""
+    gradient exchange is a single collective and an optimizer can sweep one array.
+
+    Also the OPT-IN to in-place gradient accumulation (`direct_grad` on the encoder and on `Attention`): the hand-written
+    backward passes then add their gradients straight into `flat_grad` and hand autograd None for those parameters.  That is
+    valid for plain `loss.backward()` (what the reference's loop does, gbm/classify_combined.py:446-447) and nothing else:
+    `torch.autograd.grad`, `backward(inputs=...)` and per-parameter gradient hooks need the gradients returned — use the module
+    without a FlatParams (or set `direct_grad = False` on `net` and `net.cnn.module`) for those."""
 
     def __init__(self, module):
         self.params = [p for p in module.parameters() if p.requires_grad]

@@ -531,7 +531,8 @@ def encoder_backward(net, saved, dfeats, dtype, allow_direct=True):
                     # the gradient chain of the first (20-channel) stage below this point runs on kernels that read the
                     # dense layout, when every one of them exists for these shapes: the fused backward and the fused stem backward
                     dense_cx = None
-                    if (net.dense_grads and cin == STEM_WIDTH and ops.cpad(cin) != cin and dtype == torch.bfloat16 and bi > 0 and
+                    split = dtype == torch.float32 and L.dt_code(dtype, mma=True) == L.MIL_DT_F32S
+                    if (net.dense_grads and cin == STEM_WIDTH and ops.cpad(cin) != cin and (dtype == torch.bfloat16 or split) and bi > 0 and
                             all(b.stride == 1 and b.downsample is None for b in blocks[:bi]) and
                             ops.bwd_fused_workspace_bytes(xin.shape[0], xin.shape[1], xin.shape[2], cin, cin, 3, 1, dtype, True) is not None and
                             ops.stem_bwd_dense_ok(saved["x"] if saved["xs"] is None else saved["xs"], dtype)):

@@ -121,8 +121,9 @@ class _HeadFn(torch.autograd.Function):
         # context.bn.weight to buffer.classifier.bias): ONE add of the kernel's gradient block into that run instead of one
         # autograd accumulation (a torch add launch) per parameter — the kernel writes its gradients in the same order.
         # Only under the explicit opt-in (a FlatParams owns the gradients and the caller runs plain `loss.backward()`), and
-        # only for parameters autograd asked a gradient for; otherwise every gradient is RETURNED, so that
-        # torch.autograd.grad / backward(inputs=...) / gradient hooks see them and no .grad is touched behind their back.
+        # only for parameters that required a gradient at forward time (a frozen one ends the run); without the opt-in every
+        # gradient is RETURNED, so that torch.autograd.grad / backward(inputs=...) / gradient hooks see them and no .grad is
+        # touched behind their back.
         n_fixed = 7                          # positional inputs in front of the weights
         wanted = [bool(ctx.needs_input_grad[n_fixed + i]) for i in range(len(ctx.ws))]
         out, o, run = [], 0, (_contiguous_grad_run(ctx.params, wanted) if ctx.direct else None)

@@ -397,7 +397,7 @@ def conv_dgrad_s2(dz1, dz2, wpack, cx_p, out_hw, *, act=None, slope=LEAK, dense_
     n, h, w, cz_p = dz1.shape
     hh, ww = out_hw
     dense = dense_cx is not None
-    if dz1.dtype != torch.bfloat16 and (dense or L.dt_code(dz1.dtype, mma=True) != L.MIL_DT_F32S):
+    if dz1.dtype != torch.bfloat16 and L.dt_code(dz1.dtype, mma=True) != L.MIL_DT_F32S:
         return None               # bf16, or fp32 tensors with split-precision products (the 40 -> 24 channel entry)
     _need(dz1, dz1.shape, dz1.dtype, "dz1")
     _need(dz2, dz1.shape, dz1.dtype, "dz2")
@@ -509,7 +509,7 @@ def stem_bwd_fused_nchw(x, g_pool, widx, *, workspace=None, out=None, slope=LEAK
     if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous():
         return None
     n, _, h, w = x.shape
-    dense = g_pool.shape[-1] == 20            # dense gradient layout (MIL_DT_BF16_DGRAD)
+    dense = g_pool.shape[-1] == 20            # dense gradient layout (MIL_DT_BF16_DGRAD / MIL_DT_F32S_DGRAD)
     need = ctypes.c_size_t(0)
     rc = L.lib().mil_stem_bwd_fused_nchw_workspace(ctypes.byref(need), n, h, w, L.dt_code(g_pool.dtype, dense, mma=True))
     if rc == 2 or x.data_ptr() % 16:
@@ -550,7 +550,7 @@ def stem_bwd_dense_ok(src, dtype):
         n, _, h, w = src.shape
         if not src.is_contiguous() or src.data_ptr() % 16:
             return False
-        return L.lib().mil_stem_bwd_fused_nchw_workspace(ctypes.byref(need), n, h, w, L.dt_code(dtype, True)) == 0
+        return L.lib().mil_stem_bwd_fused_nchw_workspace(ctypes.byref(need), n, h, w, L.dt_code(dtype, True, mma=True)) == 0
     n, h2, w2, _ = src.shape
     return L.lib().mil_stem_bwd_fused_workspace(ctypes.byref(need), n, h2, w2, L.dt_code(dtype, True)) == 0
 

@@ -53,6 +53,11 @@ extern "C" {
  * kernel for it return MIL_ERR_UNSUPPORTED; query with the *_workspace functions before choosing it. */
 #define MIL_DT_BF16_DGRAD 2
 #define MIL_DT_F32S 3
+/* MIL_DT_F32S with the same GRADIENT tensors stored dense as fp32: [n,H,W,20] = 80 bytes = five 16-byte pieces per pixel instead
+ * of 96 (no padding traffic on three of the four tensor passes of the stage's fused backward).  Accepted by mil_conv_bwd_fused
+ * (16x16 tiles: maps of at least 16x16), mil_conv_dgrad_s2 (40 -> 20 channels) and mil_stem_bwd_fused_nchw; query with the
+ * *_workspace functions before choosing it. */
+#define MIL_DT_F32S_DGRAD 4
 
 #define MIL_PACK_FWD 0   /* B[(tap,ci)][co] = W[co][ci][ky][kx]                     */
 #define MIL_PACK_DGRAD 1 /* B[(tap,co)][ci] = W[co][ci][k-1-ky][k-1-kx]             */

@@ -230,6 +230,17 @@ def test_fused_backward_split_precision(ops, shape, with_addend, mask):
     assert rel_err(dw.cpu(), wt.grad) < WTOL[X3] and rel_err(db.cpu(), b.grad) < WTOL[X3]
     assert all(torch.equal(p, q) for p, q in zip(out, out2))
     assert ops.conv_bwd_fused(dzg, wd, xg, cin, cout) is None          # exact-fp32 mode: no fused kernel
+    # dense gradient layout (MIL_DT_F32S_DGRAD: dz / addend / dx at 20 fp32 channels = 80 bytes per pixel, x stays padded) on the
+    # maps the 16x16-tile kernel takes: the same values and sums, bit for bit
+    with L.f32_mma(L.MIL_DT_F32S):
+        ws_need = ops.bwd_fused_workspace_bytes(n, h, w, cout, cin, 3, 1, torch.float32, True)
+        if h == 64 and w == 64:                  # the benchmark's first-stage maps must have it; smaller maps may decline
+            assert ws_need is not None, "no dense-layout split-precision fused backward for the 64x64 20-channel maps"
+        if ws_need is not None:
+            add_d = to_nhwc(addend, torch.float32)[..., :cin].contiguous() if with_addend else None
+            out3 = ops.conv_bwd_fused(dzg[..., :cout].contiguous(), wd, xg, cin, cout, addend=add_d, mask=mask)
+            assert out3[0].shape[-1] == cin and torch.equal(out3[0], dx[..., :cin].contiguous())
+            assert torch.equal(out3[1], dw) and torch.equal(out3[2], db)
 
 
 @pytest.mark.parametrize("shape", [(3, 16, 16, 20), (2, 19, 23, 20), (5, 8, 8, 20), (2, 64, 64, 20),
@@ -487,7 +498,9 @@ def test_stem_backward_fused_split_precision(ops, shape):
     # bitwise reproducible
     with L.f32_mma(L.MIL_DT_F32S):
         dw3, db3 = ops.stem_bwd_fused_nchw(x.cuda(), gpg, widx)
+        dw4, db4 = ops.stem_bwd_fused_nchw(x.cuda(), gpg[..., :20].contiguous(), widx)      # dense pooled gradient (MIL_DT_F32S_DGRAD)
     assert torch.equal(dw, dw3) and torch.equal(db, db3)
+    assert torch.equal(dw, dw4) and torch.equal(db, db4)
 
 
 STEM_FUSED_CASES = [
@@ -610,6 +623,10 @@ def test_stage_entry_data_gradient_one_pass_split_precision(ops, case, with_proj
         assert got is not None and got.dtype == torch.float32
         assert rel_err(from_nhwc(got, cin), want) < TOL[X3]
         assert float(got[..., cin:].abs().max()) == 0.0
+        if cin == 20:       # dense output layout (MIL_DT_F32S_DGRAD): the same 20 channels at 80 bytes per pixel
+            got_d = ops.conv_dgrad_s2(to_nhwc(dz1, torch.float32), to_nhwc(dz2, torch.float32) if with_proj else None, ws2, cpad(cin),
+                                      (h, w), act=to_nhwc(act, torch.float32), dense_cx=cin)
+            assert got_d is not None and got_d.shape[-1] == cin and torch.equal(got_d, got[..., :cin].contiguous())
         big = torch.zeros((2, 4, 4, 64), device="cuda")
         wbig, _ = ops.pack_weights(torch.randn(60, 40, 3, 3).cuda(), None, L.PACK_DGRAD_S2, torch.float32)
         assert ops.conv_dgrad_s2(big, None, wbig, 40, (8, 8)) is None
