@@ -283,12 +283,13 @@ def _family_kernel(fam, dtype_name):
     """(description, kernel-name keys into the rocprofv3 summaries) of a bracketed family, per compute mode."""
     x3 = dtype_name == "bf16x3"
     table = {
-        "block_fwd": ("conv_block_fwd_kernel<24,..> (whole identity block forward: conv-lrelu-conv-add-lrelu, 20 ch", ("conv_block_fwd_kernel<24,",)),
+        "block_fwd": (("conv_block_fwd_x3_kernel (whole identity block forward, split precision: conv-lrelu-conv-add-lrelu, 20 ch", ("conv_block_fwd_x3_kernel",)) if x3 else
+                      ("conv_block_fwd_kernel<24,..> (whole identity block forward: conv-lrelu-conv-add-lrelu, 20 ch", ("conv_block_fwd_kernel<24,",))),
         "conv": (("conv_igemm_pf_kernel<F32S,24,2,3,4,..>" if x3 else "conv_igemm_pf_kernel<BF16,24,2,3,4,..>") +
                  " (3x3 s1 conv, forward or data gradient, 20->20 ch",
                  ("conv_igemm_pf_kernel<F32S, 24, 2, 3, 4",) if x3 else ("conv_igemm_pf_kernel<BF16, 24, 2, 3, 4", "conv_igemm_pf_kernel<24, 2, 3, 4")),
-        "bwd_fused": (("conv_bwd_fused_kernel<F32S,24,2,3,ADD,MASK,8> (fused data+weight gradient of the 3x3 s1 conv, split precision, 20->20 ch",
-                       ("conv_bwd_fused_kernel<F32S, 24, 2, 3",)) if x3 else
+        "bwd_fused": (("conv_bwd_fused16x3_kernel<ADD,MASK> (fused data+weight gradient of the 3x3 s1 conv, split precision, 16x16 tiles, 20->20 ch",
+                       ("conv_bwd_fused16x3_kernel<", "conv_bwd_fused_kernel<F32S, 24, 2, 3")) if x3 else
                       ("conv_bwd_fused16_kernel<ADD,MASK> (fused data+weight gradient of the 3x3 s1 conv, 16x16 tiles, 20->20 ch",
                        ("conv_bwd_fused16_kernel<", "conv_bwd_fused_kernel<BF16, 24, 2, 3", "conv_bwd_fused_kernel<24, 2, 3"))),
         "wgrad": ("wgrad_kernel<..3,24,2,..> (weight+bias gradient of the 3x3 s1 conv, 20->20 ch", ("wgrad_kernel<F32S, 3, 24, 2", "wgrad_kernel<BF16, 3, 24, 2")),

@@ -283,8 +283,13 @@ static int launch_block_fwd(BlockFwdArgs a, hipStream_t st) {
     a.lds_o_off = x_bytes; a.lds_w_off = x_bytes + o_bytes; a.lds_dump_off = x_bytes + o_bytes + w_bytes;
     const int lds = a.lds_dump_off + 64;
     if (lds > 160 * 1024) return MIL_ERR_UNSUPPORTED;
+#ifdef MIL_AB_SWITCHES
     const int nw = mil_block_waves();
     auto kern = nw == 8 ? conv_block_fwd_kernel<CP, NT, 8> : conv_block_fwd_kernel<CP, NT, 4>;
+#else
+    constexpr int nw = 4;              // the 8-wave form (A/B builds only) measured no faster and spills at 128 VGPRs
+    auto kern = conv_block_fwd_kernel<CP, NT, 4>;
+#endif
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MIL_ERR_LAUNCH;
     static thread_local int occ_lds = -1, occ_n = 1;
@@ -312,11 +317,24 @@ static int launch_block_fwd(BlockFwdArgs a, hipStream_t st) {
     return MIL_OK;
 }
 
+#include <type_traits>
+#include "conv_block_fwd_x3.cuh"
+
 // o1 = lrelu(conv3x3(x)+b1), y = lrelu(conv3x3(o1)+b2+x) for an identity-shortcut block; x/o1/y [n,H,W,cp].
-// bf16, cp in {24, 40}, H and W >= 16; otherwise MIL_ERR_UNSUPPORTED (caller: two mil_conv_igemm calls).
+// bf16, cp in {24, 40}, H and W >= 16; MIL_DT_F32S (fp32 tensors, split products), cp = 24 (20 real channels), H >= 8 and
+// W >= 16; otherwise MIL_ERR_UNSUPPORTED (caller: two mil_conv_igemm calls).
 extern "C" int mil_conv_block_fwd(const void* x, const void* wpack1, const float* bias1, const void* wpack2, const float* bias2,
                                   void* o1, void* y, int n_img, int H, int W, int cp, float slope, int dtype, void* stream) {
     if (!x || !wpack1 || !wpack2 || !o1 || !y || n_img < 0 || H <= 0 || W <= 0) return MIL_ERR_ARG;
+    if (dtype == MIL_DT_F32S) {
+        if (cp != 24 || H < 8 || W < 16 || H >= 1024 || W >= 1024 || slope < 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
+        if (n_img == 0) return MIL_OK;
+        BlockFwdX3Args b{};
+        b.x = (const float*)x; b.w1 = (const char*)wpack1; b.w2 = (const char*)wpack2; b.b1 = bias1; b.b2 = bias2;
+        b.o1 = (float*)o1; b.y = (float*)y; b.slope = slope; b.apx = cp * 4;
+        b.g.n_img = n_img; b.g.H = H; b.g.W = W; b.g.Ho = H; b.g.Wo = W; b.g.ks = 5; b.g.stride = 1; b.g.pad = 2; b.g.zins = 0;
+        return launch_block_fwd_x3(b, reinterpret_cast<hipStream_t>(stream));
+    }
     if (dtype != MIL_DT_BF16 || H < 16 || W < 16 || H >= 1024 || W >= 1024 || slope < 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
     if (n_img == 0) return MIL_OK;
     BlockFwdArgs a{};

@@ -1014,8 +1014,16 @@ static int run_bwd_fused16_x3(BwdFusedArgs a, float* dw, float* db, void* ws, si
         c.z_bytes = (unsigned)(npx * gpx); c.g_bytes = (unsigned)(npx * gpx); c.x_bytes = (unsigned)(npx * xpx);
         c.gpx = gpx; c.xpx = xpx;
         const int gr = grid < c.ntiles ? grid : c.ntiles;
+#ifdef MIL_STAMP
+        static MilStampBuf sb;
+        c.stamp = sb.get((size_t)gr * 4 * 10);
+#endif
         hipLaunchKernelGGL(kern, dim3(gr), dim3(256), lds, stream, c);
         MIL_CHECK_LAUNCH();
+#ifdef MIL_STAMP
+        static const char* const ph[8] = {"barrier-top", "commit", "barrier-vis", "fetch-issue", "dgrad", "epilogue", "addend-issue", "wgrad"};
+        sb.report(a0.addend ? "conv_bwd_fused16x3_kernel<ADD>" : "conv_bwd_fused16x3_kernel", gr, 4, 8, ph, stream);
+#endif
         MilReduceJob j{};
         j.slab = (const float*)ws; j.nslab = gr; j.slab_elems = slab_elems; j.slab_cols = NTX * 16;
         j.dw = dw; j.db = db; j.cout = cout; j.cin = cin; j.ks = KS; j.kind = 1;

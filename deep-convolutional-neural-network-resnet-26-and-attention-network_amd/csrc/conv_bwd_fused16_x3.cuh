@@ -17,6 +17,7 @@
 //     channels, MIL_DT_F32S_DGRAD: five 16-byte pieces per pixel and no padding traffic); x at a.xpx (96).
 //   * a fetched 16-byte piece is four fp32 channels; it is split when it is committed to LDS (8 bytes into each plane).
 #pragma once
+#include "stamp.cuh"
 
 template <bool ADD, bool MASK>
 __global__ __launch_bounds__(256, 2) void conv_bwd_fused16x3_kernel(BwdFusedArgs a) {
@@ -54,50 +55,62 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused16x3_kernel(BwdFusedArgs
 
     // ---- halo pieces of this thread: flat piece id = tid + 256*s -> (halo pixel id/5, piece id%5): consecutive lanes read
     // consecutive 16-byte pieces (80 contiguous bytes per pixel).  h_pos = j<<20 | hy<<10 | hx, negative when unused.
-    int h_pos[NPH], h_lds[NPH];
+    // (tables in registers — this kernel has 256 VGPRs to spend —: a fetch is a bounds test and one add per piece, and a tile whose
+    // halo lies inside the image takes neither: the tile's base rides in the scalar offset of the buffer load)
+    // h_pk = LDS offset of the piece relative to ldsA (14 bits) | hx << 14 | hy << 19 | (piece == 4) << 24; negative when unused
+    int h_pk[NPH], h_rel[NPH];
 #pragma unroll
     for (int i = 0; i < NPH; ++i) {
         const int idx = tid + NTHR * i;
         const int px = idx / 5, j = idx - px * 5;
         const int hy = px / HW, hx = px - hy * HW;
         const bool used = px < HW * HW;
-        h_pos[i] = used ? (j << 20) | (hy << 10) | hx : (int)0x80000000u;
-        h_lds[i] = used ? px * PIXB + j * 8 : dump - HALO0;            // relative to ldsA
+        h_pk[i] = used ? (px * PIXB + j * 8) | (hx << 14) | (hy << 19) | ((j == 4) << 24) : (int)0x80000000u;
+        h_rel[i] = used ? ((hy + 1) * W + hx + 1) * GPX + j * 16 : (int)MIL_OOB;      // relative to the pixel one row and one column before the halo origin: never negative
     }
     u32x4_t rz[NPH];
     auto fetch_halo = [&](const TileOrigin& o) {
         const int iy0 = o.oy0 - 1, ix0 = o.ox0 - 1;
-        const int base = ((o.img0 * H + iy0) * W + ix0) * GPX;         // may be negative; valid lanes are not
+        const int base = ((o.img0 * H + iy0 - 1) * W + ix0 - 1) * GPX;         // may be negative; valid lanes' sums are not
+        if (iy0 >= 1 && ix0 >= 1 && iy0 + HW <= H && ix0 + HW <= W) {          // interior tile (wave-uniform): no per-piece test, base in the scalar offset
+#pragma unroll
+            for (int i = 0; i < NPH; ++i) rz[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_z, (unsigned)h_rel[i], base, 0);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NPH; ++i) {
-            int p = h_pos[i];
-            asm volatile("" : "+v"(p));                                // keeps the derived values out of loop-long registers
-            const int hy = (p >> 10) & 1023, hx = p & 1023, j = (p >> 20) & 7;
+            int p = h_pk[i];
+            asm volatile("" : "+v"(p));
+            const int hy = (p >> 19) & 31, hx = (p >> 14) & 31;
             const bool ok = (p >= 0) & ((unsigned)(iy0 + hy) < (unsigned)H) & ((unsigned)(ix0 + hx) < (unsigned)W);
-            rz[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_z, ok ? (unsigned)(base + (hy * W + hx) * GPX + j * 16) : MIL_OOB, 0, 0);
+            rz[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_z, ok ? (unsigned)(base + h_rel[i]) : MIL_OOB, 0, 0);
         }
     };
     // ---- x-tile pieces: flat piece id = tid + 256*s -> (tile pixel id/5, piece id%5); the padding piece of a 96-byte record
     // is never read
-    int x_pos[NPXT], x_ldso[NPXT];
+    int x_pk[NPXT], x_rel[NPXT];                                     // x_pk = LDS offset (14 bits) | tx << 14 | ty << 18
 #pragma unroll
     for (int i = 0; i < NPXT; ++i) {
         const int idx = tid + NTHR * i;
         const int px = idx / 5, j = idx - px * 5;
-        x_pos[i] = (j << 20) | ((px >> 4) << 10) | (px & 15);
-        x_ldso[i] = px * PIXX + j * 8;
+        x_pk[i] = (px * PIXX + j * 8) | ((px & 15) << 14) | ((px >> 4) << 18);
+        x_rel[i] = ((px >> 4) * W + (px & 15)) * XPX + j * 16;
     }
     u32x4_t rxt[NPXT];
     auto fetch_x = [&](const TileOrigin& o) {
         const int base = ((o.img0 * H + o.oy0) * W + o.ox0) * XPX;
         const int ylim = H - o.oy0, xlim = W - o.ox0;
+        if (ylim >= 16 && xlim >= 16) {                                 // whole tile inside the image (wave-uniform)
+#pragma unroll
+            for (int i = 0; i < NPXT; ++i) rxt[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)x_rel[i], base, 0);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NPXT; ++i) {
-            int p = x_pos[i];
+            int p = x_pk[i];
             asm volatile("" : "+v"(p));
-            const int ty = (p >> 10) & 1023, tx = p & 1023, j = (p >> 20) & 7;
-            const bool ok = (ty < ylim) & (tx < xlim);
-            rxt[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (unsigned)(base + (ty * W + tx) * XPX + j * 16) : MIL_OOB, 0, 0);
+            const bool ok = ((p >> 18) < ylim) & (((p >> 14) & 15) < xlim);
+            rxt[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (unsigned)(base + x_rel[i]) : MIL_OOB, 0, 0);
         }
     };
     auto split4 = [](const u32x4_t& rr, u32x2_t& hi, u32x2_t& lo) {
@@ -180,17 +193,20 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused16x3_kernel(BwdFusedArgs
         fetch_halo(o0); fetch_x(o0); set_goff(o0); fetch_add();
     }
 
+    MIL_STAMP_DECL(8)
     for (int tile = bid; tile < a.ntiles; tile += gridDim.x) {
+        MIL_STAMP_BEGIN()
         __syncthreads();                       // every wave has left the previous tile's loops: the images may be overwritten
+        MIL_STAMP_MARK(0)
         // ---- commit: dz halo (both planes; piece 4 also into the previous pixel's "next pixel" slot) and x tile -------------
 #pragma unroll
         for (int i = 0; i < NPH; ++i) {
-            int p = h_pos[i];
-            asm volatile("" : "+v"(p));
+            int p = h_pk[i];
+            asm volatile("" : "+v"(p));                                // keeps the values derived from p out of loop-long registers
             u32x2_t hi, lo;
             split4(rz[i], hi, lo);
-            const int l0 = h_lds[i];
-            const int l1 = (p >= 0 && ((p >> 20) & 7) == 4) ? l0 - 40 : dump - HALO0;
+            const int l0 = p >= 0 ? (p & 0x3FFF) : dump - HALO0;
+            const int l1 = (p >= 0 && ((p >> 24) & 1)) ? l0 - 40 : dump - HALO0;
             *reinterpret_cast<u32x2_t*>(ldsA + l0) = hi;
             *reinterpret_cast<u32x2_t*>(ldsA + A_PLANE + l0) = lo;
             *reinterpret_cast<u32x2_t*>(ldsA + l1) = hi;
@@ -200,16 +216,21 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused16x3_kernel(BwdFusedArgs
         for (int i = 0; i < NPXT; ++i) {
             u32x2_t hi, lo;
             split4(rxt[i], hi, lo);
-            *reinterpret_cast<u32x2_t*>(ldsX + x_ldso[i]) = hi;
-            *reinterpret_cast<u32x2_t*>(ldsX + X_PLANE + x_ldso[i]) = lo;
+            int xp = x_pk[i];
+            asm volatile("" : "+v"(xp));
+            *reinterpret_cast<u32x2_t*>(ldsX + (xp & 0x3FFF)) = hi;
+            *reinterpret_cast<u32x2_t*>(ldsX + X_PLANE + (xp & 0x3FFF)) = lo;
         }
 #pragma unroll
         for (int p = 0; p < NPAIR; ++p) goff[p] = goff_n[p];
+        MIL_STAMP_MARK(1)
         __syncthreads();                       // dz halo and x tile visible
+        MIL_STAMP_MARK(2)
         const bool more = tile + (int)gridDim.x < a.ntiles;
         const TileOrigin o_next = nxt.origin(g);
         if (more) { fetch_halo(o_next); fetch_x(o_next); }
         cur = nxt; nxt.advance();
+        MIL_STAMP_MARK(3)
 
         // ---- data gradient D[cx][pixel]: a (k-step, row tile) pipeline, fragment reads two row tiles ahead -----------------
         f32x4_t acc[MTW][NTX];
@@ -219,7 +240,19 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused16x3_kernel(BwdFusedArgs
             for (int nt = 0; nt < NTX; ++nt) acc[m][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         {
             constexpr int TOT = KSTEPS * MTW, LA = 2, R = LA + 1;
+            // column tile 1 holds channels 16-19 only (rows 0-3 of its filter fragments): rows 4-7 of its hi fragment are loaded
+            // with the LO weights of the same channels (lanes 4..7 of a lane group read lane - 4's lo half), so ONE MFMA against
+            // the pixels' hi plane yields wh*zh (rows 0-3) and wl*zh (rows 4-7); the second multiplies wh by the lo plane.  Five
+            // MFMAs per fragment pair instead of six; the epilogue adds rows 4-7 to rows 0-3 (they meet in the permlane swap).
             Frag8<F32S> ring[R], wq[2][NTX];
+            const int w1a = (r >= 4 && r < 8) ? (lane - 4) * 32 + 16 : lane * 32;
+            auto wfrag = [&](int sl, int nt) {
+                const char* p = ldsW + (sl * NTX + nt) * 64 * 32;
+                Frag8<F32S> f;
+                if (nt == 0) { f = lds_frag<F32S>(p + lane * 32); }
+                else { f.h = *reinterpret_cast<const bf16x8_t*>(p + w1a); f.l = *reinterpret_cast<const bf16x8_t*>(p + lane * 32); }
+                return f;
+            };
             auto zfrag = [&](int j) {
                 const int sl = j / MTW, m = j % MTW;
                 const char* p = ldsA + zb[sl] + koff(4 * sl) + m * ROWB;
@@ -229,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused16x3_kernel(BwdFusedArgs
                 return f;
             };
 #pragma unroll
-            for (int nt = 0; nt < NTX; ++nt) wq[0][nt] = lds_frag<F32S>(ldsW + (nt * 64 + lane) * 32);
+            for (int nt = 0; nt < NTX; ++nt) wq[0][nt] = wfrag(0, nt);
 #pragma unroll
             for (int j = 0; j < LA; ++j) ring[j % R] = zfrag(j);
 #pragma unroll
@@ -238,15 +271,17 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused16x3_kernel(BwdFusedArgs
                 if (j + LA < TOT) ring[(j + LA) % R] = zfrag(j + LA);
                 if (m == 0 && sl + 1 < KSTEPS) {
 #pragma unroll
-                    for (int nt = 0; nt < NTX; ++nt) wq[(sl + 1) & 1][nt] = lds_frag<F32S>(ldsW + (((sl + 1) * NTX + nt) * 64 + lane) * 32);
+                    for (int nt = 0; nt < NTX; ++nt) wq[(sl + 1) & 1][nt] = wfrag(sl + 1, nt);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int nt = 0; nt < NTX; ++nt) acc[m][nt] = mma8(wq[sl & 1][nt], ring[j % R], acc[m][nt]);
+                acc[m][0] = mma8(wq[sl & 1][0], ring[j % R], acc[m][0]);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[sl & 1][1].h, ring[j % R].h, acc[m][1], 0, 0, 0);      // [wh ; wl] x zh
+                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[sl & 1][1].l, ring[j % R].l, acc[m][1], 0, 0, 0);      // wh x zl
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 
+        MIL_STAMP_MARK(4)
         // ---- epilogue from registers: channels 0-15 as 8 per lane, channels 16-19 as 4 per lane (lanes with hsel == 0) -------
 #pragma unroll
         for (int p = 0; p < NPAIR; ++p) {
@@ -263,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused16x3_kernel(BwdFusedArgs
             for (int i = 0; i < 4; ++i) {
                 float lo = acc[2 * p][1][i], hi = acc[2 * p + 1][1][i];
                 if (i == 0) mil_swap16<true>(lo, hi); else mil_swap16<false>(lo, hi);
-                u[i] = lo;
+                u[i] = lo + hi;                                    // rows 0-3 (wh products) + rows 4-7 (wl x zh) of the same pixel
             }
             if constexpr (ADD) {
                 const f32x4_t t0 = __builtin_bit_cast(f32x4_t, radd[p][0]), t1 = __builtin_bit_cast(f32x4_t, radd[p][1]);
@@ -287,7 +322,9 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused16x3_kernel(BwdFusedArgs
             if (GPX == 96)                   // padded layout: the four padding channels of the pixel are zeros
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0u, 0u, 0u, 0u}, rs_dx, (o0 == MIL_OOB || !last_ok) ? MIL_OOB : o0 + 80, 0, 0);
         }
+        MIL_STAMP_MARK(5)
         if (more) { set_goff(o_next); fetch_add(); }      // next tile's addend: its registers are free now
+        MIL_STAMP_MARK(6)
 
         // ---- weight gradient, one k-step (32 pixels = two tile rows) ahead: dW' += zl*xh + zh*xl + zh*xh ---------------------
         {
@@ -326,7 +363,9 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused16x3_kernel(BwdFusedArgs
                 }
             }
         }
+        MIL_STAMP_MARK(7)
     }
+    MIL_STAMP_STORE(a.stamp, NW)
     // ---- partial sums -> slab: rows tap'*20 + co, cols ci (col 23 of the centre-tap rows = bias sums) --------------------
     constexpr int SLAB_COLS = NTX * 16;
     constexpr size_t SLAB_ELEMS = (size_t)(14 + 1) * 16 * SLAB_COLS;      // the launcher's slab pitch (generic kernel's row count)

@@ -264,14 +264,18 @@ def conv_block_fwd(x, wpack1, bias1, wpack2, bias2, *, slope=LEAK):
     """(o1, y) of an identity-shortcut residual block in one pass (see mil_conv_block_fwd), or None when the shape/dtype
     has no such kernel."""
     n, h, w, cp = x.shape
-    if x.dtype != torch.bfloat16 or cp not in BLOCK_FWD_CHANNELS or h < 16 or w < 16:
+    code = L.dt_code(x.dtype, mma=True)
+    if code == L.MIL_DT_F32S:                 # fp32 tensors, split products: the 20-channel stage (16 x 8 tiles)
+        if cp != 24 or h < 8 or w < 16:
+            return None
+    elif x.dtype != torch.bfloat16 or cp not in BLOCK_FWD_CHANNELS or h < 16 or w < 16:
         return None
     _need(x, x.shape, x.dtype, "x")
     o1 = torch.empty_like(x)
     y = torch.empty_like(x)
     end = TIMER.bracket(("block_fwd", cp, n, h, w)) if TIMER else None
     rc = L.lib().mil_conv_block_fwd(x.data_ptr(), wpack1.data_ptr(), L.ptr(bias1), wpack2.data_ptr(), L.ptr(bias2),
-                                    o1.data_ptr(), y.data_ptr(), n, h, w, cp, slope, L.dt_code(x.dtype), L.stream_ptr())
+                                    o1.data_ptr(), y.data_ptr(), n, h, w, cp, slope, code, L.stream_ptr())
     if rc == 2:
         return None
     L.check(rc, "mil_conv_block_fwd")

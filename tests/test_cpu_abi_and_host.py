@@ -350,4 +350,5 @@ def test_bench_roofline_accounting():
         for fam in ("block_fwd", "conv", "bwd_fused", "wgrad", "stem_fwd", "stem_bwd", "stem_fwd_xs", "stem_bwd_xs"):
             name, keys = bench._family_kernel(fam, mode)
             assert isinstance(name, str) and len(keys) >= 1
-    assert "F32S" in bench._family_kernel("bwd_fused", "bf16x3")[0] and "fused16" in bench._family_kernel("bwd_fused", "bf16")[0]
+    assert "fused16x3" in bench._family_kernel("bwd_fused", "bf16x3")[0] and "fused16_kernel" in bench._family_kernel("bwd_fused", "bf16")[0]
+    assert "x3" in bench._family_kernel("block_fwd", "bf16x3")[0] and "x3" not in bench._family_kernel("block_fwd", "bf16")[0]

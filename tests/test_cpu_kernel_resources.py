@@ -14,7 +14,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ALLOWED = {
     "pack_all_kernel": (0, "round-3 state: on the round-4 work list"),
     "pack_weights_kernel": (0, "round-3 state: on the round-4 work list"),
-    "conv_block_fwd_kernel<24, 2, 8>": (34, "round-3 state: on the round-4 work list"),
     "conv_bwd_fused_kernel<BF16, 24, 2, 3, false, false, 8>": (18, "round-3 state: on the round-4 work list"),
     "conv_bwd_fused_kernel<BF16, 24, 2, 3, false, true, 8>": (18, "round-3 state: on the round-4 work list"),
     "conv_bwd_fused_kernel<BF16, 24, 2, 3, true, false, 8>": (26, "round-3 state: on the round-4 work list"),

@@ -829,6 +829,41 @@ def test_identity_block_forward_one_pass(ops, case, monkeypatch):
     assert rel_err(from_nhwc(o1, c), ref1) < TOL[dt] and rel_err(from_nhwc(y, c), ref2) < 2 * TOL[dt]
 
 
+@pytest.mark.parametrize("case", [(3, 16, 16), (2, 19, 37), (2, 64, 64), (5, 8, 16), (40, 64, 64)])
+def test_identity_block_forward_one_pass_split_precision(ops, case, monkeypatch):
+    """The 20-channel identity block in one pass on fp32 tensors with bf16x3 products (MIL_DT_F32S; 16 x 8 output tiles, two
+    4-wave workgroups per CU): against torch on un-rounded operands, against the two persistent conv launches it replaces
+    (another K order: fp32 rounding apart), zero padding channels, bit-reproducible.  (40, 64, 64) = 1280 tiles: every
+    persistent workgroup walks several tiles."""
+    monkeypatch.setenv("MIL_PF_MIN_TILES", "1")
+    L = _lib()
+    n, h, w = case
+    c = 20
+    g = torch.Generator().manual_seed(911 + h + w)
+    x = torch.randn(n, c, h, w, generator=g)
+    w1 = torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5
+    w2 = torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5
+    b1, b2 = torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1
+    xg = to_nhwc(x, torch.float32)
+    with L.f32_mma(L.MIL_DT_F32S):
+        p1, bp1 = ops.pack_weights(w1.cuda(), b1.cuda(), L.PACK_FWD, torch.float32)
+        p2, bp2 = ops.pack_weights(w2.cuda(), b2.cuda(), L.PACK_FWD, torch.float32)
+        both = ops.conv_block_fwd(xg, p1, bp1, p2, bp2)
+        assert both is not None, "no split-precision block forward for this shape"
+        o1, y = both
+        again = ops.conv_block_fwd(xg, p1, bp1, p2, bp2)
+        z1 = ops.conv(xg, p1, bp1, cpad(c), ks=3, stride=1, pad=1, lrelu=True)
+        z2 = ops.conv(z1, p2, bp2, cpad(c), ks=3, stride=1, pad=1, res=xg, lrelu=True)
+    torch.cuda.synchronize()
+    assert o1.dtype == torch.float32 and torch.equal(o1, again[0]) and torch.equal(y, again[1])
+    assert float(o1[..., c:].abs().max()) == 0.0 and float(y[..., c:].abs().max()) == 0.0
+    ref1 = F.leaky_relu(F.conv2d(x, w1, b1, padding=1), LEAK)
+    ref2 = F.leaky_relu(F.conv2d(ref1, w2, b2, padding=1) + x, LEAK)
+    assert rel_err(from_nhwc(o1, c), ref1) < TOL[X3] and rel_err(from_nhwc(y, c), ref2) < 2 * TOL[X3]
+    assert rel_err(o1.cpu(), z1.cpu()) < 1e-5 and rel_err(y.cpu(), z2.cpu()) < 2e-5
+    assert ops.conv_block_fwd(xg, p1, bp1, p2, bp2) is None           # exact-fp32 mode: no such kernel
+
+
 @pytest.mark.parametrize("case", [(20, 40, 3, 16, 16), (20, 40, 2, 19, 13), (20, 40, 2, 64, 48), (40, 60, 5, 8, 8),
                                   (40, 60, 3, 32, 32), (60, 80, 3, 16, 16), (60, 80, 9, 8, 8)])
 def test_stage_entry_weight_gradients_one_pass(ops, case):
