@@ -63,7 +63,11 @@ struct BwdFusedArgs {
 // both MFMA loops take three products per fragment pair, the epilogue adds / masks / stores fp32.  24 channels only (one
 // 8-wave workgroup per CU on 94 KB of LDS): the 40-channel filter, halo and x tile do not fit together.
 template <typename T, int CZ, int NTX, int KS, bool ADD, bool MASK, int NW = 4>
-__global__ __launch_bounds__(64 * NW, T::SPLIT ? 2 : ((NW == 8 && CZ <= 24) ? 4 : MIL_BWD_WAVES)) void conv_bwd_fused_kernel(BwdFusedArgs a) {
+#ifndef MIL_BWD24_EU
+#define MIL_BWD24_EU 3          // waves per SIMD the 8-wave 24-channel generic form is compiled for: 3 = 168 VGPRs, no spill (at 4 = 128
+                                // it spilled 18-26; the 16x16-tile kernel below takes the BASELINE sizes and the 300x300 driver size)
+#endif
+__global__ __launch_bounds__(64 * NW, T::SPLIT ? 2 : ((NW == 8 && CZ <= 24) ? MIL_BWD24_EU : MIL_BWD_WAVES)) void conv_bwd_fused_kernel(BwdFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MIL_POISON(smem);
     constexpr int ESZ = T::ESZ, FRAGB = 8 * ESZ;
@@ -177,8 +181,23 @@ __global__ __launch_bounds__(64 * NW, T::SPLIT ? 2 : ((NW == 8 && CZ <= 24) ? 4 
     // The tile's x (mask + wgrad operand) and addend are needed only after the data-gradient MFMA loop; their loads are
     // issued a phase early — behind the previous tile's last barrier, under its weight-gradient loop — into the registers
     // that tile has just finished with, so the ~2 us round trip is no longer waited for in the middle of the tile.
+#ifndef MIL_BWD_LATE_ADD_C
+#define MIL_BWD_LATE_ADD_C 64     // from this many channels on, the addend is fetched behind the data-gradient loop instead of a
+#endif                            // phase early: its registers are not live across that loop (the 64-channel form spilled 15-18 VGPRs)
+    constexpr bool LATE_ADD = ADD && CZ >= MIL_BWD_LATE_ADD_C;
     unsigned ooff[NPAIR];
     u32x4_t rxc[NPAIR][NTX][NE], radd[NPAIR][NTX][NE];
+    auto fetch_add_late = [&]() {
+#pragma unroll
+        for (int p = 0; p < NPAIR; ++p)
+#pragma unroll
+            for (int nt = 0; nt < NTX; ++nt) {
+                const unsigned off = (LAST_PARTIAL && nt == NTX - 1 && !last_ok) ? MIL_OOB : ooff[p] + nt * 16 * ESZ;
+#pragma unroll
+                for (int e = 0; e < NE; ++e)
+                    radd[p][nt][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, (e == 0 || off == MIL_OOB) ? off : off + 16, 0, 0);
+            }
+    };
     auto fetch_xa = [&](const TileOrigin& o) {
         const int obase = ((o.img0 * g.Ho + o.oy0) * g.Wo + o.ox0) * (CX * ESZ);
         const int ylim = g.Ho - o.oy0, xlim = g.Wo - o.ox0, ilim = g.n_img - o.img0;
@@ -193,7 +212,7 @@ __global__ __launch_bounds__(64 * NW, T::SPLIT ? 2 : ((NW == 8 && CZ <= 24) ? 4 
                 for (int e = 0; e < NE; ++e) {
                     const unsigned oe = (e == 0 || off == MIL_OOB) ? off : off + 16;
                     rxc[p][nt][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, oe, 0, 0);
-                    if constexpr (ADD) radd[p][nt][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, oe, 0, 0);
+                    if constexpr (ADD && !LATE_ADD) radd[p][nt][e] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, oe, 0, 0);
                 }
             }
         }
@@ -272,6 +291,7 @@ __global__ __launch_bounds__(64 * NW, T::SPLIT ? 2 : ((NW == 8 && CZ <= 24) ? 4 
 
         }
         MIL_ST_MARK(2)                         // next-halo issue + data-gradient MFMA loop
+        if constexpr (LATE_ADD) fetch_add_late();      // lands while the x tile is written to LDS
         // x centre tile -> LDS [pixel][CX] (zeros outside the image: no contribution to dW)
 #pragma unroll
         for (int p = 0; p < NPAIR; ++p)

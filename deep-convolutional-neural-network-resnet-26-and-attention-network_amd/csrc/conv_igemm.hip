@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs<T> a) {
 // (1 residual/addend, 2 lrelu' mask, 4 LeakyReLU): the unused operand prefetch registers and branches disappear, which
 // for the 24-channel layers is the difference between two and three resident waves per SIMD.
 #ifndef MIL_PF_WAVES_24
-#define MIL_PF_WAVES_24 3
+#define MIL_PF_WAVES_24 2       // (3 waves per SIMD = 168 VGPRs spilled 13 in the residual / mask variants; the whole-block forward and the fused backward have taken the hot launches)
 #endif
 // which instantiations get the explicit one-step-ahead operand prefetch (it costs a second operand register set)
 #ifndef MIL_PF_PIPE
@@ -182,7 +182,15 @@ template <> struct Epi8<F32S> { u32x4_t v[2]; };
 // Every grid row walks all tiles, so the input is read once per row (the second read mostly from L2 / Infinity Cache: the
 // rows run side by side), the output once.
 template <typename T, int CINP, int NT, int KS, int MTW, int FLAGS = -1, int NW = 4, int NTALL = NT>
-__global__ __launch_bounds__(64 * NW, T::SPLIT ? (NW == 8 ? 2 : (CINP <= 24 ? 2 : 1)) : (NW == 8 ? (CINP <= 40 ? 4 : 2) : ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 24 && FLAGS >= 0 && FLAGS != 3) ? MIL_PF_WAVES_24 : (CINP <= 40 ? 2 : 1))))
+// Waves per SIMD the 8-wave 24/40-channel forms are compiled for.  The forward variants that BASELINE configurations launch
+// (FLAGS 4 / 5: bias + LeakyReLU, + residual) stay at 4 (128 VGPRs; the residual form spills 6 of them): measured round 4 on
+// MI355X, 113 us per launch at 4 against 139 us at 3 waves per SIMD with no spill (256x256 tiles; 136 vs 179 us at 300x300) — two
+// resident workgroups beat a spill-free single one.  The data-gradient variants (FLAGS -1, 2, 3: 12-27 spills at 128) are compiled
+// for 3 waves per SIMD (168 VGPRs, no spill): the fused backward kernels have taken their launches at every BASELINE size.
+#ifndef MIL_PF40_EU
+#define MIL_PF40_EU(FLAGS) (((FLAGS) == 4 || (FLAGS) == 5) ? 4 : 3)
+#endif
+__global__ __launch_bounds__(64 * NW, T::SPLIT ? (NW == 8 ? 2 : (CINP <= 24 ? 2 : 1)) : (NW == 8 ? (CINP <= 40 ? MIL_PF40_EU(FLAGS) : 2) : ((MTW == 2 && CINP <= 24) ? 4 : (CINP <= 24 && FLAGS >= 0 && FLAGS != 3) ? MIL_PF_WAVES_24 : (CINP <= 40 ? 2 : 1))))
 void conv_igemm_pf_kernel(ConvArgs<T> a, int ntiles, unsigned x_bytes, unsigned y_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MIL_POISON(smem);
@@ -676,7 +684,11 @@ static int launch_conv_pf(const ConvArgs<T>& a, hipStream_t stream, bool* taken)
 #define MIL_PF40_WAVES 8        // measured in the model: 122 / 100 us per launch with 4 waves, 114 / 88 us with 8 (four waves per SIMD)
 #endif
     if constexpr (CINP == 40 && NT == 3) {
-        if (a.g.ks == 3) return MIL_PF40_WAVES == 8 ? launch_conv_pf_ks<T, 40, 3, 3, 2, 8>(a, stream, taken) : launch_conv_pf_ks<T, 40, 3, 3>(a, stream, taken);
+#if MIL_PF40_WAVES == 8
+        if (a.g.ks == 3) return launch_conv_pf_ks<T, 40, 3, 3, 2, 8>(a, stream, taken);
+#else
+        if (a.g.ks == 3) return launch_conv_pf_ks<T, 40, 3, 3>(a, stream, taken);
+#endif
     }
     if constexpr (CINP == 40 && NT == 2) {
         if (a.g.ks == 3) return launch_conv_pf_ks<T, 40, 2, 3>(a, stream, taken);
@@ -728,6 +740,8 @@ static int launch_conv_auto(const ConvArgs<T>& a, bool small_tile, hipStream_t s
     return launch_conv<T, CINP, NT, 1>(a, stream);
 }
 
+#include "conv_stream_x3.cuh"
+
 template <typename T>
 static int dispatch_conv(const ConvArgs<T>& a, int cin_p, int cout_p, hipStream_t stream) {
     const bool small_tile = (a.g.stride == 2 && !a.g.zins);     // stride-2 forward: the halo is 4x the tile
@@ -751,6 +765,8 @@ static int dispatch_conv(const ConvArgs<T>& a, int cin_p, int cout_p, hipStream_
 // pixel-resident kernels for the small maps of the last two stages (conv_resident.hip); MIL_ERR_UNSUPPORTED for every other shape
 int mil_resident_conv(const void* x, const void* wpack, const float* bias_pad, const void* res, const void* act, void* y, int n_img,
                       int H, int W, int cp, int apply_lrelu, float slope, hipStream_t st);
+int mil_resident_conv_x3(const void* x, const void* wpack, const float* bias_pad, const void* res, const void* act, void* y, int n_img,
+                         int H, int W, int cp, int apply_lrelu, float slope, hipStream_t st);
 
 extern "C" int mil_conv_igemm(const void* x, const void* wpack, const float* bias_pad, const void* res,
                               const void* act, void* y, int n_img, int H, int W, int cin_p, int Ho, int Wo,
@@ -778,6 +794,20 @@ extern "C" int mil_conv_igemm(const void* x, const void* wpack, const float* bia
         a.act = (const float*)act; a.y = (float*)y; a.g = g; a.nsteps = nsteps; a.apply_lrelu = apply_lrelu; a.slope = slope;
         return dispatch_conv<F32>(a, cin_p, cout_p, st);
     } else if (dtype == MIL_DT_F32S) {
+        if (cin_p == cout_p && ks == 3 && stride == 1 && pad == 1 && !zero_insert && Ho == H && Wo == W) {
+            const int rc = mil_resident_conv_x3(x, wpack, bias_pad, res, act, y, n_img, H, W, cin_p, apply_lrelu, slope, st);
+            if (rc != MIL_ERR_UNSUPPORTED) return rc;
+        }
+        // 40 -> 40 channels on maps of 16 pixels and more (layer 2 at every BASELINE tile size): the filter-streaming kernel
+        if (cin_p == 40 && cout_p == 40 && ks == 3 && stride == 1 && pad == 1 && !zero_insert && Ho == H && Wo == W && H >= 16 && W >= 16 &&
+            H < 1024 && W < 1024 && slope >= 0.f && slope < 1.f && n_img > 0 &&
+            n_img * ((H + 15) >> 4) * ((W + 15) >> 4) >= mil_pf_min_tiles()) {
+            StreamX3Args s{};
+            s.x = (const float*)x; s.w = (const char*)wpack; s.bias = bias_pad; s.res = (const float*)res; s.act = (const float*)act;
+            s.y = (float*)y; s.lrelu = apply_lrelu; s.slope = slope;
+            s.g = g;
+            return launch_stream_x3<40, 3>(s, st);
+        }
         ConvArgs<F32S> a{};
         a.x = (const float*)x; a.w = (const float*)wpack; a.bias = bias_pad; a.res = (const float*)res;
         a.act = (const float*)act; a.y = (float*)y; a.g = g; a.nsteps = nsteps; a.apply_lrelu = apply_lrelu; a.slope = slope;

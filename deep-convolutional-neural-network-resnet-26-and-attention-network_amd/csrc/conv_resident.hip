@@ -244,6 +244,8 @@ __global__ __launch_bounds__(512, 2) void conv_resident_kernel(ResArgs a) {
 #endif
 }
 
+#include "conv_resident_x3.cuh"
+
 static bool mil_resident_enabled() {
     static const bool v = [] { const char* e = mil_ab_env("MIL_RESIDENT"); return !(e && e[0] == '0'); }();
     return v;
@@ -295,6 +297,17 @@ int mil_resident_conv(const void* x, const void* wpack, const float* bias_pad, c
     return resident_dispatch(a, cp, H, W, st);
 }
 
+// The same for MIL_DT_F32S (fp32 tensors, split products): 80 channels on 8x8 maps and 64 channels on 16x16 maps.
+int mil_resident_conv_x3(const void* x, const void* wpack, const float* bias_pad, const void* res, const void* act, void* y, int n_img,
+                         int H, int W, int cp, int apply_lrelu, float slope, hipStream_t st) {
+    if (!mil_resident_enabled() || n_img <= 0 || slope < 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
+    ResArgsX3 a{};
+    a.x = (const float*)x; a.n_img = n_img; a.slope = slope; a.nconv = 1;
+    a.conv[0].w = (const char*)wpack; a.conv[0].bias = bias_pad; a.conv[0].res = (const float*)res; a.conv[0].act = (const float*)act;
+    a.conv[0].out = (float*)y; a.conv[0].lrelu = apply_lrelu;
+    return resident_dispatch_x3(a, cp, H, W, st);
+}
+
 // A chain of up to MIL_CHAIN_MAX convs on the resident tile (see the header): out_0 = epi_0(conv_0(x)),
 // out_k = epi_k(conv_k(out_{k-1})).  A conv's res / act may be the output of an EARLIER conv of the same chain (each lane
 // re-reads exactly the bytes it stored itself).
@@ -305,8 +318,17 @@ extern "C" int mil_conv_chain(const void* x, const MilChainConv* convs, int ncon
                               int dtype, void* stream) {
     if (!x || !convs || nconv < 1 || nconv > MIL_CHAIN_MAX || n_img < 0) return MIL_ERR_ARG;
     for (int k = 0; k < nconv; ++k) if (!convs[k].wpack || !convs[k].out) return MIL_ERR_ARG;
-    if (dtype != MIL_DT_BF16 || slope < 0.f || slope >= 1.f || !mil_resident_enabled()) return MIL_ERR_UNSUPPORTED;
+    if ((dtype != MIL_DT_BF16 && dtype != MIL_DT_F32S) || slope < 0.f || slope >= 1.f || !mil_resident_enabled()) return MIL_ERR_UNSUPPORTED;
     if (n_img == 0) return MIL_OK;
+    if (dtype == MIL_DT_F32S) {
+        ResArgsX3 b{};
+        b.x = (const float*)x; b.n_img = n_img; b.slope = slope; b.nconv = nconv;
+        for (int k = 0; k < nconv; ++k) {
+            b.conv[k].w = (const char*)convs[k].wpack; b.conv[k].bias = convs[k].bias; b.conv[k].res = (const float*)convs[k].res;
+            b.conv[k].act = (const float*)convs[k].act; b.conv[k].out = (float*)convs[k].out; b.conv[k].lrelu = convs[k].lrelu;
+        }
+        return resident_dispatch_x3(b, cp, H, W, reinterpret_cast<hipStream_t>(stream));
+    }
     ResArgs a{};
     a.x = (const __bf16*)x; a.n_img = n_img; a.slope = slope; a.nconv = nconv;
     for (int k = 0; k < nconv; ++k) {

@@ -1,0 +1,234 @@
+// 3x3 stride-1 convolution (forward or data gradient: the packed filter decides) for the 40-channel stage in SPLIT PRECISION
+// (MIL_DT_F32S: fp32 tensors, bf16x3 products) with the FILTER STREAMED, not staged.  Included by conv_igemm.hip.
+//
+// The filter-resident persistent kernel (conv_igemm_pf_kernel<F32S,40,..>) keeps 74 KB of [hi | lo] fragments in LDS next to a
+// 57 KB halo tile in both planes: one 8-wave workgroup per CU, every wave marching through commit / barrier / MFMA phases with
+// the others (0.28 ms per conv for 0.11 ms of matrix work).  Here LDS holds only the halo planes of a 16x16-pixel tile (52 KB)
+// and every wave reads the packed fragments of a k-step from L1/L2 into registers one k-step ahead (2 KB per wave-load and
+// column tile; four row tiles per wave re-use each fragment for twelve MFMAs): TWO to THREE independent 4-wave workgroups per
+// CU, each SIMD alternating between their waves.  Epilogue per (row tile, column tile) and lane: four consecutive channels of a
+// pixel = one 16-byte fp32 piece: out = mask( lrelu?( acc + bias? + res? ) ), the contract of mil_conv_igemm.
+#pragma once
+
+struct StreamX3Args {
+    const float* x;         // [n,H,W,C]
+    const char* w;          // packed MIL_DT_F32S fragments [KSTEPS][NT][64][32 B] (MIL_PACK_FWD or MIL_PACK_DGRAD)
+    const float* bias;      // [NT*16] or null
+    const float* res;       // [n,H,W,C] or null
+    const float* act;       // [n,H,W,C] or null
+    float* y;               // [n,H,W,C]
+    ConvGeom g;             // 16x16 tiles of one image
+    int lrelu;
+    float slope;
+};
+
+template <int C, int NT>
+__global__ __launch_bounds__(256, 2) void conv_stream_x3_kernel(StreamX3Args a, int ntiles, unsigned bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    MIL_POISON(smem);
+    constexpr int CG = C / 8, NTHR = 256, PPP = C / 4;               // 16-byte pieces (four fp32 channels) per pixel
+    constexpr int PIXB = mil_pix_pitch(C, 2);
+    constexpr int HW = 18, PLANE = HW * HW * PIXB;                   // hi plane, then lo plane
+    constexpr int KSTEPS = (9 * CG + 3) / 4;
+    constexpr int MTW = 4;                                           // row tiles per wave: 16 rows of 16 pixels / 4 waves
+    constexpr int NPX = (HW * HW * PPP + NTHR - 1) / NTHR;
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, gq = lane >> 4;
+    const int dumpo = 2 * PLANE;                                     // 64-byte dump slot behind the planes
+    const int H = g.H, W = g.W;
+    const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, bytes);
+    const __amdgpu_buffer_rsrc_t rs_res = mil_rsrc(a.res, a.res ? bytes : 0);
+    const __amdgpu_buffer_rsrc_t rs_act = mil_rsrc(a.act, a.act ? bytes : 0);
+    const __amdgpu_buffer_rsrc_t rs_y = mil_rsrc(a.y, bytes);
+    const __amdgpu_buffer_rsrc_t rs_w = mil_rsrc(a.w, KSTEPS * NT * 2048);
+
+    // halo pieces: flat id = tid + 256*i -> (pixel id/PPP, piece id%PPP); h_pk = LDS offset (16 bits) | hx << 16 | hy << 21, < 0 unused
+    // (+ piece << 26: the global offset is recomputed per tile — five vector instructions per piece against 36 MFMAs — to keep
+    // the register budget of the loop below)
+    int h_pk[NPX];
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+        const int idx = tid + NTHR * i;
+        const int px = idx / PPP, j = idx - px * PPP;
+        const int hy = px / HW, hx = px - hy * HW;
+        const bool used = px < HW * HW;
+        h_pk[i] = used ? (px * PIXB + j * 8) | (hx << 16) | (hy << 21) | (j << 26) : (int)0x80000000u;
+    }
+    int koff[KSTEPS];                                                // per-lane fragment offset from the top-left tap's record
+#pragma unroll
+    for (int sl = 0; sl < KSTEPS; ++sl) {
+        const int q = 4 * sl + gq;
+        int tap = q / CG, cg = q - tap * CG;
+        if (tap >= 9) { tap = 0; cg = 0; }                           // zero weights: any finite record
+        koff[sl] = ((tap / 3) * HW + (tap % 3)) * PIXB + cg * 16;
+    }
+    const int pixbase = (wave * MTW * HW + r) * PIXB;                // tile row 4*wave [+m], column r: + m * HW * PIXB
+    const int o_rel = (wave * MTW * W + r) * (C * 4) + gq * 16;      // + m * W * C*4 + nt * 64
+    f32x4_t bias_r[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias_r[nt][i] = a.bias ? a.bias[nt * 16 + gq * 4 + i] : 0.f;
+
+    TileWalker cur, nxt;
+    const int bid = mil_xcd_block_id();
+    cur.init(g, bid, gridDim.x);
+    nxt = cur; nxt.advance();
+    u32x4_t rx[NPX];
+    auto fetch = [&](const TileOrigin& o) {
+        const int iy0 = o.oy0 - 1, ix0 = o.ox0 - 1;
+        const int base = ((o.img0 * H + iy0) * W + ix0) * (C * 4);     // may be negative; valid lanes' sums are not
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            int p = h_pk[i];
+            asm volatile("" : "+v"(p));
+            const int hy = (p >> 21) & 31, hx = (p >> 16) & 31, j = (p >> 26) & 15;
+            const bool ok = (p >= 0) & ((unsigned)(iy0 + hy) < (unsigned)H) & ((unsigned)(ix0 + hx) < (unsigned)W);
+            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (unsigned)(base + (hy * W + hx) * (C * 4) + j * 16) : MIL_OOB, 0, 0);
+        }
+    };
+    if (bid < ntiles) fetch(cur.origin(g));
+    const int G = gridDim.x;
+    for (int tile = bid; tile < ntiles; tile += G) {
+        const TileOrigin o = cur.origin(g);
+        __syncthreads();                       // the previous tile's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            int p = h_pk[i];
+            asm volatile("" : "+v"(p));
+            const f32x4_t v = __builtin_bit_cast(f32x4_t, rx[i]);
+            bf16x4_t h, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const __bf16 t = (__bf16)v[j];
+                h[j] = t;
+                l[j] = (__bf16)(v[j] - (float)t);
+            }
+            const int l0 = p >= 0 ? (p & 0xFFFF) : dumpo;
+            *reinterpret_cast<bf16x4_t*>(smem + l0) = h;
+            *reinterpret_cast<bf16x4_t*>(smem + (p >= 0 ? l0 + PLANE : dumpo + 8)) = l;
+        }
+        __syncthreads();                       // halo planes visible
+
+        f32x4_t acc[MTW][NT];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = bias_r[nt];
+        {
+            // the (k-step, row tile) loop flattened: pixel fragments two row-tile steps ahead in a ring of three, the filter
+            // fragments of k-step sl+1 requested from L1/L2 at the start of k-step sl (four row tiles = 36 MFMAs to land)
+            constexpr int TOT = KSTEPS * MTW, LA = 2, R = LA + 1;
+            Frag8<F32S> wq[2][NT], ring[R];
+            auto fetch_w = [&](int sl) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    wq[sl & 1][nt].h = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(lane * 32), (sl * NT + nt) * 2048, 0));
+                    wq[sl & 1][nt].l = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(lane * 32 + 16), (sl * NT + nt) * 2048, 0));
+                }
+            };
+            auto xfrag = [&](int j) {
+                const char* p = smem + pixbase + koff[j / MTW] + (j % MTW) * (HW * PIXB);
+                Frag8<F32S> f;
+                f.h = *reinterpret_cast<const bf16x8_t*>(p);
+                f.l = *reinterpret_cast<const bf16x8_t*>(p + PLANE);
+                return f;
+            };
+            fetch_w(0);
+#pragma unroll
+            for (int j = 0; j < LA; ++j) ring[j % R] = xfrag(j);
+#pragma unroll
+            for (int j = 0; j < TOT; ++j) {
+                const int sl = j / MTW, m = j % MTW;
+                if (j + LA < TOT) ring[(j + LA) % R] = xfrag(j + LA);
+                if (m == 0 && sl + 1 < KSTEPS) fetch_w(sl + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wq[sl & 1][nt], ring[j % R], acc[m][nt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the next tile's halo: requested behind the MFMA loop (its 52 registers do not fit beside the loop's operand sets); the
+        // other workgroups of the CU run their loops while it lands
+        if (tile + G < ntiles) fetch(nxt.origin(g));
+        cur = nxt; nxt.advance();
+        // ---- epilogue: residual / mask operands requested now (the operand registers of the loop are free), 16 bytes each ----
+        const int obase = ((o.img0 * H + o.oy0) * W + o.ox0) * (C * 4);
+        const int ylim = H - o.oy0 - wave * MTW, xok = r < W - o.ox0;
+        // (two row tiles at a time: 12 operand registers per row tile and operand)
+#pragma unroll
+        for (int mh = 0; mh < MTW; mh += 2) {
+            u32x4_t rr[2][NT], ra[2][NT];
+            unsigned off[2];
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                const int m = mh + mm;
+                off[mm] = (m < ylim && xok) ? (unsigned)(obase + o_rel + m * W * (C * 4)) : MIL_OOB;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const unsigned oo = (off[mm] == MIL_OOB || nt * 16 + gq * 4 >= C) ? MIL_OOB : off[mm] + nt * 64;
+                    if (a.res) rr[mm][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, oo, 0, 0);
+                    if (a.act) ra[mm][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, oo, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const unsigned oo = (off[mm] == MIL_OOB || nt * 16 + gq * 4 >= C) ? MIL_OOB : off[mm] + nt * 64;
+                    f32x4_t v = acc[mh + mm][nt];
+                    if (a.res) {
+                        const f32x4_t t = __builtin_bit_cast(f32x4_t, rr[mm][nt]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] += t[i];
+                    }
+                    if (a.lrelu) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], v[i] * a.slope);
+                    }
+                    if (a.act) {
+                        const f32x4_t t = __builtin_bit_cast(f32x4_t, ra[mm][nt]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] *= (t[i] > 0.f ? 1.f : a.slope);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_y, oo, 0, 0);
+                }
+        }
+    }
+}
+
+// 3x3 stride-1 pad-1 C -> C conv on fp32 tensors with split products, maps of at least 16x16: MIL_ERR_UNSUPPORTED otherwise.
+template <int C, int NT>
+static int launch_stream_x3(StreamX3Args a, hipStream_t st) {
+    constexpr int PIXB = mil_pix_pitch(C, 2), lds = 2 * 18 * 18 * PIXB + 64;
+    ConvGeom& g = a.g;
+    g.tw_log2 = 4; g.th_log2 = 4; g.ti_log2 = 0;
+    g.tiles_x = (g.W + 15) >> 4; g.tiles_y = (g.H + 15) >> 4; g.n_groups = g.n_img;
+    g.hh = 18; g.hw = 18;
+    auto kern = conv_stream_x3_kernel<C, NT>;
+    static std::atomic<unsigned long long> attr_set{0};
+    if (mil_device_needs(attr_set)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MIL_ERR_LAUNCH;
+        mil_device_done(attr_set);
+    }
+    const int per_cu = mil_resident_per_cu(kern, lds, 3, 256);
+    const size_t img = (size_t)g.H * g.W * C * 4;
+    int chunk = mil_imgs_under_2g(img);
+    const int n_total = g.n_img;
+    for (int i0 = 0; i0 < n_total; i0 += chunk) {
+        const int n = (n_total - i0 < chunk) ? n_total - i0 : chunk;
+        StreamX3Args c = a;
+        c.g.n_img = n; c.g.n_groups = n;
+        c.x = a.x + (size_t)i0 * (img / 4); c.y = a.y + (size_t)i0 * (img / 4);
+        if (a.res) c.res = a.res + (size_t)i0 * (img / 4);
+        if (a.act) c.act = a.act + (size_t)i0 * (img / 4);
+        const int ntiles = n * g.tiles_y * g.tiles_x;
+        int grid = mil_num_cus() * per_cu;
+        if (grid > ntiles) grid = ntiles;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, c, ntiles, (unsigned)(img * n));
+        MIL_CHECK_LAUNCH();
+    }
+    return MIL_OK;
+}

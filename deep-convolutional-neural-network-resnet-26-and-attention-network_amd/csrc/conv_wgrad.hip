@@ -59,7 +59,7 @@ __host__ __device__ constexpr int mil_wgrad_halo_max(int cinp, bool proj) {
 #endif
 template <typename T, int KS, int CINP, int NT, int MSPLIT, bool PF, int NW = 4, bool PROJ = false>
 #ifndef MIL_WGRAD_X3_WAVES
-#define MIL_WGRAD_X3_WAVES 4        // split precision, 8-wave workgroups: waves per SIMD the register budget is held to
+#define MIL_WGRAD_X3_WAVES 2        // split precision, 8-wave workgroups: waves per SIMD the register budget is held to (4 = 128 VGPRs spilled 22)
 #endif
 __global__ __launch_bounds__(64 * NW, NW == 8 ? ((T::SPLIT && CINP <= 24 && NT <= 2) ? MIL_WGRAD_X3_WAVES : 2) : ((PF && CINP > 40) ? 1 : 0)) void wgrad_kernel(WgradArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -158,8 +158,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((T::SPLIT && CINP <= 24 && NT <
             cur = nxt; nxt.advance();
         } else {
             const TileOrigin o = mil_tile_origin(g, tile);
-            mil_load_halo<T, CINP>(ldsX, a.x, g, o, tid, 256);
-            mil_load_otile<T, COUTP>(ldsZ, a.dz, g, o, tid, 256, a.tile_px);
+            mil_load_halo<T, CINP>(ldsX, a.x, g, o, tid, NTHR);
+            mil_load_otile<T, COUTP>(ldsZ, a.dz, g, o, tid, NTHR, a.tile_px);
         }
         __syncthreads();
         if constexpr (T::TR16) {
@@ -420,8 +420,11 @@ static int plan_wgrad(ConvGeom& g, WgradPlan& pl, int* lds_z_off, bool proj = fa
     // 256-px tiles when the halo fits comfortably, else 64-px tiles (stride-2 layers, f32 wide layers)
     constexpr bool PF_OK = T::TR16 && (!T::SPLIT || CINP < 64);            // bf16, and fp32 with split-precision products: the register-prefetch pipeline
     const int hmax = mil_wgrad_halo_max(CINP, proj);
+    // split precision, 64 / 80 channels (no register prefetch): 128-pixel tiles on eight-wave workgroups — four 32-pixel k-steps
+    // per pair of barriers and two waves per SIMD, where the 64-pixel tiles of the 4-wave form ran the matrix pipe 19 % busy
+    constexpr bool WIDE_X3 = T::SPLIT && CINP >= 64;
     for (int lg = 8; lg >= 6; --lg) {
-        if (lg == 7 && hmax == 400) continue;             // 128-pixel tiles only where the prefetch registers are sized for their halo
+        if (lg == 7 && hmax == 400 && !WIDE_X3) continue;  // 128-pixel tiles only where the prefetch registers are sized for their halo
         mil_geom_tiles(g, lg);
         const int xb = ((((g.hh * g.hw) << g.ti_log2) * PIXB) + 15) & ~15;
         const int zb = (1 << lg) * PIXZ * (proj ? 2 : 1);
@@ -477,9 +480,10 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     // (24 channels / 24 columns at four waves per SIMD; 40 channels or columns at two — 240-390 VGPRs would spill at four —, where
     // the 4-wave form's 397 registers leave ONE wave per SIMD)
     constexpr int NW = (PF_OK && (CINP >= 64 || T::SPLIT)) ? 8 : 4;
-    const int nthr = pf ? 64 * NW : 256;
+    constexpr int NW0 = (T::SPLIT && CINP >= 64) ? 8 : 4;         // waves of the form without register prefetch
+    const int nthr = pf ? 64 * NW : 64 * NW0;
     if (PROJ && !pf) return MIL_ERR_UNSUPPORTED;                 // the paired form exists for the persistent bf16 kernel only
-    auto kern = pf ? wgrad_kernel<T, KS, CINP, NT, MSPLIT, PF_OK, NW, PROJ && PF_OK> : wgrad_kernel<T, KS, CINP, NT, MSPLIT, false>;
+    auto kern = pf ? wgrad_kernel<T, KS, CINP, NT, MSPLIT, PF_OK, NW, PROJ && PF_OK> : wgrad_kernel<T, KS, CINP, NT, MSPLIT, false, NW0>;
     if (pl.lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds) != hipSuccess)
             return MIL_ERR_LAUNCH;
@@ -543,7 +547,11 @@ static int dispatch_wgrad_pair(const void* x, const void* dz1, const void* dz2, 
 #define MIL_WGP(CI, NTV, MS) return run_wgrad<T, 3, CI, NTV, MS, true>(x, dz1, dw3, db3, ws, ws_bytes, g, cout, cin, 0, accumulate, query, need, st, dz2, dw1)
     if (cinp == 24 && coutp == 40) MIL_WGP(24, 3, 1);
     if (cinp == 40 && coutp == 64) MIL_WGP(40, 4, 1);
+    // (64 -> 80: NOT paired.  The paired instantiation spilled 59 VGPRs at its 256-register cap and measured 124 us per launch
+    // against 56 + 25 us for the two separate weight-gradient launches (round 4, 256x256 tiles; 306 vs 138 + 54 us at 300x300).)
+#ifdef MIL_PAIR64
     if (cinp == 64 && coutp == 80) MIL_WGP(64, 5, 2);
+#endif
 #undef MIL_WGP
     return MIL_ERR_UNSUPPORTED;
 }
@@ -562,7 +570,11 @@ static int dispatch_wgrad(const void* x, const void* dz, float* dw, float* db, v
         if (cinp == 64 && coutp == 64) MIL_WG(3, 64, 4, 1);
         if (cinp == 80 && coutp == 80) MIL_WG(3, 80, 5, 2);
         if (cinp == 24 && coutp == 40) MIL_WG(3, 24, 3, 1);
-        if (cinp == 40 && coutp == 64) MIL_WG(3, 40, 4, 1);
+        if (cinp == 40 && coutp == 64) {
+            // split precision: the rows in two grid halves (23 row tiles x 4 column tiles of accumulators beside the doubled
+            // prefetch registers spilled 30 VGPRs in one)
+            if constexpr (T::SPLIT) { MIL_WG(3, 40, 4, 2); } else { MIL_WG(3, 40, 4, 1); }
+        }
         if (cinp == 64 && coutp == 80) MIL_WG(3, 64, 5, 2);
     }
     if (g.ks == 1) {

@@ -428,7 +428,8 @@ def encoder_backward(net, saved, dfeats, dtype, allow_direct=True):
         has no such kernel (then the per-block path below runs)."""
         li, j, depth = net.block_position(bi)
         e = bi - depth + 1
-        if j != depth - 1 or depth < 2 or depth > 3 or not net.fuse_backward or dtype != torch.bfloat16:
+        split_ = dtype == torch.float32 and L.dt_code(dtype, mma=True) == L.MIL_DT_F32S
+        if j != depth - 1 or depth < 2 or depth > 3 or not net.fuse_backward or not (dtype == torch.bfloat16 or split_):
             return None
         ent = blocks[e]
         if ent.stride != 2 or ent.downsample is None or any(b.stride != 1 or b.downsample is not None for b in blocks[e + 1:bi + 1]):

@@ -297,7 +297,8 @@ def conv_chain(x, convs, *, slope=LEAK):
     when the shape/dtype has no such kernel.  `convs`: dicts with w, and optionally bias, res, act, lrelu; res / act are
     tensors, or an int k = the output of conv k of this chain (k earlier than the conv that names it)."""
     n, h, w, cp = x.shape
-    if x.dtype != torch.bfloat16 or (cp, h, w) not in RESIDENT_SHAPES or not 1 <= len(convs) <= 6:
+    code = L.dt_code(x.dtype, mma=True)
+    if code not in (L.MIL_DT_BF16, L.MIL_DT_F32S) or (cp, h, w) not in RESIDENT_SHAPES or not 1 <= len(convs) <= 6:
         return None
     _need(x, x.shape, x.dtype, "x")
     outs = [torch.empty_like(x) for _ in convs]
@@ -318,7 +319,7 @@ def conv_chain(x, convs, *, slope=LEAK):
         arr[k].out = outs[k].data_ptr()
         arr[k].lrelu = 1 if c.get("lrelu") else 0
     end = TIMER.bracket(("chain", cp, n, h, w, len(convs))) if TIMER else None
-    rc = L.lib().mil_conv_chain(x.data_ptr(), ctypes.addressof(arr), len(convs), n, h, w, cp, slope, L.dt_code(x.dtype), L.stream_ptr())
+    rc = L.lib().mil_conv_chain(x.data_ptr(), ctypes.addressof(arr), len(convs), n, h, w, cp, slope, code, L.stream_ptr())
     if rc == 2:
         return None
     L.check(rc, "mil_conv_chain")
@@ -339,7 +340,8 @@ def conv_s2_entry(x, wpack3, bias_pad, wpack1, cout_p, *, slope=LEAK):
     """(lrelu(conv3x3_s2(x)+b), conv1x1_s2(x)) in one pass over x (see mil_conv_s2_entry), or None when the shape/dtype
     has no such kernel."""
     n, h, w, cin_p = x.shape
-    if x.dtype != torch.bfloat16:
+    code = L.dt_code(x.dtype, mma=True)
+    if code not in (L.MIL_DT_BF16, L.MIL_DT_F32S):
         return None
     _need(x, x.shape, x.dtype, "x")
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
@@ -347,7 +349,7 @@ def conv_s2_entry(x, wpack3, bias_pad, wpack1, cout_p, *, slope=LEAK):
     y2 = torch.empty_like(y1)
     end = TIMER.bracket(("s2_entry", cin_p, cout_p, n, h, w)) if TIMER else None
     rc = L.lib().mil_conv_s2_entry(x.data_ptr(), wpack3.data_ptr(), L.ptr(bias_pad), wpack1.data_ptr(), y1.data_ptr(),
-                                   y2.data_ptr(), n, h, w, cin_p, cout_p, slope, L.dt_code(x.dtype), L.stream_ptr())
+                                   y2.data_ptr(), n, h, w, cin_p, cout_p, slope, code, L.stream_ptr())
     if rc == 2:
         return None
     L.check(rc, "mil_conv_s2_entry")

@@ -52,6 +52,9 @@ CONV_CASES = [
     (20, 40, 3, 2, 3, 19, 13),
     (20, 40, 1, 2, 2, 16, 16),
     (40, 40, 3, 1, 5, 8, 8),        # 8x8 maps: 4 images per tile
+    (40, 40, 3, 1, 3, 32, 32),      # layer 2 at 256x256 tiles; bf16x3 + persistent: the filter-streaming kernel (conv_stream_x3.cuh)
+    (40, 40, 3, 1, 2, 19, 37),      # the same, ragged 16x16 tiles in both directions
+    (40, 40, 3, 1, 150, 32, 32),    # 600 tiles: more than the resident workgroups, several tiles each
     (40, 60, 3, 2, 2, 10, 10),
     (40, 60, 1, 2, 3, 9, 7),
     (60, 60, 3, 1, 2, 16, 16),      # bf16: the pixel-resident kernel (three images per workgroup)
@@ -714,6 +717,40 @@ def test_stage_entry_forward_pair_one_pass(ops, case):
         assert float(y1[..., cout:].float().abs().max()) == 0.0 and float(y2[..., cout:].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("case", [(20, 40, 3, 16, 16), (20, 40, 2, 19, 13), (20, 40, 2, 64, 48), (20, 40, 40, 64, 64),
+                                  (40, 60, 5, 8, 8), (40, 60, 3, 32, 32), (40, 60, 9, 6, 6), (40, 60, 70, 32, 32)])
+def test_stage_entry_forward_pair_split_precision(ops, case):
+    """The stage-entry forward pair on fp32 tensors with bf16x3 products (MIL_DT_F32S: 20 -> 40 and 40 -> 60 channels; the
+    filter streamed from L1/L2, only the input halo planes in LDS) vs torch on un-rounded operands and vs the two generic
+    launches; bit-reproducible; padded channels zero.  The large cases give every persistent workgroup several tiles."""
+    L = _lib()
+    cin, cout, n, h, w = case
+    g = torch.Generator().manual_seed(611 + cin + h + n)
+    x = torch.randn(n, cin, h, w, generator=g)
+    w3 = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    w1 = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    xg = to_nhwc(x, torch.float32)
+    with L.f32_mma(L.MIL_DT_F32S):
+        p3, bp = ops.pack_weights(w3.cuda(), b.cuda(), L.PACK_FWD, torch.float32)
+        p1, _ = ops.pack_weights(w1.cuda(), None, L.PACK_FWD, torch.float32)
+        pair = ops.conv_s2_entry(xg, p3, bp, p1, cpad(cout))
+        assert pair is not None, "no split-precision stage-entry forward pair for this shape"
+        y1, y2 = pair
+        again = ops.conv_s2_entry(xg, p3, bp, p1, cpad(cout))
+        z1 = ops.conv(xg, p3, bp, cpad(cout), ks=3, stride=2, pad=1, lrelu=True)
+        z2 = ops.conv(xg, p1, None, cpad(cout), ks=1, stride=2, pad=0)
+        big = ops.conv_s2_entry(torch.zeros(2, 8, 8, 64, device="cuda"), p3, bp, p1, 80)
+    torch.cuda.synchronize()
+    assert big is None                                      # 64 -> 80 channels: the generic kernels
+    assert y1.dtype == torch.float32 and torch.equal(y1, again[0]) and torch.equal(y2, again[1])
+    assert rel_err(from_nhwc(y1, cout), F.leaky_relu(F.conv2d(x, w3, b, stride=2, padding=1), LEAK)) < TOL[X3]
+    assert rel_err(from_nhwc(y2, cout), F.conv2d(x, w1, None, stride=2)) < TOL[X3]
+    assert rel_err(y1.cpu(), z1.cpu()) < 1e-5 and rel_err(y2.cpu(), z2.cpu()) < 1e-5
+    if cpad(cout) > cout:
+        assert float(y1[..., cout:].abs().max()) == 0.0 and float(y2[..., cout:].abs().max()) == 0.0
+
+
 @pytest.fixture(params=[0, 1, 2], ids=["grid=resident", "grid=1", "grid=2"])
 def resident_grid_cap(request, monkeypatch):
     """The pixel-resident kernels are persistent over groups of images, but a workgroup only walks a second group when there
@@ -787,6 +824,63 @@ def test_conv_pair_equals_two_launches(ops, shape, resident_grid_cap):
     # other shapes decline
     assert ops.conv_pair(torch.zeros(2, 16, 16, 80, device="cuda", dtype=dt), p1, bp1, p2, bp2) is None
     assert ops.conv_pair(torch.zeros(2, 8, 8, 64, device="cuda", dtype=dt), p1, bp1, p2, bp2) is None
+
+
+@pytest.mark.parametrize("shape", [(80, 8, 3), (80, 8, 4), (80, 8, 21), (60, 16, 2), (60, 16, 5)])
+def test_conv_chain_split_precision(ops, shape, resident_grid_cap):
+    """The pixel-resident kernels on fp32 tensors with bf16x3 products (MIL_DT_F32S: 80 channels on 8x8 maps, four images per
+    workgroup; 64 on 16x16, one image): block forward, data-gradient chain and a five-conv chain against torch on un-rounded
+    operands; a chain equals its convs run one launch at a time BIT FOR BIT (same kernel, and a conv re-splits exactly the
+    fp32 values its predecessor stored); padded channels stay zero; ragged last groups and multi-group walks (grid caps)."""
+    L = _lib()
+    c, hw, n = shape
+    cp = cpad(c)
+    g = torch.Generator().manual_seed(900 + n + c)
+    x = torch.randn(n, c, hw, hw, generator=g)
+    w1 = torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5
+    w2 = torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5
+    b1, b2 = torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1
+    dzt = torch.randn(n, c, hw, hw, generator=g)
+    xg, dz = to_nhwc(x, torch.float32), to_nhwc(dzt, torch.float32)
+    tol = 2 * TOL[X3]
+    with L.f32_mma(L.MIL_DT_F32S):
+        p1, bp1 = ops.pack_weights(w1.cuda(), b1.cuda(), L.PACK_FWD, torch.float32)
+        p2, bp2 = ops.pack_weights(w2.cuda(), b2.cuda(), L.PACK_FWD, torch.float32)
+        d1, _ = ops.pack_weights(w1.cuda(), None, L.PACK_DGRAD, torch.float32)
+        d2, _ = ops.pack_weights(w2.cuda(), None, L.PACK_DGRAD, torch.float32)
+        both = ops.conv_pair(xg, p1, bp1, p2, bp2, lreluA=True, resB=xg, lreluB=True)
+        assert both is not None, "no split-precision pixel-resident kernel for this shape"
+        o1, y = both
+        o1_s = ops.conv(xg, p1, bp1, cp, ks=3, stride=1, pad=1, lrelu=True)
+        y_s = ops.conv(o1_s, p2, bp2, cp, ks=3, stride=1, pad=1, res=xg, lrelu=True)
+        chain = ops.conv_pair(dz, d2, None, d1, None, actA=o1, resB=dz, actB=xg)
+        dmid_s = ops.conv(dz, d2, None, cp, ks=3, stride=1, pad=1, act=o1)
+        dx_s = ops.conv(dmid_s, d1, None, cp, ks=3, stride=1, pad=1, res=dz, act=xg)
+        short = to_nhwc(torch.randn(n, c, hw, hw, generator=g), torch.float32)
+        convs = [dict(w=p2, bias=bp2, res=short, lrelu=True),
+                 dict(w=p1, bias=bp1, lrelu=True), dict(w=p2, bias=bp2, res=0, lrelu=True),
+                 dict(w=p1, bias=bp1, lrelu=True), dict(w=p2, bias=bp2, res=2, lrelu=True)]
+        outs = ops.conv_chain(xg, convs)
+        r0 = ops.conv(xg, p2, bp2, cp, ks=3, stride=1, pad=1, res=short, lrelu=True)
+        r1 = ops.conv(r0, p1, bp1, cp, ks=3, stride=1, pad=1, lrelu=True)
+        r2 = ops.conv(r1, p2, bp2, cp, ks=3, stride=1, pad=1, res=r0, lrelu=True)
+        r3 = ops.conv(r2, p1, bp1, cp, ks=3, stride=1, pad=1, lrelu=True)
+        r4 = ops.conv(r3, p2, bp2, cp, ks=3, stride=1, pad=1, res=r2, lrelu=True)
+    torch.cuda.synchronize()
+    assert o1.dtype == torch.float32
+    assert torch.equal(o1, o1_s) and torch.equal(y, y_s)
+    assert chain is not None and torch.equal(chain[0], dmid_s) and torch.equal(chain[1], dx_s)
+    assert outs is not None and all(torch.equal(u, v) for u, v in zip(outs, (r0, r1, r2, r3, r4)))
+    t1 = F.leaky_relu(F.conv2d(x, w1, b1, padding=1), LEAK)
+    t2 = F.leaky_relu(F.conv2d(t1, w2, b2, padding=1) + x, LEAK)
+    assert rel_err(from_nhwc(o1, c), t1) < TOL[X3] and rel_err(from_nhwc(y, c), t2) < tol
+    m1, mx = torch.where(t1 > 0, 1.0, LEAK), torch.where(x > 0, 1.0, LEAK)
+    dmid_t = F.conv_transpose2d(dzt, w2, padding=1) * m1
+    dx_t = (F.conv_transpose2d(dmid_t, w1, padding=1) + dzt) * mx
+    assert rel_err(from_nhwc(chain[0], c), dmid_t) < tol and rel_err(from_nhwc(chain[1], c), dx_t) < 2 * tol
+    if cp > c:
+        for t in (o1, y, chain[0], chain[1], outs[4]):
+            assert float(t[..., c:].abs().max()) == 0.0
 
 
 BLOCK_FWD_CASES = [
@@ -883,6 +977,14 @@ def test_stage_entry_weight_gradients_one_pass(ops, case):
     ((y1 * dz1).sum() + (y2 * dz2).sum()).backward()
     xg, d1, d2 = to_nhwc(x, dt), to_nhwc(dz1, dt), to_nhwc(dz2, dt)
     out = ops.conv_wgrad_pair(xg, d1, d2, cin, cout)
+    if cin == 60:
+        # 64 -> 80 channels: not paired since round 4 (the paired instantiation spilled 59 VGPRs and measured 124 us against
+        # 56 + 25 us for the two separate launches): the entry point declines and the caller runs the separate launches
+        assert out is None
+        s3, sb = ops.conv_wgrad(xg, d1, cin, cout, ks=3, stride=2, pad=1)
+        s1, _ = ops.conv_wgrad(xg, d2, cin, cout, ks=1, stride=2, pad=0, want_bias=False)
+        assert rel_err(s3.cpu(), w3.grad) < 3e-5 and rel_err(sb.cpu(), b3.grad) < 3e-5 and rel_err(s1.cpu(), w1.grad) < 3e-5
+        return
     assert out is not None
     dw3, db3, dw1, _ws = out
     assert rel_err(dw3.cpu(), w3.grad) < 3e-5 and rel_err(db3.cpu(), b3.grad) < 3e-5 and rel_err(dw1.cpu(), w1.grad) < 3e-5
