@@ -66,11 +66,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_x3_kernel(StreamX3Args a, 
     }
     const int pixbase = (wave * MTW * HW + r) * PIXB;                // tile row 4*wave [+m], column r: + m * HW * PIXB
     const int o_rel = (wave * MTW * W + r) * (C * 4) + gq * 16;      // + m * W * C*4 + nt * 64
-    f32x4_t bias_r[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bias_r[nt][i] = a.bias ? a.bias[nt * 16 + gq * 4 + i] : 0.f;
+    const __amdgpu_buffer_rsrc_t rs_b = mil_rsrc(a.bias, a.bias ? NT * 64 : 0);        // read per tile in the epilogue (12 registers less in the loop)
 
     TileWalker cur, nxt;
     const int bid = mil_xcd_block_id();
@@ -116,11 +112,11 @@ __global__ __launch_bounds__(256, 2) void conv_stream_x3_kernel(StreamX3Args a, 
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = bias_r[nt];
+            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         {
-            // the (k-step, row tile) loop flattened: pixel fragments two row-tile steps ahead in a ring of three, the filter
+            // the (k-step, row tile) loop flattened: pixel fragments one row-tile step ahead, the filter
             // fragments of k-step sl+1 requested from L1/L2 at the start of k-step sl (four row tiles = 36 MFMAs to land)
-            constexpr int TOT = KSTEPS * MTW, LA = 2, R = LA + 1;
+            constexpr int TOT = KSTEPS * MTW, LA = 1, R = LA + 1;      // one row-tile step (9 MFMAs) covers an LDS read; two spill
             Frag8<F32S> wq[2][NT], ring[R];
             auto fetch_w = [&](int sl) {
 #pragma unroll
@@ -158,6 +154,9 @@ __global__ __launch_bounds__(256, 2) void conv_stream_x3_kernel(StreamX3Args a, 
         const int obase = ((o.img0 * H + o.oy0) * W + o.ox0) * (C * 4);
         const int ylim = H - o.oy0 - wave * MTW, xok = r < W - o.ox0;
         // (two row tiles at a time: 12 operand registers per row tile and operand)
+        f32x4_t bias_r[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bias_r[nt] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (unsigned)(nt * 64 + gq * 16), 0, 0));      // no bias: zeros
 #pragma unroll
         for (int mh = 0; mh < MTW; mh += 2) {
             u32x4_t rr[2][NT], ra[2][NT];
@@ -179,6 +178,8 @@ __global__ __launch_bounds__(256, 2) void conv_stream_x3_kernel(StreamX3Args a, 
                 for (int nt = 0; nt < NT; ++nt) {
                     const unsigned oo = (off[mm] == MIL_OOB || nt * 16 + gq * 4 >= C) ? MIL_OOB : off[mm] + nt * 64;
                     f32x4_t v = acc[mh + mm][nt];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += bias_r[nt][i];
                     if (a.res) {
                         const f32x4_t t = __builtin_bit_cast(f32x4_t, rr[mm][nt]);
 #pragma unroll

@@ -230,9 +230,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((T::SPLIT && CINP <= 24 && NT <
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bf[nt] = tr_pair(z0 + nt * 32, z1 + nt * 32);
                 if constexpr (T::SPLIT) {        // MIL_DT_F32S: dW += x_lo*dz_hi + x_hi*dz_lo + x_hi*dz_hi from the hi/lo planes of both tiles
-                    bf16x8_t bl[NT];
+                    bf16x8_t bl[NT], bl2[PROJ ? NT : 1];
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) bl[nt] = tr_pair(z0 + COUTP * 2 + nt * 32, z1 + COUTP * 2 + nt * 32);
+                    if constexpr (PROJ) {
+                        if (proj_i >= 0) {       // wave-uniform: hi and lo planes of the projection's dz tile
+                            const char* y0 = ldsZ2 + (k32 + 8 * gq + q4) * PIXZ + p * 8;
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                bf2[nt] = tr_pair(y0 + nt * 32, y0 + 4 * PIXZ + nt * 32);
+                                bl2[nt] = tr_pair(y0 + COUTP * 2 + nt * 32, y0 + 4 * PIXZ + COUTP * 2 + nt * 32);
+                            }
+                        }
+                    }
 #pragma unroll
                     for (int i = 0; i < MW; ++i) {
                         if (mvalid[i]) {         // wave-uniform
@@ -243,6 +253,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((T::SPLIT && CINP <= 24 && NT <
                                 acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bf[nt], acc[i][nt], 0, 0, 0);
                                 acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bl[nt], acc[i][nt], 0, 0, 0);
                                 acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[nt], acc[i][nt], 0, 0, 0);
+                            }
+                            if constexpr (PROJ) {
+                                if (i == proj_i) {
+#pragma unroll
+                                    for (int nt = 0; nt < NT; ++nt) {
+                                        accp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bf2[nt], accp[nt], 0, 0, 0);
+                                        accp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bl2[nt], accp[nt], 0, 0, 0);
+                                        accp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf2[nt], accp[nt], 0, 0, 0);
+                                    }
+                                }
                             }
                         }
                     }
@@ -542,8 +562,13 @@ template <typename T>
 static int dispatch_wgrad_pair(const void* x, const void* dz1, const void* dz2, float* dw3, float* db3, float* dw1, void* ws,
                                size_t ws_bytes, const ConvGeom& g, int cout, int cin, int accumulate, bool query, size_t* need,
                                hipStream_t st) {
-    if constexpr (T::DT != MIL_DT_BF16) return MIL_ERR_UNSUPPORTED;
+    if constexpr (T::DT != MIL_DT_BF16 && T::DT != MIL_DT_F32S) return MIL_ERR_UNSUPPORTED;
     const int cinp = mil_cpad(cin), coutp = mil_cpad(cout);
+    if constexpr (T::SPLIT) {                    // split precision: the 20 -> 40 channel entry (the larger ones sit at their register cap)
+        if (cinp == 24 && coutp == 40)
+            return run_wgrad<T, 3, 24, 3, 1, true>(x, dz1, dw3, db3, ws, ws_bytes, g, cout, cin, 0, accumulate, query, need, st, dz2, dw1);
+        return MIL_ERR_UNSUPPORTED;
+    }
 #define MIL_WGP(CI, NTV, MS) return run_wgrad<T, 3, CI, NTV, MS, true>(x, dz1, dw3, db3, ws, ws_bytes, g, cout, cin, 0, accumulate, query, need, st, dz2, dw1)
     if (cinp == 24 && coutp == 40) MIL_WGP(24, 3, 1);
     if (cinp == 40 && coutp == 64) MIL_WGP(40, 4, 1);
@@ -1086,9 +1111,12 @@ static int wgrad_pair_entry(const void* x, const void* dz1, const void* dz2, flo
                             size_t ws_bytes, int n_img, int H, int W, int cin, int Ho, int Wo, int cout, int accumulate,
                             int dtype, bool query, size_t* need, void* stream) {
     if (n_img < 0 || H <= 0 || W <= 0 || Ho != (H - 1) / 2 + 1 || Wo != (W - 1) / 2 + 1) return MIL_ERR_ARG;
-    if (dtype != MIL_DT_BF16) return MIL_ERR_UNSUPPORTED;
+    if (dtype != MIL_DT_BF16 && dtype != MIL_DT_F32S) return MIL_ERR_UNSUPPORTED;
     ConvGeom g{};
     g.n_img = n_img; g.H = H; g.W = W; g.Ho = Ho; g.Wo = Wo; g.ks = 3; g.stride = 2; g.pad = 1; g.zins = 0;
+    if (dtype == MIL_DT_F32S)
+        return dispatch_wgrad_pair<F32S>(x, dz1, dz2, dw3, db3, dw1, ws, ws_bytes, g, cout, cin, accumulate, query, need,
+                                         reinterpret_cast<hipStream_t>(stream));
     return dispatch_wgrad_pair<BF16>(x, dz1, dz2, dw3, db3, dw1, ws, ws_bytes, g, cout, cin, accumulate, query, need,
                                      reinterpret_cast<hipStream_t>(stream));
 }

@@ -366,13 +366,14 @@ def conv_wgrad_pair(x, dz1, dz2, cin, cout, *, workspace=None, out=None):
     mil_conv_wgrad_pair), or None when the shape/dtype has no such kernel.  out = (dw3, db3, dw1) accumulates in place."""
     n, h, w, _ = x.shape
     _, ho, wo, _ = dz1.shape
-    if x.dtype != torch.bfloat16 or not WGRAD_PAIR:
+    code = L.dt_code(x.dtype, mma=True)
+    if code not in (L.MIL_DT_BF16, L.MIL_DT_F32S) or not WGRAD_PAIR:
         return None
     _need(x, (n, h, w, cpad(cin)), x.dtype, "x")
     _need(dz1, (n, ho, wo, cpad(cout)), x.dtype, "dz1")
     _need(dz2, (n, ho, wo, cpad(cout)), x.dtype, "dz2")
     need = ctypes.c_size_t(0)
-    rc = L.lib().mil_conv_wgrad_pair_workspace(ctypes.byref(need), n, h, w, cin, ho, wo, cout, L.dt_code(x.dtype))
+    rc = L.lib().mil_conv_wgrad_pair_workspace(ctypes.byref(need), n, h, w, cin, ho, wo, cout, code)
     if rc == 2:
         return None
     L.check(rc, "mil_conv_wgrad_pair_workspace")
@@ -389,7 +390,7 @@ def conv_wgrad_pair(x, dz1, dz2, cin, cout, *, workspace=None, out=None):
         _need(dw1, (cout, cin, 1, 1), torch.float32, "dw1")
     rc = L.lib().mil_conv_wgrad_pair(x.data_ptr(), dz1.data_ptr(), dz2.data_ptr(), dw3.data_ptr(), db3.data_ptr(), dw1.data_ptr(),
                                      workspace.data_ptr(), workspace.numel() * workspace.element_size(), n, h, w, cin, ho, wo,
-                                     cout, 0 if out is None else 1, L.dt_code(x.dtype), L.stream_ptr())
+                                     cout, 0 if out is None else 1, code, L.stream_ptr())
     if rc == 2:
         return None
     L.check(rc, "mil_conv_wgrad_pair")

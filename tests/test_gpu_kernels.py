@@ -999,6 +999,38 @@ def test_stage_entry_weight_gradients_one_pass(ops, case):
     assert torch.equal(rerun[0], dw3) and torch.equal(rerun[2], dw1) and torch.equal(rerun[1], db3)
 
 
+@pytest.mark.parametrize("case", [(20, 40, 3, 16, 16), (20, 40, 2, 19, 13), (20, 40, 2, 64, 48), (20, 40, 70, 64, 64)])
+def test_stage_entry_weight_gradients_one_pass_split_precision(ops, case):
+    """The paired stage-entry weight gradients (3x3/s2 + 1x1/s2 from one pass over the block input) on fp32 tensors with bf16x3
+    products (MIL_DT_F32S; 20 -> 40 channels) vs autograd on un-rounded operands and vs the two separate launches; the larger
+    entries decline."""
+    L = _lib()
+    cin, cout, n, h, w = case
+    g = torch.Generator().manual_seed(431 + n + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    w3 = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    w1 = torch.zeros(cout, cin, 1, 1, requires_grad=True)
+    b3 = torch.zeros(cout, requires_grad=True)
+    y1 = F.conv2d(x, w3, b3, stride=2, padding=1)
+    y2 = F.conv2d(x, w1, None, stride=2)
+    dz1, dz2 = torch.randn(y1.shape, generator=g), torch.randn(y2.shape, generator=g)
+    ((y1 * dz1).sum() + (y2 * dz2).sum()).backward()
+    xg, d1, d2 = to_nhwc(x, torch.float32), to_nhwc(dz1, torch.float32), to_nhwc(dz2, torch.float32)
+    with L.f32_mma(L.MIL_DT_F32S):
+        out = ops.conv_wgrad_pair(xg, d1, d2, cin, cout)
+        assert out is not None, "no split-precision paired stage-entry weight gradient for 20 -> 40 channels"
+        dw3, db3, dw1, _ws = out
+        s3, sb = ops.conv_wgrad(xg, d1, cin, cout, ks=3, stride=2, pad=1)
+        s1, _ = ops.conv_wgrad(xg, d2, cin, cout, ks=1, stride=2, pad=0, want_bias=False)
+        rerun = ops.conv_wgrad_pair(xg, d1, d2, cin, cout)
+        big = ops.conv_wgrad_pair(torch.zeros(2, 8, 8, 40, device="cuda"), torch.zeros(2, 4, 4, 64, device="cuda"),
+                                  torch.zeros(2, 4, 4, 64, device="cuda"), 40, 60)
+    assert big is None
+    assert rel_err(dw3.cpu(), w3.grad) < WTOL[X3] and rel_err(db3.cpu(), b3.grad) < WTOL[X3] and rel_err(dw1.cpu(), w1.grad) < WTOL[X3]
+    assert rel_err(dw3.cpu(), s3.cpu()) < 1e-5 and rel_err(dw1.cpu(), s1.cpu()) < 1e-5 and rel_err(db3.cpu(), sb.cpu()) < 1e-5
+    assert torch.equal(rerun[0], dw3) and torch.equal(rerun[2], dw1) and torch.equal(rerun[1], db3)
+
+
 def test_fused_backward_splits_launches_above_2gib(ops):
     """Tensors beyond the 2 GiB reach of a buffer descriptor: the fused backward walks them in image chunks, later chunks
     accumulating into dW/db.  Checked against two calls on halves that each fit (no CPU reference at this size)."""
