@@ -568,7 +568,7 @@ static int dispatch_wgrad_pair(const void* x, const void* dz1, const void* dz2, 
         if (cinp == 24 && coutp == 40)
             return run_wgrad<T, 3, 24, 3, 1, true>(x, dz1, dw3, db3, ws, ws_bytes, g, cout, cin, 0, accumulate, query, need, st, dz2, dw1);
         return MIL_ERR_UNSUPPORTED;
-    }
+    } else {
 #define MIL_WGP(CI, NTV, MS) return run_wgrad<T, 3, CI, NTV, MS, true>(x, dz1, dw3, db3, ws, ws_bytes, g, cout, cin, 0, accumulate, query, need, st, dz2, dw1)
     if (cinp == 24 && coutp == 40) MIL_WGP(24, 3, 1);
     if (cinp == 40 && coutp == 64) MIL_WGP(40, 4, 1);
@@ -579,6 +579,7 @@ static int dispatch_wgrad_pair(const void* x, const void* dz1, const void* dz2, 
 #endif
 #undef MIL_WGP
     return MIL_ERR_UNSUPPORTED;
+    }
 }
 
 template <typename T>
