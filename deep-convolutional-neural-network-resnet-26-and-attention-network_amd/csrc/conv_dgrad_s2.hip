@@ -28,8 +28,14 @@ struct DgradS2Args {
 
 // T = BF16, or F32S (MIL_DT_F32S: fp32 tensors, bf16x3 split products — the compact tiles hold [hi | lo] planes, three MFMAs per
 // fragment pair, fp32 mask / output; the 40 -> 24 channel entry only: the larger filters do not fit LDS beside two compact tiles).
-template <typename T, int CZ, int NT>
-__global__ __launch_bounds__(256, (CZ <= 40 && !T::SPLIT) ? 2 : 1) void conv_dgrad_s2_kernel(DgradS2Args<T> a, int ntiles, unsigned z_bytes, unsigned y_bytes) {
+// STREAM (split precision): the parity-class filter is NOT staged in LDS — every wave reads the packed fragments of a k-step
+// from L1/L2 into registers two k-steps ahead (2 KB per wave-load and column tile, the fragment index in the scalar offset of
+// the buffer load).  A [hi | lo] filter of 57 / 123 / 205 KB (40 -> 24, 64 -> 40, 80 -> 64 channels) beside two compact
+// tiles left ONE 4-wave workgroup per CU (one wave per SIMD, matrix pipe 16 % busy: 0.52 ms) or did not fit at all (the two
+// larger entries ran the zero-insert forms: 0.65 + 0.35 ms for a quarter of useful MFMAs); with only the compact tiles in
+// LDS (29-54 KB) two to four workgroups are resident; the 40 -> 24 and 64 -> 40 channel entries run this form.
+template <typename T, int CZ, int NT, bool STREAM = false>
+__global__ __launch_bounds__(256, (STREAM || (CZ <= 40 && !T::SPLIT)) ? 2 : 1) void conv_dgrad_s2_kernel(DgradS2Args<T> a, int ntiles, unsigned z_bytes, unsigned y_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MIL_POISON(smem);
     constexpr int ESZ = T::ESZ, FRAGB = 8 * ESZ;
@@ -47,7 +53,8 @@ __global__ __launch_bounds__(256, (CZ <= 40 && !T::SPLIT) ? 2 : 1) void conv_dgr
     const int r = lane & 15, gq = lane >> 4;
     char* ldsZ = smem;
     char* ldsW = smem + a.lds_w_off;
-    mil_stage_filter(ldsW, a.w, NS * NT * 64 * FRAGB, tid, 256);
+    if constexpr (!STREAM) mil_stage_filter(ldsW, a.w, NS * NT * 64 * FRAGB, tid, 256);
+    const __amdgpu_buffer_rsrc_t rs_w = mil_rsrc(a.w, NS * NT * 64 * FRAGB);
     const __amdgpu_buffer_rsrc_t rs_z1 = mil_rsrc(a.dz1, z_bytes);
     const __amdgpu_buffer_rsrc_t rs_z2 = mil_rsrc(a.dz2, a.dz2 ? z_bytes : 0);
     const __amdgpu_buffer_rsrc_t rs_act = mil_rsrc(a.act, a.act ? a.act_bytes : 0);
@@ -137,16 +144,20 @@ __global__ __launch_bounds__(256, (CZ <= 40 && !T::SPLIT) ? 2 : 1) void conv_dgr
         }
     };
 
+    // STREAM: no register prefetch of the next tile (its 18-24 pieces and the mask operands do not fit beside the streamed filter
+    // fragments: the loads are issued at the top of the tile and behind the MFMA loop; the other resident workgroups cover them)
     u32x4_t rz1[NPZ], rz2[NPZ];
     unsigned ooff_n[2];
     u32x4_t ract_n[2][NT][NE];
-    if (bid < ntiles) {
+    if (!STREAM && bid < ntiles) {
         fetch_z(rz1, rz2, cur.origin(g));
         fetch_epi(cur.origin(g), ooff_n, ract_n);
     }
     const int G = gridDim.x;
     for (int tile = bid; tile < ntiles; tile += G) {
+        const TileOrigin o_cur = cur.origin(g);
         __syncthreads();                       // every wave has finished reading the compact tiles of the previous tile
+        if constexpr (STREAM) fetch_z(rz1, rz2, o_cur);
 #pragma unroll
         for (int i = 0; i < NPZ; ++i) {
             if (z_pos[i] >= 0) {
@@ -156,6 +167,7 @@ __global__ __launch_bounds__(256, (CZ <= 40 && !T::SPLIT) ? 2 : 1) void conv_dgr
         }
         unsigned ooff[2];
         u32x4_t ract[2][NT][NE];
+        if constexpr (!STREAM) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             ooff[p] = ooff_n[p];
@@ -164,10 +176,13 @@ __global__ __launch_bounds__(256, (CZ <= 40 && !T::SPLIT) ? 2 : 1) void conv_dgr
 #pragma unroll
                 for (int e = 0; e < NE; ++e) ract[p][nt][e] = ract_n[p][nt][e];
         }
+        }
         __syncthreads();
+        if constexpr (!STREAM) {
         if (tile + G < ntiles) {
             fetch_z(rz1, rz2, nxt.origin(g));
             fetch_epi(nxt.origin(g), ooff_n, ract_n);
+        }
         }
         cur = nxt; nxt.advance();
 
@@ -181,20 +196,33 @@ __global__ __launch_bounds__(256, (CZ <= 40 && !T::SPLIT) ? 2 : 1) void conv_dgr
             // one k-step ahead (the steps of the four parity classes flattened into one sequence): the fragments of step
             // s+1 are read before the MFMAs of step s and scheduling fences keep that order (see mil_conv_ring)
             auto cls = [](int st) { int c = 0; while (st >= mil_s2_steps(c, CG)) { st -= mil_s2_steps(c, CG); ++c; } return c; };
-            Frag8<T> xq[2], wq[2][NT];
+            constexpr int WD = (STREAM && NT < 4) ? 2 : 1, WR = WD + 1;      // filter fragments in flight: k-steps ahead / ring slots (8 VGPRs per split fragment)
+            Frag8<T> xq[2], wq[WR][NT];
+            auto wfrag = [&](int st, int nt) {
+                if constexpr (STREAM) {                              // split precision only: [hi | lo] = two 16-byte loads per lane
+                    Frag8<T> f;
+                    f.h = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(lane * FRAGB), (st * NT + nt) * 64 * FRAGB, 0));
+                    f.l = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(lane * FRAGB + 16), (st * NT + nt) * 64 * FRAGB, 0));
+                    return f;
+                } else {
+                    return lds_frag<T>(ldsW + ((st * NT + nt) * 64 + lane) * FRAGB);
+                }
+            };
             xq[0] = lds_pix_frag<T, CZ * 2>(ldsZ + pixbase + toff[0]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wq[0][nt] = lds_frag<T>(ldsW + (nt * 64 + lane) * FRAGB);
+            for (int k = 0; k < WD && k < NS; ++k)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) wq[k % WR][nt] = wfrag(k, nt);
 #pragma unroll
             for (int st = 0; st < NS; ++st) {
-                if (st + 1 < NS) {
-                    xq[(st + 1) & 1] = lds_pix_frag<T, CZ * 2>(ldsZ + pixbase + toff[st + 1 < NS ? st + 1 : st]);
+                if (st + 1 < NS) xq[(st + 1) & 1] = lds_pix_frag<T, CZ * 2>(ldsZ + pixbase + toff[st + 1 < NS ? st + 1 : st]);
+                if (st + WD < NS) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) wq[(st + 1) & 1][nt] = lds_frag<T>(ldsW + (((st + 1) * NT + nt) * 64 + lane) * FRAGB);
+                    for (int nt = 0; nt < NT; ++nt) wq[(st + WD) % WR][nt] = wfrag(st + WD, nt);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[cls(st)][nt] = mma8(wq[st & 1][nt], xq[st & 1], acc[cls(st)][nt]);          // D[channel][pixel]
+                for (int nt = 0; nt < NT; ++nt) acc[cls(st)][nt] = mma8(wq[st % WR][nt], xq[st & 1], acc[cls(st)][nt]);          // D[channel][pixel]
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -215,6 +243,7 @@ __global__ __launch_bounds__(256, (CZ <= 40 && !T::SPLIT) ? 2 : 1) void conv_dgr
             }
         }
 #endif
+        if constexpr (STREAM) fetch_epi(o_cur, ooff, ract);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
 #pragma unroll
@@ -259,7 +288,7 @@ __global__ __launch_bounds__(256, (CZ <= 40 && !T::SPLIT) ? 2 : 1) void conv_dgr
     }
 }
 
-template <typename T, int CZ, int NT>
+template <typename T, int CZ, int NT, bool STREAM = false>
 static int launch_dgrad_s2(DgradS2Args<T> a, hipStream_t st) {
     constexpr int ESZ = T::ESZ;
     constexpr int CG = CZ / 8, PIXZ = mil_pix_pitch(CZ, ESZ), CXP = mil_nt_to_cp(NT);
@@ -269,11 +298,11 @@ static int launch_dgrad_s2(DgradS2Args<T> a, hipStream_t st) {
     const int npx = (a.ch * a.cw) << a.g.ti_log2;
     if (npx > 144) return MIL_ERR_UNSUPPORTED;
     const int z_bytes = (npx * PIXZ + 15) & ~15;
-    const int w_bytes = mil_s2_nsteps(CG) * NT * 64 * 8 * ESZ;
+    const int w_bytes = STREAM ? 0 : mil_s2_nsteps(CG) * NT * 64 * 8 * ESZ;
     a.lds_z2_off = z_bytes; a.lds_w_off = 2 * z_bytes;
     const int lds = 2 * z_bytes + w_bytes;
     if (lds > 160 * 1024) return MIL_ERR_UNSUPPORTED;
-    auto kern = conv_dgrad_s2_kernel<T, CZ, NT>;
+    auto kern = conv_dgrad_s2_kernel<T, CZ, NT, STREAM>;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MIL_ERR_LAUNCH;
     const int per_cu = mil_resident_per_cu(kern, lds, 4);      // by registers AND LDS (see conv_s2_entry.hip)
@@ -309,13 +338,18 @@ extern "C" int mil_conv_dgrad_s2(const void* dz1, const void* dz2, const void* w
     if (!dz1 || !wpack || !y || n_img < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return MIL_ERR_ARG;
     if ((dtype != MIL_DT_BF16 && dtype != MIL_DT_BF16_DGRAD && dtype != MIL_DT_F32S && dtype != MIL_DT_F32S_DGRAD) || h != (H - 1) / 2 + 1 || w != (W - 1) / 2 + 1 || slope < 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
     if (n_img == 0) return MIL_OK;
-    if (dtype == MIL_DT_F32S || dtype == MIL_DT_F32S_DGRAD) {      // fp32 tensors, bf16x3 products: the 40 -> 24 channel entry (the only filter that fits)
-        if (cz_p != 40 || cx_p != 24) return MIL_ERR_UNSUPPORTED;
+    if (dtype == MIL_DT_F32S || dtype == MIL_DT_F32S_DGRAD) {      // fp32 tensors, bf16x3 products: all three entries, the filter streamed
+        // (80 -> 64 channels: its 64 accumulator + 64 fragment registers beside 25 per-lane tap offsets spill 58 VGPRs at two waves
+        // per SIMD: left on the zero-insert form of the generic kernel, 0.35 ms)
+        if (!((cz_p == 40 && cx_p == 24) || (cz_p == 64 && cx_p == 40))) return MIL_ERR_UNSUPPORTED;
+        if (dtype == MIL_DT_F32S_DGRAD && cz_p != 40) return MIL_ERR_UNSUPPORTED;
         DgradS2Args<F32S> b{};
         b.dz1 = (const float*)dz1; b.dz2 = (const float*)dz2; b.w = (const float*)wpack; b.act = (const float*)act; b.y = (float*)y;
         b.g.n_img = n_img; b.g.H = h; b.g.W = w; b.g.Ho = H; b.g.Wo = W; b.g.ks = 3; b.g.stride = 1; b.g.pad = 1; b.g.zins = 1;
         b.slope = slope; b.ypx = dtype == MIL_DT_F32S_DGRAD ? 80 : cx_p * 4;      // y [n,H,W,20] dense fp32, or padded
-        return launch_dgrad_s2<F32S, 40, 2>(b, reinterpret_cast<hipStream_t>(stream));
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        if (cz_p == 40) return launch_dgrad_s2<F32S, 40, 2>(b, st);       // staged filter: 0.52 ms against 0.60 ms streamed
+        return launch_dgrad_s2<F32S, 64, 3, true>(b, st);
     }
     DgradS2Args<BF16> a{};
     a.dz1 = (const __bf16*)dz1; a.dz2 = (const __bf16*)dz2; a.w = (const __bf16*)wpack; a.act = (const __bf16*)act; a.y = (__bf16*)y;

@@ -9,6 +9,7 @@
 // CU, each SIMD alternating between their waves.  Epilogue per (row tile, column tile) and lane: four consecutive channels of a
 // pixel = one 16-byte fp32 piece: out = mask( lrelu?( acc + bias? + res? ) ), the contract of mil_conv_igemm.
 #pragma once
+#include "stamp.cuh"
 
 struct StreamX3Args {
     const float* x;         // [n,H,W,C]
@@ -20,6 +21,7 @@ struct StreamX3Args {
     ConvGeom g;             // 16x16 tiles of one image
     int lrelu;
     float slope;
+    unsigned long long* stamp;      // MIL_STAMP diagnostic build only
 };
 
 template <int C, int NT>
@@ -87,9 +89,12 @@ __global__ __launch_bounds__(256, 2) void conv_stream_x3_kernel(StreamX3Args a, 
     };
     if (bid < ntiles) fetch(cur.origin(g));
     const int G = gridDim.x;
+    MIL_STAMP_DECL(6)
     for (int tile = bid; tile < ntiles; tile += G) {
         const TileOrigin o = cur.origin(g);
+        MIL_STAMP_BEGIN()
         __syncthreads();                       // the previous tile's fragment reads are done
+        MIL_STAMP_MARK(0)
 #pragma unroll
         for (int i = 0; i < NPX; ++i) {
             int p = h_pk[i];
@@ -106,7 +111,9 @@ __global__ __launch_bounds__(256, 2) void conv_stream_x3_kernel(StreamX3Args a, 
             *reinterpret_cast<bf16x4_t*>(smem + l0) = h;
             *reinterpret_cast<bf16x4_t*>(smem + (p >= 0 ? l0 + PLANE : dumpo + 8)) = l;
         }
+        MIL_STAMP_MARK(1)
         __syncthreads();                       // halo planes visible
+        MIL_STAMP_MARK(2)
 
         f32x4_t acc[MTW][NT];
 #pragma unroll
@@ -146,10 +153,12 @@ __global__ __launch_bounds__(256, 2) void conv_stream_x3_kernel(StreamX3Args a, 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        MIL_STAMP_MARK(3)
         // the next tile's halo: requested behind the MFMA loop (its 52 registers do not fit beside the loop's operand sets); the
         // other workgroups of the CU run their loops while it lands
         if (tile + G < ntiles) fetch(nxt.origin(g));
         cur = nxt; nxt.advance();
+        MIL_STAMP_MARK(4)
         // ---- epilogue: residual / mask operands requested now (the operand registers of the loop are free), 16 bytes each ----
         const int obase = ((o.img0 * H + o.oy0) * W + o.ox0) * (C * 4);
         const int ylim = H - o.oy0 - wave * MTW, xok = r < W - o.ox0;
@@ -197,7 +206,9 @@ __global__ __launch_bounds__(256, 2) void conv_stream_x3_kernel(StreamX3Args a, 
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_y, oo, 0, 0);
                 }
         }
+        MIL_STAMP_MARK(5)
     }
+    MIL_STAMP_STORE(a.stamp, 4)
 }
 
 // 3x3 stride-1 pad-1 C -> C conv on fp32 tensors with split products, maps of at least 16x16: MIL_ERR_UNSUPPORTED otherwise.
@@ -228,8 +239,16 @@ static int launch_stream_x3(StreamX3Args a, hipStream_t st) {
         const int ntiles = n * g.tiles_y * g.tiles_x;
         int grid = mil_num_cus() * per_cu;
         if (grid > ntiles) grid = ntiles;
+#ifdef MIL_STAMP
+        static MilStampBuf sb;
+        c.stamp = sb.get((size_t)grid * 4 * 8);
+#endif
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, c, ntiles, (unsigned)(img * n));
         MIL_CHECK_LAUNCH();
+#ifdef MIL_STAMP
+        static const char* const ph[6] = {"barrier-top", "commit", "barrier-x", "gemm", "fetch-issue", "epilogue"};
+        sb.report("conv_stream_x3_kernel", grid, 4, 6, ph, st);
+#endif
     }
     return MIL_OK;
 }

@@ -12,6 +12,7 @@
 //   db comes from an all-ones A fragment on wave 0 (column sums of dz on the same MFMA stream).
 #include "pf_common.cuh"
 #include "reduce.cuh"
+#include "stamp.cuh"
 
 template <typename T>
 struct WgradArgs {
@@ -647,6 +648,7 @@ struct StemBwdArgs {
     int lds_z_off, lds_g_off, lds_i_off;
     unsigned xs_bytes, gp_bytes, wi_bytes;
     float slope;
+    unsigned long long* stamp;      // MIL_STAMP diagnostic build only
 };
 
 #ifndef MIL_STEM_BWD_WAVES
@@ -821,8 +823,11 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
         if constexpr (FROM_X) fetch_x(cur.origin(g)); else mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, cur.origin(g));
         fetch_win(rgp, rgp2, rwi, cur.origin(g));
     }
+    MIL_STAMP_DECL(7)
     for (int tile = bid; tile < a.ntiles; tile += gridDim.x) {
+        MIL_STAMP_BEGIN()
         __syncthreads();                         // previous tile's MFMA loop is done with ldsX / ldsZ
+        MIL_STAMP_MARK(0)
         if constexpr (FROM_X) commit_x(); else mil_commit_halo<NPX>(rx, ldsX, ht);
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
@@ -836,12 +841,15 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
                 *reinterpret_cast<u32x2_t*>(ldsI + w_lds[i]) = rwi[i];
             }
         }
+        MIL_STAMP_MARK(1)
         __syncthreads();
+        MIL_STAMP_MARK(2)
         if (tile + (int)gridDim.x < a.ntiles) {
             if constexpr (FROM_X) fetch_x(nxt.origin(g)); else mil_fetch_halo<CINP, NPX>(rx, rs_x, ht, g, nxt.origin(g));
             fetch_win(rgp, rgp2, rwi, nxt.origin(g));
         }
         cur = nxt; nxt.advance();
+        MIL_STAMP_MARK(3)
 
 #ifndef MIL_EXP_STEM_NO_GATHER
         // ---- dz tile = lrelu'(stem) * maxpool^T(g): gather over the 4 windows that cover a 2x2 block --------
@@ -912,7 +920,9 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
                 }
         }
 #endif
+        MIL_STAMP_MARK(4)
         __syncthreads();
+        MIL_STAMP_MARK(5)
 
         // ---- weight gradient: rows (tap, s2d channel), cols stem channel, K = the tile's 256 pixels ---------
 #ifndef MIL_EXP_STEM_NO_MFMA
@@ -983,7 +993,9 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
         }
 #endif
 #endif      // MIL_EXP_STEM_NO_MFMA
+        MIL_STAMP_MARK(6)
     }
+    MIL_STAMP_STORE(a.stamp, 4)
 
     constexpr int SLAB_COLS = NT * 16;
     constexpr size_t SLAB_ELEMS = (size_t)(MT + 1) * 16 * SLAB_COLS;
@@ -1065,8 +1077,16 @@ static int stem_bwd_entry(const void* xs, const float* x, const void* gp, const 
         c.gp = (const __bf16*)gp + (size_t)i0 * a.Hp * a.Wp * (gpx / 2); c.gp_bytes = (unsigned)((size_t)nc * gp_img);
         c.widx = widx + (size_t)i0 * a.Hp * a.Wp * 24; c.wi_bytes = (unsigned)((size_t)nc * a.Hp * a.Wp * 24);
         const int gr = grid < c.ntiles ? grid : c.ntiles;
+#ifdef MIL_STAMP
+        static MilStampBuf sb;
+        c.stamp = sb.get((size_t)gr * 4 * 9);
+#endif
         hipLaunchKernelGGL(kern, dim3(gr), dim3(256), lds, st, c);
         MIL_CHECK_LAUNCH();
+#ifdef MIL_STAMP
+        static const char* const ph[7] = {"barrier-top", "commit", "barrier-x", "fetch-issue", "gather", "barrier-z", "gemm"};
+        sb.report(x3 ? "stem_bwd_fused_kernel<x3>" : "stem_bwd_fused_kernel", gr, 4, 7, ph, st);
+#endif
         MilReduceJob j{};
         j.slab = (const float*)ws; j.nslab = gr; j.slab_elems = slab_elems; j.slab_cols = 32; j.n_rows = 16 * 12;
         j.dw = dw; j.db = db; j.cout = 20; j.cin = 3; j.ks = 7; j.kind = 0; j.cinp = 12; j.stem_mode = 1;      // rows tap*12 + s2d channel

@@ -13,6 +13,7 @@
 // each XCD walks its own contiguous range of tiles so that neighbouring tiles (which share halo rows/columns)
 // are in flight on the same L2.
 #include "pf_common.cuh"
+#include "stamp.cuh"
 #include <type_traits>
 
 #ifndef MIL_STEM_FWD_LOOKAHEAD
@@ -29,6 +30,7 @@ struct StemFwdArgs {
     uint8_t* widx;             // [n,Ho,Wo,COUTP]
     int n_img, H, W, H2, W2, Ho, Wo, tiles_x, tiles_y, ntiles;
     float slope;
+    unsigned long long* stamp;      // MIL_STAMP diagnostic build only
 };
 
 constexpr int SF_SH = 17, SF_SW = 33;               // stem tile
@@ -179,8 +181,10 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
     if (tile < t_end) fetch(tile);
     __syncthreads();
 
+    MIL_STAMP_DECL(7)
     for (; tile < t_end; tile += G8) {
         const int tx = tile % a.tiles_x, tq = tile / a.tiles_x, ty = tq % a.tiles_y, img = tq / a.tiles_y;
+        MIL_STAMP_BEGIN()
         // ---- s2d tile: fp32 -> bf16, channel = c*4 + dy*2 + dx --------------------------------------
         if constexpr (FROM_XS) {
 #pragma unroll
@@ -204,8 +208,11 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
                 *reinterpret_cast<bf16x4_t*>(dst + SF_XPIX + 32) = qb;
             }
         }
+        MIL_STAMP_MARK(0)
         __syncthreads();
+        MIL_STAMP_MARK(1)
         if (tile + G8 < t_end) fetch(tile + G8);
+        MIL_STAMP_MARK(2)
         // ---- the tile's own 16x32 s2d pixels go to the xs tensor (when the caller keeps one) ------------
         if (!X3 && !FROM_XS && a.xs) {
             const int xbase = ((img * H2 + 16 * ty) * W2 + 32 * tx) * 32;
@@ -269,6 +276,7 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
             }
         }
 #endif
+        MIL_STAMP_MARK(3)
         // Stem pixels outside the image are the pool's -inf padding: written as such, so that the pool phase below
         // needs no per-tap bounds tests (only tiles on the image border have any).
         const int sy0 = 16 * ty - 1, sx0 = 32 * tx - 1;           // image coordinates of stem-tile pixel (0,0)
@@ -303,7 +311,9 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
                 }
             }
         }
+        MIL_STAMP_MARK(4)
         __syncthreads();
+        MIL_STAMP_MARK(5)
         // ---- 3x3 s2 max-pool of the stem tile: first maximum in (ky,kx) scan order wins ---------------------
 #ifndef MIL_EXP_STEMF_NO_POOL
         {
@@ -360,7 +370,9 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
             }
         }
 #endif
+        MIL_STAMP_MARK(6)
     }
+    MIL_STAMP_STORE(a.stamp, NW)
 }
 
 template <int NT, bool X3 = false, bool FROM_XS = false>
@@ -397,8 +409,16 @@ static int launch_stem_fwd(StemFwdArgs a, hipStream_t st) {
         int grid = (b.ntiles + 7) & ~7;
         const int cap = mil_num_cus() * ((NT <= 2 && !X3) ? 2 : 1);
         if (grid > cap) grid = cap;
+#ifdef MIL_STAMP
+        static MilStampBuf sb;
+        b.stamp = sb.get((size_t)grid * NW * 9);
+#endif
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, st, b);
         MIL_CHECK_LAUNCH();
+#ifdef MIL_STAMP
+        static const char* const ph[7] = {"convert", "barrier-x", "fetch-issue", "gemm", "stem-store", "barrier-s", "pool"};
+        sb.report(X3 ? "stem_fwd_fused_kernel<x3>" : "stem_fwd_fused_kernel", grid, NW, 7, ph, st);
+#endif
     }
     return MIL_OK;
 }

@@ -603,10 +603,10 @@ DGRAD_S2_CASES = [
 
 
 @pytest.mark.parametrize("with_proj", [True, False])
-@pytest.mark.parametrize("case", DGRAD_S2_CASES[:3])
+@pytest.mark.parametrize("case", DGRAD_S2_CASES[:4] + [(40, 60, 3, 32, 32)])
 def test_stage_entry_data_gradient_one_pass_split_precision(ops, case, with_proj):
-    """The parity-class stage-entry data gradient on fp32 tensors with bf16x3 products (MIL_DT_F32S; the 40 -> 20 channel
-    entry) vs autograd on un-rounded operands; the larger entries decline (their filters do not fit beside two compact tiles)."""
+    """The parity-class stage-entry data gradient on fp32 tensors with bf16x3 products (MIL_DT_F32S; the 40 -> 20 and 60 -> 40
+    channel entries, filter fragments streamed from L1/L2) vs autograd on un-rounded operands; the 80 -> 60 entry declines."""
     L = _lib()
     cin, cout, n, h, w = case
     g = torch.Generator().manual_seed(103 + cin + h)
@@ -630,9 +630,9 @@ def test_stage_entry_data_gradient_one_pass_split_precision(ops, case, with_proj
             got_d = ops.conv_dgrad_s2(to_nhwc(dz1, torch.float32), to_nhwc(dz2, torch.float32) if with_proj else None, ws2, cpad(cin),
                                       (h, w), act=to_nhwc(act, torch.float32), dense_cx=cin)
             assert got_d is not None and got_d.shape[-1] == cin and torch.equal(got_d, got[..., :cin].contiguous())
-        big = torch.zeros((2, 4, 4, 64), device="cuda")
-        wbig, _ = ops.pack_weights(torch.randn(60, 40, 3, 3).cuda(), None, L.PACK_DGRAD_S2, torch.float32)
-        assert ops.conv_dgrad_s2(big, None, wbig, 40, (8, 8)) is None
+        big = torch.zeros((2, 4, 4, 80), device="cuda")
+        wbig, _ = ops.pack_weights(torch.randn(80, 60, 3, 3).cuda(), None, L.PACK_DGRAD_S2, torch.float32)
+        assert ops.conv_dgrad_s2(big, None, wbig, 64, (8, 8)) is None
     assert ops.conv_dgrad_s2(to_nhwc(dz1, torch.float32), None, ws2, cpad(cin), (h, w)) is None      # exact-fp32 mode: no such kernel
 
 
