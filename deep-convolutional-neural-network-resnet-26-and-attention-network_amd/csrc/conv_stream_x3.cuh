@@ -10,6 +10,9 @@
 // pixel = one 16-byte fp32 piece: out = mask( lrelu?( acc + bias? + res? ) ), the contract of mil_conv_igemm.
 #pragma once
 #include "stamp.cuh"
+#ifndef MIL_STREAM_FULL_EPI
+#define MIL_STREAM_FULL_EPI 0
+#endif
 
 struct StreamX3Args {
     const float* x;         // [n,H,W,C]
@@ -24,7 +27,7 @@ struct StreamX3Args {
     unsigned long long* stamp;      // MIL_STAMP diagnostic build only
 };
 
-template <int C, int NT>
+template <int C, int NT, bool RES, bool ACT>
 __global__ __launch_bounds__(256, 2) void conv_stream_x3_kernel(StreamX3Args a, int ntiles, unsigned bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MIL_POISON(smem);
@@ -41,8 +44,8 @@ __global__ __launch_bounds__(256, 2) void conv_stream_x3_kernel(StreamX3Args a, 
     const int dumpo = 2 * PLANE;                                     // 64-byte dump slot behind the planes
     const int H = g.H, W = g.W;
     const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, bytes);
-    const __amdgpu_buffer_rsrc_t rs_res = mil_rsrc(a.res, a.res ? bytes : 0);
-    const __amdgpu_buffer_rsrc_t rs_act = mil_rsrc(a.act, a.act ? bytes : 0);
+    const __amdgpu_buffer_rsrc_t rs_res = mil_rsrc(a.res, RES ? bytes : 0);
+    const __amdgpu_buffer_rsrc_t rs_act = mil_rsrc(a.act, ACT ? bytes : 0);
     const __amdgpu_buffer_rsrc_t rs_y = mil_rsrc(a.y, bytes);
     const __amdgpu_buffer_rsrc_t rs_w = mil_rsrc(a.w, KSTEPS * NT * 2048);
 
@@ -124,12 +127,16 @@ __global__ __launch_bounds__(256, 2) void conv_stream_x3_kernel(StreamX3Args a, 
             // the (k-step, row tile) loop flattened: pixel fragments one row-tile step ahead, the filter
             // fragments of k-step sl+1 requested from L1/L2 at the start of k-step sl (four row tiles = 36 MFMAs to land)
             constexpr int TOT = KSTEPS * MTW, LA = 1, R = LA + 1;      // one row-tile step (9 MFMAs) covers an LDS read; two spill
-            Frag8<F32S> wq[2][NT], ring[R];
+#ifndef MIL_STREAM_WD
+#define MIL_STREAM_WD 1
+#endif
+            constexpr int WD = MIL_STREAM_WD, WR = WD + 1;             // filter fragments: k-steps ahead / ring slots
+            Frag8<F32S> wq[WR][NT], ring[R];
             auto fetch_w = [&](int sl) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    wq[sl & 1][nt].h = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(lane * 32), (sl * NT + nt) * 2048, 0));
-                    wq[sl & 1][nt].l = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(lane * 32 + 16), (sl * NT + nt) * 2048, 0));
+                    wq[sl % WR][nt].h = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(lane * 32), (sl * NT + nt) * 2048, 0));
+                    wq[sl % WR][nt].l = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(lane * 32 + 16), (sl * NT + nt) * 2048, 0));
                 }
             };
             auto xfrag = [&](int j) {
@@ -139,57 +146,54 @@ __global__ __launch_bounds__(256, 2) void conv_stream_x3_kernel(StreamX3Args a, 
                 f.l = *reinterpret_cast<const bf16x8_t*>(p + PLANE);
                 return f;
             };
-            fetch_w(0);
+#pragma unroll
+            for (int k = 0; k < WD; ++k) fetch_w(k);
 #pragma unroll
             for (int j = 0; j < LA; ++j) ring[j % R] = xfrag(j);
 #pragma unroll
             for (int j = 0; j < TOT; ++j) {
                 const int sl = j / MTW, m = j % MTW;
                 if (j + LA < TOT) ring[(j + LA) % R] = xfrag(j + LA);
-                if (m == 0 && sl + 1 < KSTEPS) fetch_w(sl + 1);
+                if (m == 0 && sl + WD < KSTEPS) fetch_w(sl + WD);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wq[sl & 1][nt], ring[j % R], acc[m][nt]);
+                for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wq[sl % WR][nt], ring[j % R], acc[m][nt]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         MIL_STAMP_MARK(3)
-        // the next tile's halo: requested behind the MFMA loop (its 52 registers do not fit beside the loop's operand sets); the
-        // other workgroups of the CU run their loops while it lands
-        if (tile + G < ntiles) fetch(nxt.origin(g));
-        cur = nxt; nxt.advance();
-        MIL_STAMP_MARK(4)
-        // ---- epilogue: residual / mask operands requested now (the operand registers of the loop are free), 16 bytes each ----
+        // ---- epilogue operands (16 bytes each), requested BEFORE the next tile's halo: loads return in order, so the epilogue waits
+        // for its own pieces only while the 13 halo pieces stay in flight behind them (requested after the halo, every tile paid two
+        // full memory round trips here: 43 % of the tile time).  The operand registers of the loop are free by now.
         const int obase = ((o.img0 * H + o.oy0) * W + o.ox0) * (C * 4);
         const int ylim = H - o.oy0 - wave * MTW, xok = r < W - o.ox0;
-        // (two row tiles at a time: 12 operand registers per row tile and operand)
         f32x4_t bias_r[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bias_r[nt] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (unsigned)(nt * 64 + gq * 16), 0, 0));      // no bias: zeros
+        constexpr int MH = (RES && ACT && !MIL_STREAM_FULL_EPI) ? MTW / 2 : MTW;             // both operands: 96 registers beside the halo pieces do not fit -> two halves
+        u32x4_t rr[RES ? MH : 1][NT], ra[ACT ? MH : 1][NT];
+        auto epi_off = [&](int m, int nt) {
+            return (m < ylim && xok && nt * 16 + gq * 4 < C) ? (unsigned)(obase + o_rel + m * W * (C * 4) + nt * 64) : MIL_OOB;
+        };
+        auto epi_load = [&](int m0) {
 #pragma unroll
-        for (int mh = 0; mh < MTW; mh += 2) {
-            u32x4_t rr[2][NT], ra[2][NT];
-            unsigned off[2];
-#pragma unroll
-            for (int mm = 0; mm < 2; ++mm) {
-                const int m = mh + mm;
-                off[mm] = (m < ylim && xok) ? (unsigned)(obase + o_rel + m * W * (C * 4)) : MIL_OOB;
+            for (int mm = 0; mm < MH; ++mm)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const unsigned oo = (off[mm] == MIL_OOB || nt * 16 + gq * 4 >= C) ? MIL_OOB : off[mm] + nt * 64;
-                    if (a.res) rr[mm][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, oo, 0, 0);
-                    if (a.act) ra[mm][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, oo, 0, 0);
+                    const unsigned oo = epi_off(m0 + mm, nt);
+                    if constexpr (RES) rr[mm][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, oo, 0, 0);
+                    if constexpr (ACT) ra[mm][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, oo, 0, 0);
                 }
-            }
+        };
+        auto epi_store = [&](int m0) {
 #pragma unroll
-            for (int mm = 0; mm < 2; ++mm)
+            for (int mm = 0; mm < MH; ++mm)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const unsigned oo = (off[mm] == MIL_OOB || nt * 16 + gq * 4 >= C) ? MIL_OOB : off[mm] + nt * 64;
-                    f32x4_t v = acc[mh + mm][nt];
+                    f32x4_t v = acc[m0 + mm][nt];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] += bias_r[nt][i];
-                    if (a.res) {
+                    if constexpr (RES) {
                         const f32x4_t t = __builtin_bit_cast(f32x4_t, rr[mm][nt]);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] += t[i];
@@ -198,14 +202,20 @@ __global__ __launch_bounds__(256, 2) void conv_stream_x3_kernel(StreamX3Args a, 
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], v[i] * a.slope);
                     }
-                    if (a.act) {
+                    if constexpr (ACT) {
                         const f32x4_t t = __builtin_bit_cast(f32x4_t, ra[mm][nt]);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] *= (t[i] > 0.f ? 1.f : a.slope);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_y, oo, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_y, epi_off(m0 + mm, nt), 0, 0);
                 }
-        }
+        };
+        epi_load(0);
+        if (tile + G < ntiles) fetch(nxt.origin(g));
+        cur = nxt; nxt.advance();
+        MIL_STAMP_MARK(4)
+        epi_store(0);
+        if constexpr (MH < MTW) { epi_load(MH); epi_store(MH); }
         MIL_STAMP_MARK(5)
     }
     MIL_STAMP_STORE(a.stamp, 4)
@@ -219,10 +229,14 @@ static int launch_stream_x3(StreamX3Args a, hipStream_t st) {
     g.tw_log2 = 4; g.th_log2 = 4; g.ti_log2 = 0;
     g.tiles_x = (g.W + 15) >> 4; g.tiles_y = (g.H + 15) >> 4; g.n_groups = g.n_img;
     g.hh = 18; g.hw = 18;
-    auto kern = conv_stream_x3_kernel<C, NT>;
+    using Kern = void (*)(StreamX3Args, int, unsigned);
+    const Kern kerns[4] = {conv_stream_x3_kernel<C, NT, false, false>, conv_stream_x3_kernel<C, NT, true, false>,
+                           conv_stream_x3_kernel<C, NT, false, true>, conv_stream_x3_kernel<C, NT, true, true>};
+    const Kern kern = kerns[(a.res ? 1 : 0) + (a.act ? 2 : 0)];
     static std::atomic<unsigned long long> attr_set{0};
     if (mil_device_needs(attr_set)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MIL_ERR_LAUNCH;
+        for (const Kern k : kerns)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MIL_ERR_LAUNCH;
         mil_device_done(attr_set);
     }
     const int per_cu = mil_resident_per_cu(kern, lds, 3, 256);

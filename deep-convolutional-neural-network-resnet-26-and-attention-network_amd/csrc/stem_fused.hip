@@ -240,8 +240,24 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
             // MFMA pair behind an lgkmcnt(0): 72 LDS round trips per tile and wave, two thirds of this kernel's time.
             constexpr int TOT = KSTEPS * SF_MT, LA = MIL_STEM_FWD_LOOKAHEAD, R = LA + 1;
             Frag8<T> ring[R], wq[2][NT];
+            // X3, 20 channels: column tile 1 has four real rows (channels 16-19), so its rows 4-7 carry the LO halves of the same
+            // channels (lanes r = 4..7 read lane r-4's lo half): [wh ; wl] x xh, then wh x xl — two MFMAs instead of three; the
+            // epilogue adds rows 4-7 onto rows 0-3
+            constexpr bool FOLD = X3 && NT == 2;
+            const int w1h = (FOLD && r >= 4 && r < 8) ? (64 + lane - 4) * FRAGB + 16 : (64 + lane) * FRAGB;
+            auto wfrag = [&](int sl, int nt) {
+                if constexpr (FOLD) {
+                    if (nt == 1) {
+                        Frag8<T> f;
+                        f.h = *reinterpret_cast<const bf16x8_t*>(ldsW + sl * NT * 64 * FRAGB + w1h);
+                        f.l = *reinterpret_cast<const bf16x8_t*>(ldsW + ((sl * NT + 1) * 64 + lane) * FRAGB);      // the hi half: rows 4-15 are zero weights
+                        return f;
+                    }
+                }
+                return lds_frag<T>(ldsW + ((sl * NT + nt) * 64 + lane) * FRAGB);
+            };
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wq[0][nt] = lds_frag<T>(ldsW + (nt * 64 + lane) * FRAGB);
+            for (int nt = 0; nt < NT; ++nt) wq[0][nt] = wfrag(0, nt);
 #pragma unroll
             for (int j = 0; j < LA; ++j)
                 ring[j % R] = lds_pix_frag<T, 32>(ldsX + pixbase[j % SF_MT] + (((j / SF_MT) >> 1) * SF_XW + 2 * ((j / SF_MT) & 1)) * SF_XPIX);
@@ -254,11 +270,17 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
                 }
                 if (m == 0 && sl + 1 < KSTEPS) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) wq[(sl + 1) & 1][nt] = lds_frag<T>(ldsW + (((sl + 1) * NT + nt) * 64 + lane) * FRAGB);
+                    for (int nt = 0; nt < NT; ++nt) wq[(sl + 1) & 1][nt] = wfrag(sl + 1, nt);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (FOLD) {
+                    acc[m][0] = mma8(wq[sl & 1][0], ring[j % R], acc[m][0]);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[sl & 1][1].h, ring[j % R].h, acc[m][1], 0, 0, 0);      // [wh ; wl] x xh
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[sl & 1][1].l, ring[j % R].l, acc[m][1], 0, 0, 0);      // wh x xl
+                } else {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wq[sl & 1][nt], ring[j % R], acc[m][nt]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -287,6 +309,14 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
             if (border) {                                     // rare: recompute the pixel's tile coordinates instead of keeping a table
                 const int tp = (wave + NW * m) * 16 + r, sy = (tp * 1986) >> 16, sx = tp - sy * SF_SW;      // tp / 33 for tp < 1024
                 inside = (unsigned)(sy0 + sy) < (unsigned)H2 && (unsigned)(sx0 + sx) < (unsigned)W2;
+            }
+            if constexpr (X3 && NT == 2 && MIL_STEM_FWD_LOOKAHEAD > 0) {      // column tile 1: rows 4-7 (lane group gq == 1) hold wl*xh of rows 0-3
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float t0 = acc[m][1][i], t1 = t0;
+                    if (i == 0) mil_swap16<true>(t0, t1); else mil_swap16<false>(t0, t1);      // t1 of lane group 0 = group 1's value
+                    acc[m][1][i] = gq == 0 ? acc[m][1][i] + t1 : 0.f;        // channels 20-23 are padding: exact zeros
+                }
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {

@@ -625,7 +625,8 @@ def test_stage_entry_data_gradient_one_pass_split_precision(ops, case, with_proj
                                 act=to_nhwc(act, torch.float32))
         assert got is not None and got.dtype == torch.float32
         assert rel_err(from_nhwc(got, cin), want) < TOL[X3]
-        assert float(got[..., cin:].abs().max()) == 0.0
+        if cpad(cin) > cin:
+            assert float(got[..., cin:].abs().max()) == 0.0
         if cin == 20:       # dense output layout (MIL_DT_F32S_DGRAD): the same 20 channels at 80 bytes per pixel
             got_d = ops.conv_dgrad_s2(to_nhwc(dz1, torch.float32), to_nhwc(dz2, torch.float32) if with_proj else None, ws2, cpad(cin),
                                       (h, w), act=to_nhwc(act, torch.float32), dense_cx=cin)
