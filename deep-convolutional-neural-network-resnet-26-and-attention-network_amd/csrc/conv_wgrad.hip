@@ -26,6 +26,7 @@ struct WgradArgs {
     unsigned x_bytes, z_bytes;   // buffer-descriptor sizes (prefetch-pipelined path)
     const typename T::elem* dz2; // PROJ: gradient of the 1x1/s2 projection's output (same shape as dz)
     int lds_z2_off;
+    unsigned long long* stamp;   // MIL_STAMP diagnostic build only
 };
 
 __device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
@@ -46,13 +47,18 @@ __device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
 // instead of once per weight-gradient launch.  Its rows are appended to the slab behind the bias tile.
 // which instantiations take the explicit one-step-ahead operand prefetch (second operand register set): the persistent
 // bf16 forms below 64 input channels; the 64/80-channel forms sit at 232-256 VGPRs already
-__host__ __device__ constexpr int mil_wgrad_halo_max(int cinp, bool proj) {
+#ifndef MIL_WGRAD_X3_WIDE_PF
+#define MIL_WGRAD_X3_WIDE_PF 1      // split precision, 64 channels: register prefetch of the next 128-pixel tile (80 channels: 26 VGPRs spilled)
+#endif
+__host__ __device__ constexpr int mil_wgrad_halo_max(int cinp, bool proj, bool split = false) {
+    if (split && cinp >= 64) return 200;            // 128-pixel tiles: 18x10 pixels, or two 10x10 images
 #ifdef MIL_WGRAD_PAIR24_64PX
     return 400;
 #else
     return (proj && cinp <= 24) ? 576 : 400;
 #endif
 }
+__host__ __device__ constexpr int mil_wgrad_tile_max(int cinp, bool split) { return (split && cinp >= 64) ? 128 : 256; }
 #ifdef MIL_WGRAD_NO_PIPE
 #define MIL_WGRAD_PIPE(BF, PF, CINP, NW, PROJ) false
 #else
@@ -121,8 +127,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((T::SPLIT && CINP <= 24 && NT <
     // through buffer descriptors + tile-invariant tables (pf_common.cuh) keeps the per-tile VALU work small.
     // halo pixels the register prefetch is sized for: 400, or 576 for the paired 24-channel stage entry (128-pixel tiles at
     // stride 2 stage 17x33 = 561 pixels; 64-pixel tiles left two k-steps of MFMAs per pair of barriers: 223 us for 148 us of traffic)
-    constexpr int NPX = PF ? (mil_wgrad_halo_max(CINP, PROJ) * (CINP * ESZ / 16) + NTHR - 1) / NTHR : 1;
-    constexpr int NPZ = PF ? (256 * (COUTP * ESZ / 16) + NTHR - 1) / NTHR : 1;
+    constexpr int NPX = PF ? (mil_wgrad_halo_max(CINP, PROJ, T::SPLIT) * (CINP * ESZ / 16) + NTHR - 1) / NTHR : 1;
+    constexpr int NPZ = PF ? (mil_wgrad_tile_max(CINP, T::SPLIT) * (COUTP * ESZ / 16) + NTHR - 1) / NTHR : 1;
     u32x4_t rx[NPX], rz[NPZ], rz2[PROJ ? NPZ : 1];
     char* ldsZ2 = smem + a.lds_z2_off;
     __amdgpu_buffer_rsrc_t rs_z2;
@@ -145,12 +151,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((T::SPLIT && CINP <= 24 && NT <
             if constexpr (PROJ) mil_fetch_otile<COUTP, NPZ, T>(rz2, rs_z2, zt, g, cur.origin(g));
         }
     }
+    MIL_STAMP_DECL(5)
     for (int tile = bid; tile < a.ntiles; tile += gridDim.x) {
+        MIL_STAMP_BEGIN()
         __syncthreads();
+        MIL_STAMP_MARK(0)
         if constexpr (PF) {
             mil_commit_halo<NPX, T, CINP>(rx, ldsX, ht);
             mil_commit_otile<NPZ, T, COUTP>(rz, ldsZ, zt);
             if constexpr (PROJ) mil_commit_otile<NPZ, T, COUTP>(rz2, ldsZ2, zt);
+            MIL_STAMP_MARK(1)
             if (tile + (int)gridDim.x < a.ntiles) {
                 mil_fetch_halo<CINP, NPX, T>(rx, rs_x, ht, g, nxt.origin(g));
                 mil_fetch_otile<COUTP, NPZ, T>(rz, rs_z, zt, g, nxt.origin(g));
@@ -161,8 +171,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((T::SPLIT && CINP <= 24 && NT <
             const TileOrigin o = mil_tile_origin(g, tile);
             mil_load_halo<T, CINP>(ldsX, a.x, g, o, tid, NTHR);
             mil_load_otile<T, COUTP>(ldsZ, a.dz, g, o, tid, NTHR, a.tile_px);
+            MIL_STAMP_MARK(1)
         }
+        MIL_STAMP_MARK(2)
         __syncthreads();
+        MIL_STAMP_MARK(3)
         if constexpr (T::TR16) {
             const int q4 = (lane & 15) >> 2, p = lane & 3, gq = lane >> 4;
             bf16x8_t ones;
@@ -331,7 +344,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((T::SPLIT && CINP <= 24 && NT <
                 }
             }
         }
+        MIL_STAMP_MARK(4)
     }
+    MIL_STAMP_STORE(a.stamp, NW)
 
     // one slab per workgroup column; row = (tap*CINP + ci), col = co; bias sums live in tile MT
     constexpr int SLAB_COLS = NT * 16;
@@ -439,12 +454,14 @@ static int plan_wgrad(ConvGeom& g, WgradPlan& pl, int* lds_z_off, bool proj = fa
     constexpr int RG = KS * KS * (CINP / 8);
     constexpr int MT = (RG + 1) / 2;
     // 256-px tiles when the halo fits comfortably, else 64-px tiles (stride-2 layers, f32 wide layers)
-    constexpr bool PF_OK = T::TR16 && (!T::SPLIT || CINP < 64);            // bf16, and fp32 with split-precision products: the register-prefetch pipeline
-    const int hmax = mil_wgrad_halo_max(CINP, proj);
-    // split precision, 64 / 80 channels (no register prefetch): 128-pixel tiles on eight-wave workgroups — four 32-pixel k-steps
+    constexpr bool PF_OK = T::TR16 && (!T::SPLIT || CINP < 64 || (MIL_WGRAD_X3_WIDE_PF && CINP == 64));            // bf16, and fp32 with split-precision products: the register-prefetch pipeline
+    const int hmax = mil_wgrad_halo_max(CINP, proj, T::SPLIT);
+    // split precision, 64 / 80 channels: 128-pixel tiles on eight-wave workgroups (64 channels with the register prefetch of the next tile:
+    // 0.89 -> 0.64 ms per five launches; the stamps had 40 % of a tile in the synchronous load) — four 32-pixel k-steps
     // per pair of barriers and two waves per SIMD, where the 64-pixel tiles of the 4-wave form ran the matrix pipe 19 % busy
     constexpr bool WIDE_X3 = T::SPLIT && CINP >= 64;
     for (int lg = 8; lg >= 6; --lg) {
+        if (lg == 8 && WIDE_X3 && PF_OK) continue;          // its prefetch registers are sized for 128-pixel tiles
         if (lg == 7 && hmax == 400 && !WIDE_X3) continue;  // 128-pixel tiles only where the prefetch registers are sized for their halo
         mil_geom_tiles(g, lg);
         const int xb = ((((g.hh * g.hw) << g.ti_log2) * PIXB) + 15) & ~15;
@@ -481,13 +498,14 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     a.lds_z2_off = lds_z_off + (1 << pl.tile_px_log2) * mil_pix_pitch(mil_nt_to_cp(NT), T::ESZ);
     // register-prefetch pipeline for the bf16 path when the halo is small enough for its register budget
     // (split precision at >= 64 channels: the doubled prefetch registers spill — 130-250 VGPRs — so those keep the plain loader)
-    constexpr bool PF_OK = T::TR16 && (!T::SPLIT || CINP < 64);
+    constexpr bool PF_OK = T::TR16 && (!T::SPLIT || CINP < 64 || (MIL_WGRAD_X3_WIDE_PF && CINP == 64));
     const size_t xb_total = (size_t)g.n_img * g.H * g.W * CINP * T::ESZ;
     const size_t zb_total = (size_t)g.n_img * g.Ho * g.Wo * mil_nt_to_cp(NT) * T::ESZ;
     // buffer descriptors address < 2 GiB: a larger tensor is walked in image chunks, one launch and one set of slabs per chunk
     // (the stem's fp32 space-to-depth input is 2.1 GB at 2048 tiles of 256x256)
     const size_t x_img = (size_t)g.H * g.W * CINP * T::ESZ, z_img = (size_t)g.Ho * g.Wo * mil_nt_to_cp(NT) * T::ESZ;
-    const bool pf = PF_OK && (((g.hh * g.hw) << g.ti_log2) <= mil_wgrad_halo_max(CINP, PROJ)) && g.hh < 1024 && g.hw < 1024;
+    const bool pf = PF_OK && (((g.hh * g.hw) << g.ti_log2) <= mil_wgrad_halo_max(CINP, PROJ, T::SPLIT)) && (1 << pl.tile_px_log2) <= mil_wgrad_tile_max(CINP, T::SPLIT) &&
+                    g.hh < 1024 && g.hw < 1024;
     int chunk = g.n_img > 0 ? g.n_img : 1;
     if (pf && (xb_total > mil_buffer_limit() || zb_total > mil_buffer_limit())) {
         chunk = mil_imgs_under_2g(x_img > z_img ? x_img : z_img);
@@ -535,8 +553,21 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
         if (a.dz2) b.dz2 = a.dz2 + (size_t)i0 * (z_img / T::ESZ);
         b.x_bytes = (unsigned)(x_img * n); b.z_bytes = (unsigned)(z_img * n);
         b.slab = a.slab + (size_t)c * pl.grid_x * pl.slab_elems;
+#ifdef MIL_STAMP
+        static MilStampBuf sb;
+        const int nwv = nthr / 64;
+        b.stamp = (T::SPLIT && MSPLIT == 1) ? sb.get((size_t)pl.grid_x * nwv * 7) : nullptr;
+#endif
         hipLaunchKernelGGL(kern, dim3(pl.grid_x, MSPLIT), dim3(nthr), pl.lds, stream, b);
         MIL_CHECK_LAUNCH();
+#ifdef MIL_STAMP
+        if (b.stamp) {
+            static const char* const ph[5] = {"barrier-top", "commit", "fetch-issue", "barrier-x", "gemm"};
+            char nm[64];
+            snprintf(nm, sizeof nm, "wgrad_kernel<F32S,%d,%d,%d>", KS, CINP, NT);
+            sb.report(nm, pl.grid_x, nwv, 5, ph, stream);
+        }
+#endif
     }
     pl.grid_x *= nchunk;                         // slabs to reduce
     const int n_rows = KS * KS * CINP;

@@ -22,10 +22,12 @@
  *                          Accepted by mil_pack_conv_weights / mil_pack_job_fill (fragments [hi | lo], the byte count of
  *                          MIL_DT_F32), mil_conv_igemm, mil_conv_wgrad(_workspace), and — fused forms, where the shape has
  *                          one (MIL_ERR_UNSUPPORTED otherwise: the caller falls back to the un-fused calls) —
- *                          mil_conv_bwd_fused(_workspace) (20-channel layers), mil_conv_dgrad_s2 (the 40 -> 20 channel entry),
- *                          mil_stem_fwd_fused (xs must be null: no space-to-depth copy) and
- *                          mil_stem_bwd_fused_nchw(_workspace); every pointwise entry point takes MIL_DT_F32 for the same
- *                          tensors.
+ *                          mil_conv_bwd_fused(_workspace) (20-channel layers), mil_conv_block_fwd (20-channel identity
+ *                          blocks, maps of at least 8x16), mil_conv_chain (64 / 80 channels on 16x16 / 8x8 maps),
+ *                          mil_conv_s2_entry (20 -> 40 and 40 -> 60 channels), mil_conv_wgrad_pair (20 -> 40 channels),
+ *                          mil_conv_dgrad_s2 (the 40 -> 20 and 60 -> 40 channel entries), mil_stem_fwd_fused (xs must be
+ *                          null: no space-to-depth copy) and mil_stem_bwd_fused_nchw(_workspace); every pointwise entry
+ *                          point takes MIL_DT_F32 for the same tensors.
  *   - master weights, biases, all gradients of parameters, and the whole MIL head are fp32.
  */
 #ifndef MIL_HIP_H

@@ -31,6 +31,21 @@ def r_hilo(x):                  # a tensor stored as a bf16 hi + bf16 lo pair
     return hi + lo
 
 
+def r_hi_lo8_fixed(x):         # 3 bytes: bf16 hi + int8 lo in units of 2^(exponent(hi) - 15): covers the half-ulp of hi, 15-16 significant bits in all
+    hi = bf(x)
+    e = torch.floor(torch.log2(hi.abs().clamp_min(1e-38)))
+    unit = torch.exp2(e - 15)
+    lo8 = torch.clamp(torch.round((x - hi) / unit), -128, 127)
+    return hi + lo8 * unit
+
+
+def r_hi_lo8_float(x):         # 3 bytes: bf16 hi + an 8-bit float lo (1 sign, 4 exponent, 3 mantissa bits; exponent relative to hi's)
+    hi = bf(x)
+    lo = x - hi
+    m, e = torch.frexp(lo)
+    return hi + torch.ldexp(torch.round(m * 16) / 16, e)
+
+
 def r_fp16(x):
     return x.to(torch.float16).to(x.dtype)
 
@@ -74,6 +89,8 @@ FORMATS = [
     Fmt("fp32 store, bf16x4 split mul", ident, conv_split4),
     Fmt("bf16 hi+lo store, bf16x3 split mul", r_hilo, conv_split3),
     Fmt("fp32 block in/out, bf16 mid, bf16x3 mul", "mid", conv_split3),
+    Fmt("3-byte store (hi + int8 lo), bf16x3 mul", r_hi_lo8_fixed, conv_split3),
+    Fmt("3-byte store (hi + e4m3-like lo), bf16x3 mul", r_hi_lo8_float, conv_split3),
 ]
 
 
