@@ -13,6 +13,9 @@
 // fp32 piece, so the epilogue needs no lane exchange: residual / mask operands are loaded and the output is stored 16 bytes
 // per (row tile, column tile) and lane.
 #pragma once
+#ifndef MIL_RESX3_BD
+#define MIL_RESX3_BD 2
+#endif
 
 struct ResConvX3 {
     const char* w;          // packed MIL_DT_F32S fragments [KSTEPS][NT][64][32 B] (MIL_PACK_FWD or MIL_PACK_DGRAD)
@@ -41,10 +44,15 @@ struct ResGeomX3 {
     static constexpr int TILE = 2 * PLANE;
     static constexpr int KSTEPS = (9 * CG + 3) / 4;
     static constexpr int TPI = S * S / 16;                    // 16-pixel row tiles per image
-    static constexpr int MW = IMGS * TPI / 8;                 // row tiles per wave
+    // The eight waves as WM row groups x WN column groups.  64 channels: 4 x 2 — a wave owns four row tiles and TWO of the four
+    // column tiles, so a streamed 2 KB fragment pair feeds four MFMA triples instead of two: per k-step and CU 32 KB from L1
+    // (512 cycles of its 64 B/clk) and 64 KB of pixel fragments from LDS (512 cycles) beside 768 cycles of MFMAs per SIMD; the
+    // 8 x 1 arrangement asked L1 for 64 KB = 1024 cycles (matrix pipe 0.43 busy).  80 channels (five column tiles): 8 x 1.
+    static constexpr int WN = (NT % 2 == 0) ? 2 : 1, WM = 8 / WN, NTW = NT / WN;
+    static constexpr int MW = IMGS * TPI / WM;                // row tiles per wave
     static constexpr int NPIECE = IMGS * S * S * (C / 4);     // 16-byte pieces (four fp32 channels) of a group of images
     static constexpr int NP = NPIECE / 512;
-    static_assert(NPIECE % 512 == 0 && (IMGS * TPI) % 8 == 0 && C % 16 == 0, "shape");
+    static_assert(NPIECE % 512 == 0 && (IMGS * TPI) % WM == 0 && C % 16 == 0, "shape");
     static_assert(TILE <= 160 * 1024, "LDS");
 };
 
@@ -52,11 +60,13 @@ template <int C, int S, int IMGS>
 __global__ __launch_bounds__(512, 2) void conv_resident_x3_kernel(ResArgsX3 a) {
     using G = ResGeomX3<C, S, IMGS>;
     constexpr int CG = G::CG, NT = G::NT, PIX = G::PIX, HS = G::HS, IMG = G::IMG, PLANE = G::PLANE, KSTEPS = G::KSTEPS, TPI = G::TPI, MW = G::MW, NP = G::NP;
+    constexpr int WN = G::WN, NTW = G::NTW;
     extern __shared__ __attribute__((aligned(16))) char tile[];
     MIL_POISON(tile);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, gq = lane >> 4;
+    const int wm = wave / WN, nt0 = (wave % WN) * NTW;       // row group, first column tile of this wave (wave-uniform)
     const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, a.bytes);
 
     // pull every conv's filter into L2 now (see conv_resident_kernel): one dword per 128-byte line and thread, never used
@@ -79,13 +89,13 @@ __global__ __launch_bounds__(512, 2) void conv_resident_x3_kernel(ResArgsX3 a) {
             *reinterpret_cast<u32x4_t*>(tile + im * IMG + (hy * HS + hx) * PIX + j * 16) = u32x4_t{0u, 0u, 0u, 0u};
         }
     }
-    // this wave's row tiles t = wave*MW + m: image t / TPI, pixels (t % TPI)*16 + r of it
+    // this wave's row tiles t = wm*MW + m: image t / TPI, pixels (t % TPI)*16 + r of it
     int pixbase[MW];                 // top-left tap record of lane r's pixel (hi plane)
     int pixrec[MW];                  // the pixel's own record (interior), for the chain's write-back
     int pixglb[MW];                  // (image in group * S*S + pixel) of lane r's pixel
 #pragma unroll
     for (int m = 0; m < MW; ++m) {
-        const int t = wave * MW + m, im = t / TPI, p = (t % TPI) * 16 + r;
+        const int t = wm * MW + m, im = t / TPI, p = (t % TPI) * 16 + r;
         pixbase[m] = im * IMG + ((p / S) * HS + (p % S)) * PIX;
         pixrec[m] = im * IMG + (((p / S) + 1) * HS + (p % S) + 1) * PIX;
         pixglb[m] = im * (S * S) + p;
@@ -128,22 +138,22 @@ __global__ __launch_bounds__(512, 2) void conv_resident_x3_kernel(ResArgsX3 a) {
             const __amdgpu_buffer_rsrc_t rs_res = mil_rsrc(cv.res, cv.res ? a.bytes : 0);
             const __amdgpu_buffer_rsrc_t rs_act = mil_rsrc(cv.act, cv.act ? a.bytes : 0);
             const __amdgpu_buffer_rsrc_t rs_out = mil_rsrc(cv.out, a.bytes);
-            f32x4_t acc[MW][NT];
+            f32x4_t acc[MW][NTW];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
+            for (int nt = 0; nt < NTW; ++nt) {
                 f32x4_t b;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) b[i] = cv.bias ? cv.bias[nt * 16 + gq * 4 + i] : 0.f;
+                for (int i = 0; i < 4; ++i) b[i] = cv.bias ? cv.bias[(nt0 + nt) * 16 + gq * 4 + i] : 0.f;
 #pragma unroll
                 for (int m = 0; m < MW; ++m) acc[m][nt] = b;
             }
-            constexpr int BD = 1;                  // k-steps of filter fragments in flight per wave (8 VGPRs per fragment)
-            Frag8<F32S> bq[BD + 1][NT], aq[2][MW];
+            constexpr int BD = WN == 2 ? MIL_RESX3_BD : 1;    // k-steps of filter fragments in flight per wave (8 VGPRs per fragment): L2 latency against 24 MFMAs per k-step (three: no change)
+            Frag8<F32S> bq[BD + 1][NTW], aq[2][MW];
             auto fetch_b = [&](int ks) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    bq[ks % (BD + 1)][nt].h = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(lane * 32), (ks * NT + nt) * 2048, 0));
-                    bq[ks % (BD + 1)][nt].l = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(lane * 32 + 16), (ks * NT + nt) * 2048, 0));
+                for (int nt = 0; nt < NTW; ++nt) {
+                    bq[ks % (BD + 1)][nt].h = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(lane * 32 + nt0 * 2048), (ks * NT + nt) * 2048, 0));
+                    bq[ks % (BD + 1)][nt].l = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(lane * 32 + nt0 * 2048 + 16), (ks * NT + nt) * 2048, 0));
                 }
             };
             // k-group q = 4*ks + gq = (tap, 8-channel group) -> byte offset of its 16 bytes from the top-left tap's record; a q beyond
@@ -174,27 +184,32 @@ __global__ __launch_bounds__(512, 2) void conv_resident_x3_kernel(ResArgsX3 a) {
 #pragma unroll
                 for (int m = 0; m < MW; ++m)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(bq[ks % (BD + 1)][nt], aq[ks & 1][m], acc[m][nt]);      // D[channel][pixel]
+                    for (int nt = 0; nt < NTW; ++nt) acc[m][nt] = mma8(bq[ks % (BD + 1)][nt], aq[ks & 1][m], acc[m][nt]);      // D[channel][pixel]
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (to_lds) __syncthreads();           // every wave is past its last read of the planes this epilogue overwrites
-            // ---- epilogue: four consecutive channels of a pixel per lane and column tile ------------------------------------------
+            // ---- epilogue: four consecutive channels of a pixel per lane and column tile; the residual / mask operands of ALL of the
+            // wave's pieces are requested before the barrier (one memory round trip per conv, not one per row tile) ---------------
+            unsigned goff[MW];
+            u32x4_t rr[MW][NTW], ra[MW][NTW];
 #pragma unroll
             for (int m = 0; m < MW; ++m) {
-                const int im = (wave * MW + m) / TPI;
-                const bool img_ok = img0 + im < a.n_img;
-                const unsigned goff = img_ok ? (unsigned)((img0 * (S * S) + pixglb[m]) * (C * 4) + gq * 16) : MIL_OOB;
-                u32x4_t rr[NT], ra[NT];
+                const int im = (wm * MW + m) / TPI;
+                goff[m] = img0 + im < a.n_img ? (unsigned)((img0 * (S * S) + pixglb[m]) * (C * 4) + gq * 16 + nt0 * 64) : MIL_OOB;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    if (cv.res) rr[nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, goff == MIL_OOB ? MIL_OOB : goff + nt * 64, 0, 0);
-                    if (cv.act) ra[nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, goff == MIL_OOB ? MIL_OOB : goff + nt * 64, 0, 0);
+                for (int nt = 0; nt < NTW; ++nt) {
+                    if (cv.res) rr[m][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, goff[m] == MIL_OOB ? MIL_OOB : goff[m] + nt * 64, 0, 0);
+                    if (cv.act) ra[m][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, goff[m] == MIL_OOB ? MIL_OOB : goff[m] + nt * 64, 0, 0);
                 }
+            }
+            if (to_lds) __syncthreads();           // every wave is past its last read of the planes this epilogue overwrites
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
+            for (int m = 0; m < MW; ++m) {
+                const bool img_ok = goff[m] != MIL_OOB;
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
                     f32x4_t v = acc[m][nt];
                     if (cv.res) {
-                        const f32x4_t tt = __builtin_bit_cast(f32x4_t, rr[nt]);
+                        const f32x4_t tt = __builtin_bit_cast(f32x4_t, rr[m][nt]);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] += tt[i];
                     }
@@ -203,16 +218,16 @@ __global__ __launch_bounds__(512, 2) void conv_resident_x3_kernel(ResArgsX3 a) {
                         for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], v[i] * a.slope);      // 0 < slope < 1
                     }
                     if (cv.act) {
-                        const f32x4_t tt = __builtin_bit_cast(f32x4_t, ra[nt]);
+                        const f32x4_t tt = __builtin_bit_cast(f32x4_t, ra[m][nt]);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] *= (tt[i] > 0.f ? 1.f : a.slope);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_out, goff == MIL_OOB ? MIL_OOB : goff + nt * 64, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_out, img_ok ? goff[m] + nt * 64 : MIL_OOB, 0, 0);
                     if (to_lds) {                  // the next conv's input planes (zeros for images beyond the launch)
                         u32x2_t hi, lo;
                         split4(v, hi, lo);
                         if (!img_ok) { hi = u32x2_t{0u, 0u}; lo = u32x2_t{0u, 0u}; }
-                        char* d = tile + pixrec[m] + nt * 32 + gq * 8;
+                        char* d = tile + pixrec[m] + (nt0 + nt) * 32 + gq * 8;
                         *reinterpret_cast<u32x2_t*>(d) = hi;
                         *reinterpret_cast<u32x2_t*>(d + PLANE) = lo;
                     }
