@@ -50,15 +50,25 @@ __device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
 #ifndef MIL_WGRAD_X3_WIDE_PF
 #define MIL_WGRAD_X3_WIDE_PF 1      // split precision, 64 channels: register prefetch of the next 128-pixel tile (80 channels: 26 VGPRs spilled)
 #endif
-__host__ __device__ constexpr int mil_wgrad_halo_max(int cinp, bool proj, bool split = false) {
-    if (split && cinp >= 64) return 200;            // 128-pixel tiles: 18x10 pixels, or two 10x10 images
+#ifndef MIL_WGRAD_X3_HALF40
+#define MIL_WGRAD_X3_HALF40 1       // split precision, 40 -> 40 channels: 128-pixel tiles on TWO 4-wave workgroups per CU
+#endif
+// Split precision, 3x3 stride-1 40 -> 40 channels: 128-pixel tiles (58 KB of LDS) on 4-wave workgroups, two per CU, instead of
+// 256-pixel tiles on one 8-wave workgroup (123 KB): the phase stamps had 45 % of a tile outside the MFMA loop (request burst,
+// commit, barriers) with every wave of the CU in the same phase; two independent workgroups run those phases under each
+// other's MFMAs.
+__host__ __device__ constexpr bool mil_wgrad_x3_half(bool split, int ks, int cinp, int nt, int msplit, bool proj) {
+    return MIL_WGRAD_X3_HALF40 && split && ks == 3 && cinp == 40 && nt == 3 && msplit == 1 && !proj;
+}
+__host__ __device__ constexpr int mil_wgrad_halo_max(int cinp, bool proj, bool split = false, bool half = false) {
+    if ((split && cinp >= 64) || half) return 200;  // 128-pixel tiles: 18x10 pixels, or two 10x10 images
 #ifdef MIL_WGRAD_PAIR24_64PX
     return 400;
 #else
     return (proj && cinp <= 24) ? 576 : 400;
 #endif
 }
-__host__ __device__ constexpr int mil_wgrad_tile_max(int cinp, bool split) { return (split && cinp >= 64) ? 128 : 256; }
+__host__ __device__ constexpr int mil_wgrad_tile_max(int cinp, bool split, bool half = false) { return ((split && cinp >= 64) || half) ? 128 : 256; }
 #ifdef MIL_WGRAD_NO_PIPE
 #define MIL_WGRAD_PIPE(BF, PF, CINP, NW, PROJ) false
 #else
@@ -68,7 +78,7 @@ template <typename T, int KS, int CINP, int NT, int MSPLIT, bool PF, int NW = 4,
 #ifndef MIL_WGRAD_X3_WAVES
 #define MIL_WGRAD_X3_WAVES 2        // split precision, 8-wave workgroups: waves per SIMD the register budget is held to (4 = 128 VGPRs spilled 22)
 #endif
-__global__ __launch_bounds__(64 * NW, NW == 8 ? ((T::SPLIT && CINP <= 24 && NT <= 2) ? MIL_WGRAD_X3_WAVES : 2) : ((PF && CINP > 40) ? 1 : 0)) void wgrad_kernel(WgradArgs<T> a) {
+__global__ __launch_bounds__(64 * NW, NW == 8 ? ((T::SPLIT && CINP <= 24 && NT <= 2) ? MIL_WGRAD_X3_WAVES : 2) : ((PF && CINP > 40) ? 1 : ((PF && T::SPLIT) ? 2 : 0))) void wgrad_kernel(WgradArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MIL_POISON(smem);
     constexpr int ESZ = T::ESZ;
@@ -127,8 +137,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((T::SPLIT && CINP <= 24 && NT <
     // through buffer descriptors + tile-invariant tables (pf_common.cuh) keeps the per-tile VALU work small.
     // halo pixels the register prefetch is sized for: 400, or 576 for the paired 24-channel stage entry (128-pixel tiles at
     // stride 2 stage 17x33 = 561 pixels; 64-pixel tiles left two k-steps of MFMAs per pair of barriers: 223 us for 148 us of traffic)
-    constexpr int NPX = PF ? (mil_wgrad_halo_max(CINP, PROJ, T::SPLIT) * (CINP * ESZ / 16) + NTHR - 1) / NTHR : 1;
-    constexpr int NPZ = PF ? (mil_wgrad_tile_max(CINP, T::SPLIT) * (COUTP * ESZ / 16) + NTHR - 1) / NTHR : 1;
+    constexpr bool HALF = NW == 4 && mil_wgrad_x3_half(T::SPLIT, KS, CINP, NT, MSPLIT, PROJ);
+    constexpr int NPX = PF ? (mil_wgrad_halo_max(CINP, PROJ, T::SPLIT, HALF) * (CINP * ESZ / 16) + NTHR - 1) / NTHR : 1;
+    constexpr int NPZ = PF ? (mil_wgrad_tile_max(CINP, T::SPLIT, HALF) * (COUTP * ESZ / 16) + NTHR - 1) / NTHR : 1;
     u32x4_t rx[NPX], rz[NPZ], rz2[PROJ ? NPZ : 1];
     char* ldsZ2 = smem + a.lds_z2_off;
     __amdgpu_buffer_rsrc_t rs_z2;
@@ -455,13 +466,15 @@ static int plan_wgrad(ConvGeom& g, WgradPlan& pl, int* lds_z_off, bool proj = fa
     constexpr int MT = (RG + 1) / 2;
     // 256-px tiles when the halo fits comfortably, else 64-px tiles (stride-2 layers, f32 wide layers)
     constexpr bool PF_OK = T::TR16 && (!T::SPLIT || CINP < 64 || (MIL_WGRAD_X3_WIDE_PF && CINP == 64));            // bf16, and fp32 with split-precision products: the register-prefetch pipeline
-    const int hmax = mil_wgrad_halo_max(CINP, proj, T::SPLIT);
+    constexpr bool HALF = mil_wgrad_x3_half(T::SPLIT, KS, CINP, NT, MSPLIT, false);
+    const bool half = HALF && !proj;
+    const int hmax = mil_wgrad_halo_max(CINP, proj, T::SPLIT, half);
     // split precision, 64 / 80 channels: 128-pixel tiles on eight-wave workgroups (64 channels with the register prefetch of the next tile:
     // 0.89 -> 0.64 ms per five launches; the stamps had 40 % of a tile in the synchronous load) — four 32-pixel k-steps
     // per pair of barriers and two waves per SIMD, where the 64-pixel tiles of the 4-wave form ran the matrix pipe 19 % busy
     constexpr bool WIDE_X3 = T::SPLIT && CINP >= 64;
     for (int lg = 8; lg >= 6; --lg) {
-        if (lg == 8 && WIDE_X3 && PF_OK) continue;          // its prefetch registers are sized for 128-pixel tiles
+        if (lg == 8 && ((WIDE_X3 && PF_OK) || half)) continue;          // its prefetch registers are sized for 128-pixel tiles
         if (lg == 7 && hmax == 400 && !WIDE_X3) continue;  // 128-pixel tiles only where the prefetch registers are sized for their halo
         mil_geom_tiles(g, lg);
         const int xb = ((((g.hh * g.hw) << g.ti_log2) * PIXB) + 15) & ~15;
@@ -504,7 +517,8 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     // buffer descriptors address < 2 GiB: a larger tensor is walked in image chunks, one launch and one set of slabs per chunk
     // (the stem's fp32 space-to-depth input is 2.1 GB at 2048 tiles of 256x256)
     const size_t x_img = (size_t)g.H * g.W * CINP * T::ESZ, z_img = (size_t)g.Ho * g.Wo * mil_nt_to_cp(NT) * T::ESZ;
-    const bool pf = PF_OK && (((g.hh * g.hw) << g.ti_log2) <= mil_wgrad_halo_max(CINP, PROJ, T::SPLIT)) && (1 << pl.tile_px_log2) <= mil_wgrad_tile_max(CINP, T::SPLIT) &&
+    constexpr bool HALF = mil_wgrad_x3_half(T::SPLIT, KS, CINP, NT, MSPLIT, PROJ);
+    const bool pf = PF_OK && (((g.hh * g.hw) << g.ti_log2) <= mil_wgrad_halo_max(CINP, PROJ, T::SPLIT, HALF)) && (1 << pl.tile_px_log2) <= mil_wgrad_tile_max(CINP, T::SPLIT, HALF) &&
                     g.hh < 1024 && g.hw < 1024;
     int chunk = g.n_img > 0 ? g.n_img : 1;
     if (pf && (xb_total > mil_buffer_limit() || zb_total > mil_buffer_limit())) {
@@ -518,7 +532,7 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     // the waves per SIMD hide their latency instead)
     // (24 channels / 24 columns at four waves per SIMD; 40 channels or columns at two — 240-390 VGPRs would spill at four —, where
     // the 4-wave form's 397 registers leave ONE wave per SIMD)
-    constexpr int NW = (PF_OK && (CINP >= 64 || T::SPLIT)) ? 8 : 4;
+    constexpr int NW = HALF ? 4 : ((PF_OK && (CINP >= 64 || T::SPLIT)) ? 8 : 4);
     constexpr int NW0 = (T::SPLIT && CINP >= 64) ? 8 : 4;         // waves of the form without register prefetch
     const int nthr = pf ? 64 * NW : 64 * NW0;
     if (PROJ && !pf) return MIL_ERR_UNSUPPORTED;                 // the paired form exists for the persistent bf16 kernel only
