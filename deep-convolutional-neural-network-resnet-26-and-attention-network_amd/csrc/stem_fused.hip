@@ -33,18 +33,30 @@ struct StemFwdArgs {
     unsigned long long* stamp;      // MIL_STAMP diagnostic build only
 };
 
-constexpr int SF_SH = 17, SF_SW = 33;               // stem tile
-constexpr int SF_XH = 20, SF_XW = 38, SF_NPAIR = 19;  // s2d tile; a "pair" = 2 s2d pixels = 4 input columns
+// Tile = PH x 16 pooled pixels.  PH = 8 (bf16): 17x33 stem pixels <- 20x38 s2d pixels.  PH = 4 (split precision): 9x33 <- 12x38,
+// which, with the filter streamed from L1/L2 instead of staged, is 70 KB of LDS: TWO 4-wave workgroups per CU, each running its
+// convert / store / pool phases under the other's MFMAs (the 8x16 form was one 8-wave workgroup per CU on 156 KB, every wave of
+// the CU in the same phase: gemm 39 % of a tile in the phase stamps).  Measured: 2.00 -> 1.89 ms per launch (2048 tiles of 256x256).
+#ifndef MIL_STEM_X3_PH
+#define MIL_STEM_X3_PH 4
+#endif
+__host__ __device__ constexpr int sf_ph(bool x3) { return x3 ? MIL_STEM_X3_PH : 8; }
+__host__ __device__ constexpr bool sf_wstream(bool x3) { return x3 && MIL_STEM_X3_PH < 8; }
+constexpr int SF_SW = 33;                           // stem tile width
+constexpr int SF_XW = 38, SF_NPAIR = 19;            // s2d tile width; a "pair" = 2 s2d pixels = 4 input columns
+__host__ __device__ constexpr int sf_sh(int ph) { return 2 * ph + 1; }      // stem tile rows
+__host__ __device__ constexpr int sf_xh(int ph) { return 2 * ph + 4; }      // s2d tile rows
 // s2d pixel record in LDS: 16 ch bf16 = 32 B at an odd 16-B slot pitch (48); split precision (X3): [hi 32 B][lo 32 B] at pitch 80
 __host__ __device__ constexpr int sf_xpix(bool x3) { return x3 ? 80 : 48; }
-__host__ __device__ constexpr int sf_xbytes(bool x3) { return SF_XH * SF_XW * sf_xpix(x3); }  // 36480 / 60800
-constexpr int SF_NITEM = SF_XH * SF_NPAIR * 3;      // (row, pair, colour) load items
-constexpr int SF_NSTEM = SF_SH * SF_SW;             // 561
-constexpr int SF_MTILES = 36;                       // 16-pixel row tiles of the stem tile (36*16 = 576 >= 561)
+__host__ __device__ constexpr int sf_xbytes(bool x3) { return sf_xh(sf_ph(x3)) * SF_XW * sf_xpix(x3); }  // 36480 (bf16, 20 rows) / 36480 (split, 12 rows)
+__host__ __device__ constexpr int sf_nitem(int ph) { return sf_xh(ph) * SF_NPAIR * 3; }      // (row, pair, colour) load items
+__host__ __device__ constexpr int sf_nstem(int ph) { return sf_sh(ph) * SF_SW; }             // 561 / 297
+__host__ __device__ constexpr int sf_mtiles(int ph) { return (sf_nstem(ph) + 15) / 16; }     // 16-pixel row tiles of the stem tile: 36 / 19
 
 template <int NT, bool X3 = false>
 __host__ __device__ constexpr int sf_lds_bytes() {
-    return sf_xbytes(X3) + ((SF_NSTEM * mil_pix_pitch(mil_nt_to_cp(NT), X3 ? 4 : 2) + 15) & ~15) + 8 * NT * 64 * (X3 ? 32 : 16) + 256;   // + dump slot
+    return sf_xbytes(X3) + ((sf_nstem(sf_ph(X3)) * mil_pix_pitch(mil_nt_to_cp(NT), X3 ? 4 : 2) + 15) & ~15) +
+           (sf_wstream(X3) ? 0 : 8 * NT * 64 * (X3 ? 32 : 16)) + 256;   // + dump slot
 }
 
 // NW = waves per workgroup.  The kernel is VALU-bound (pool compare/select, activation, conversions) and at 4 waves per
@@ -59,6 +71,9 @@ template <int NT, int NW, bool X3 = false, bool FROM_XS = false>
 __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 6 ? 3 : 2)) : 1)) void stem_fwd_fused_kernel(StemFwdArgs a) {
     static_assert(!(X3 && FROM_XS), "the space-to-depth feed is bf16");
     using T = typename std::conditional<X3, F32S, BF16>::type;
+    constexpr int PH = sf_ph(X3);                             // pooled rows per tile
+    constexpr bool WSTREAM = sf_wstream(X3);                  // filter fragments from L1/L2, not from LDS
+    constexpr int SF_SH = sf_sh(PH), SF_XH = sf_xh(PH), SF_NITEM = sf_nitem(PH), SF_NSTEM = sf_nstem(PH), SF_MTILES = sf_mtiles(PH);
     constexpr int SF_XPIX = sf_xpix(X3), SF_XBYTES = sf_xbytes(X3);
     constexpr int OESZ = X3 ? 4 : 2;                          // bytes per element of the stem tile / pooled output
     constexpr int FRAGB = X3 ? 32 : 16;
@@ -70,7 +85,7 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
     constexpr int SF_NLOAD = ((FROM_XS ? SF_XH * SF_XW * 2 : SF_NITEM) + NTHR - 1) / NTHR;      // FROM_XS: items = 16-byte halves of the tile's s2d records
     constexpr int SF_MT = (SF_MTILES + NW - 1) / NW;          // row tiles per wave
     constexpr int NXS = (1024 + NTHR - 1) / NTHR;             // 16-byte pieces of the tile's own 16x32 s2d pixels per thread
-    constexpr int NPOOL = (128 * NG4 + NTHR - 1) / NTHR;      // (pooled pixel, 4-channel group) items per thread
+    constexpr int NPOOL = (PH * 16 * NG4 + NTHR - 1) / NTHR;  // (pooled pixel, 4-channel group) items per thread
     constexpr bool LAST_PARTIAL = (COUTP % 16) != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MIL_POISON(smem);
@@ -84,7 +99,7 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     {
-        mil_stage_filter(ldsW, a.w, KSTEPS * NT * 64 * FRAGB, tid, NTHR);
+        if constexpr (!WSTREAM) mil_stage_filter(ldsW, a.w, KSTEPS * NT * 64 * FRAGB, tid, NTHR);
         for (int i = tid * 16; i < SF_XBYTES; i += NTHR * 16)          // channels 12..15 of every s2d pixel stay zero
             *reinterpret_cast<uint4*>(ldsX + i) = make_uint4(0, 0, 0, 0);
     }
@@ -135,7 +150,7 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
     for (int i = 0; i < NPOOL; ++i) {
         const int id = tid + NTHR * i;
         p_lds[i] = 15 << 20; p_rel[i] = 0;
-        if (id < 128 * NG4) {
+        if (id < PH * 16 * NG4) {
             const int c4 = id % NG4, pp = id / NG4, py = pp >> 4, px = pp & 15;
             p_lds[i] = (((2 * py) * SF_SW + 2 * px) * SPIX + c4 * 4 * OESZ) | (py << 20) | (px << 24);
             p_rel[i] = (py * Wo + px) * COUTP + c4 * 4;
@@ -156,7 +171,7 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
     u32x4_t r0[SF_NLOAD], r1[FROM_XS ? 1 : SF_NLOAD];
     auto fetch = [&](int t) {
         const int tx = t % a.tiles_x, q = t / a.tiles_x, ty = q % a.tiles_y, img = q / a.tiles_y;
-        const int y0 = 16 * ty - 3, c0 = 64 * tx - 8;            // first s2d row / first input column of the tile
+        const int y0 = 2 * PH * ty - 3, c0 = 64 * tx - 8;        // first s2d row / first input column of the tile
         if constexpr (FROM_XS) {
             const int x0 = 32 * tx - 4;                          // first s2d column of the tile
             const int base = ((img * H2 + y0) * W2 + x0) * 32;
@@ -239,13 +254,21 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
             // ahead, and scheduling fences keep that order.  Left alone, hipcc reads each fragment right in front of its
             // MFMA pair behind an lgkmcnt(0): 72 LDS round trips per tile and wave, two thirds of this kernel's time.
             constexpr int TOT = KSTEPS * SF_MT, LA = MIL_STEM_FWD_LOOKAHEAD, R = LA + 1;
-            Frag8<T> ring[R], wq[2][NT];
+            constexpr int WD = WSTREAM ? 2 : 1, WR = WD + 1;      // filter fragments: k-steps ahead (streamed: an L2 round trip against 25 MFMAs per k-step) / ring slots
+            Frag8<T> ring[R], wq[WR][NT];
             // X3, 20 channels: column tile 1 has four real rows (channels 16-19), so its rows 4-7 carry the LO halves of the same
             // channels (lanes r = 4..7 read lane r-4's lo half): [wh ; wl] x xh, then wh x xl — two MFMAs instead of three; the
             // epilogue adds rows 4-7 onto rows 0-3
             constexpr bool FOLD = X3 && NT == 2;
             const int w1h = (FOLD && r >= 4 && r < 8) ? (64 + lane - 4) * FRAGB + 16 : (64 + lane) * FRAGB;
+            const __amdgpu_buffer_rsrc_t rs_w = mil_rsrc(a.w, KSTEPS * NT * 64 * FRAGB);
             auto wfrag = [&](int sl, int nt) {
+                if constexpr (WSTREAM) {             // (FOLD form only) 16 bytes per lane and half, the k-step in the scalar offset
+                    Frag8<T> f;
+                    f.h = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(nt == 1 ? w1h : lane * FRAGB), sl * NT * 64 * FRAGB, 0));
+                    f.l = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(nt == 1 ? (64 + lane) * FRAGB : lane * FRAGB + 16), sl * NT * 64 * FRAGB, 0));
+                    return f;
+                } else
                 if constexpr (FOLD) {
                     if (nt == 1) {
                         Frag8<T> f;
@@ -257,7 +280,9 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
                 return lds_frag<T>(ldsW + ((sl * NT + nt) * 64 + lane) * FRAGB);
             };
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wq[0][nt] = wfrag(0, nt);
+            for (int k = 0; k < WD; ++k)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) wq[k][nt] = wfrag(k, nt);
 #pragma unroll
             for (int j = 0; j < LA; ++j)
                 ring[j % R] = lds_pix_frag<T, 32>(ldsX + pixbase[j % SF_MT] + (((j / SF_MT) >> 1) * SF_XW + 2 * ((j / SF_MT) & 1)) * SF_XPIX);
@@ -268,18 +293,18 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
                     const int jn = j + LA, sn = jn / SF_MT;
                     ring[jn % R] = lds_pix_frag<T, 32>(ldsX + pixbase[jn % SF_MT] + ((sn >> 1) * SF_XW + 2 * (sn & 1)) * SF_XPIX);
                 }
-                if (m == 0 && sl + 1 < KSTEPS) {
+                if (m == 0 && sl + WD < KSTEPS) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) wq[(sl + 1) & 1][nt] = wfrag(sl + 1, nt);
+                    for (int nt = 0; nt < NT; ++nt) wq[(sl + WD) % WR][nt] = wfrag(sl + WD, nt);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (FOLD) {
-                    acc[m][0] = mma8(wq[sl & 1][0], ring[j % R], acc[m][0]);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[sl & 1][1].h, ring[j % R].h, acc[m][1], 0, 0, 0);      // [wh ; wl] x xh
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[sl & 1][1].l, ring[j % R].l, acc[m][1], 0, 0, 0);      // wh x xl
+                    acc[m][0] = mma8(wq[sl % WR][0], ring[j % R], acc[m][0]);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[sl % WR][1].h, ring[j % R].h, acc[m][1], 0, 0, 0);      // [wh ; wl] x xh
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[sl % WR][1].l, ring[j % R].l, acc[m][1], 0, 0, 0);      // wh x xl
                 } else {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wq[sl & 1][nt], ring[j % R], acc[m][nt]);
+                for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wq[sl % WR][nt], ring[j % R], acc[m][nt]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -301,7 +326,7 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
         MIL_STAMP_MARK(3)
         // Stem pixels outside the image are the pool's -inf padding: written as such, so that the pool phase below
         // needs no per-tap bounds tests (only tiles on the image border have any).
-        const int sy0 = 16 * ty - 1, sx0 = 32 * tx - 1;           // image coordinates of stem-tile pixel (0,0)
+        const int sy0 = 2 * PH * ty - 1, sx0 = 32 * tx - 1;       // image coordinates of stem-tile pixel (0,0)
         const bool border = sy0 < 0 || sx0 < 0 || sy0 + SF_SH > H2 || sx0 + SF_SW > W2;
 #pragma unroll
         for (int m = 0; m < SF_MT; ++m) {
@@ -347,8 +372,8 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
         // ---- 3x3 s2 max-pool of the stem tile: first maximum in (ky,kx) scan order wins ---------------------
 #ifndef MIL_EXP_STEMF_NO_POOL
         {
-            const int obase = ((img * Ho + 8 * ty) * Wo + 16 * tx) * COUTP;
-            const int ylim = Ho - 8 * ty, xlim = Wo - 16 * tx;
+            const int obase = ((img * Ho + PH * ty) * Wo + 16 * tx) * COUTP;
+            const int ylim = Ho - PH * ty, xlim = Wo - 16 * tx;
 #pragma unroll
             for (int it = 0; it < NPOOL; ++it) {
                 const int py = (p_lds[it] >> 20) & 15, px = p_lds[it] >> 24;
@@ -416,7 +441,8 @@ static int launch_stem_fwd(StemFwdArgs a, hipStream_t st) {
 #ifndef MIL_STEM_FWD_WAVES
 #define MIL_STEM_FWD_WAVES 4
 #endif
-    constexpr int NW = X3 ? 8 : (NT <= 2 ? MIL_STEM_FWD_WAVES : 4);
+    constexpr int NW = X3 ? (sf_wstream(true) ? 4 : 8) : (NT <= 2 ? MIL_STEM_FWD_WAVES : 4);
+    a.tiles_y = (a.Ho + sf_ph(X3) - 1) / sf_ph(X3);
     auto kern = stem_fwd_fused_kernel<NT, NW, X3, FROM_XS>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MIL_ERR_LAUNCH;
@@ -437,7 +463,7 @@ static int launch_stem_fwd(StemFwdArgs a, hipStream_t st) {
         b.widx = a.widx + (size_t)i0 * a.Ho * a.Wo * COUTP;
         b.ntiles = b.n_img * a.tiles_y * a.tiles_x;
         int grid = (b.ntiles + 7) & ~7;
-        const int cap = mil_num_cus() * ((NT <= 2 && !X3) ? 2 : 1);
+        const int cap = mil_num_cus() * ((NT <= 2 && (!X3 || sf_wstream(true))) ? 2 : 1);
         if (grid > cap) grid = cap;
 #ifdef MIL_STAMP
         static MilStampBuf sb;
