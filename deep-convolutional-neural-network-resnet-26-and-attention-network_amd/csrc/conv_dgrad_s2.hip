@@ -33,9 +33,10 @@ struct DgradS2Args {
 // the buffer load).  A [hi | lo] filter of 57 / 123 / 205 KB (40 -> 24, 64 -> 40, 80 -> 64 channels) beside two compact
 // tiles left ONE 4-wave workgroup per CU (one wave per SIMD, matrix pipe 16 % busy: 0.52 ms) or did not fit at all (the two
 // larger entries ran the zero-insert forms: 0.65 + 0.35 ms for a quarter of useful MFMAs); with only the compact tiles in
-// LDS (29-54 KB) two to four workgroups are resident; the 40 -> 24 and 64 -> 40 channel entries run this form.
+// LDS (29-54 KB) two to four workgroups are resident (80 channels: one, for its registers); the 64 -> 40 and 80 -> 64 channel
+// entries run this form (the 40 -> 24 entry measured 0.60 ms streamed: it keeps the staged filter).
 template <typename T, int CZ, int NT, bool STREAM = false>
-__global__ __launch_bounds__(256, (STREAM || (CZ <= 40 && !T::SPLIT)) ? 2 : 1) void conv_dgrad_s2_kernel(DgradS2Args<T> a, int ntiles, unsigned z_bytes, unsigned y_bytes) {
+__global__ __launch_bounds__(256, ((STREAM && CZ < 80) || (CZ <= 40 && !T::SPLIT)) ? 2 : 1) void conv_dgrad_s2_kernel(DgradS2Args<T> a, int ntiles, unsigned z_bytes, unsigned y_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MIL_POISON(smem);
     constexpr int ESZ = T::ESZ, FRAGB = 8 * ESZ;
@@ -146,10 +147,13 @@ __global__ __launch_bounds__(256, (STREAM || (CZ <= 40 && !T::SPLIT)) ? 2 : 1) v
 
     // STREAM: no register prefetch of the next tile (its 18-24 pieces and the mask operands do not fit beside the streamed filter
     // fragments: the loads are issued at the top of the tile and behind the MFMA loop; the other resident workgroups cover them)
+    // (80 channels, streamed: ONE wave per SIMD — 64 accumulator + 64 fragment registers beside 25 tap offsets do not fit 256 —
+    // so the next tile IS prefetched in registers, as in the staged form)
+    constexpr bool NOPF = STREAM && CZ < 80;
     u32x4_t rz1[NPZ], rz2[NPZ];
     unsigned ooff_n[2];
     u32x4_t ract_n[2][NT][NE];
-    if (!STREAM && bid < ntiles) {
+    if (!NOPF && bid < ntiles) {
         fetch_z(rz1, rz2, cur.origin(g));
         fetch_epi(cur.origin(g), ooff_n, ract_n);
     }
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256, (STREAM || (CZ <= 40 && !T::SPLIT)) ? 2 : 1) v
     for (int tile = bid; tile < ntiles; tile += G) {
         const TileOrigin o_cur = cur.origin(g);
         __syncthreads();                       // every wave has finished reading the compact tiles of the previous tile
-        if constexpr (STREAM) fetch_z(rz1, rz2, o_cur);
+        if constexpr (NOPF) fetch_z(rz1, rz2, o_cur);
 #pragma unroll
         for (int i = 0; i < NPZ; ++i) {
             if (z_pos[i] >= 0) {
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256, (STREAM || (CZ <= 40 && !T::SPLIT)) ? 2 : 1) v
         }
         unsigned ooff[2];
         u32x4_t ract[2][NT][NE];
-        if constexpr (!STREAM) {
+        if constexpr (!NOPF) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             ooff[p] = ooff_n[p];
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(256, (STREAM || (CZ <= 40 && !T::SPLIT)) ? 2 : 1) v
         }
         }
         __syncthreads();
-        if constexpr (!STREAM) {
+        if constexpr (!NOPF) {
         if (tile + G < ntiles) {
             fetch_z(rz1, rz2, nxt.origin(g));
             fetch_epi(nxt.origin(g), ooff_n, ract_n);
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256, (STREAM || (CZ <= 40 && !T::SPLIT)) ? 2 : 1) v
             }
         }
 #endif
-        if constexpr (STREAM) fetch_epi(o_cur, ooff, ract);
+        if constexpr (NOPF) fetch_epi(o_cur, ooff, ract);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
 #pragma unroll
@@ -339,9 +343,10 @@ extern "C" int mil_conv_dgrad_s2(const void* dz1, const void* dz2, const void* w
     if ((dtype != MIL_DT_BF16 && dtype != MIL_DT_BF16_DGRAD && dtype != MIL_DT_F32S && dtype != MIL_DT_F32S_DGRAD) || h != (H - 1) / 2 + 1 || w != (W - 1) / 2 + 1 || slope < 0.f || slope >= 1.f) return MIL_ERR_UNSUPPORTED;
     if (n_img == 0) return MIL_OK;
     if (dtype == MIL_DT_F32S || dtype == MIL_DT_F32S_DGRAD) {      // fp32 tensors, bf16x3 products: all three entries, the filter streamed
-        // (80 -> 64 channels: its 64 accumulator + 64 fragment registers beside 25 per-lane tap offsets spill 58 VGPRs at two waves
-        // per SIMD: left on the zero-insert form of the generic kernel, 0.35 ms)
-        if (!((cz_p == 40 && cx_p == 24) || (cz_p == 64 && cx_p == 40))) return MIL_ERR_UNSUPPORTED;
+        // (80 -> 64 channels: 64 accumulator + 64 fragment registers beside 25 per-lane tap offsets spill 58 VGPRs at two waves per
+        // SIMD, so that entry runs ONE wave per SIMD with the next tile prefetched in registers — against 0.34 ms on the
+        // zero-insert form of the generic kernel)
+        if (!((cz_p == 40 && cx_p == 24) || (cz_p == 64 && cx_p == 40) || (cz_p == 80 && cx_p == 64))) return MIL_ERR_UNSUPPORTED;
         if (dtype == MIL_DT_F32S_DGRAD && cz_p != 40) return MIL_ERR_UNSUPPORTED;
         DgradS2Args<F32S> b{};
         b.dz1 = (const float*)dz1; b.dz2 = (const float*)dz2; b.w = (const float*)wpack; b.act = (const float*)act; b.y = (float*)y;
@@ -349,7 +354,8 @@ extern "C" int mil_conv_dgrad_s2(const void* dz1, const void* dz2, const void* w
         b.slope = slope; b.ypx = dtype == MIL_DT_F32S_DGRAD ? 80 : cx_p * 4;      // y [n,H,W,20] dense fp32, or padded
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
         if (cz_p == 40) return launch_dgrad_s2<F32S, 40, 2>(b, st);       // staged filter: 0.52 ms against 0.60 ms streamed
-        return launch_dgrad_s2<F32S, 64, 3, true>(b, st);
+        if (cz_p == 64) return launch_dgrad_s2<F32S, 64, 3, true>(b, st);
+        return launch_dgrad_s2<F32S, 80, 4, true>(b, st);
     }
     DgradS2Args<BF16> a{};
     a.dz1 = (const __bf16*)dz1; a.dz2 = (const __bf16*)dz2; a.w = (const __bf16*)wpack; a.act = (const __bf16*)act; a.y = (__bf16*)y;

@@ -28,7 +28,7 @@ struct S2EntryX3Args {
 };
 
 template <int CINP, int NT, int TPX>
-__global__ __launch_bounds__(256, 2) void conv_s2_entry_x3_kernel(S2EntryX3Args a, int ntiles, unsigned x_bytes, unsigned y_bytes) {
+__global__ __launch_bounds__(256, CINP >= 64 ? 1 : 2) void conv_s2_entry_x3_kernel(S2EntryX3Args a, int ntiles, unsigned x_bytes, unsigned y_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MIL_POISON(smem);
     constexpr bool K20 = CINP == 24;

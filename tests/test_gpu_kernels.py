@@ -603,10 +603,11 @@ DGRAD_S2_CASES = [
 
 
 @pytest.mark.parametrize("with_proj", [True, False])
-@pytest.mark.parametrize("case", DGRAD_S2_CASES[:4] + [(40, 60, 3, 32, 32)])
+@pytest.mark.parametrize("case", DGRAD_S2_CASES + [(40, 60, 3, 32, 32)])
 def test_stage_entry_data_gradient_one_pass_split_precision(ops, case, with_proj):
-    """The parity-class stage-entry data gradient on fp32 tensors with bf16x3 products (MIL_DT_F32S; the 40 -> 20 and 60 -> 40
-    channel entries, filter fragments streamed from L1/L2) vs autograd on un-rounded operands; the 80 -> 60 entry declines."""
+    """The parity-class stage-entry data gradient on fp32 tensors with bf16x3 products (MIL_DT_F32S; all three entries: the
+    40 -> 20 channel filter staged in LDS, the 60 -> 40 and 80 -> 60 channel filters streamed from L1/L2) vs autograd on
+    un-rounded operands."""
     L = _lib()
     cin, cout, n, h, w = case
     g = torch.Generator().manual_seed(103 + cin + h)
@@ -631,9 +632,6 @@ def test_stage_entry_data_gradient_one_pass_split_precision(ops, case, with_proj
             got_d = ops.conv_dgrad_s2(to_nhwc(dz1, torch.float32), to_nhwc(dz2, torch.float32) if with_proj else None, ws2, cpad(cin),
                                       (h, w), act=to_nhwc(act, torch.float32), dense_cx=cin)
             assert got_d is not None and got_d.shape[-1] == cin and torch.equal(got_d, got[..., :cin].contiguous())
-        big = torch.zeros((2, 4, 4, 80), device="cuda")
-        wbig, _ = ops.pack_weights(torch.randn(80, 60, 3, 3).cuda(), None, L.PACK_DGRAD_S2, torch.float32)
-        assert ops.conv_dgrad_s2(big, None, wbig, 64, (8, 8)) is None
     assert ops.conv_dgrad_s2(to_nhwc(dz1, torch.float32), None, ws2, cpad(cin), (h, w)) is None      # exact-fp32 mode: no such kernel
 
 
@@ -719,9 +717,10 @@ def test_stage_entry_forward_pair_one_pass(ops, case):
 
 
 @pytest.mark.parametrize("case", [(20, 40, 3, 16, 16), (20, 40, 2, 19, 13), (20, 40, 2, 64, 48), (20, 40, 40, 64, 64),
-                                  (40, 60, 5, 8, 8), (40, 60, 3, 32, 32), (40, 60, 9, 6, 6), (40, 60, 70, 32, 32)])
+                                  (40, 60, 5, 8, 8), (40, 60, 3, 32, 32), (40, 60, 9, 6, 6), (40, 60, 70, 32, 32),
+                                  (60, 80, 5, 16, 16), (60, 80, 3, 13, 19), (60, 80, 7, 4, 4), (60, 80, 300, 16, 16)])
 def test_stage_entry_forward_pair_split_precision(ops, case):
-    """The stage-entry forward pair on fp32 tensors with bf16x3 products (MIL_DT_F32S: 20 -> 40 and 40 -> 60 channels; the
+    """The stage-entry forward pair on fp32 tensors with bf16x3 products (MIL_DT_F32S: all three stage entries; the
     filter streamed from L1/L2, only the input halo planes in LDS) vs torch on un-rounded operands and vs the two generic
     launches; bit-reproducible; padded channels zero.  The large cases give every persistent workgroup several tiles."""
     L = _lib()
@@ -741,9 +740,7 @@ def test_stage_entry_forward_pair_split_precision(ops, case):
         again = ops.conv_s2_entry(xg, p3, bp, p1, cpad(cout))
         z1 = ops.conv(xg, p3, bp, cpad(cout), ks=3, stride=2, pad=1, lrelu=True)
         z2 = ops.conv(xg, p1, None, cpad(cout), ks=1, stride=2, pad=0)
-        big = ops.conv_s2_entry(torch.zeros(2, 8, 8, 64, device="cuda"), p3, bp, p1, 80)
     torch.cuda.synchronize()
-    assert big is None                                      # 64 -> 80 channels: the generic kernels
     assert y1.dtype == torch.float32 and torch.equal(y1, again[0]) and torch.equal(y2, again[1])
     assert rel_err(from_nhwc(y1, cout), F.leaky_relu(F.conv2d(x, w3, b, stride=2, padding=1), LEAK)) < TOL[X3]
     assert rel_err(from_nhwc(y2, cout), F.conv2d(x, w1, None, stride=2)) < TOL[X3]
