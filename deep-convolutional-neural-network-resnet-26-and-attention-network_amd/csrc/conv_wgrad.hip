@@ -979,6 +979,11 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
         {
             static_assert(MT == 4 * MW, "every wave owns MW full row tiles");
             constexpr int NL2 = X3 ? 2 : 1;                  // operand planes: hi (+ lo)
+            // X3: column tile 1 has four real columns (stem channels 16-19), so its columns 4-7 carry the LO halves of the same
+            // channels (the lanes that read the 4-channel piece of channels 20-23 read the lo plane's piece of 16-19 instead):
+            // x_hi * [dz_hi | dz_lo] then x_lo * dz_hi — two MFMAs instead of three; columns 4-7 are added onto 0-3 at the end.
+            // bf[1][1] holds that folded fragment (there is no separate lo fragment of column tile 1).
+            const int fold1 = (X3 && p4 == 1) ? 40 : 0;
             bf16x8_t bc[NL2][NT], ac[NL2][MW], bn[NL2][NT], an[NL2][MW];
             auto load = [&](int k32, bf16x8_t (&bf)[NL2][NT], bf16x8_t (&af)[NL2][MW]) {
                 const int kb = mil_pix_base<PIXB>(g, k32, 1);
@@ -986,7 +991,10 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
 #pragma unroll
                 for (int pl = 0; pl < NL2; ++pl) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bf[pl][nt] = mil_tr_pair(z0 + pl * 48 + nt * 32, z0 + pl * 48 + 4 * PIXZ + nt * 32);
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int zo = (X3 && pl == 1 && nt == 1) ? 32 + fold1 : pl * 48 + nt * 32;
+                        bf[pl][nt] = mil_tr_pair(z0 + zo, z0 + zo + 4 * PIXZ);
+                    }
 #pragma unroll
                     for (int i = 0; i < MW; ++i) af[pl][i] = mil_tr_pair(ldsX + kb + wpl0 + toff[i] + pl * 32, ldsX + kb + wpl1 + toff[i] + pl * 32);
                 }
@@ -1002,7 +1010,8 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
                     for (int nt = 0; nt < NT; ++nt) {
                         if constexpr (X3) {
                             acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[1][i], bc[0][nt], acc[i][nt], 0, 0, 0);
-                            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[0][i], bc[1][nt], acc[i][nt], 0, 0, 0);
+                            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[0][i], bc[1][nt], acc[i][nt], 0, 0, 0);      // nt 1: the folded fragment = x_hi * [dz_hi | dz_lo]
+                            if (nt == 1) continue;
                         }
                         acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[0][i], bc[0][nt], acc[i][nt], 0, 0, 0);
                     }
@@ -1053,8 +1062,14 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                slab[(size_t)(mt * 16 + gq * 4 + e) * SLAB_COLS + nt * 16 + col] = acc[i][nt][e];
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[i][nt][e];
+                if (X3 && nt == 1 && MIL_STEM_BWD_PIPE) {      // folded column tile: columns 4-7 (the lo products) onto columns 0-3
+                    const float up = __shfl_down(v, 4, 16);
+                    v = col < 4 ? v + up : 0.f;
+                }
+                slab[(size_t)(mt * 16 + gq * 4 + e) * SLAB_COLS + nt * 16 + col] = v;
+            }
     }
     // bias sums -> slab row MT*16: 64 pixel-block threads per channel, added in thread order
     __syncthreads();                             // the last tile's MFMA loop is done with the LDS tiles
