@@ -10,6 +10,9 @@
 // second compact tile.  Wave w owns row tile w (16 pixels) of every class; the paired 16-byte register epilogue
 // of the persistent conv kernel then stores two horizontally adjacent output pixels per lane pair.
 #include "pf_common.cuh"
+#ifndef MIL_DGRAD_S2_X3_NW8
+#define MIL_DGRAD_S2_X3_NW8 1
+#endif
 
 template <typename T>
 struct DgradS2Args {
@@ -35,8 +38,11 @@ struct DgradS2Args {
 // larger entries ran the zero-insert forms: 0.65 + 0.35 ms for a quarter of useful MFMAs); with only the compact tiles in
 // LDS (29-54 KB) two to four workgroups are resident (80 channels: one, for its registers); the 64 -> 40 and 80 -> 64 channel
 // entries run this form (the 40 -> 24 entry measured 0.60 ms streamed: it keeps the staged filter).
-template <typename T, int CZ, int NT, bool STREAM = false>
-__global__ __launch_bounds__(256, ((STREAM && CZ < 80) || (CZ <= 40 && !T::SPLIT)) ? 2 : 1) void conv_dgrad_s2_kernel(DgradS2Args<T> a, int ntiles, unsigned z_bytes, unsigned y_bytes) {
+// NW = 8 (split precision, 40 -> 24 channels, maps of at least 16x32): 512-pixel output tiles (16 rows x 32 columns, compact
+// tiles of 9x17 pixels) on eight waves that share ONE staged filter — two waves per SIMD instead of the one the 4-wave form
+// is left with (57 KB filter + 252 VGPRs: matrix pipe 0.14 busy, 0.52 ms).
+template <typename T, int CZ, int NT, bool STREAM = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (NW == 8 || (STREAM && CZ < 80) || (CZ <= 40 && !T::SPLIT)) ? 2 : 1) void conv_dgrad_s2_kernel(DgradS2Args<T> a, int ntiles, unsigned z_bytes, unsigned y_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MIL_POISON(smem);
     constexpr int ESZ = T::ESZ, FRAGB = 8 * ESZ;
@@ -46,7 +52,8 @@ __global__ __launch_bounds__(256, ((STREAM && CZ < 80) || (CZ <= 40 && !T::SPLIT
     constexpr int PIXZ = mil_pix_pitch(CZ, ESZ);
     constexpr int CXP = mil_nt_to_cp(NT);
     constexpr int NS = mil_s2_nsteps(CG);
-    constexpr int NPZ = (144 * N16 + 255) / 256;             // <= 144 compact halo pixels (16 images of 3x3)
+    constexpr int NTHR = 64 * NW;
+    constexpr int NPZ = ((NW == 8 ? 153 : 144) * N16 + NTHR - 1) / NTHR;      // <= 144 compact halo pixels (16 images of 3x3); NW 8: 9x17
     constexpr bool LAST_PARTIAL = (CXP % 16) != 0;
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -54,7 +61,7 @@ __global__ __launch_bounds__(256, ((STREAM && CZ < 80) || (CZ <= 40 && !T::SPLIT
     const int r = lane & 15, gq = lane >> 4;
     char* ldsZ = smem;
     char* ldsW = smem + a.lds_w_off;
-    if constexpr (!STREAM) mil_stage_filter(ldsW, a.w, NS * NT * 64 * FRAGB, tid, 256);
+    if constexpr (!STREAM) mil_stage_filter(ldsW, a.w, NS * NT * 64 * FRAGB, tid, NTHR);
     const __amdgpu_buffer_rsrc_t rs_w = mil_rsrc(a.w, NS * NT * 64 * FRAGB);
     const __amdgpu_buffer_rsrc_t rs_z1 = mil_rsrc(a.dz1, z_bytes);
     const __amdgpu_buffer_rsrc_t rs_z2 = mil_rsrc(a.dz2, a.dz2 ? z_bytes : 0);
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(256, ((STREAM && CZ < 80) || (CZ <= 40 && !T::SPLIT
         const int total = ((CH * CW) << g.ti_log2) * N16;
 #pragma unroll
         for (int i = 0; i < NPZ; ++i) {
-            const int idx = tid + 256 * i;
+            const int idx = tid + NTHR * i;
             z_pos[i] = -1; z_lds[i] = 0; z_rel[i] = 0;
             if (idx < total) {
                 const int p = idx / N16, j = idx - p * N16;
@@ -292,24 +299,26 @@ __global__ __launch_bounds__(256, ((STREAM && CZ < 80) || (CZ <= 40 && !T::SPLIT
     }
 }
 
-template <typename T, int CZ, int NT, bool STREAM = false>
+template <typename T, int CZ, int NT, bool STREAM = false, int NW = 4>
 static int launch_dgrad_s2(DgradS2Args<T> a, hipStream_t st) {
     constexpr int ESZ = T::ESZ;
     constexpr int CG = CZ / 8, PIXZ = mil_pix_pitch(CZ, ESZ), CXP = mil_nt_to_cp(NT);
+    if constexpr (NW == 8) mil_geom_set(a.g, 5, 4, 0);         // 16 x 32 output pixels of one image
+    else
     mil_geom_tiles(a.g, 8);
     if (a.g.tw_log2 < 1 || a.g.th_log2 < 1) return MIL_ERR_UNSUPPORTED;
     a.ch = (1 << a.g.th_log2) / 2 + 1; a.cw = (1 << a.g.tw_log2) / 2 + 1;
     const int npx = (a.ch * a.cw) << a.g.ti_log2;
-    if (npx > 144) return MIL_ERR_UNSUPPORTED;
+    if (npx > (NW == 8 ? 153 : 144)) return MIL_ERR_UNSUPPORTED;
     const int z_bytes = (npx * PIXZ + 15) & ~15;
     const int w_bytes = STREAM ? 0 : mil_s2_nsteps(CG) * NT * 64 * 8 * ESZ;
     a.lds_z2_off = z_bytes; a.lds_w_off = 2 * z_bytes;
     const int lds = 2 * z_bytes + w_bytes;
     if (lds > 160 * 1024) return MIL_ERR_UNSUPPORTED;
-    auto kern = conv_dgrad_s2_kernel<T, CZ, NT, STREAM>;
+    auto kern = conv_dgrad_s2_kernel<T, CZ, NT, STREAM, NW>;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         return MIL_ERR_LAUNCH;
-    const int per_cu = mil_resident_per_cu(kern, lds, 4);      // by registers AND LDS (see conv_s2_entry.hip)
+    const int per_cu = mil_resident_per_cu(kern, lds, 4, 64 * NW);      // by registers AND LDS (see conv_s2_entry.hip)
     const size_t z_img = (size_t)a.g.H * a.g.W * CZ * ESZ, act_img = (size_t)a.g.Ho * a.g.Wo * CXP * ESZ, y_img = (size_t)a.g.Ho * a.g.Wo * a.ypx;
     int chunk = mil_imgs_under_2g(z_img > act_img ? z_img : act_img);
     if (chunk >= 16) chunk &= ~15;
@@ -327,7 +336,7 @@ static int launch_dgrad_s2(DgradS2Args<T> a, hipStream_t st) {
         const int ntiles = c.g.n_groups * c.g.tiles_y * c.g.tiles_x;
         int grid = mil_num_cus() * per_cu;
         if (grid > ntiles) grid = ntiles;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, c, ntiles, (unsigned)(z_img * n), (unsigned)(y_img * n));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, st, c, ntiles, (unsigned)(z_img * n), (unsigned)(y_img * n));
         MIL_CHECK_LAUNCH();
     }
     return MIL_OK;
@@ -353,7 +362,10 @@ extern "C" int mil_conv_dgrad_s2(const void* dz1, const void* dz2, const void* w
         b.g.n_img = n_img; b.g.H = h; b.g.W = w; b.g.Ho = H; b.g.Wo = W; b.g.ks = 3; b.g.stride = 1; b.g.pad = 1; b.g.zins = 1;
         b.slope = slope; b.ypx = dtype == MIL_DT_F32S_DGRAD ? 80 : cx_p * 4;      // y [n,H,W,20] dense fp32, or padded
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-        if (cz_p == 40) return launch_dgrad_s2<F32S, 40, 2>(b, st);       // staged filter: 0.52 ms against 0.60 ms streamed
+        if (cz_p == 40) {               // staged filter: 0.52 ms against 0.60 ms streamed; eight waves on one staged filter where the map allows
+            if (MIL_DGRAD_S2_X3_NW8 && H >= 16 && W >= 32) return launch_dgrad_s2<F32S, 40, 2, false, 8>(b, st);
+            return launch_dgrad_s2<F32S, 40, 2>(b, st);
+        }
         if (cz_p == 64) return launch_dgrad_s2<F32S, 64, 3, true>(b, st);
         return launch_dgrad_s2<F32S, 80, 4, true>(b, st);
     }

@@ -603,11 +603,11 @@ DGRAD_S2_CASES = [
 
 
 @pytest.mark.parametrize("with_proj", [True, False])
-@pytest.mark.parametrize("case", DGRAD_S2_CASES + [(40, 60, 3, 32, 32)])
+@pytest.mark.parametrize("case", DGRAD_S2_CASES + [(40, 60, 3, 32, 32), (20, 40, 2, 33, 70), (20, 40, 9, 64, 64)])
 def test_stage_entry_data_gradient_one_pass_split_precision(ops, case, with_proj):
     """The parity-class stage-entry data gradient on fp32 tensors with bf16x3 products (MIL_DT_F32S; all three entries: the
-    40 -> 20 channel filter staged in LDS, the 60 -> 40 and 80 -> 60 channel filters streamed from L1/L2) vs autograd on
-    un-rounded operands."""
+    40 -> 20 channel filter staged in LDS — on 512-pixel tiles and eight waves where the map is at least 16x32, else 256-pixel
+    tiles and four — the 60 -> 40 and 80 -> 60 channel filters streamed from L1/L2) vs autograd on un-rounded operands."""
     L = _lib()
     cin, cout, n, h, w = case
     g = torch.Generator().manual_seed(103 + cin + h)
