@@ -9,6 +9,38 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+// Split-precision operands: v = hi + lo with hi = bf16(v), lo = bf16(v - hi).  v - hi is exact in fp32, and v_dot2c_f32_bf16
+// against the constant pair (-1, 0) / (0, -1) computes it straight from the PACKED hi pair: one conversion, two dot
+// instructions and one conversion per two values (the plain form unpacks hi first: 13 vector instructions per four values
+// against 8).  Every commit and every split epilogue of the MIL_DT_F32S kernels goes through these two.
+#ifndef MIL_SPLIT_DOT2
+#define MIL_SPLIT_DOT2 1
+#endif
+__device__ __forceinline__ void mil_split2(float v0, float v1, bf16x2_t& hi, bf16x2_t& lo) {
+    hi[0] = (__bf16)v0; hi[1] = (__bf16)v1;
+#if MIL_SPLIT_DOT2
+    // The constant pairs go through an opaque SGPR: written as literals, hipcc (ROCm 7.2) folds {-1, 0} into the INLINE constant
+    // -1.0, which v_dot2c_f32_bf16 reads as 0xBF800000 = {0, -1} — the wrong operand, no diagnostic (tools/dev/split_probe.hip:
+    // every second value wrong as literals, 0 differences in 4 M values incl. zeros, denormals and 3e38 this way).
+    unsigned c0 = 0x0000BF80u, c1 = 0xBF800000u;
+    asm("" : "+s"(c0));
+    asm("" : "+s"(c1));
+    const bf16x2_t m0 = __builtin_bit_cast(bf16x2_t, c0), m1 = __builtin_bit_cast(bf16x2_t, c1);
+    lo[0] = (__bf16)__builtin_amdgcn_fdot2_f32_bf16(hi, m0, v0, false);
+    lo[1] = (__bf16)__builtin_amdgcn_fdot2_f32_bf16(hi, m1, v1, false);
+#else
+    lo[0] = (__bf16)(v0 - (float)hi[0]); lo[1] = (__bf16)(v1 - (float)hi[1]);
+#endif
+}
+__device__ __forceinline__ void mil_split4(const f32x4_t& v, bf16x4_t& hi, bf16x4_t& lo) {
+    bf16x2_t h0, l0, h1, l1;
+    mil_split2(v[0], v[1], h0, l0);
+    mil_split2(v[2], v[3], h1, l1);
+    hi = bf16x4_t{h0[0], h0[1], h1[0], h1[1]};
+    lo = bf16x4_t{l0[0], l0[1], l1[0], l1[1]};
+}
 
 #define MIL_OK 0
 #define MIL_ERR_ARG 1

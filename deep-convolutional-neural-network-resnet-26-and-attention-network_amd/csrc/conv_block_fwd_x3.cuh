@@ -136,12 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv_block_fwd_x3_kernel(BlockFwdX3Arg
         }
     auto split4 = [](const f32x4_t& v, u32x2_t& hi, u32x2_t& lo) {
         bf16x4_t h, l;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const __bf16 t = (__bf16)v[j];
-            h[j] = t;
-            l[j] = (__bf16)(v[j] - (float)t);
-        }
+        mil_split4(v, h, l);
         hi = __builtin_bit_cast(u32x2_t, h);
         lo = __builtin_bit_cast(u32x2_t, l);
     };

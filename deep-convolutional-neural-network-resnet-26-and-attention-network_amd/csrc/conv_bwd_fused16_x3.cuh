@@ -116,12 +116,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused16x3_kernel(BwdFusedArgs
     auto split4 = [](const u32x4_t& rr, u32x2_t& hi, u32x2_t& lo) {
         const f32x4_t v = __builtin_bit_cast(f32x4_t, rr);
         bf16x4_t h, l;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const __bf16 t = (__bf16)v[j];
-            h[j] = t;
-            l[j] = (__bf16)(v[j] - (float)t);
-        }
+        mil_split4(v, h, l);
         hi = __builtin_bit_cast(u32x2_t, h);
         lo = __builtin_bit_cast(u32x2_t, l);
     };

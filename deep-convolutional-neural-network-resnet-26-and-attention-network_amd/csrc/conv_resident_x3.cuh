@@ -102,12 +102,7 @@ __global__ __launch_bounds__(512, 2) void conv_resident_x3_kernel(ResArgsX3 a) {
     }
     auto split4 = [](const f32x4_t& v, u32x2_t& hi, u32x2_t& lo) {
         bf16x4_t h, l;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const __bf16 t = (__bf16)v[j];
-            h[j] = t;
-            l[j] = (__bf16)(v[j] - (float)t);
-        }
+        mil_split4(v, h, l);
         hi = __builtin_bit_cast(u32x2_t, h);
         lo = __builtin_bit_cast(u32x2_t, l);
     };

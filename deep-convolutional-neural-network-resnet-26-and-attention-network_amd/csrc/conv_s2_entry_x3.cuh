@@ -105,12 +105,7 @@ __global__ __launch_bounds__(256, CINP >= 64 ? 1 : 2) void conv_s2_entry_x3_kern
         for (int i = 0; i < 4; ++i) bias_r[nt][i] = a.bias ? a.bias[nt * 16 + gq * 4 + i] : 0.f;
     auto split4 = [](const f32x4_t& v, u32x2_t& hi, u32x2_t& lo) {
         bf16x4_t h, l;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const __bf16 t = (__bf16)v[j];
-            h[j] = t;
-            l[j] = (__bf16)(v[j] - (float)t);
-        }
+        mil_split4(v, h, l);
         hi = __builtin_bit_cast(u32x2_t, h);
         lo = __builtin_bit_cast(u32x2_t, l);
     };

@@ -104,12 +104,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_x3_kernel(StreamX3Args a, 
             asm volatile("" : "+v"(p));
             const f32x4_t v = __builtin_bit_cast(f32x4_t, rx[i]);
             bf16x4_t h, l;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const __bf16 t = (__bf16)v[j];
-                h[j] = t;
-                l[j] = (__bf16)(v[j] - (float)t);
-            }
+            mil_split4(v, h, l);
             const int l0 = p >= 0 ? (p & 0xFFFF) : dumpo;
             *reinterpret_cast<bf16x4_t*>(smem + l0) = h;
             *reinterpret_cast<bf16x4_t*>(smem + (p >= 0 ? l0 + PLANE : dumpo + 8)) = l;

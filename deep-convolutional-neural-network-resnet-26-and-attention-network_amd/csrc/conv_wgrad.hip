@@ -778,10 +778,12 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
             const f32x4_t v0 = __builtin_bit_cast(f32x4_t, lr0[i]), v1 = __builtin_bit_cast(f32x4_t, lr1[i]);
             const float fa[4] = {v0[0], v0[1], v1[0], v1[1]}, fb[4] = {v0[2], v0[3], v1[2], v1[3]};
             bf16x4_t pa, pb, qa, qb;
+            if constexpr (X3) {
+                mil_split4(f32x4_t{fa[0], fa[1], fa[2], fa[3]}, pa, qa);
+                mil_split4(f32x4_t{fb[0], fb[1], fb[2], fb[3]}, pb, qb);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                pa[j] = (__bf16)fa[j]; pb[j] = (__bf16)fb[j];
-                if constexpr (X3) { qa[j] = (__bf16)(fa[j] - (float)pa[j]); qb[j] = (__bf16)(fb[j] - (float)pb[j]); }
+                for (int j = 0; j < 4; ++j) { pa[j] = (__bf16)fa[j]; pb[j] = (__bf16)fb[j]; }
             }
             const int d0 = l_lds[i] & 0xFFFFF;
             const int d1 = (l_lds[i] >> 20) ? a.lds_dump_off : d0 + PIXB;
@@ -949,13 +951,11 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
                     unsigned* dst = reinterpret_cast<unsigned*>(ldsZ + tp * PIXZ + bc6 * 12);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-                        bf16x2_t pr;
-                        pr[0] = (__bf16)gsum[dy][dx][2 * k]; pr[1] = (__bf16)gsum[dy][dx][2 * k + 1];
+                        bf16x2_t pr, lo;
+                        if constexpr (X3) mil_split2(gsum[dy][dx][2 * k], gsum[dy][dx][2 * k + 1], pr, lo);
+                        else { pr[0] = (__bf16)gsum[dy][dx][2 * k]; pr[1] = (__bf16)gsum[dy][dx][2 * k + 1]; }
                         dst[k] = __builtin_bit_cast(unsigned, pr);
                         if constexpr (X3) {                      // lo plane of the dz record; the bias sums take the fp32 values themselves
-                            bf16x2_t lo;
-                            lo[0] = (__bf16)(gsum[dy][dx][2 * k] - (float)pr[0]); lo[1] = (__bf16)(gsum[dy][dx][2 * k + 1] - (float)pr[1]);
                             dst[12 + k] = __builtin_bit_cast(unsigned, lo);
                             bsum[2 * k] += gsum[dy][dx][2 * k]; bsum[2 * k + 1] += gsum[dy][dx][2 * k + 1];
                         } else {

@@ -131,12 +131,7 @@ __device__ __forceinline__ void mil_commit_piece(char* p, const u32x4_t& r) {
     if constexpr (T::SPLIT) {
         const f32x4_t v = __builtin_bit_cast(f32x4_t, r);
         bf16x4_t hi, lo;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const __bf16 h = (__bf16)v[j];
-            hi[j] = h;
-            lo[j] = (__bf16)(v[j] - (float)h);
-        }
+        mil_split4(v, hi, lo);
         *reinterpret_cast<bf16x4_t*>(p) = hi;
         *reinterpret_cast<bf16x4_t*>(p + LO) = lo;
     } else {

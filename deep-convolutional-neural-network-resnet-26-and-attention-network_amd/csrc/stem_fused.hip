@@ -210,10 +210,12 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
             const f32x4_t v0 = __builtin_bit_cast(f32x4_t, r0[i]), v1 = __builtin_bit_cast(f32x4_t, r1[i]);
             const float fa[4] = {v0[0], v0[1], v1[0], v1[1]}, fb[4] = {v0[2], v0[3], v1[2], v1[3]};
             bf16x4_t pa, pb, qa, qb;
+            if constexpr (X3) {
+                mil_split4(f32x4_t{fa[0], fa[1], fa[2], fa[3]}, pa, qa);
+                mil_split4(f32x4_t{fb[0], fb[1], fb[2], fb[3]}, pb, qb);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                pa[j] = (__bf16)fa[j]; pb[j] = (__bf16)fb[j];
-                if constexpr (X3) { qa[j] = (__bf16)(fa[j] - (float)pa[j]); qb[j] = (__bf16)(fb[j] - (float)pb[j]); }
+                for (int j = 0; j < 4; ++j) { pa[j] = (__bf16)fa[j]; pb[j] = (__bf16)fb[j]; }
             }
             char* dst = smem + (l_lds[i] & 0x3FFFF);
             *reinterpret_cast<bf16x4_t*>(dst) = pa;
