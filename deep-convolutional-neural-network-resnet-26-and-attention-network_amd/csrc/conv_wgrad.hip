@@ -465,7 +465,7 @@ static int plan_wgrad(ConvGeom& g, WgradPlan& pl, int* lds_z_off, bool proj = fa
     constexpr int RG = KS * KS * (CINP / 8);
     constexpr int MT = (RG + 1) / 2;
     // 256-px tiles when the halo fits comfortably, else 64-px tiles (stride-2 layers, f32 wide layers)
-    constexpr bool PF_OK = T::TR16 && (!T::SPLIT || CINP < 64 || (MIL_WGRAD_X3_WIDE_PF && CINP == 64));            // bf16, and fp32 with split-precision products: the register-prefetch pipeline
+    constexpr bool PF_OK = T::TR16 && (!T::SPLIT || CINP < 64 || (MIL_WGRAD_X3_WIDE_PF && (CINP == 64 || (CINP == 80 && MSPLIT >= 3))));            // bf16, and fp32 with split-precision products: the register-prefetch pipeline
     constexpr bool HALF = mil_wgrad_x3_half(T::SPLIT, KS, CINP, NT, MSPLIT, false);
     const bool half = HALF && !proj;
     const int hmax = mil_wgrad_halo_max(CINP, proj, T::SPLIT, half);
@@ -511,7 +511,7 @@ static int run_wgrad(const void* x, const void* dz, float* dw, float* db, void* 
     a.lds_z2_off = lds_z_off + (1 << pl.tile_px_log2) * mil_pix_pitch(mil_nt_to_cp(NT), T::ESZ);
     // register-prefetch pipeline for the bf16 path when the halo is small enough for its register budget
     // (split precision at >= 64 channels: the doubled prefetch registers spill — 130-250 VGPRs — so those keep the plain loader)
-    constexpr bool PF_OK = T::TR16 && (!T::SPLIT || CINP < 64 || (MIL_WGRAD_X3_WIDE_PF && CINP == 64));
+    constexpr bool PF_OK = T::TR16 && (!T::SPLIT || CINP < 64 || (MIL_WGRAD_X3_WIDE_PF && (CINP == 64 || (CINP == 80 && MSPLIT >= 3))));
     const size_t xb_total = (size_t)g.n_img * g.H * g.W * CINP * T::ESZ;
     const size_t zb_total = (size_t)g.n_img * g.Ho * g.Wo * mil_nt_to_cp(NT) * T::ESZ;
     // buffer descriptors address < 2 GiB: a larger tensor is walked in image chunks, one launch and one set of slabs per chunk
@@ -640,7 +640,7 @@ static int dispatch_wgrad(const void* x, const void* dz, float* dw, float* db, v
         if (cinp == 24 && coutp == 24) MIL_WG(3, 24, 2, 1);
         if (cinp == 40 && coutp == 40) MIL_WG(3, 40, 3, 1);
         if (cinp == 64 && coutp == 64) MIL_WG(3, 64, 4, 1);
-        if (cinp == 80 && coutp == 80) MIL_WG(3, 80, 5, 2);
+        if (cinp == 80 && coutp == 80) { if constexpr (T::SPLIT) { MIL_WG(3, 80, 5, 3); } else { MIL_WG(3, 80, 5, 2); } }
         if (cinp == 24 && coutp == 40) MIL_WG(3, 24, 3, 1);
         if (cinp == 40 && coutp == 64) {
             // split precision: the rows in two grid halves (23 row tiles x 4 column tiles of accumulators beside the doubled
