@@ -233,8 +233,9 @@ def _hip_patterns(saved):
     return pat
 
 
+@pytest.mark.parametrize("n", [24, 40], ids=["24-tiles-persistent-forced", "40-tiles-grids-wrap"])
 @pytest.mark.parametrize("dtype", [torch.float32, X3, torch.bfloat16], ids=["fp32", "bf16x3", "bf16"])
-def test_encoder_gradients_on_its_own_activation_pattern(golden_dir, dtype, monkeypatch):
+def test_encoder_gradients_on_its_own_activation_pattern(golden_dir, dtype, n, monkeypatch):
     """The encoder's vector-Jacobian product against fp64 ON THE SAME LINEAR PIECE.  ResNet-26 with LeakyReLU and max-pool is
     piecewise linear; two correct fp32 evaluations differ in the branch of the few elements whose pre-activation is within
     rounding of zero, and ONE such element in a 327,680-element map moves the gradients of everything upstream by 5e-3 of
@@ -244,12 +245,15 @@ def test_encoder_gradients_on_its_own_activation_pattern(golden_dir, dtype, monk
     left is the arithmetic of the kernels: every one of the 54 encoder gradients (L2 error relative to the tensor's norm)
     within 1e-5 of fp64 in fp32 (measured 1.4e-6), 2e-4 with bf16x3 products (measured 5e-5), 4e-2 with bf16 storage
     (measured 1.3e-2: eight significant bits per stored tensor through 26 layers — the 12-23 % gradient-norm deviations the
-    end-to-end bf16 tests see are branch flips, not bf16-rounded sums)."""
+    end-to-end bf16 tests see are branch flips, not bf16-rounded sums).
+    n = 24 forces the persistent kernels onto these small launches (MIL_PF_MIN_TILES=1); n = 40 runs the production dispatch
+    at a size where the stem (2560 tiles) and the 20-channel kernels (640 tiles) have more tiles than resident workgroups
+    (512), so every persistent workgroup walks several tiles with its prefetch in flight."""
     from mil_amd import _lib as L
     from mil_amd import encoder
-    monkeypatch.setenv("MIL_PF_MIN_TILES", "1")
+    if n == 24:
+        monkeypatch.setenv("MIL_PF_MIN_TILES", "1")
     torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
-    n = 24
     x = synth_bag(n, 256, 256, 20260131)
     w = _weights(golden_dir)
     net = _model(golden_dir, dtype)
