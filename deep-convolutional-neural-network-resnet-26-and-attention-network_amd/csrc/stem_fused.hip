@@ -378,6 +378,7 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
             const int ylim = Ho - PH * ty, xlim = Wo - 16 * tx;
 #pragma unroll
             for (int it = 0; it < NPOOL; ++it) {
+                if (wave * 64 + NTHR * it >= PH * 16 * NG4) continue;      // a wave whose 64 items of this round all lie behind the last one (wave-uniform)
                 const int py = (p_lds[it] >> 20) & 15, px = p_lds[it] >> 24;
                 const char* src = ldsS + (p_lds[it] & 0xFFFFF);
                 float best[4];
