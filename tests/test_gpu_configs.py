@@ -350,13 +350,16 @@ def test_config2_full_size_properties(golden_dir, dtype):
     assert m_err < (1e-3 if dtype == X3 else 0.2)
 
 
-def test_config3_full_size_bf16_properties(golden_dir):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, X3], ids=["bf16", "bf16x3"])
+def test_config3_full_size_properties(golden_dir, dtype):
     """8 bags x 128 tiles @512x512 in ONE launch sequence (BASELINE configs[2] as bench.py --size 512 --tiles 128 runs it):
-    layer-1 tensors are 2.1 GiB here, so the kernels that address through 32-bit buffer offsets split their launches.
+    layer-1 tensors are 2.1 GiB in bf16 and 4.3 GiB on the split-precision path (fp32 tensors: twice across the 2 GiB reach of
+    a buffer descriptor), so the kernels that address through 32-bit buffer offsets split their launches.
     Size-independent properties: finite everywhere, every attention map sums to 1, a tile's features do not depend on
-    the launch it shares (first tiles re-encoded alone), two runs bit-identical (no atomics, fixed-order reductions)."""
+    the launch it shares (first tiles re-encoded alone; 1e-4 on the split-precision path), two runs bit-identical (no atomics,
+    fixed-order reductions)."""
     import mil_amd
-    net = _model(golden_dir, torch.bfloat16)
+    net = _model(golden_dir, dtype)
     flat = mil_amd.FlatParams(net)
     gen = torch.Generator(device="cuda").manual_seed(321)
     x = torch.empty((1024, 3, 512, 512), dtype=torch.float32, device="cuda")
@@ -380,7 +383,7 @@ def test_config3_full_size_bf16_properties(golden_dir):
         alone_first, alone_last = net.cnn(x[:4]), net.cnn(x[-4:])              # generic (non-persistent) kernels
     big_first, big_last = outs[0]["Fterm"][:4], runs[0][3]
     for a, b in ((alone_first, big_first), (alone_last, big_last)):           # last tiles sit beyond the 2 GiB mark
-        assert float((a - b).abs().max() / b.abs().max()) < 3e-2
+        assert float((a - b).abs().max() / b.abs().max()) < (1e-4 if dtype == X3 else 3e-2)
 
 
 # ---- configs[4]: one 4096-tile bag, forward only ---------------------------------------------------------------------

@@ -84,6 +84,15 @@ def _worker(rank, world, port, out):
         with torch.no_grad():
             whole = ref(x.cuda(), torch.tensor([2]))
         tp_ok = all(torch.allclose(tp[k], whole[k], rtol=1e-5, atol=1e-7) for k in ("Aterm", "Mterm", "Fterm", "wROIs", "y_pred"))
+        # the same check on the split-precision (default) and the bf16 paths: the slices run other launch sizes than the whole
+        # bag, the gathered features must still give the whole-bag output (fp32 storage: 1e-4; bf16 storage: bf16 noise)
+        for dt, rtol, atol in (("bf16x3", 1e-4, 1e-6), (torch.bfloat16, 5e-2, 1e-3)):
+            net_dt = _net(dt)
+            tp_dt = net_dt.forward_tile_parallel(sl.cuda(), torch.tensor([2]))
+            with torch.no_grad():
+                whole_dt = net_dt(x.cuda(), torch.tensor([2]))
+            tp_ok = tp_ok and all(torch.allclose(tp_dt[k], whole_dt[k], rtol=rtol, atol=atol) for k in ("Aterm", "Mterm", "Fterm", "wROIs", "y_pred"))
+            tp_ok = tp_ok and tuple(tp_dt["Aterm"].shape) == (3, 23)
         out.put((rank, replicas_equal, grad_err, scale > 0, tp_ok, tuple(tp["Aterm"].shape)))
     finally:
         dist.destroy_process_group()

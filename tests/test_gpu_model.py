@@ -115,6 +115,24 @@ def test_bf16x3_outputs_match_reference_golden(golden_dir, name):
     assert worst < (0.2 if name == "eval_n2_256" else 5e-2)      # branch flips; N=2: ill-conditioned BN backward
 
 
+def test_default_constructed_module_is_inside_the_reference_tolerance(golden_dir):
+    """`Attention(n_classes, class_weights)` exactly as gbm/classify_combined.py:518 calls it — no keyword — must land inside
+    the north-star gate (1e-3 absolute on logits / attention weights / probabilities / loss vs the reference golden): the
+    default compute mode is the split-precision one; bf16 is the opt-in fast mode."""
+    import mil_amd
+    g = np.load(os.path.join(golden_dir, "eval_n8_64_cw.npz"))
+    w = np.load(os.path.join(golden_dir, "weights.npz"))
+    net = mil_amd.Attention(3, torch.tensor(g["class_weights"]))
+    assert net.compute_dtype == mil_amd.BF16X3
+    net.load_state_dict({k: torch.tensor(w[k]) for k in w.keys()}, strict=True)
+    net.eval()
+    out = net(torch.tensor(g["x"]).cuda(), torch.tensor(g["y"]).cuda())
+    assert list(out.keys()) == OUT_KEYS
+    for k in ("Mterm", "Aterm", "y_pred", "loss", "wROIs", "Bterm"):
+        assert _maxabs(out[k].detach().cpu().numpy(), g["out." + k]) < 1e-3, k
+    assert np.array_equal(out["y_pred_hat"].cpu().numpy(), g["out.y_pred_hat"])
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_fp32_gradients_match_reference_golden(golden_dir, name):
     net, g, out = _run_case(golden_dir, name, torch.float32)
@@ -328,33 +346,39 @@ def test_benchmark_sized_launch_properties(golden_dir, monkeypatch):
         assert torch.equal(outs[1]["Aterm"], outs2[1]["Aterm"])
 
 
-def test_live_driver_tile_size_and_ragged_bags(golden_dir):
+@pytest.mark.parametrize("dtype", [torch.float32, "bf16x3"], ids=["fp32", "bf16x3"])
+def test_live_driver_tile_size_and_ragged_bags(golden_dir, dtype):
     """The reference's live driver feeds 300x300 tiles (gbm/classify_combined.py:412; maps 150->75->38->19->10, no
-    power of two anywhere) and bags of any size up to 2500 (RoiBuilder.py:230).  fp32 path vs the CPU oracle on
-    ragged bags encoded in one launch; bf16 path for shape/finite checks on a larger ragged batch."""
+    power of two anywhere) and bags of any size up to 2500 (RoiBuilder.py:230).  The exact-fp32 path AND the split-precision
+    path (whose odd maps take other kernels than every power-of-two size: ragged edge tiles, generic fall-backs) vs the CPU
+    oracle on ragged bags encoded in one launch: logits / attention weights / probabilities / loss within 1e-3, four
+    gradients; bf16 path for shape/finite checks on a larger ragged batch."""
     w = np.load(os.path.join(golden_dir, "weights.npz"))
     gen = torch.Generator().manual_seed(31)
     sizes = [5, 2, 9]
     x = torch.randn(sum(sizes), 3, 300, 300, generator=gen).clamp_(-1, 1)
     labels = torch.tensor([1, 0, 2])
-    net = _model(golden_dir, torch.float32).eval()
+    net = _model(golden_dir, dtype).eval()
     outs = net.forward_bags((x.cuda(), sizes), labels)
     torch.stack([o["loss"] for o in outs]).sum().backward()
     sd = orc.load_state(w, requires_grad=True)
     off, tot = 0, 0.0
     for b, n in enumerate(sizes):
         ref = orc.attention_forward(sd, x[off:off + n], labels[b:b + 1])
-        assert _maxabs(outs[b]["Aterm"].cpu().numpy(), ref["Aterm"].numpy()) < 1e-3
-        assert _rel(outs[b]["Fterm"].cpu().numpy(), ref["Fterm"].numpy()) < 2e-4
-        assert _maxabs(outs[b]["Mterm"].cpu().numpy(), ref["Mterm"].numpy()) < 1e-3
+        for k in ("Aterm", "Mterm", "y_pred", "loss"):
+            assert _maxabs(outs[b][k].detach().cpu().numpy(), ref[k].detach().numpy()) < 1e-3, (b, k)
+        assert _rel(outs[b]["Fterm"].cpu().numpy(), ref["Fterm"].numpy()) < (2e-4 if dtype == torch.float32 else 1e-4)
         tot = tot + ref["loss"]
         off += n
     tot.backward()
     params = dict(net.named_parameters())
     for k in ("cnn.module.conv1.weight", "cnn.module.layer2.0.downsample.0.weight", "cnn.module.layer4.2.conv2.weight",
               "attention.lin1.weight"):
-        # 1e-2: one of the bags has 2 instances, whose batch-norm backward is ill-conditioned (see the oracle test)
-        assert _rel(params[k].grad.cpu().numpy(), sd[k].grad.numpy()) < 1e-2, k
+        # 1e-2: one of the bags has 2 instances, whose batch-norm backward is ill-conditioned (see the oracle test);
+        # split precision: LeakyReLU branch flips on top (DESIGN.md section 1)
+        assert _rel(params[k].grad.cpu().numpy(), sd[k].grad.numpy()) < (1e-2 if dtype == torch.float32 else 5e-2), k
+    if dtype != torch.float32:
+        return
     net16 = _model(golden_dir, torch.bfloat16).eval()
     sizes16 = [37, 3, 60]
     x16 = torch.randn(sum(sizes16), 3, 300, 300, generator=gen).clamp_(-1, 1).cuda()

@@ -107,7 +107,7 @@ def test_s2d_feed_is_bit_identical_to_the_fp32_tensor_api(golden_dir, monkeypatc
     sizes, labels = [14, 10], torch.tensor([2, 0])
     runs = []
     for feed in (tiles, s2d):
-        net = mil_amd.Attention(3).eval()
+        net = mil_amd.Attention(3, compute_dtype=torch.bfloat16).eval()
         net.load_state_dict({k: torch.tensor(w[k]) for k in w.keys()})
         outs = net.forward_bags((feed, sizes), labels)
         outs.loss.sum().backward()
@@ -120,7 +120,7 @@ def test_s2d_feed_is_bit_identical_to_the_fp32_tensor_api(golden_dir, monkeypatc
     for k, g in runs[0][1].items():
         assert torch.equal(g, runs[1][1][k]), k
     # one bag through the reference-style call, S2dTiles handle
-    net = mil_amd.Attention(3).eval()
+    net = mil_amd.Attention(3, compute_dtype=torch.bfloat16).eval()
     net.load_state_dict({k: torch.tensor(w[k]) for k in w.keys()})
     one = net(s2d[:14], torch.tensor([2]))
     assert torch.equal(one["Aterm"], runs[0][0][0]["Aterm"])
