@@ -516,10 +516,31 @@ STEM_FUSED_CASES = [
 ]
 
 
+def _check_winner_records(widx, stem, ref, cout, value_tol):
+    """Winner records [n,Hp,Wp,cp] against the fp32 stem activation `stem` [n,cout,H2,W2] they were taken from: the value at
+    the recorded tap equals the window maximum (within `value_tol` of the map's scale: a near-tie may pick the other
+    candidate), and bit 4 says whether the maximum is <= 0."""
+    n = stem.shape[0]
+    hp, wp_ = ref.shape[2:]
+    rec = widx[..., :cout].permute(0, 3, 1, 2).cpu()
+    tap = (rec & 15).long()
+    assert int(tap.max()) <= 8
+    win = F.unfold(F.pad(stem, (1, 1, 1, 1), value=float("-inf")), 3, stride=2).view(n, cout, 9, hp, wp_)
+    picked = win.gather(2, tap.unsqueeze(2)).squeeze(2)
+    scale = float(ref.abs().max())
+    assert float((picked - ref).abs().max()) < value_tol * scale
+    clear = ref.abs() > value_tol * scale
+    assert bool((((rec >> 4) & 1).bool() == (ref <= 0))[clear].all())
+
+
 @pytest.mark.parametrize("case", STEM_FUSED_CASES)
-def test_stem_forward_fused_is_bit_identical_to_the_three_kernels(ops, case):
-    """s2d + 7x7/s2 conv + bias + LeakyReLU + max-pool in one pass must reproduce the unfused chain exactly (same packed
-    filter, same accumulation order, same bf16 roundings); the unfused kernels are checked against torch above."""
+def test_stem_forward_fused_against_the_three_kernels_and_torch(ops, case):
+    """s2d + 7x7/s2 conv + bias + LeakyReLU + max-pool in one pass.  The 64-channel form (alt_resnet) reproduces the unfused
+    chain bit for bit.  The 20-channel form (round 5) pools the fp32 accumulators in registers, as the reference pools fp32
+    activations (gbm/model.py:51-53), where the unfused chain pools the bf16-ROUNDED stem tensor: rounding is monotonic, so
+    the pooled VALUES agree except where the position code in the low four mantissa bits moves a bf16 rounding (< 1e-3 of the
+    elements, one bf16 step); the winner records are checked against the fp32 activation itself — the recorded tap holds the
+    window maximum."""
     L = _lib()
     n, h, w, cout, slope = case
     g = torch.Generator().manual_seed(17 + h + w)
@@ -537,14 +558,26 @@ def test_stem_forward_fused_is_bit_identical_to_the_three_kernels(ops, case):
     xs1, pool1, widx1 = fused
     torch.cuda.synchronize()
     assert torch.equal(xs0, xs1)
-    assert torch.equal(pool0.view(torch.int16), pool1.view(torch.int16))
-    assert torch.equal(widx0, widx1)
-    # and against torch directly (bf16 operands, fp32 accumulate)
-    ref = F.max_pool2d(F.leaky_relu(F.conv2d(round_to(x.cpu(), dt), round_to(wt.cpu(), dt), b.cpu(), stride=2, padding=3), slope), 3, 2, 1)
+    # against torch directly (bf16 operands, fp32 accumulate, fp32 pooling)
+    stem_ref = F.leaky_relu(F.conv2d(round_to(x.cpu(), dt), round_to(wt.cpu(), dt), b.cpu(), stride=2, padding=3), slope)
+    ref = F.max_pool2d(stem_ref, 3, 2, 1)
     assert rel_err(from_nhwc(pool1, cout), ref) < TOL[dt]
+    if cout == 64:
+        assert torch.equal(pool0.view(torch.int16), pool1.view(torch.int16))
+        assert torch.equal(widx0, widx1)
+    else:
+        a, c = pool0.float(), pool1.float()
+        d = (a - c).abs()
+        ulp = torch.maximum(a.abs(), c.abs()).clamp_min(2.0 ** -126).log2().floor().exp2() * 2.0 ** -7
+        assert bool((d <= ulp).all()) and float((d > 0).float().mean()) < 1e-3
+        assert float(pool1[..., cout:].float().abs().max()) == 0.0
+        _check_winner_records(widx1, stem_ref, ref, cout, 2e-5)
     # without the space-to-depth copy (what the encoder runs): same pooled map and winner records
     xs2, pool2, widx2 = ops.stem_fwd_fused(x, wp, bp, cp, slope=slope, dtype=dt, keep_s2d=False)
     assert xs2 is None and torch.equal(pool1.view(torch.int16), pool2.view(torch.int16)) and torch.equal(widx1, widx2)
+    # and fed by the bf16 space-to-depth records themselves
+    fed = ops.stem_fwd_fused_xs(xs0, wp, bp, cp, slope=slope)
+    assert fed is not None and torch.equal(fed[0].view(torch.int16), pool1.view(torch.int16)) and torch.equal(fed[1], widx1)
 
 
 @pytest.mark.parametrize("case", STEM_FUSED_CASES[:4])
@@ -572,15 +605,14 @@ def test_stem_forward_fused_split_precision(ops, case):
     assert rel_err(from_nhwc(pool, cout), ref) < TOL[X3]
     assert float(pool[..., cout:].abs().max()) == 0.0
     # winner records: value at the recorded tap == the window maximum (within the kernel's error), sign bit == (max <= 0)
+    _check_winner_records(widx, stem, ref, cout, 1e-4)
+    # the recorded winner is torch's own (first maximum in scan order) wherever the window has no near-tie
     hp, wp_ = ref.shape[2:]
-    rec = widx[..., :cout].permute(0, 3, 1, 2).cpu()
-    tap = (rec & 15).long()
     win = F.unfold(F.pad(stem, (1, 1, 1, 1), value=float("-inf")), 3, stride=2).view(n, cout, 9, hp, wp_)
-    picked = win.gather(2, tap.unsqueeze(2)).squeeze(2)
-    scale = float(ref.abs().max())
-    assert float((picked - ref).abs().max()) < 1e-4 * scale
-    clear = ref.abs() > 1e-4 * scale
-    assert bool((((rec >> 4) & 1).bool() == (ref <= 0))[clear].all())
+    top2 = win.topk(2, dim=2).values
+    clear = (top2[:, :, 0] - top2[:, :, 1]) > 1e-4 * float(ref.abs().max())
+    tap = (widx[..., :cout].permute(0, 3, 1, 2).cpu() & 15).long()
+    assert bool((tap == win.argmax(dim=2))[clear].all())
 
 
 def test_stem_forward_fused_declines_unsupported_shapes(ops):
