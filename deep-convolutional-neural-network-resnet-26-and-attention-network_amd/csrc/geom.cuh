@@ -330,6 +330,25 @@ __host__ __device__ constexpr bool mil_pack_has_k20(int mode, int cout, int cin,
     return ks == 3 && ((mode == 0 && cin == 20) || (mode == 1 && cout == 20));
 }
 
+// ---- K-packed order of the stem's 4x4 filter over the 12 real space-to-depth channels ("SK6") ----------------------------
+// A space-to-depth record is [c0: 4 ch][c1: 4 ch][c2: 4 ch][4 padding channels]; the standard order spends 32 eight-channel
+// k-groups (8 k-steps) on 16 taps x 16 channels, a quarter of them padding.  Here the c2 halves of two horizontally
+// neighbouring taps share a k-group — the kernel keeps [c2 of the NEXT pixel] in the record's padding bytes, so the group is
+// still one aligned 16-byte read:
+//   q = 6*ty + g:  g = 0..3: tap (ty, g), channels 0-7;   g = 4: taps (ty,0),(ty,1) channels 8-11;   g = 5: taps (ty,2),(ty,3)
+// 24 k-groups = 6 k-steps (-25 % MFMAs and fragment reads).  The packed stem filter of a 20-channel stem carries these six
+// k-steps BEHIND the eight standard ones.
+#define MIL_SK6_STEPS 6
+__host__ __device__ inline K20Elem mil_sk6_elem(int q, int e) {
+    const int ty = q / 6, g = q - ty * 6;
+    if (g < 4) return K20Elem{ty * 4 + g, e};
+    return K20Elem{ty * 4 + (g == 4 ? 0 : 2) + (e >> 2), 8 + (e & 3)};
+}
+__host__ __device__ constexpr int mil_sk6_off(int q, int row_pitch, int pix_pitch) {
+    return (q / 6) * row_pitch + ((q % 6) < 4 ? (q % 6) : ((q % 6) == 4 ? 0 : 2)) * pix_pitch + ((q % 6) >= 4 ? 16 : 0);
+}
+__host__ __device__ constexpr bool mil_pack_has_sk6(int mode, int cout) { return mode == 2 && cout <= 32; }      // MIL_PACK_STEM, two column tiles
+
 // Fixed-order sum over slabs for the weight-gradient reductions: thread group gq of MIL_RED_GROUPS sums slabs gq,
 // gq+G, gq+2G, ... (8 independent loads in flight per thread, added in index order), group 0 then adds the G partial
 // sums in order.  The tree depends only on (nslab, G): bitwise reproducible run to run.

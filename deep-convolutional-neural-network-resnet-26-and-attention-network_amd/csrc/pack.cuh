@@ -35,8 +35,8 @@ __host__ inline void mil_pack_job_dims(PackJob* j) {
     j->NT = (cout_exec + 15) / 16;
     j->nsteps_std = (ks_exec * ks_exec * j->CG + 3) / 4;
     if (mode == MIL_PACK_DGRAD_S2) { j->CG = mil_cpad(cout) / 8; j->NT = (mil_cpad(cin) + 15) / 16; j->nsteps_std = mil_s2_nsteps(j->CG); }
-    j->k20 = mil_pack_has_k20(mode, cout, cin, ks) ? 1 : 0;
-    j->nsteps = j->nsteps_std + (j->k20 ? MIL_K20_STEPS : 0);
+    j->k20 = mil_pack_has_k20(mode, cout, cin, ks) ? 1 : (mil_pack_has_sk6(mode, cout) ? 2 : 0);      // 2: the stem's SK6 order
+    j->nsteps = j->nsteps_std + (j->k20 == 1 ? MIL_K20_STEPS : j->k20 == 2 ? MIL_SK6_STEPS : 0);
 }
 
 // element idx of job j's packed buffer (also fills bias_pad from the first NT*16 indices)
@@ -56,7 +56,8 @@ __device__ __forceinline__ void mil_pack_job_elem(const PackJob& j, int idx) {
     } else {
         int tap, kin;
         if (s >= j.nsteps_std) {
-            const K20Elem k = mil_k20_elem(4 * (s - j.nsteps_std) + (lane >> 4), e);
+            const K20Elem k = j.mode == MIL_PACK_STEM ? mil_sk6_elem(4 * (s - j.nsteps_std) + (lane >> 4), e)
+                                                      : mil_k20_elem(4 * (s - j.nsteps_std) + (lane >> 4), e);
             tap = k.tap < 0 ? kk : k.tap; kin = k.ch;
         } else {
             const int q = 4 * s + (lane >> 4);

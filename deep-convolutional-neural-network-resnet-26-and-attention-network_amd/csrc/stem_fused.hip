@@ -477,7 +477,7 @@ template <bool X3> __host__ __device__ constexpr int sp_xbytes() { return SP_XH 
 #endif
 template <bool X3> __host__ __device__ constexpr bool sp_wlds() { return !X3 && MIL_SP_WLDS; }
 template <bool X3> __host__ __device__ constexpr int sp_nbuf() { return (X3 || sp_wlds<X3>()) ? 1 : 2; }
-template <bool X3> __host__ __device__ constexpr int sp_lds_bytes() { return sp_nbuf<X3>() * (sp_xbytes<X3>() + 256) + 128 + (sp_wlds<X3>() ? 8 * 2 * 64 * 16 : 0); }      // + the bias vector (+ the filter)
+template <bool X3> __host__ __device__ constexpr int sp_lds_bytes() { return 64 + sp_nbuf<X3>() * (sp_xbytes<X3>() + 256) + 160 + (sp_wlds<X3>() ? MIL_SK6_STEPS * 2 * 64 * 16 : 0); }      // spare + tiles + the bias vector (+ the filter)
 
 __device__ __forceinline__ float sp_key(float v, unsigned code) {           // low nibble := position code
     return __uint_as_float((__float_as_uint(v) & ~15u) | code);
@@ -536,45 +536,49 @@ template <bool X3, bool FROM_XS>
 __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(StemFwdArgs a) {
     static_assert(!(X3 && FROM_XS), "the space-to-depth feed is bf16");
     using T = typename std::conditional<X3, F32S, BF16>::type;
-    constexpr int NT = 2, COUTP = 24, NTHR = 256, KSTEPS = 8, PH = 8;
+    constexpr int NT = 2, COUTP = 24, NTHR = 256, KSTEPS = MIL_SK6_STEPS, KSTEPS_STD = 8, PH = 8;      // the SK6 order of geom.cuh: 6 k-steps
     constexpr int XPIX = sf_xpix(X3), XBYTES = sp_xbytes<X3>(), NBUF = sp_nbuf<X3>(), BUFSTRIDE = XBYTES + 256;
+    constexpr int SPARE = 64;                                 // in front of the tile: the "next pixel" slot of the pixel left of column 0
     constexpr int FRAGB = X3 ? 32 : 16, OESZ = X3 ? 4 : 2;
     constexpr int NITEM = SP_XH * SF_NPAIR * 3;
     constexpr int NLOAD = ((FROM_XS ? SP_XH * SF_XW * 2 : NITEM) + NTHR - 1) / NTHR;
     constexpr int NXS = 1024 / NTHR;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    MIL_POISON(smem);
-    constexpr int dump = XBYTES;                              // behind each buffer: where the unused table slots write
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    MIL_POISON(smem_raw);
+    char* smem = smem_raw;
+    constexpr int dump = XBYTES + SPARE;                      // behind each buffer: where the unused table slots write
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, gq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     for (int i = tid * 16; i < NBUF * BUFSTRIDE; i += NTHR * 16)         // channels 12..15 of every s2d pixel stay zero
         *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
+    smem += SPARE;
     const int H = a.H, W = a.W, H2 = a.H2, W2 = a.W2, Ho = a.Ho, Wo = a.Wo;
     const __amdgpu_buffer_rsrc_t rs_x = FROM_XS ? mil_rsrc(a.xs_in, (unsigned)((size_t)a.n_img * H2 * W2 * 32))
                                                 : mil_rsrc(a.x, (unsigned)((size_t)a.n_img * 3 * H * W * 4));
     const __amdgpu_buffer_rsrc_t rs_xs = mil_rsrc(a.xs, (unsigned)((size_t)a.n_img * H2 * W2 * 32));
     const __amdgpu_buffer_rsrc_t rs_p = mil_rsrc(a.pool, (unsigned)((size_t)a.n_img * Ho * Wo * COUTP * OESZ));
     const __amdgpu_buffer_rsrc_t rs_i = mil_rsrc(a.widx, (unsigned)((size_t)a.n_img * Ho * Wo * COUTP));
-    const __amdgpu_buffer_rsrc_t rs_w = mil_rsrc(a.w, KSTEPS * NT * 64 * FRAGB);
+    constexpr int W_OFF = KSTEPS_STD * NT * 64 * FRAGB;       // the SK6 k-steps sit behind the eight standard ones
+    const __amdgpu_buffer_rsrc_t rs_w = mil_rsrc(static_cast<const char*>(a.w) + W_OFF, KSTEPS * NT * 64 * FRAGB);
 
     // ---- tile-invariant tables (input -> s2d tile: as in the kernel above) --------------------------
     int l_lds[NLOAD], l_rel[NLOAD];
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
         const int idx = tid + NTHR * i;
-        l_lds[i] = dump | (31 << 18); l_rel[i] = 0;
+        l_lds[i] = dump | (31 << 18); l_rel[i] = 0;           // bits 0-15: LDS offset; bit 16: this piece carries the c2 channels (written twice)
         if constexpr (FROM_XS) {
             if (idx < SP_XH * SF_XW * 2) {
                 const int half = idx & 1, col = (idx >> 1) % SF_XW, row = (idx >> 1) / SF_XW;
-                l_lds[i] = ((row * SF_XW + col) * XPIX + half * 16) | (row << 18) | (col << 24);
+                l_lds[i] = ((row * SF_XW + col) * XPIX + half * 16) | (half << 16) | (row << 18) | (col << 24);
                 l_rel[i] = (row * W2 + col) * 32 + half * 16;
             }
         } else
         if (idx < NITEM) {
             const int pair = idx % SF_NPAIR, t = idx / SF_NPAIR;
             const int c = t % 3, row = t / 3;
-            l_lds[i] = ((row * SF_XW + 2 * pair) * XPIX + c * 8) | (row << 18) | (pair << 24);
+            l_lds[i] = ((row * SF_XW + 2 * pair) * XPIX + c * 8) | ((c == 2 ? 1 : 0) << 16) | (row << 18) | (pair << 24);
             l_rel[i] = ((c * H + 2 * row) * W + 4 * pair) * 4;
         }
     }
@@ -585,27 +589,37 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(StemFwdArgs a) {
     // ---- per-lane constants of the pooling layout -------------------------------------------------------
     // stem pixel (row 4*wave-1+rho, column 2*r+par) of the tile reads s2d pixels (4*wave+rho+ty, 2*r+par+2+tx); a lane's k-group
     // is tap (sl>>1, 2*(sl&1) + (gq>>1)), channel half gq&1
-    const int lane_base = (4 * wave * SF_XW + 2 * r + 2 + (gq >> 1)) * XPIX + (gq & 1) * 16;
+    // (SK6 order: the lane group's k-group of k-step s is q = 4*s + gq, at mil_sk6_off(q) from the record under tap (0,0))
+    const int lane_base = (4 * wave * SF_XW + 2 * r + 2) * XPIX;
     const int rE = r < 4 ? r : 4;                               // edge tile: pixel lane = stem row of the wave (lanes 5.. repeat row 4)
-    const int laneE_base = ((4 * wave + rE) * SF_XW + 1 + (gq >> 1)) * XPIX + (gq & 1) * 16;
+    const int laneE_delta = ((4 * wave + rE) * SF_XW + 1) * XPIX - lane_base;
+    int kaddr[KSTEPS];                                          // lane_base + the k-group's offset, per k-step
+#pragma unroll
+    for (int sl = 0; sl < KSTEPS; ++sl) {
+        int o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (gq == k) o = mil_sk6_off(4 * sl + k, SF_XW * XPIX, XPIX);
+        kaddr[sl] = lane_base + o;
+    }
     // position codes: (stem row & 3) << 2 | (stem column & 3); tile origins are multiples of 4 in both directions
     const unsigned cc_even = 2u * (r & 1), cc_odd = cc_even + 1u;
     const unsigned cc_edge = ((unsigned)((rE + 3) & 3) << 2) | 3u;
-    unsigned long long lut[2] = {0ull, 0ull};                   // code -> tap ky*3+kx, per pooled row of the wave
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int code = 0; code < 16; ++code) {
-            const int ky = ((code >> 2) + (p ? 3 : 1)) & 3, kx = ((code & 3) + ((r & 1) ? 3 : 1)) & 3;
-            const unsigned long long k = (ky < 3 && kx < 3) ? (unsigned long long)(ky * 3 + kx) : 0ull;
-            lut[p] |= k << (4 * code);
-        }
+    // code -> tap ky*3+kx tables, one 64-bit word per (pooled row of the wave, lane parity): kept in LDS (read once per pooled row)
     // the bias is added to the POOLED value (max(v) + b = max(v + b)): the accumulators start at zero and the 32 floats wait in LDS
     char* ldsB = smem + NBUF * BUFSTRIDE;
     if (tid < 32) reinterpret_cast<float*>(ldsB)[tid] = a.bias ? a.bias[tid] : 0.f;
+    if (tid >= 64 && tid < 68) {
+        const int p = (tid >> 1) & 1, odd = tid & 1;
+        unsigned long long lut = 0ull;
+        for (int code = 0; code < 16; ++code) {
+            const int ky = ((code >> 2) + (p ? 3 : 1)) & 3, kx = ((code & 3) + (odd ? 3 : 1)) & 3;
+            lut |= ((ky < 3 && kx < 3) ? (unsigned long long)(ky * 3 + kx) : 0ull) << (4 * code);
+        }
+        reinterpret_cast<unsigned long long*>(ldsB + 128)[p * 2 + odd] = lut;
+    }
     constexpr bool WLDS = sp_wlds<X3>();
-    char* ldsW = ldsB + 128;
-    if constexpr (WLDS) mil_stage_filter(ldsW, a.w, KSTEPS * NT * 64 * FRAGB, tid, NTHR);
+    char* ldsW = ldsB + 160;
+    if constexpr (WLDS) mil_stage_filter(ldsW, static_cast<const char*>(a.w) + W_OFF, KSTEPS * NT * 64 * FRAGB, tid, NTHR);
     float sentv = -3.0e38f;
     asm volatile("" : "+v"(sentv));                             // a VGPR: v_cndmask_b32_e64 has one constant-bus slot, taken by the mask
     const float slope = a.slope;
@@ -643,7 +657,6 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(StemFwdArgs a) {
     };
     if (tile < t_end) fetch(tile);
     __syncthreads();
-
     int buf = 0;
     MIL_STAMP_DECL(5)
     for (; tile < t_end; tile += G8) {
@@ -653,7 +666,19 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(StemFwdArgs a) {
         // ---- s2d tile: fp32 -> bf16 (hi / lo planes in split precision), channel = c*4 + dy*2 + dx ---------------------
         if constexpr (FROM_XS) {
 #pragma unroll
-            for (int i = 0; i < NLOAD; ++i) *reinterpret_cast<u32x4_t*>(ldsX + (l_lds[i] & 0x3FFFF)) = r0[i];
+            for (int i = 0; i < NLOAD; ++i) {
+                // half 0 = [c0 c1]: 16 bytes as they are; half 1 = [c2 | padding]: its c2 also goes into the padding bytes of the
+                // pixel to the left (that pixel's "c2 of the next pixel"), and only 8 bytes into its own record
+                char* dst = ldsX + (l_lds[i] & 0xFFFF);
+                if (tid & 1) {
+                    const u32x2_t c2 = u32x2_t{r0[i][0], r0[i][1]};
+                    const bool first = (l_lds[i] >> 24) == 0;          // column 0: its left neighbour lies outside the tile
+                    *reinterpret_cast<u32x2_t*>(dst) = c2;
+                    *reinterpret_cast<u32x2_t*>(first ? ldsX + dump : dst - XPIX + 8) = c2;
+                } else {
+                    *reinterpret_cast<u32x4_t*>(dst) = r0[i];
+                }
+            }
         } else
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
@@ -667,12 +692,20 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(StemFwdArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { pa[j] = (__bf16)fa[j]; pb[j] = (__bf16)fb[j]; }
             }
-            char* dst = ldsX + (l_lds[i] & 0x3FFFF);
+            char* dst = ldsX + (l_lds[i] & 0xFFFF);
             *reinterpret_cast<bf16x4_t*>(dst) = pa;
             *reinterpret_cast<bf16x4_t*>(dst + XPIX) = pb;
+            // colour 2 (s2d channels 8-11) a second time: behind the c2 of the pixel to the left ("c2 of the next pixel", SK6 order)
+            const bool c2 = (l_lds[i] >> 16) & 1;
+            char* dupb = c2 ? dst + 8 : ldsX + dump;                   // pixel 2*pair  <- c2 of pixel 2*pair + 1
+            char* dupa = (c2 && (l_lds[i] >> 24) != 0) ? dst - XPIX + 8 : ldsX + dump;      // pixel 2*pair - 1 <- c2 of pixel 2*pair (pair 0: outside the tile)
+            *reinterpret_cast<bf16x4_t*>(dupb) = pb;
+            *reinterpret_cast<bf16x4_t*>(dupa) = pa;
             if constexpr (X3) {
                 *reinterpret_cast<bf16x4_t*>(dst + 32) = qa;
                 *reinterpret_cast<bf16x4_t*>(dst + XPIX + 32) = qb;
+                *reinterpret_cast<bf16x4_t*>(dupb + 32) = qb;
+                *reinterpret_cast<bf16x4_t*>(dupa + 32) = qa;
             }
         }
         MIL_STAMP_MARK(0)
@@ -687,7 +720,8 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(StemFwdArgs a) {
             for (int i = 0; i < NXS; ++i) {
                 constexpr int RPI = NTHR / 64;
                 const bool ok = x_row0 + RPI * i < (ylim < 16 ? ylim : 16) && x_col < xlim;
-                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(ldsX + x_lds0 + i * (RPI * SF_XW * XPIX));
+                u32x4_t v = *reinterpret_cast<const u32x4_t*>(ldsX + x_lds0 + i * (RPI * SF_XW * XPIX));
+                if (tid & 1) { v[2] = 0u; v[3] = 0u; }             // the record's padding channels hold the next pixel's c2 in LDS only
                 __builtin_amdgcn_raw_buffer_store_b128(v, rs_xs, ok ? (unsigned)(xbase + x_rel0 + i * (RPI * W2 * 32)) : MIL_OOB, 0, 0);
             }
         }
@@ -728,8 +762,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(StemFwdArgs a) {
             };
             auto xaddr = [&](int j) -> const char* {
                 const int sl = j / MT, m = j % MT;
-                const int step = ((sl >> 1) * SF_XW + 2 * (sl & 1)) * XPIX;
-                return m < 10 ? ldsX + lane_base + ((m >> 1) * SF_XW + (m & 1)) * XPIX + step : ldsX + laneE_base + step;
+                return m < 10 ? ldsX + kaddr[sl] + ((m >> 1) * SF_XW + (m & 1)) * XPIX : ldsX + kaddr[sl] + laneE_delta;
             };
 #pragma unroll
             for (int k = 0; k < WD; ++k)
@@ -823,11 +856,12 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(StemFwdArgs a) {
             const unsigned pix = (unsigned)((img * Ho + py) * Wo + px);
             float y[8];
             unsigned rec[2] = {0u, 0u};
+            const unsigned long long lut = *reinterpret_cast<const unsigned long long*>(ldsB + 128 + (p * 2 + (r & 1)) * 8);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float K = sp_max3(h[2 * p][q], h[2 * p + 1][q], h[2 * p + 2][q]);
                 const unsigned kb = __float_as_uint(K);
-                const unsigned k = (unsigned)(lut[p] >> ((kb << 2) & 60u)) & 15u;
+                const unsigned k = (unsigned)(lut >> ((kb << 2) & 60u)) & 15u;
                 const float v = (X3 ? __uint_as_float((kb & ~15u) | 8u) : K) + (q < 4 ? bias0[q & 3] : bias1[q & 3]);
                 rec[q >> 2] |= (k | ((__float_as_uint(v) >> 27) & 16u)) << (8 * (q & 3));
                 y[q] = sp_lrelu(v, slope);
