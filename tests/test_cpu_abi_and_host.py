@@ -41,7 +41,9 @@ def test_host_side_queries_need_no_gpu():
     assert lib.mil_packed_weight_elems(ctypes.byref(n), 40, 40, 3, 0) == 0
     assert n.value == 12 * 3 * 64 * 8                  # 45 channel groups -> 12 k-steps, 3 column tiles (no second order)
     assert lib.mil_packed_weight_elems(ctypes.byref(n), 20, 3, 7, 2) == 0
-    assert n.value == 8 * 2 * 64 * 8                   # stem as 4x4 over 16 s2d channels
+    assert n.value == (8 + 6) * 2 * 64 * 8             # stem as 4x4 over 16 s2d channels: 8 k-steps; + the K-packed SK6 order's 6 (round 5)
+    assert lib.mil_packed_weight_elems(ctypes.byref(n), 64, 3, 7, 2) == 0
+    assert n.value == 8 * 4 * 64 * 8                   # alt_resnet's 64-channel stem: the standard order only
     assert lib.mil_conv_wgrad_workspace(ctypes.byref(n), 8, 64, 64, 20, 64, 64, 20, 3, 1, 1, 0, 1) == 0
     assert n.value > 0
     assert lib.mil_conv_wgrad_workspace(ctypes.byref(n), 8, 64, 64, 33, 64, 64, 20, 3, 1, 1, 0, 1) == 2   # unsupported width
