@@ -61,21 +61,27 @@ struct ResGeom {
     static constexpr int IMG = HS * HS * PIX;
     static constexpr int TILE = IMGS * IMG;
     static constexpr int KSTEPS = (9 * CG + 3) / 4;
-    static constexpr int TPI = S * S / 16;                    // 16-pixel row tiles per image
-    static constexpr int MW = IMGS * TPI / 8;                 // row tiles per wave
-    static constexpr int NPIECE = IMGS * S * S * CG;          // 16-byte pieces of a group of images
-    static constexpr int NP = NPIECE / 512;
-    // a wave's row tiles are exactly one image's (80 channels: 4 and 4): no wave ever reads another wave's records, so the
-    // two convs of a pair need no workgroup barrier between them
-    static constexpr bool WAVE_IS_IMAGE = (TPI == MW);
-    static_assert(NPIECE % 512 == 0 && (IMGS * TPI) % 8 == 0 && MW % 2 == 0 && C % 16 == 0, "shape");
+    // The pixels of the group's images form ONE list (image-major); row tile t = pixels 16t .. 16t+15 of it.  Where S*S is a
+    // multiple of 16 (8x8, 16x16 maps) a row tile lies in one image; on the live driver's maps (300x300 tiles: 19x19 and 10x10,
+    // round 5) it may straddle two, and the last tiles are partly / wholly beyond the list: such lanes compute on the last real
+    // pixel's record (finite) and store nothing.
+    static constexpr int NPIX = IMGS * S * S;
+    static constexpr int TILES = (NPIX + 15) / 16;
+    static constexpr int MW = ((TILES + 7) / 8 + 1) / 2 * 2;  // row tiles per wave (even: the epilogue pairs them)
+    static constexpr bool RAGGED = (S * S) % 16 != 0 || TILES != 8 * MW;
+    static constexpr int NPIECE = NPIX * CG;                  // 16-byte pieces of a group of images
+    static constexpr int NP = (NPIECE + 511) / 512;
+    // a wave's row tiles are exactly one image's (80 channels on 8x8 maps: 4 and 4): no wave ever reads another wave's records,
+    // so the two convs of a pair need no workgroup barrier between them
+    static constexpr bool WAVE_IS_IMAGE = !RAGGED && (S * S / 16 == MW);
+    static_assert(C % 16 == 0, "shape");
     static_assert(TILE <= 160 * 1024, "LDS");
 };
 
 template <int C, int S, int IMGS>
 __global__ __launch_bounds__(512, 2) void conv_resident_kernel(ResArgs a) {
     using G = ResGeom<C, S, IMGS>;
-    constexpr int CG = G::CG, NT = G::NT, PIX = G::PIX, HS = G::HS, IMG = G::IMG, KSTEPS = G::KSTEPS, TPI = G::TPI, MW = G::MW, NP = G::NP;
+    constexpr int CG = G::CG, NT = G::NT, PIX = G::PIX, HS = G::HS, IMG = G::IMG, KSTEPS = G::KSTEPS, MW = G::MW, NP = G::NP, NPIX = G::NPIX;
     extern __shared__ __attribute__((aligned(16))) char tile[];
     MIL_POISON(tile);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -109,11 +115,13 @@ __global__ __launch_bounds__(512, 2) void conv_resident_kernel(ResArgs a) {
             *reinterpret_cast<u32x4_t*>(tile + im * IMG + (hy * HS + hx) * PIX + j * 16) = u32x4_t{0u, 0u, 0u, 0u};
         }
     }
-    // this wave's row tiles t = wave*MW + m: image t / TPI, pixels (t % TPI)*16 + r of it; top-left tap record of lane r
+    // this wave's row tiles t = wave*MW + m: pixels 16t + r of the group's pixel list; top-left tap record of lane r
     int pixbase[MW];
 #pragma unroll
     for (int m = 0; m < MW; ++m) {
-        const int t = wave * MW + m, im = t / TPI, p = (t % TPI) * 16 + r;
+        int P = (wave * MW + m) * 16 + r;
+        if (G::RAGGED && P >= NPIX) P = NPIX - 1;           // beyond the list: any written record
+        const int im = P / (S * S), p = P - im * (S * S);
         pixbase[m] = im * IMG + ((p / S) * HS + (p % S)) * PIX;
     }
     // epilogue: after the permlane swap between row tiles 2p and 2p+1 a lane holds channels 16*nt + 8*(gq>>1) .. +7 of
@@ -133,7 +141,8 @@ __global__ __launch_bounds__(512, 2) void conv_resident_kernel(ResArgs a) {
             for (int i = 0; i < NP; ++i) {
                 const int idx = tid + 512 * i, pl = idx / CG, j = idx - pl * CG;
                 const int im = pl / (S * S), p = pl - im * (S * S);
-                *reinterpret_cast<u32x4_t*>(tile + im * IMG + (((p / S) + 1) * HS + (p % S) + 1) * PIX + j * 16) = v[i];
+                if (!G::RAGGED || idx < G::NPIECE)
+                    *reinterpret_cast<u32x4_t*>(tile + im * IMG + (((p / S) + 1) * HS + (p % S) + 1) * PIX + j * 16) = v[i];
             }
         }
 
@@ -191,14 +200,16 @@ __global__ __launch_bounds__(512, 2) void conv_resident_kernel(ResArgs a) {
             // ---- epilogue, 8 channels per lane ------------------------------------------------------------------------
 #pragma unroll
             for (int p = 0; p < MW / 2; ++p) {
-                const int t = wave * MW + 2 * p + (gq & 1), im = t / TPI, px = (t % TPI) * 16 + r;
-                const bool img_ok = img0 + im < a.n_img;
+                const int P = (wave * MW + 2 * p + (gq & 1)) * 16 + r;
+                const bool in_list = !G::RAGGED || P < NPIX;
+                const int Pc = in_list ? P : NPIX - 1, im = Pc / (S * S), px = Pc - im * (S * S);
+                const bool img_ok = in_list && img0 + im < a.n_img;
                 const unsigned goff = img_ok ? (unsigned)(((img0 + im) * (S * S) + px) * (C * 2) + c_off) : MIL_OOB;
                 u32x4_t rr[NT], ra[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    if (cv.res) rr[nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, goff + nt * 32, 0, 0);
-                    if (cv.act) ra[nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, goff + nt * 32, 0, 0);
+                    if (cv.res) rr[nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, goff == MIL_OOB ? MIL_OOB : goff + nt * 32, 0, 0);
+                    if (cv.act) ra[nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, goff == MIL_OOB ? MIL_OOB : goff + nt * 32, 0, 0);
                 }
                 const int loff = im * IMG + (((px / S) + 1) * HS + (px % S) + 1) * PIX + c_off;
 #pragma unroll
@@ -229,8 +240,8 @@ __global__ __launch_bounds__(512, 2) void conv_resident_kernel(ResArgs a) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) ov[i] = (__bf16)v[i];
                     const u32x4_t ou = __builtin_bit_cast(u32x4_t, ov);
-                    __builtin_amdgcn_raw_buffer_store_b128(ou, rs_out, goff + nt * 32, 0, 0);
-                    if (to_lds) *reinterpret_cast<u32x4_t*>(tile + loff + nt * 32) = img_ok ? ou : u32x4_t{0u, 0u, 0u, 0u};      // the next conv's input
+                    __builtin_amdgcn_raw_buffer_store_b128(ou, rs_out, goff == MIL_OOB ? MIL_OOB : goff + nt * 32, 0, 0);
+                    if (to_lds && in_list) *reinterpret_cast<u32x4_t*>(tile + loff + nt * 32) = img_ok ? ou : u32x4_t{0u, 0u, 0u, 0u};      // the next conv's input
                 }
             }
         };
@@ -278,6 +289,9 @@ static int resident_dispatch(ResArgs a, int cp, int H, int W, hipStream_t st) {
     a.bytes = (unsigned)((size_t)a.n_img * H * W * cp * 2);
     if (cp == 80 && H == 8 && W == 8) return launch_resident<80, 8, 8>(a, st);
     if (cp == 64 && H == 16 && W == 16) return launch_resident<64, 16, 3>(a, st);
+    // the live driver's 300x300 tiles (gbm/classify_combined.py:412): 10x10 and 19x19 maps
+    if (cp == 80 && H == 10 && W == 10) return launch_resident<80, 10, 5>(a, st);       // 500 pixels = 32 row tiles (31.25 real), 127 KB
+    if (cp == 64 && H == 19 && W == 19) return launch_resident<64, 19, 2>(a, st);       // 722 pixels = 46 of 48 row-tile slots, 127 KB
     return MIL_ERR_UNSUPPORTED;
 }
 

@@ -43,23 +43,26 @@ struct ResGeomX3 {
     static constexpr int PLANE = IMGS * IMG;                  // hi plane, then lo plane
     static constexpr int TILE = 2 * PLANE;
     static constexpr int KSTEPS = (9 * CG + 3) / 4;
-    static constexpr int TPI = S * S / 16;                    // 16-pixel row tiles per image
+    static constexpr int NPIX = IMGS * S * S;                 // the group's pixels as ONE list (see ResGeom, conv_resident.hip)
+    static constexpr int TILES = (NPIX + 15) / 16;
     // The eight waves as WM row groups x WN column groups.  64 channels: 4 x 2 — a wave owns four row tiles and TWO of the four
     // column tiles, so a streamed 2 KB fragment pair feeds four MFMA triples instead of two: per k-step and CU 32 KB from L1
     // (512 cycles of its 64 B/clk) and 64 KB of pixel fragments from LDS (512 cycles) beside 768 cycles of MFMAs per SIMD; the
     // 8 x 1 arrangement asked L1 for 64 KB = 1024 cycles (matrix pipe 0.43 busy).  80 channels (five column tiles): 8 x 1.
-    static constexpr int WN = (NT % 2 == 0) ? 2 : 1, WM = 8 / WN, NTW = NT / WN;
-    static constexpr int MW = IMGS * TPI / WM;                // row tiles per wave
-    static constexpr int NPIECE = IMGS * S * S * (C / 4);     // 16-byte pieces (four fp32 channels) of a group of images
-    static constexpr int NP = NPIECE / 512;
-    static_assert(NPIECE % 512 == 0 && (IMGS * TPI) % WM == 0 && C % 16 == 0, "shape");
+    // (more than four row tiles per wave in the 4 x 2 arrangement — the 19x19 maps — would need 96 pixel-fragment registers: 8 x 1)
+    static constexpr int WN = (NT % 2 == 0 && (TILES + 3) / 4 <= 4) ? 2 : 1, WM = 8 / WN, NTW = NT / WN;
+    static constexpr int MW = (TILES + WM - 1) / WM;          // row tiles per wave
+    static constexpr bool RAGGED = (S * S) % 16 != 0 || TILES != WM * MW;
+    static constexpr int NPIECE = NPIX * (C / 4);             // 16-byte pieces (four fp32 channels) of a group of images
+    static constexpr int NP = (NPIECE + 511) / 512;
+    static_assert(C % 16 == 0, "shape");
     static_assert(TILE <= 160 * 1024, "LDS");
 };
 
 template <int C, int S, int IMGS>
 __global__ __launch_bounds__(512, 2) void conv_resident_x3_kernel(ResArgsX3 a) {
     using G = ResGeomX3<C, S, IMGS>;
-    constexpr int CG = G::CG, NT = G::NT, PIX = G::PIX, HS = G::HS, IMG = G::IMG, PLANE = G::PLANE, KSTEPS = G::KSTEPS, TPI = G::TPI, MW = G::MW, NP = G::NP;
+    constexpr int CG = G::CG, NT = G::NT, PIX = G::PIX, HS = G::HS, IMG = G::IMG, PLANE = G::PLANE, KSTEPS = G::KSTEPS, MW = G::MW, NP = G::NP, NPIX = G::NPIX;
     constexpr int WN = G::WN, NTW = G::NTW;
     extern __shared__ __attribute__((aligned(16))) char tile[];
     MIL_POISON(tile);
@@ -89,16 +92,18 @@ __global__ __launch_bounds__(512, 2) void conv_resident_x3_kernel(ResArgsX3 a) {
             *reinterpret_cast<u32x4_t*>(tile + im * IMG + (hy * HS + hx) * PIX + j * 16) = u32x4_t{0u, 0u, 0u, 0u};
         }
     }
-    // this wave's row tiles t = wm*MW + m: image t / TPI, pixels (t % TPI)*16 + r of it
+    // this wave's row tiles t = wm*MW + m: pixels 16t + r of the group's pixel list
     int pixbase[MW];                 // top-left tap record of lane r's pixel (hi plane)
     int pixrec[MW];                  // the pixel's own record (interior), for the chain's write-back
-    int pixglb[MW];                  // (image in group * S*S + pixel) of lane r's pixel
+    int pixglb[MW];                  // (image in group * S*S + pixel) of lane r's pixel; -1: beyond the list (ragged shapes)
 #pragma unroll
     for (int m = 0; m < MW; ++m) {
-        const int t = wm * MW + m, im = t / TPI, p = (t % TPI) * 16 + r;
+        const int P = (wm * MW + m) * 16 + r;
+        const int Pc = (G::RAGGED && P >= NPIX) ? NPIX - 1 : P;
+        const int im = Pc / (S * S), p = Pc - im * (S * S);
         pixbase[m] = im * IMG + ((p / S) * HS + (p % S)) * PIX;
         pixrec[m] = im * IMG + (((p / S) + 1) * HS + (p % S) + 1) * PIX;
-        pixglb[m] = im * (S * S) + p;
+        pixglb[m] = (G::RAGGED && P >= NPIX) ? -1 : Pc;
     }
     auto split4 = [](const f32x4_t& v, u32x2_t& hi, u32x2_t& lo) {
         bf16x4_t h, l;
@@ -123,8 +128,10 @@ __global__ __launch_bounds__(512, 2) void conv_resident_x3_kernel(ResArgsX3 a) {
                 u32x2_t hi, lo;
                 split4(__builtin_bit_cast(f32x4_t, v[i]), hi, lo);
                 char* d = tile + im * IMG + (((p / S) + 1) * HS + (p % S) + 1) * PIX + j * 8;
-                *reinterpret_cast<u32x2_t*>(d) = hi;
-                *reinterpret_cast<u32x2_t*>(d + PLANE) = lo;
+                if (!G::RAGGED || idx < G::NPIECE) {
+                    *reinterpret_cast<u32x2_t*>(d) = hi;
+                    *reinterpret_cast<u32x2_t*>(d + PLANE) = lo;
+                }
             }
         }
 
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void conv_resident_x3_kernel(ResArgsX3 a) {
 #pragma unroll
                 for (int m = 0; m < MW; ++m) acc[m][nt] = b;
             }
-            constexpr int BD = WN == 2 ? MIL_RESX3_BD : 1;    // k-steps of filter fragments in flight per wave (8 VGPRs per fragment): L2 latency against 24 MFMAs per k-step (three: no change)
+            constexpr int BD = (WN == 2 && MW <= 4) ? MIL_RESX3_BD : 1;    // k-steps of filter fragments in flight per wave (8 VGPRs per fragment): L2 latency against 24 MFMAs per k-step (three: no change)
             Frag8<F32S> bq[BD + 1][NTW], aq[2][MW];
             auto fetch_b = [&](int ks) {
 #pragma unroll
@@ -184,47 +191,56 @@ __global__ __launch_bounds__(512, 2) void conv_resident_x3_kernel(ResArgsX3 a) {
             }
             // ---- epilogue: four consecutive channels of a pixel per lane and column tile; the residual / mask operands of ALL of the
             // wave's pieces are requested before the barrier (one memory round trip per conv, not one per row tile) ---------------
-            unsigned goff[MW];
-            u32x4_t rr[MW][NTW], ra[MW][NTW];
+            // (ragged shapes with more than four row tiles per wave: in two halves — the operand registers of all six do not fit)
+            constexpr int EH = MW > 4 ? 2 : 1, MH = (MW + EH - 1) / EH;
+            unsigned goff[MH];
+            u32x4_t rr[MH][NTW], ra[MH][NTW];
 #pragma unroll
-            for (int m = 0; m < MW; ++m) {
-                const int im = (wm * MW + m) / TPI;
-                goff[m] = img0 + im < a.n_img ? (unsigned)((img0 * (S * S) + pixglb[m]) * (C * 4) + gq * 16 + nt0 * 64) : MIL_OOB;
+            for (int eh = 0; eh < EH; ++eh) {
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) {
-                    if (cv.res) rr[m][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, goff[m] == MIL_OOB ? MIL_OOB : goff[m] + nt * 64, 0, 0);
-                    if (cv.act) ra[m][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, goff[m] == MIL_OOB ? MIL_OOB : goff[m] + nt * 64, 0, 0);
+                for (int mm = 0; mm < MH; ++mm) {
+                    const int m = eh * MH + mm;
+                    if (m >= MW) continue;
+                    const int im = pixglb[m] / (S * S);
+                    goff[mm] = (pixglb[m] >= 0 && img0 + im < a.n_img) ? (unsigned)((img0 * (S * S) + pixglb[m]) * (C * 4) + gq * 16 + nt0 * 64) : MIL_OOB;
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        if (cv.res) rr[mm][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, goff[mm] == MIL_OOB ? MIL_OOB : goff[mm] + nt * 64, 0, 0);
+                        if (cv.act) ra[mm][nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, goff[mm] == MIL_OOB ? MIL_OOB : goff[mm] + nt * 64, 0, 0);
+                    }
                 }
-            }
-            if (to_lds) __syncthreads();           // every wave is past its last read of the planes this epilogue overwrites
+                if (to_lds && eh == 0) __syncthreads();           // every wave is past its last read of the planes this epilogue overwrites
 #pragma unroll
-            for (int m = 0; m < MW; ++m) {
-                const bool img_ok = goff[m] != MIL_OOB;
+                for (int mm = 0; mm < MH; ++mm) {
+                    const int m = eh * MH + mm;
+                    if (m >= MW) continue;
+                    const bool img_ok = goff[mm] != MIL_OOB;
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) {
-                    f32x4_t v = acc[m][nt];
-                    if (cv.res) {
-                        const f32x4_t tt = __builtin_bit_cast(f32x4_t, rr[m][nt]);
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        f32x4_t v = acc[m][nt];
+                        if (cv.res) {
+                            const f32x4_t tt = __builtin_bit_cast(f32x4_t, rr[mm][nt]);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] += tt[i];
-                    }
-                    if (cv.lrelu) {
+                            for (int i = 0; i < 4; ++i) v[i] += tt[i];
+                        }
+                        if (cv.lrelu) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], v[i] * a.slope);      // 0 < slope < 1
-                    }
-                    if (cv.act) {
-                        const f32x4_t tt = __builtin_bit_cast(f32x4_t, ra[m][nt]);
+                            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], v[i] * a.slope);      // 0 < slope < 1
+                        }
+                        if (cv.act) {
+                            const f32x4_t tt = __builtin_bit_cast(f32x4_t, ra[mm][nt]);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] *= (tt[i] > 0.f ? 1.f : a.slope);
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_out, img_ok ? goff[m] + nt * 64 : MIL_OOB, 0, 0);
-                    if (to_lds) {                  // the next conv's input planes (zeros for images beyond the launch)
-                        u32x2_t hi, lo;
-                        split4(v, hi, lo);
-                        if (!img_ok) { hi = u32x2_t{0u, 0u}; lo = u32x2_t{0u, 0u}; }
-                        char* d = tile + pixrec[m] + (nt0 + nt) * 32 + gq * 8;
-                        *reinterpret_cast<u32x2_t*>(d) = hi;
-                        *reinterpret_cast<u32x2_t*>(d + PLANE) = lo;
+                            for (int i = 0; i < 4; ++i) v[i] *= (tt[i] > 0.f ? 1.f : a.slope);
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_out, img_ok ? goff[mm] + nt * 64 : MIL_OOB, 0, 0);
+                        if (to_lds && (!G::RAGGED || pixglb[m] >= 0)) {      // the next conv's input planes (zeros for images beyond the launch)
+                            u32x2_t hi, lo;
+                            split4(v, hi, lo);
+                            if (!img_ok) { hi = u32x2_t{0u, 0u}; lo = u32x2_t{0u, 0u}; }
+                            char* d = tile + pixrec[m] + (nt0 + nt) * 32 + gq * 8;
+                            *reinterpret_cast<u32x2_t*>(d) = hi;
+                            *reinterpret_cast<u32x2_t*>(d + PLANE) = lo;
+                        }
                     }
                 }
             }
@@ -261,5 +277,8 @@ static int resident_dispatch_x3(ResArgsX3 a, int cp, int H, int W, hipStream_t s
     a.bytes = (unsigned)((size_t)a.n_img * H * W * cp * 4);
     if (cp == 80 && H == 8 && W == 8) return launch_resident_x3<80, 8, 4>(a, st);
     if (cp == 64 && H == 16 && W == 16) return launch_resident_x3<64, 16, 1>(a, st);
+    // the live driver's 300x300 tiles: 10x10 and 19x19 maps (ragged pixel lists, see ResGeomX3)
+    if (cp == 80 && H == 10 && W == 10) return launch_resident_x3<80, 10, 2>(a, st);      // 200 pixels = 13 of 16 row-tile slots, 101 KB
+    if (cp == 64 && H == 19 && W == 19) return launch_resident_x3<64, 19, 1>(a, st);      // 361 pixels = 23 of 24 row-tile slots, 127 KB
     return MIL_ERR_UNSUPPORTED;
 }

@@ -284,7 +284,7 @@ def conv_block_fwd(x, wpack1, bias1, wpack2, bias2, *, slope=LEAK):
     return o1, y
 
 
-RESIDENT_SHAPES = ((80, 8, 8), (64, 16, 16))     # (padded channels, H, W) with a pixel-resident kernel
+RESIDENT_SHAPES = ((80, 8, 8), (64, 16, 16), (80, 10, 10), (64, 19, 19))     # (padded channels, H, W) with a pixel-resident kernel (the last two: the 300x300 driver size)
 
 
 class _ChainConv(ctypes.Structure):

@@ -569,7 +569,7 @@ def test_stem_forward_fused_against_the_three_kernels_and_torch(ops, case):
         a, c = pool0.float(), pool1.float()
         d = (a - c).abs()
         ulp = torch.maximum(a.abs(), c.abs()).clamp_min(2.0 ** -126).log2().floor().exp2() * 2.0 ** -7
-        assert bool((d <= ulp).all()) and float((d > 0).float().mean()) < 1e-3
+        assert bool((d <= ulp + 2e-5).all()) and float((d > 0).float().mean()) < 1e-3      # + fp32 summation noise where conv and bias cancel
         assert float(pool1[..., cout:].float().abs().max()) == 0.0
         _check_winner_records(widx1, stem_ref, ref, cout, 2e-5)
     # without the space-to-depth copy (what the encoder runs): same pooled map and winner records
@@ -792,7 +792,8 @@ def resident_grid_cap(request, monkeypatch):
     return request.param
 
 
-@pytest.mark.parametrize("shape", [(80, 8, 3), (80, 8, 8), (80, 8, 21), (80, 8, 29), (60, 16, 2), (60, 16, 3), (60, 16, 10)])
+@pytest.mark.parametrize("shape", [(80, 8, 3), (80, 8, 8), (80, 8, 21), (80, 8, 29), (60, 16, 2), (60, 16, 3), (60, 16, 10),
+                                   (80, 10, 3), (80, 10, 11), (60, 19, 2), (60, 19, 5)])     # 10x10 / 19x19: the 300x300 driver size (ragged pixel lists)
 def test_conv_pair_equals_two_launches(ops, shape, resident_grid_cap):
     """mil_conv_pair (two 3x3 convs back to back on LDS-resident whole images: 80 channels on 8x8 maps, 64 on 16x16) in both
     of its roles — a whole identity block forward and a block's data-gradient chain — against two mil_conv_igemm calls
@@ -856,7 +857,7 @@ def test_conv_pair_equals_two_launches(ops, shape, resident_grid_cap):
     assert ops.conv_pair(torch.zeros(2, 8, 8, 64, device="cuda", dtype=dt), p1, bp1, p2, bp2) is None
 
 
-@pytest.mark.parametrize("shape", [(80, 8, 3), (80, 8, 4), (80, 8, 21), (60, 16, 2), (60, 16, 5)])
+@pytest.mark.parametrize("shape", [(80, 8, 3), (80, 8, 4), (80, 8, 21), (60, 16, 2), (60, 16, 5), (80, 10, 3), (80, 10, 5), (60, 19, 2), (60, 19, 3)])
 def test_conv_chain_split_precision(ops, shape, resident_grid_cap):
     """The pixel-resident kernels on fp32 tensors with bf16x3 products (MIL_DT_F32S: 80 channels on 8x8 maps, four images per
     workgroup; 64 on 16x16, one image): block forward, data-gradient chain and a five-conv chain against torch on un-rounded
