@@ -17,6 +17,9 @@
 //   * x / o1 / y are addressed at a RUN-TIME pixel stride a.apx: 96 bytes (24 padded channels) or 80 (dense 20 channels).
 #pragma once
 #include "stamp.cuh"
+#ifndef MIL_BFX3_STORE_AUX
+#define MIL_BFX3_STORE_AUX 0            // cache policy of the o1 / y stores (gfx940 encoding: 1 = sc0, 2 = nt, 16 = sc1).  Measured (round 5, 2048 tiles): plain 0.84 ms per launch, nt 1.12, sc1 1.75 — write-through stores do not buy the x halo more L2, they stall the epilogue
+#endif
 
 struct BlockFwdX3Args {
     const float* x;         // [n,H,W,apx/4]
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void conv_block_fwd_x3_kernel(BlockFwdX3Arg
                         *reinterpret_cast<u32x2_t*>(ldsO + (d1 == OFF_DUMP - (OFF_O + SPARE) ? d1 + 8 : d1 + O_PLANE)) = lo;
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_o,
-                                                           (ooff == MIL_OOB || !real) ? MIL_OOB : ooff + nt * 64, 0, 0);
+                                                           (ooff == MIL_OOB || !real) ? MIL_OOB : ooff + nt * 64, 0, MIL_BFX3_STORE_AUX);
                     if (nt == 1 && APX == 96)                            // padded layout: the pixel's four padding channels
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0u, 0u, 0u, 0u}, rs_o, (ooff == MIL_OOB || gq != 0) ? MIL_OOB : ooff + 80, 0, 0);
                 }
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void conv_block_fwd_x3_kernel(BlockFwdX3Arg
         const unsigned eoff = e_ok ? (unsigned)(obase + (e_ty * W + r) * APX + hsel * 32) : MIL_OOB;
         const u32x4_t rr0 = __builtin_amdgcn_raw_buffer_load_b128(rs_x, eoff, 0, 0);
         const u32x4_t rr1 = __builtin_amdgcn_raw_buffer_load_b128(rs_x, eoff == MIL_OOB ? MIL_OOB : eoff + 16, 0, 0);
-        const u32x4_t rr2 = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (eoff == MIL_OOB || !last_ok) ? MIL_OOB : eoff + 64, 0, 0);
+        const u32x4_t rr2 = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (eoff == MIL_OOB || !last_ok) ? MIL_OOB : eoff + 64, 0, MIL_BFX3_STORE_AUX);
         MIL_STAMP_MARK(5)
         __syncthreads();                       // mid tile visible
         MIL_STAMP_MARK(6)
@@ -318,10 +321,10 @@ __global__ __launch_bounds__(256, 2) void conv_block_fwd_x3_kernel(BlockFwdX3Arg
                 s = v[4 + i] + t1[i]; v[4 + i] = fmaxf(s, s * a.slope);
                 s = u[i] + t2[i]; u[i] = fmaxf(s, s * a.slope);
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4_t{v[0], v[1], v[2], v[3]}), rs_y, eoff, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4_t{v[4], v[5], v[6], v[7]}), rs_y, eoff == MIL_OOB ? MIL_OOB : eoff + 16, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4_t{v[0], v[1], v[2], v[3]}), rs_y, eoff, 0, MIL_BFX3_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4_t{v[4], v[5], v[6], v[7]}), rs_y, eoff == MIL_OOB ? MIL_OOB : eoff + 16, 0, MIL_BFX3_STORE_AUX);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4_t{u[0], u[1], u[2], u[3]}), rs_y,
-                                                   (eoff == MIL_OOB || !last_ok) ? MIL_OOB : eoff + 64, 0, 0);
+                                                   (eoff == MIL_OOB || !last_ok) ? MIL_OOB : eoff + 64, 0, MIL_BFX3_STORE_AUX);
             if (APX == 96)
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0u, 0u, 0u, 0u}, rs_y, (eoff == MIL_OOB || !last_ok) ? MIL_OOB : eoff + 80, 0, 0);
         }

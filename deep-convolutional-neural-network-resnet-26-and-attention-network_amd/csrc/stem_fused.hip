@@ -470,7 +470,7 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
 constexpr int SP_XH = 20;                                   // s2d rows of an 8x16-pooled-pixel tile
 template <bool X3> __host__ __device__ constexpr int sp_xbytes() { return SP_XH * SF_XW * sf_xpix(X3); }      // 36480 / 60800
 #ifndef MIL_SP_PRIO
-#define MIL_SP_PRIO 0                 // >0: the vector-instruction phases (maxima, decode, convert) at this priority (measured: 865 -> 953 / 981 us at 1 / 3)
+#define MIL_SP_PRIO 0                 // >0: the vector-instruction phases (maxima, decode, convert) at this priority (measured round 5 at equal repetition counts: no difference beyond the 3 % run-to-run spread)
 #endif
 #ifndef MIL_SP_WLDS
 #define MIL_SP_WLDS 1                 // bf16: filter fragments staged in LDS (16 KB) and ONE s2d buffer; 0: streamed from L1/L2, two buffers

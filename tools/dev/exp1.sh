@@ -1,4 +1,5 @@
 P=$PWD/deep-convolutional-neural-network-resnet-26-and-attention-network_amd
-python tools/dev/time_stem.py bf16 2>&1 | grep stem_fwd
-python tools/dev/time_stem.py bf16x3 2>&1 | grep stem_fwd
-for v in s32 s64 s100; do echo "== $v"; MIL_LIB_PATH=$P/libmil_hip_$v.so python tools/dev/time_stem.py bf16 2>&1 | grep stem_fwd;  MIL_LIB_PATH=$P/libmil_hip_$v.so python tools/dev/time_stem.py bf16x3 2>&1 | grep stem_fwd; done
+for m in bf16 bf16x3; do for v in "" nosp s64 p1 la4 la3 ""; do
+  if [ -z "$v" ]; then unset MIL_LIB_PATH; else export MIL_LIB_PATH=$P/libmil_hip_$v.so; fi
+  echo "== $m '$v'"; python tools/dev/time_stem.py $m 2>&1 | grep "stem_"
+done; done
