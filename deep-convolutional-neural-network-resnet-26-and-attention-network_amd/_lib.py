@@ -42,6 +42,7 @@ _vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
 _SIGS = {
     "mil_abi_version": ([], _i),
     "mil_stream_copy": ([_vp, _vp, _sz, _vp], _i),
+    "mil_split_probe": ([_vp, _vp, _vp, _i, _vp], _i),
     "mil_stem_s2d": ([_vp, _vp, _i, _i, _i, _i, _vp], _i),
     "mil_packed_weight_elems": ([_c.POINTER(_sz), _i, _i, _i, _i], _i),
     "mil_pack_conv_weights": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),

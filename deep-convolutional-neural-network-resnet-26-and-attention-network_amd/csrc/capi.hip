@@ -24,6 +24,28 @@ extern "C" int mil_stream_copy(void* dst, const void* src, size_t bytes, void* s
     return MIL_OK;
 }
 
+// The hi / lo split of MIL_DT_F32S exactly as every split-precision kernel takes it (mil_split2, common.cuh): hi = bf16(v),
+// lo = bf16(v - hi), pairs (2i, 2i+1) through v_dot2c_f32_bf16.  A test entry (tests/test_gpu_kernels.py): the dot-product form
+// must equal the plain subtraction bit for bit on finite pairs; a non-finite element turns its PAIR partner's lo half into NaN
+// (the dot product multiplies the partner's hi by zero: Inf * 0), which the plain form would not — documented, and harmless on
+// this path: a tensor with an Inf / NaN in it already fails every finite check downstream.
+__global__ void split_probe_kernel(const float* __restrict__ v, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, int n2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2) return;
+    bf16x2_t h, l;
+    mil_split2(v[2 * i], v[2 * i + 1], h, l);
+    const unsigned hu = __builtin_bit_cast(unsigned, h), lu = __builtin_bit_cast(unsigned, l);
+    hi[2 * i] = (unsigned short)(hu & 0xffffu); hi[2 * i + 1] = (unsigned short)(hu >> 16);
+    lo[2 * i] = (unsigned short)(lu & 0xffffu); lo[2 * i + 1] = (unsigned short)(lu >> 16);
+}
+extern "C" int mil_split_probe(const float* v, uint16_t* hi, uint16_t* lo, int n, void* stream) {
+    if (!v || !hi || !lo || n < 0 || (n & 1)) return MIL_ERR_ARG;
+    if (n == 0) return MIL_OK;
+    hipLaunchKernelGGL(split_probe_kernel, dim3((n / 2 + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), v, hi, lo, n / 2);
+    MIL_CHECK_LAUNCH();
+    return MIL_OK;
+}
+
 #ifdef MIL_POISON_LDS
 // Diagnostic build only: proves that the poisoning reaches the whole dynamic segment (out[i] = LDS word i after MIL_POISON).
 __global__ void poison_probe_kernel(unsigned* out, int words) {

@@ -73,6 +73,10 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
     using T = typename std::conditional<X3, F32S, BF16>::type;
     constexpr int PH = sf_ph(X3);                             // pooled rows per tile
     constexpr bool WSTREAM = sf_wstream(X3);                  // filter fragments from L1/L2, not from LDS
+    // the streamed branch of wfrag() is written for the folded split-precision form only (column tile 1 = [wh ; wl]) and for the
+    // pipelined loop (the MIL_STEM_FWD_LOOKAHEAD == 0 loop reads ldsW, which is not staged when the filter streams)
+    static_assert(!WSTREAM || (X3 && NT == 2), "streamed filter fragments: folded split-precision form only");
+    static_assert(!WSTREAM || MIL_STEM_FWD_LOOKAHEAD > 0, "streamed filter fragments need the pipelined MFMA loop");
     constexpr int SF_SH = sf_sh(PH), SF_XH = sf_xh(PH), SF_NITEM = sf_nitem(PH), SF_NSTEM = sf_nstem(PH), SF_MTILES = sf_mtiles(PH);
     constexpr int SF_XPIX = sf_xpix(X3), SF_XBYTES = sf_xbytes(X3);
     constexpr int OESZ = X3 ? 4 : 2;                          // bytes per element of the stem tile / pooled output
@@ -161,6 +165,10 @@ __global__ __launch_bounds__(64 * NW, X3 ? 2 : (NT <= 2 ? (NW == 8 ? 4 : (NW == 
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) bias_r[nt][i] = a.bias ? a.bias[nt * 16 + gq * 4 + i] : 0.f;
+    if constexpr (X3 && NT == 2 && MIL_STEM_FWD_LOOKAHEAD > 0) {      // folded column tile 1: rows 4-15 accumulate w_lo * x_hi of rows 0-3 — they
+#pragma unroll                                                       // start at zero whatever bias_pad[20..] holds (the public C ABI does not promise zeros there)
+        for (int i = 0; i < 4; ++i) bias_r[1][i] = gq == 0 ? bias_r[1][i] : 0.f;
+    }
 
     // ---- tile walk: XCD x (= blockIdx & 7) owns tiles [x*per, (x+1)*per) ---------------------------
     const int G8 = gridDim.x >> 3, per = (a.ntiles + 7) >> 3;

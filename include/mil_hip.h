@@ -23,11 +23,13 @@
  *                          MIL_DT_F32), mil_conv_igemm, mil_conv_wgrad(_workspace), and — fused forms, where the shape has
  *                          one (MIL_ERR_UNSUPPORTED otherwise: the caller falls back to the un-fused calls) —
  *                          mil_conv_bwd_fused(_workspace) (20-channel layers), mil_conv_block_fwd (20-channel identity
- *                          blocks, maps of at least 8x16), mil_conv_chain (64 / 80 channels on 16x16 / 8x8 maps),
- *                          mil_conv_s2_entry (20 -> 40 and 40 -> 60 channels), mil_conv_wgrad_pair (20 -> 40 channels),
- *                          mil_conv_dgrad_s2 (the 40 -> 20 and 60 -> 40 channel entries), mil_stem_fwd_fused (xs must be
- *                          null: no space-to-depth copy) and mil_stem_bwd_fused_nchw(_workspace); every pointwise entry
- *                          point takes MIL_DT_F32 for the same tensors.
+ *                          blocks, maps of at least 8x16), mil_conv_chain (64 / 80 channels on 16x16 / 8x8 maps, and on the
+ *                          19x19 / 10x10 maps of 300x300 tiles), mil_conv_s2_entry (all three stage entries: 20 -> 40,
+ *                          40 -> 60 and 60 -> 80 channels, i.e. padded 24 -> 40, 40 -> 64, 64 -> 80), mil_conv_wgrad_pair
+ *                          (20 -> 40 channels), mil_conv_dgrad_s2 (all three entries: 40 -> 20, 60 -> 40 and 80 -> 60
+ *                          channels; the dense-output code MIL_DT_F32S_DGRAD only for the 40 -> 20 entry, cz_p == 40),
+ *                          mil_stem_fwd_fused (xs must be null: no space-to-depth copy) and
+ *                          mil_stem_bwd_fused_nchw(_workspace); every pointwise entry point takes MIL_DT_F32 for the same tensors.
  *   - master weights, biases, all gradients of parameters, and the whole MIL head are fp32.
  */
 #ifndef MIL_HIP_H
@@ -73,6 +75,11 @@ int mil_abi_version(void);
  * reference op: the calibration kernel bench.py times to state what a plain read+write stream reaches on the box, next to the
  * 8 TB/s specification its roofline fractions are priced against. */
 int mil_stream_copy(void* dst, const void* src, size_t bytes, void* stream);
+/* Diagnostic: the hi / lo bf16 split of MIL_DT_F32S as the split-precision kernels apply it to operands on their way into LDS
+ * (hi = bf16(v), lo = bf16(v - hi); element pairs (2i, 2i+1) share one v_dot2c_f32_bf16 pair).  v [n] fp32 -> hi, lo [n] bf16 bit
+ * patterns; n even.  Finite pairs: bit-identical to the plain subtraction.  A non-finite element makes its pair partner's lo a
+ * NaN (Inf * 0 in the dot product). */
+int mil_split_probe(const float* v, uint16_t* hi, uint16_t* lo, int n, void* stream);
 
 /* ---- input packing ------------------------------------------------------------------------
  * fp32 NCHW tiles [n,3,H,W] (what `Attention.forward` receives, gbm/model.py:189-196) ->
@@ -235,15 +242,23 @@ int mil_conv_dgrad_s2(const void* dz1, const void* dz2, const void* wpack, const
  * MaxPool2d(3,2,1) in one pass over the fp32 NCHW tiles (gbm/model.py:24-26,51-53; alt_resnet.py:81-84,128-131
  * with slope 0).  Writes xs [n,H/2,W/2,16] (kept for the stem weight gradient; NULL = keep none, the backward is
  * then mil_stem_bwd_fused_nchw), pool [n,Hp,Wp,cout_p] and the
- * winner records widx; bit-identical to mil_stem_s2d -> mil_conv_igemm(ks=4) -> mil_maxpool_fwd, whose
- * intermediate tensors are never materialised.  cout_p 24 or 64; H even, W % 4 == 0, x 16-byte aligned,
- * otherwise MIL_ERR_UNSUPPORTED (the caller then uses the three calls). */
+ * winner records widx (format of mil_maxpool_fwd); the intermediate tensors of mil_stem_s2d -> mil_conv_igemm(ks=4) ->
+ * mil_maxpool_fwd are never materialised.  cout_p 64 (alt_resnet): bit-identical to that chain.  cout_p 24 (the 20-channel
+ * stem, round 5): the maximum is taken over the fp32 accumulators in registers, as the reference pools fp32 activations
+ * (gbm/model.py:51-53) — the chain pools the bf16-rounded stem tensor — so pool agrees with the chain's except where the
+ * position code kept in the low four mantissa bits moves a bf16 rounding (< 1e-3 of the elements, one bf16 step), and
+ * the recorded winner is the fp32 maximum (values that agree to 2^-19 compare by position; exact ties arise only between
+ * identical input patches, whose weight-gradient contributions are identical whichever of them the gradient is routed to).
+ * The packed filter (MIL_PACK_STEM) of a 20-channel stem carries six K-packed k-steps behind the eight standard ones
+ * (mil_packed_weight_elems says so); bias_pad needs 32 floats.  H even, W % 4 == 0, x 16-byte aligned, otherwise
+ * MIL_ERR_UNSUPPORTED (the caller then uses the three calls). */
 int mil_stem_fwd_fused(const float* x_nchw, const void* wpack, const float* bias_pad, void* xs, void* pool,
                        uint8_t* widx, int n_img, int H, int W, int cout_p, float slope, int dtype, void* stream);
 /* The same pass fed by the bf16 space-to-depth tensor xs [n,H2,W2,16] itself (mil_tile_preprocess_s2d's output): a
  * pre-processed tile then never exists as fp32 (RoiBuilder.py:193-210 -> gbm/model.py:24,51 without the fp32 stack in
  * between).  pool / widx are bit-identical to mil_stem_fwd_fused on the fp32 tiles xs is the bf16 rounding of; the
- * backward is mil_stem_bwd_fused(xs, ...).  bf16 only. */
+ * backward is mil_stem_bwd_fused(xs, ...).  bf16 only.  (The kernel keeps the next pixel's channels 8-11 in the padding
+ * channels 12-15 of its LDS copy of a record; the tensor's own padding channels are not read and need not be zero.) */
 int mil_stem_fwd_fused_xs(const void* xs, const void* wpack, const float* bias_pad, void* pool, uint8_t* widx, int n_img,
                           int H2, int W2, int cout_p, float slope, int dtype, void* stream);
 

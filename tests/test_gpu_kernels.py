@@ -1128,3 +1128,34 @@ def test_poisoned_lds_build_really_poisons():
     assert lib.mil_poison_probe(out.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream) == 0
     torch.cuda.synchronize()
     assert bool((out == 0x7FC07FC0).all())
+
+
+def test_split_precision_operand_split_is_the_plain_subtraction():
+    """Every split-precision kernel takes hi = bf16(v), lo = bf16(v - hi) through `mil_split2` (common.cuh): pairs of values
+    share a v_dot2c_f32_bf16 pair against the packed constants {-1, 0} / {0, -1} hidden from hipcc's inline-constant folding
+    (ROCm 7.2 folds them into the wrong operand otherwise, no diagnostic).  The instruction form must equal the plain
+    subtraction BIT FOR BIT on finite pairs — zeros, denormals, the largest finite values, random exponents — and the
+    documented non-finite behaviour must hold: an Inf / NaN element keeps a non-finite hi, and turns ITS PAIR PARTNER's lo half
+    into NaN (Inf * 0 inside the dot product), the partner's hi staying exact."""
+    L = _lib()
+    g = torch.Generator().manual_seed(7)
+    n = 1 << 20
+    v = torch.randn(n, generator=g) * torch.exp2(torch.randint(-60, 60, (n,), generator=g).float())
+    special = torch.tensor([0.0, -0.0, 1e-40, -1e-40, 1.17549435e-38, 3.3895314e38, -3.3895314e38, 1.0, 255.0 / 256, 1.00390625, 65280.0, 1e-30])
+    v[:special.numel()] = special
+    v = v.cuda().contiguous()
+    hi = torch.empty(n, dtype=torch.int16, device="cuda")
+    lo = torch.empty(n, dtype=torch.int16, device="cuda")
+    L.check(L.lib().mil_split_probe(v.data_ptr(), hi.data_ptr(), lo.data_ptr(), n, L.stream_ptr()), "mil_split_probe")
+    h_ref = v.to(torch.bfloat16)
+    l_ref = (v - h_ref.float()).to(torch.bfloat16)
+    assert torch.equal(hi, h_ref.view(torch.int16)) and torch.equal(lo, l_ref.view(torch.int16))
+    # non-finite neighbours
+    w = torch.tensor([1.5, float("inf"), float("nan"), 2.75, -float("inf"), -3.0, 0.1, 0.2], device="cuda")
+    hi2 = torch.empty(8, dtype=torch.int16, device="cuda")
+    lo2 = torch.empty(8, dtype=torch.int16, device="cuda")
+    L.check(L.lib().mil_split_probe(w.data_ptr(), hi2.data_ptr(), lo2.data_ptr(), 8, L.stream_ptr()), "mil_split_probe")
+    h2, l2 = hi2.view(torch.bfloat16).float().cpu(), lo2.view(torch.bfloat16).float().cpu()
+    assert h2[0] == 1.5 and torch.isinf(h2[1]) and torch.isnan(h2[2]) and h2[3] == 2.75 and h2[5] == -3.0
+    assert torch.isnan(l2[0]) and torch.isnan(l2[3]) and torch.isnan(l2[5])           # partners of Inf / NaN / -Inf
+    assert bool(torch.isfinite(l2[6:]).all()) and float(l2[6]) == float((torch.tensor(0.1) - torch.tensor(0.1).to(torch.bfloat16).float()).to(torch.bfloat16))

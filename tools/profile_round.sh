@@ -62,6 +62,10 @@ python3 bench.py --infer --bags 1 --tiles 4096 --steps 10 --warmup 3 --no-cpu-ba
 python3 bench.py --dtype bf16x3 --size 512 --tiles 128 --steps 5 --warmup 2 --no-cpu-baseline --no-extra-paths 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_bf16x3_cfg3_512.json
 python3 bench.py --dtype bf16x3 --infer --bags 1 --tiles 4096 --steps 5 --warmup 2 --no-cpu-baseline --no-extra-paths 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_bf16x3_cfg5_infer4096.json
 echo "cfg3 / cfg5 lines done"
+# the live driver's size (gbm/classify_combined.py:412: 300x300 tiles; no BASELINE config): 8 bags x 200 tiles, both compute modes
+python3 bench.py --size 300 --tiles 200 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_live300.json
+python3 bench.py --dtype bf16x3 --size 300 --tiles 200 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_bf16x3_live300.json
+echo "live-driver-size lines done"
 
 echo "all profiles written"
 mkdir -p gpurun_out/profiles_out
