@@ -55,7 +55,7 @@ class ResNet(nn.Module):
     """Tile encoder [T,3,H,W] fp32 -> [T,num_classes] fp32 (gbm/model.py:14-61)."""
 
     def __init__(self, block=BasicResBlock, layers=(3, 3, 3, 3), num_classes=80, zero_init_residual=False,
-                 groups=1, width_per_group=64, compute_dtype=torch.bfloat16):
+                 groups=1, width_per_group=64, compute_dtype=L.BF16X3):
         super().__init__()
         if block is not BasicResBlock or groups != 1 or width_per_group != 64:
             raise ValueError("the HIP encoder implements BasicResBlock with groups=1, base_width=64")
