@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-extra-paths", action="store_true", help="skip the bf16x3_path / fp32_path / alt_resnet_path sub-records")
+    ap.add_argument("--no-traffic-pass", action="store_true",
+                    help="do not measure roofline.traffic in this run (two child rocprofv3 PMC passes of a 2-step run of this "
+                         "command, ~20 s each); the committed summaries under profiles/ are quoted instead")
     ap.add_argument("--overlap", action="store_true", help="run the separate weight-gradient launches on a side stream "
                     "(measured: same throughput on this workload, +2%% at 512 tiles, -24%% at 64 tiles; off by default)")
     ap.add_argument("--no-overlap", action="store_true", help="(default now) weight-gradient launches on the main stream")
@@ -167,7 +170,8 @@ def path_record(args, mode, w, x_all, sizes, labels, dev, copy_gbps):
     if mode == "bf16x3":
         peak = MFMA_PEAK_BF16_TFLOPS / 3.0
         rec["frac_of_bf16x3_mfma_peak"] = tfl / peak
-        rec["roofline"] = roofline_record("bf16x3", timer.durations_ms(), peak, copy_gbps, tfl, profile_tag="bf16x3") if timer else None
+        pmc_live = None if (args.no_traffic_pass or args.infer) else measure_traffic_in_run("bf16x3", args.size, args.tiles, args.bags)
+        rec["roofline"] = roofline_record("bf16x3", timer.durations_ms(), peak, copy_gbps, tfl, profile_tag="bf16x3", pmc_live=pmc_live) if timer else None
         rec["note"] = ("same workload and step as `value`; fp32 tensors, every conv / weight gradient as bf16x3 split products "
                        "(hi*hi + lo*hi + hi*lo, fp32 accumulate): logits within 2.5e-4 of the fp32 CPU reference, attention "
                        "weights within 3e-6 (tests/test_gpu_configs.py asserts 1e-3 on Mterm / Aterm / y_pred / loss)")
@@ -221,6 +225,64 @@ def alt_resnet_record(dev):
             "roofline": roof,
             "workload": "alt_resnet.ResNet(BasicBlock,[3,3,3,3]) 64/128/256/512 ch, 256 tiles @256x256x3, fwd+bwd, "
                         "21.15 GFLOP/tile (SURVEY.md §8d)"}
+
+
+# ---- HBM traffic of this box, this library, this run ----------------------------------------------------------------
+_LIVE_PMC = {}
+
+
+def measure_traffic_in_run(dtype_name, size, tiles, bags, timeout=240):
+    """HBM bytes per launch of every kernel of the step, measured NOW: two child `rocprofv3 --kernel-trace --pmc` passes
+    (FETCH_SIZE, WRITE_SIZE — separate runs, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; counters summed per
+    dispatch, FETCH_SIZE doubled: the gfx950 correction for wide coalesced reads) of a 2-step run of this same command as
+    child processes of this one.  Returns the dict profiles/make_pmc_traffic.py writes, or None when rocprofv3 is missing or
+    a pass fails (the committed summaries are quoted then, marked as such)."""
+    key = (dtype_name, size, tiles, bags)
+    if key in _LIVE_PMC:
+        return _LIVE_PMC[key]
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith("ROCPROF") for k in os.environ):
+        return None                                      # this process is itself being profiled: no profiler inside a profiler
+    import importlib.util
+    import shutil
+    import subprocess
+    import tempfile
+    out = None
+    try:
+        rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+        if not os.path.exists(rocprof):
+            raise RuntimeError("rocprofv3 not found")
+        spec = importlib.util.spec_from_file_location("make_pmc_traffic", os.path.join(ROOT, "profiles", "make_pmc_traffic.py"))
+        mk = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mk)
+        tmp = tempfile.mkdtemp(prefix="mil_pmc_", dir="/tmp")
+        child = [sys.executable, os.path.join(ROOT, "bench.py"), "--dtype", dtype_name, "--size", str(size), "--tiles", str(tiles),
+                 "--bags", str(bags), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timer", "--no-extra-paths",
+                 "--no-traffic-pass"]
+        env = dict(os.environ, TMPDIR="/tmp")
+        per = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            # the program itself after `--` (no wrapper); kernel-trace + ONE counter group per pass
+            res = subprocess.run([rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child,
+                                 cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
+            if res.returncode != 0:
+                raise RuntimeError(f"rocprofv3 {counter} pass exited {res.returncode}")
+            per[counter] = mk.per_kernel(d, counter)
+        kernels = {}
+        for k in sorted(set(per["FETCH_SIZE"]) | set(per["WRITE_SIZE"])):
+            if len(k) > 300:
+                continue
+            n, fkb = per["FETCH_SIZE"].get(k, (0, 0.0))
+            n2, wkb = per["WRITE_SIZE"].get(k, (n, 0.0))
+            fb, wb = 2.0 * fkb * 1024.0, wkb * 1024.0
+            kernels[k] = {"launches": n or n2, "fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb}
+        shutil.rmtree(tmp, ignore_errors=True)
+        out = {"kernels": kernels, "_library_sha16": library_sha16(), "_live": True}
+    except Exception as e:  # noqa: BLE001 — any failure here must not cost the benchmark line
+        sys.stderr.write(f"[bench] in-run traffic pass skipped: {e}\n")
+        out = None
+    _LIVE_PMC[key] = out
+    return out
 
 
 # ---- roofline of the dominant kernel ------------------------------------------------------------------------------
@@ -316,7 +378,7 @@ def timer_wants(label):
     return False
 
 
-def roofline_record(dtype_name, spans, peak, copy_gbps, achieved_model_tflops, profile_tag=None):
+def roofline_record(dtype_name, spans, peak, copy_gbps, achieved_model_tflops, profile_tag=None, pmc_live=None):
     """`spans` = [(label, ms)] of every bracketed launch (HIP events on the launch stream, see timer_wants).  The family
     with the largest total time in the timed region is the dominant kernel; its algorithmic bytes / FLOPs per launch are
     averaged over the launches as they ran (_family_cost)."""
@@ -343,16 +405,23 @@ def roofline_record(dtype_name, spans, peak, copy_gbps, achieved_model_tflops, p
     pmc_keys = _family_kernel(fam, dtype_name)[1]
     traffic = traffic_source = None
     suffix = "" if profile_tag in (None, "bf16") else "_" + profile_tag
-    pmc = _profile_json(f"pmc_traffic{suffix}.json")                   # rocprofv3 PMC passes of this same command (tools/profile_round.sh)
-    if pmc and n_img == 2048:
+    live = bool(pmc_live)
+    # measured in this run (child rocprofv3 passes on this box, measure_traffic_in_run) when available, else the committed
+    # summary of the builder's run of this command (tools/profile_round.sh)
+    pmc = pmc_live if live else _profile_json(f"pmc_traffic{suffix}.json")
+    if pmc and (n_img == 2048 or live):
         hit = [v for k, v in pmc.get("kernels", {}).items() if any(key in k for key in pmc_keys)]     # all template variants of the family
         if hit:
             traffic = sum(v["hbm_bytes"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit)
             # the counters come from the committed rocprofv3 summaries of the builder's own run of this command
             # (tools/profile_round.sh), NOT from the process that prints this line: say so in the record itself
-            traffic_source = {"file": f"profiles/pmc_traffic{suffix}.json", "library_sha16": pmc.get("_library_sha16"),
+            traffic_source = {"file": None if live else f"profiles/pmc_traffic{suffix}.json",
+                              "how": ("two child rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE x2 per the gfx950 correction, WRITE_SIZE) of a "
+                                      "2-step run of this command, by this process, on this box") if live else
+                                     "committed summary of the builder's rocprofv3 passes of this command (tools/profile_round.sh)",
+                              "library_sha16": pmc.get("_library_sha16"),
                               "matches_running_library": pmc.get("_library_sha16") == library_sha16(),
-                              "traffic_measured_in_this_run": False}
+                              "traffic_measured_in_this_run": live}
     sq = _profile_json(f"sq_counters{suffix}.json")                    # SQ PMC passes of this same command
     sq_rec = None
     if sq and n_img == 2048:
@@ -388,7 +457,7 @@ def roofline_record(dtype_name, spans, peak, copy_gbps, achieved_model_tflops, p
         "frac_of_measured_stream_copy": (alg_gbps / copy_gbps) if copy_gbps else None,
         "whole_step_model_tflops": achieved_model_tflops,
         "whole_step_frac_of_mfma_peak": achieved_model_tflops / peak,
-        "sq_counters": sq_rec, "traffic_source": traffic_source, "traffic_measured_in_this_run": False,
+        "sq_counters": sq_rec, "traffic_source": traffic_source, "traffic_measured_in_this_run": bool(live and traffic is not None),
         "other_timed_kernels": others,
     }
     if ai < ridge:
@@ -592,8 +661,11 @@ def main():
         achieved_model_tflops = value * (GFLOP_PER_TILE_FWD_256 if args.infer else GFLOP_PER_TILE_FWD_BWD_256) * scale / 1e3
         # bf16x3: three bf16 MFMAs per product -> a third of the dense bf16 peak per model FLOP
         peak = {"bf16": MFMA_PEAK_BF16_TFLOPS, "f32": MFMA_PEAK_F32_TFLOPS, "bf16x3": MFMA_PEAK_BF16_TFLOPS / 3.0}[args.dtype]
+        pmc_live = None
+        if timer and world == 1 and not args.infer and not args.no_traffic_pass and args.dtype in ("bf16", "bf16x3"):
+            pmc_live = measure_traffic_in_run(args.dtype, args.size, args.tiles, args.bags)
         roofline = roofline_record(args.dtype, timer.durations_ms(), peak, copy_gbps, achieved_model_tflops,
-                                   profile_tag=args.dtype) if timer else None
+                                   profile_tag=args.dtype, pmc_live=pmc_live) if timer else None
         if tile_parallel:
             par = (f"tile-parallel tp{world}: one bag's tiles sharded over the ranks, all-gather of H [N/{world},80] over RCCL, "
                    "replicated head")

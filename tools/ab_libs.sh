@@ -10,9 +10,9 @@ OUT=gpurun_out/ab_$VAR
 mkdir -p $OUT
 for which in default $VAR; do
   if [ $which = default ]; then unset MIL_LIB_PATH; else export MIL_LIB_PATH=$PKG/libmil_hip_$VAR.so; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$which -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths --no-kernel-timer "$@" > $OUT/$which.json 2> $OUT/$which.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$which -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths --no-traffic-pass --no-kernel-timer "$@" > $OUT/$which.json 2> $OUT/$which.err
   cp "$(ls $OUT/$which/*/*kernel_stats.csv | head -n 1)" $OUT/${which}_kernel_stats.csv
   rm -rf $OUT/$which
-  python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths --no-kernel-timer "$@" > $OUT/${which}_line.json 2>> $OUT/$which.err
+  python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths --no-traffic-pass --no-kernel-timer "$@" > $OUT/${which}_line.json 2>> $OUT/$which.err
 done
 echo done

@@ -10,9 +10,9 @@ ROUND=${1:-r02}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$ROUND
 mkdir -p $OUT profiles
-BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-extra-paths"
+BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-extra-paths --no-traffic-pass"
 
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths --no-kernel-timer > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths --no-traffic-pass --no-kernel-timer > $OUT/stats.log 2>&1
 cp "$(ls $OUT/stats/*/*kernel_stats.csv | head -n 1)" profiles/${ROUND}_bench_kernel_stats.csv
 echo "stats done"
 
@@ -30,8 +30,8 @@ echo "sq2 done"
 python3 profiles/summarise_sq_counters.py $OUT/sq1 $OUT/sq2 profiles/sq_counters.json "$ROUND: $BENCH" > profiles/${ROUND}_sq_counters.txt
 cp profiles/sq_counters.json profiles/${ROUND}_sq_counters.json
 # the same passes for the split-precision path (fp32 tensors, bf16x3 products): kernel stats + HBM traffic + SQ counters
-X3="python3 bench.py --dtype bf16x3 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-extra-paths"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/x3_stats -- python3 bench.py --dtype bf16x3 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths --no-kernel-timer > $OUT/x3_stats.log 2>&1
+X3="python3 bench.py --dtype bf16x3 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-extra-paths --no-traffic-pass"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/x3_stats -- python3 bench.py --dtype bf16x3 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths --no-traffic-pass --no-kernel-timer > $OUT/x3_stats.log 2>&1
 cp "$(ls $OUT/x3_stats/*/*kernel_stats.csv | head -n 1)" profiles/${ROUND}_bf16x3_kernel_stats.csv
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/x3_fetch -- $X3 > $OUT/x3_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/x3_write -- $X3 > $OUT/x3_write.log 2>&1
@@ -56,15 +56,15 @@ python3 bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench.err
 tail -n 1 $OUT/bench_line.json > profiles/${ROUND}_bench_line.json
 echo "bench done"
 # the other single-GPU configurations of BASELINE.json (512x512 tiles; one 4096-tile bag, forward only)
-python3 bench.py --size 512 --tiles 128 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_cfg3_512.json
-python3 bench.py --infer --bags 1 --tiles 4096 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_cfg5_infer4096.json
+python3 bench.py --size 512 --tiles 128 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths --no-traffic-pass 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_cfg3_512.json
+python3 bench.py --infer --bags 1 --tiles 4096 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths --no-traffic-pass 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_cfg5_infer4096.json
 # the split-precision path at the other single-GPU configurations
-python3 bench.py --dtype bf16x3 --size 512 --tiles 128 --steps 5 --warmup 2 --no-cpu-baseline --no-extra-paths 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_bf16x3_cfg3_512.json
-python3 bench.py --dtype bf16x3 --infer --bags 1 --tiles 4096 --steps 5 --warmup 2 --no-cpu-baseline --no-extra-paths 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_bf16x3_cfg5_infer4096.json
+python3 bench.py --dtype bf16x3 --size 512 --tiles 128 --steps 5 --warmup 2 --no-cpu-baseline --no-extra-paths --no-traffic-pass 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_bf16x3_cfg3_512.json
+python3 bench.py --dtype bf16x3 --infer --bags 1 --tiles 4096 --steps 5 --warmup 2 --no-cpu-baseline --no-extra-paths --no-traffic-pass 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_bf16x3_cfg5_infer4096.json
 echo "cfg3 / cfg5 lines done"
 # the live driver's size (gbm/classify_combined.py:412: 300x300 tiles; no BASELINE config): 8 bags x 200 tiles, both compute modes
-python3 bench.py --size 300 --tiles 200 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_live300.json
-python3 bench.py --dtype bf16x3 --size 300 --tiles 200 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_bf16x3_live300.json
+python3 bench.py --size 300 --tiles 200 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths --no-traffic-pass 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_live300.json
+python3 bench.py --dtype bf16x3 --size 300 --tiles 200 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-paths --no-traffic-pass 2>> $OUT/bench.err | tail -n 1 > profiles/${ROUND}_bench_line_bf16x3_live300.json
 echo "live-driver-size lines done"
 
 echo "all profiles written"
