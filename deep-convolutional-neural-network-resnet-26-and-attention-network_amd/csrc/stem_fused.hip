@@ -755,12 +755,16 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(StemFwdArgs a) {
             // in order).  Split precision has no registers for it inside the loop (two operand planes): requested behind the loop.
             constexpr int FETCH_AT = X3 ? -1 : (WLDS ? 0 : (KSTEPS - 1 - WD) * MT);
             Frag8<T> ring[R], wq[WR][NT];
-            const int w1h = (X3 && r >= 4 && r < 8) ? (64 + lane - 4) * FRAGB + 16 : (64 + lane) * FRAGB;
+#ifndef MIL_SP_X3_FOLD
+#define MIL_SP_X3_FOLD 1              // split precision, column tile 1 (channels 16-19): [wh ; wl] x xh, then wh x xl (two MFMAs + a lane exchange in the
+#endif                                // epilogue) instead of three MFMAs; measured 1395 vs 1425 us per launch (round 5)
+            constexpr bool FOLD = X3 && MIL_SP_X3_FOLD;
+            const int w1h = (FOLD && r >= 4 && r < 8) ? (64 + lane - 4) * FRAGB + 16 : (64 + lane) * FRAGB;
             auto wfrag = [&](int sl, int nt) {
                 Frag8<T> f;
                 if constexpr (X3) {       // column tile 1: rows 4-7 carry the LO halves of channels 16-19 ([wh ; wl] x xh, then wh x xl)
                     f.h = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(nt == 1 ? w1h : lane * FRAGB), sl * NT * 64 * FRAGB, 0));
-                    f.l = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(nt == 1 ? (64 + lane) * FRAGB : lane * FRAGB + 16), sl * NT * 64 * FRAGB, 0));
+                    f.l = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(nt == 1 ? (64 + lane) * FRAGB + (FOLD ? 0 : 16) : lane * FRAGB + 16), sl * NT * 64 * FRAGB, 0));
                 } else if constexpr (WLDS) {
                     f.v = *reinterpret_cast<const bf16x8_t*>(ldsW + ((sl * NT + nt) * 64 + lane) * FRAGB);
                 } else {
@@ -790,7 +794,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(StemFwdArgs a) {
                     if (has_next) fetch(tile + G8);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (X3) {
+                if constexpr (FOLD) {
                     acc[m][0] = mma8(wq[sl % WR][0], ring[j % R], acc[m][0]);
                     acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[sl % WR][1].h, ring[j % R].h, acc[m][1], 0, 0, 0);      // [wh ; wl] x xh
                     acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[sl % WR][1].l, ring[j % R].l, acc[m][1], 0, 0, 0);      // wh x xl
@@ -809,7 +813,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(StemFwdArgs a) {
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         MIL_STAMP_MARK(2)
-        if constexpr (X3) {              // column tile 1: rows 4-7 (lane group 1) hold w_lo * x_hi of rows 0-3 — add them, zero the padding channels
+        if constexpr (X3 && MIL_SP_X3_FOLD) {      // column tile 1: rows 4-7 (lane group 1) hold w_lo * x_hi of rows 0-3 — add them, zero the padding channels
 #pragma unroll
             for (int m = 0; m < 11; ++m) {
 #pragma unroll
