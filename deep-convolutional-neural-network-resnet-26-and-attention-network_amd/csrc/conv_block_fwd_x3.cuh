@@ -333,8 +333,57 @@ __global__ __launch_bounds__(256, 2) void conv_block_fwd_x3_kernel(BlockFwdX3Arg
     MIL_STAMP_STORE(a.stamp, NW)
 }
 
+#include "conv_block_strip_x3.cuh"
+
+// The row-walk form (conv_block_strip_x3.cuh) takes 64-pixel-wide maps when whole images fill the resident workgroups well:
+// its unit of work is an image (S = H/2 + 1 steps of two rows, each measured at ~0.83 of the time of a 16 x 8 tile), the tiled
+// form's a tile.  MIL_BLOCK_STRIP (a TEST knob, read per call: "0" never, "1" whenever the map is 64 wide) lets the tests
+// compare the two forms bit for bit on small inputs.
+static bool mil_block_strip_wanted(const ConvGeom& g, int n_img, int grid_cap) {
+    if (g.W != 64) return false;
+    const char* e = getenv("MIL_BLOCK_STRIP");
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    const long tiles = (long)n_img * ((g.H + 7) >> 3) * 4;
+    const long cost_tile = (tiles + grid_cap - 1) / grid_cap * 6;           // measured: ~12 k cycles per tile, ~10 k per row-pair step
+    const long cost_strip = (long)((n_img + grid_cap - 1) / grid_cap) * (((g.H + 1) >> 1) + 1) * 5;
+    return cost_strip < cost_tile;
+}
+
+static int launch_block_strip_x3(BlockFwdX3Args a, hipStream_t st) {
+    const ConvGeom& g = a.g;
+    constexpr int lds = MIL_STRIP_X3_LDS;
+    auto kern = conv_block_strip_x3_kernel;
+    static std::atomic<unsigned long long> attr_set{0};
+    if (mil_device_needs(attr_set)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MIL_ERR_LAUNCH;
+        mil_device_done(attr_set);
+    }
+    const int per_cu = mil_resident_per_cu(kern, lds, 2, 256);
+    const size_t img = (size_t)g.H * g.W * a.apx;
+    const int chunk = mil_imgs_under_2g(img);
+    for (int i0 = 0; i0 < g.n_img; i0 += chunk) {
+        const int n = (g.n_img - i0 < chunk) ? g.n_img - i0 : chunk;
+        BlockFwdX3Args c = a;
+        c.x = a.x + (size_t)i0 * (img / 4); c.o1 = a.o1 + (size_t)i0 * (img / 4); c.y = a.y + (size_t)i0 * (img / 4);
+        int grid = mil_num_cus() * per_cu;
+        if (grid > n) grid = n;
+#ifdef MIL_STAMP
+        static MilStampBuf sb;
+        c.stamp = sb.get((size_t)grid * 4 * 11);
+#endif
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, c, n, (unsigned)(img * n));
+        MIL_CHECK_LAUNCH();
+#ifdef MIL_STAMP
+        static const char* const ph[9] = {"barrier-top", "commit", "barrier-x", "fetch-issue", "conv1", "conv1-epilogue", "barrier-mid", "conv2", "conv2-epilogue"};
+        sb.report("conv_block_strip_x3_kernel", grid, 4, 9, ph, st);
+#endif
+    }
+    return MIL_OK;
+}
+
 static int launch_block_fwd_x3(BlockFwdX3Args a, hipStream_t st) {
     ConvGeom& g = a.g;
+    if (mil_block_strip_wanted(g, g.n_img, mil_num_cus() * 2)) return launch_block_strip_x3(a, st);
     g.tw_log2 = 4; g.th_log2 = 3; g.ti_log2 = 0;
     g.tiles_x = (g.W + 15) >> 4; g.tiles_y = (g.H + 7) >> 3; g.n_groups = g.n_img;
     g.hh = 12; g.hw = 20;

@@ -989,6 +989,44 @@ def test_identity_block_forward_one_pass_split_precision(ops, case, monkeypatch)
     assert ops.conv_block_fwd(xg, p1, bp1, p2, bp2) is None           # exact-fp32 mode: no such kernel
 
 
+@pytest.mark.parametrize("case", [(2, 64, 0), (5, 17, 0), (3, 8, 0), (9, 64, 3), (700, 16, 0), (1030, 10, 0)])
+def test_identity_block_forward_row_walk_equals_tiled(ops, case, monkeypatch):
+    """The row-walk form of the split-precision block forward (conv_block_strip_x3_kernel: a workgroup walks a 64-pixel-wide image
+    two rows at a time, input and mid activation in 4-row LDS rings) against the 16 x 8-tile form on the same inputs: the same
+    arithmetic per output element, so bit for bit; odd heights (a row pair half outside), one image per workgroup and several
+    (700 and 1030 images on 512 resident workgroups), the launch split by the buffer limit (9 images, 3 per launch)."""
+    monkeypatch.setenv("MIL_PF_MIN_TILES", "1")
+    L = _lib()
+    n, h, per_launch = case
+    c, w = 20, 64
+    g = torch.Generator().manual_seed(1213 + n + h)
+    x = torch.randn(n, c, h, w, generator=g)
+    w1 = torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5
+    w2 = torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5
+    b1, b2 = torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1
+    xg = to_nhwc(x, torch.float32)
+    if per_launch:
+        monkeypatch.setenv("MIL_BUFFER_LIMIT_BYTES", str(per_launch * h * w * 96 + 4096))
+    with L.f32_mma(L.MIL_DT_F32S):
+        p1, bp1 = ops.pack_weights(w1.cuda(), b1.cuda(), L.PACK_FWD, torch.float32)
+        p2, bp2 = ops.pack_weights(w2.cuda(), b2.cuda(), L.PACK_FWD, torch.float32)
+        monkeypatch.setenv("MIL_BLOCK_STRIP", "0")
+        tiled = ops.conv_block_fwd(xg, p1, bp1, p2, bp2)
+        monkeypatch.setenv("MIL_BLOCK_STRIP", "1")
+        walk = ops.conv_block_fwd(xg, p1, bp1, p2, bp2)
+        again = ops.conv_block_fwd(xg, p1, bp1, p2, bp2)
+    torch.cuda.synchronize()
+    assert tiled is not None and walk is not None
+    for t, v, u in zip(tiled, walk, again):
+        assert torch.equal(v, u)
+        assert float(v[..., c:].abs().max()) == 0.0
+        assert torch.equal(t.view(torch.int32), v.view(torch.int32)), float((t - v).abs().max())
+    if n <= 9:
+        ref1 = F.leaky_relu(F.conv2d(x, w1, b1, padding=1), LEAK)
+        ref2 = F.leaky_relu(F.conv2d(ref1, w2, b2, padding=1) + x, LEAK)
+        assert rel_err(from_nhwc(walk[0], c), ref1) < TOL[X3] and rel_err(from_nhwc(walk[1], c), ref2) < 2 * TOL[X3]
+
+
 @pytest.mark.parametrize("case", [(20, 40, 3, 16, 16), (20, 40, 2, 19, 13), (20, 40, 2, 64, 48), (40, 60, 5, 8, 8),
                                   (40, 60, 3, 32, 32), (60, 80, 3, 16, 16), (60, 80, 9, 8, 8)])
 def test_stage_entry_weight_gradients_one_pass(ops, case):
