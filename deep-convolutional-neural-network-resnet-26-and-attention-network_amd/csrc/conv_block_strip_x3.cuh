@@ -66,6 +66,11 @@ __global__ __launch_bounds__(256, 2) void conv_block_strip_x3_kernel(BlockFwdX3A
         if (tid < 60) {
             const int pl = tid / 15, rem = tid - pl * 15, rec = rem / 3, pc = rem - rec * 3;
             *reinterpret_cast<u32x4_t*>(smem + pl * PLANE + rec * ROW + pc * 16) = u32x4_t{0u, 0u, 0u, 0u};
+        } else if (tid >= 64 && tid < 80) {
+            // ... and the "next pixel" slot of column 63 of every ring row: its next pixel is the zero column, which no commit
+            // writes; the zero-weight half of k-groups 21-23 reads it (0 x whatever the previous kernel left there, NaNs included)
+            const int pl = (tid - 64) >> 2, rr = (tid - 64) & 3;
+            *reinterpret_cast<u32x2_t*>(smem + pl * PLANE + (rr * RP + SW) * PIXB + 40) = u32x2_t{0u, 0u};
         }
     }
     const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, bytes);
