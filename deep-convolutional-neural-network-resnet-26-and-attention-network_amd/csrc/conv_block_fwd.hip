@@ -317,6 +317,218 @@ static int launch_block_fwd(BlockFwdArgs a, hipStream_t st) {
     return MIL_OK;
 }
 
+// ---- the same block as a ROW WALK on 64-pixel-wide maps (the layer-1 maps of 256 x 256 tiles), bf16, 24 channels -------------
+// A workgroup owns a whole image and walks down it four rows (256 pixels) at a time, the tile spanning the full width.  The input
+// and the mid activation live in two 8-row LDS rings (row pitch 65 records: column 64 of a row IS column -1 of the next, one
+// shared zero record).  A step commits the four NEW input rows 4s .. 4s+3 (12 KB, contiguous in the NHWC tensor), computes mid
+// rows 4s-1 .. 4s+2 from input rows 4s-2 .. 4s+3, copies them to o1, and computes output rows 4s-4 .. 4s-1 from mid rows
+// 4s-5 .. 4s with the residual read from the input ring.  Against the 16 x 16 tiles: the input is staged once (1.0 x instead of
+// 400 / 256 halo pixels per tile), conv1 runs on 16 row tiles per step instead of 21 (of 24) — at one prologue step per image
+// (mid rows -1 .. 2) and one epilogue step whose conv1 sees one real row.  Same arithmetic per output element: bit-identical.
+// Ring rows wrap: the row part of a fragment offset is ((base + m + ky) & 7) * ROW, rebuilt per step (28 mads).
+// 78.8 KB of LDS: two 4-wave workgroups per CU.  Whole images are the unit of work: launch_block_fwd takes this form when the
+// images fill the resident workgroups evenly enough (mil_block_strip_wanted; MIL_BLOCK_STRIP = 0 / 1 is a TEST knob).
+constexpr int MIL_STRIP_PLANE = (8 * 65 + 1) * 48;
+constexpr int MIL_STRIP_W_BYTES = 7 * 2 * 64 * 16;
+constexpr int MIL_STRIP_LDS = 2 * MIL_STRIP_PLANE + 2 * MIL_STRIP_W_BYTES + 64;
+
+__global__ __launch_bounds__(256, 2) void conv_block_strip_kernel(BlockFwdArgs a, int n_img, unsigned bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    MIL_POISON(smem);
+    constexpr int NT = 2, NTHR = 256, KSTEPS = 7, CG = 3, MT = 4;
+    constexpr int PIXB = 48, SW = 64, RP = SW + 1, ROW = RP * PIXB;  // 3120 bytes per ring row
+    constexpr int PLANE = MIL_STRIP_PLANE, W_BYTES = MIL_STRIP_W_BYTES;
+    constexpr int OFF_X = 0, OFF_O = PLANE, OFF_W1 = 2 * PLANE, OFF_W2 = OFF_W1 + W_BYTES, OFF_DUMP = OFF_W2 + W_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, gq = lane >> 4;
+    char* ldsX = smem + OFF_X;
+    char* ldsO = smem + OFF_O;
+    const int H = a.g.H;
+    const int S = ((H + 3) >> 2) + 1;                                // steps per image: one per four rows + the last output rows
+    mil_stage_filter(smem + OFF_W1, a.w1, W_BYTES, tid, NTHR);
+    mil_stage_filter(smem + OFF_W2, a.w2, W_BYTES, tid, NTHR);
+    // the zero columns of both rings: records 0, 65, .., 520 (nothing ever writes them again)
+    if (tid < 2 * 9 * 3) {
+        const int pl = tid / 27, rem = tid - pl * 27, rec = rem / 3, pc = rem - rec * 3;
+        *reinterpret_cast<u32x4_t*>(smem + pl * PLANE + rec * ROW + pc * 16) = u32x4_t{0u, 0u, 0u, 0u};
+    }
+    const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, bytes);
+    const __amdgpu_buffer_rsrc_t rs_o = mil_rsrc(a.o1, bytes);
+    const __amdgpu_buffer_rsrc_t rs_y = mil_rsrc(a.y, bytes);
+
+    // four rows = 256 pixels x 3 pieces (16 B = eight channels): flat id = tid + 256*i = byte offset / 16 inside the row group
+    constexpr int NPX = 3;
+    int p_lds[NPX], p_row[NPX];
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+        const int idx = tid + NTHR * i, px = idx / CG, j = idx - px * CG;
+        p_row[i] = px >> 6;
+        p_lds[i] = ((px & 63) + 1) * PIXB + j * 16;                  // inside its ring row
+    }
+    // k-group q = 4*sl + gq = (tap, 8-channel group): column / channel part of the fragment offset, filter row in the low bits
+    int kq[KSTEPS];
+#pragma unroll
+    for (int sl = 0; sl < KSTEPS; ++sl) {
+        const int q = 4 * sl + gq;
+        int tap = q / CG, cg = q - tap * CG;
+        if (tap >= 9) { tap = 0; cg = 0; }                           // zero weights: any finite operand
+        kq[sl] = ((tap % 3) * PIXB + cg * 16) | (tap / 3);
+    }
+    const int col = wave * 16 + r;                                   // this lane's pixel column in both convs
+    const int pb = col * PIXB;                                       // record under the top-left tap: column col - 1 = record col
+    const bool last_ok = (gq >> 1) == 0;                             // column tile 1 holds channels 16-23 only
+    f32x4_t b1r[NT], b2r[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            b1r[nt][i] = a.b1 ? a.b1[nt * 16 + gq * 4 + i] : 0.f;
+            b2r[nt][i] = a.b2 ? a.b2[nt * 16 + gq * 4 + i] : 0.f;
+        }
+    int koff[MT][KSTEPS];
+    u32x4_t rx[NPX];
+    // input rows 4s .. 4s+3 of image img (rows beyond the image: zeros = the bottom padding); no branch around the loads
+    auto fetch = [&](int img, int s) {
+        const int y0 = 4 * s;
+        const int base = (img * H + y0) * (SW * PIXB);
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            const bool ok = y0 + p_row[i] < H;
+            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (unsigned)(base + (tid + NTHR * i) * 16) : MIL_OOB, 0, 0);
+        }
+    };
+    const int G = gridDim.x;
+    int img = blockIdx.x, s = 0;
+    if (img < n_img) fetch(img, 0);
+    while (img < n_img) {
+        const int nb = (s & 1) * 4;                                  // ring rows of the new input rows
+        __syncthreads();                       // previous step: every read of both rings is done
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) *reinterpret_cast<u32x4_t*>(ldsX + (nb + p_row[i]) * ROW + p_lds[i]) = rx[i];
+        if (s == 0) {
+            // input rows -2, -1 (ring rows 6, 7) are the top padding: records 390 .. 520 (131 x 48 B = 393 pieces)
+            for (int id = tid; id < 393; id += NTHR) *reinterpret_cast<u32x4_t*>(ldsX + 6 * ROW + id * 16) = u32x4_t{0u, 0u, 0u, 0u};
+        }
+        __syncthreads();                       // new input rows visible
+        int ns = s + 1, nimg = img;
+        if (ns == S) { ns = 0; nimg += G; }
+        if (nimg < n_img) fetch(nimg, ns);
+        // conv row m, filter row ky: input rows 4s-2+m+ky (ring row = row & 7) for conv1, mid rows 4s-5+m+ky (ring row =
+        // (row + 3) & 7) for conv2 — the same ring rows
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int sl = 0; sl < KSTEPS; ++sl)
+                koff[m][sl] = ((nb + 6 + m + (kq[sl] & 3)) & 7) * ROW + (kq[sl] & ~3);
+        const int ibase = img * H * (SW * PIXB);
+
+        // ---- conv1: mid rows 4s-1 .. 4s+2 -> the mid ring's rows (nb + 2 + m) & 7 -----------------------------------------
+        {
+            f32x4_t acc[MT][NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[m][nt] = b1r[nt];
+            mil_conv_ring<NT, MT, KSTEPS, 2>(acc, smem + OFF_W1, lane, [&](int sl, int m) { return ldsX + pb + koff[m][sl]; });
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const bool inside = (unsigned)(4 * s - 1 + m) < (unsigned)H;     // wave-uniform: a mid row outside the image is conv2's zero padding
+                const int sdst = ((nb + 2 + m) & 7) * ROW + (col + 1) * PIXB + gq * 8;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    bf16x4_t ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float v = acc[m][nt][e]; ov[e] = (__bf16)fmaxf(v, v * a.slope); }
+                    u32x2_t ou = __builtin_bit_cast(u32x2_t, ov);
+                    ou[0] = inside ? ou[0] : 0u; ou[1] = inside ? ou[1] : 0u;
+                    const int dst = (nt == NT - 1 && gq >= 2) ? OFF_DUMP - OFF_O : sdst + nt * 32;
+                    *reinterpret_cast<u32x2_t*>(ldsO + dst) = ou;
+                }
+            }
+        }
+        __syncthreads();                       // new mid rows visible
+
+        // ---- the new mid rows -> o1 tensor (kept for the backward): 12 KB, contiguous -----------------------------------------
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+            const int jy = 4 * s - 1 + p_row[i];
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(ldsO + ((nb + 2 + p_row[i]) & 7) * ROW + p_lds[i]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, (unsigned)jy < (unsigned)H ? (unsigned)(ibase + (4 * s - 1) * (SW * PIXB) + (tid + NTHR * i) * 16) : MIL_OOB, 0, 0);
+        }
+        if (s > 0) {
+            // ---- conv2 + residual (input ring) + LeakyReLU -> y rows 4s-4 .. 4s-1 ---------------------------------------------
+            f32x4_t acc[MT][NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[m][nt] = b2r[nt];
+            mil_conv_ring<NT, MT, KSTEPS, 2>(acc, smem + OFF_W2, lane, [&](int sl, int m) { return ldsO + pb + koff[m][sl]; });
+#pragma unroll
+            for (int p = 0; p < MT / 2; ++p) {
+                const int rr = 2 * p + (gq & 1), ey = 4 * s - 4 + rr;    // after the swap a lane holds 8 channels of pixel (rr, col)
+                const unsigned ooff = ey < H ? (unsigned)(ibase + (ey * SW + col) * PIXB + (gq >> 1) * 16) : MIL_OOB;
+                const int xres = ((nb + 4 + rr) & 7) * ROW + (col + 1) * PIXB + (gq >> 1) * 16;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float lo = acc[2 * p][nt][i], hi = acc[2 * p + 1][nt][i];
+                        if (i == 0) mil_swap16<true>(lo, hi); else mil_swap16<false>(lo, hi);
+                        v[i] = lo;
+                        v[4 + i] = hi;
+                    }
+                    const bool chan_ok = nt < NT - 1 || last_ok;
+                    const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(ldsX + (chan_ok ? xres + nt * 32 : 0));
+                    bf16x8_t ov;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { const float q = v[i] + (float)t[i]; ov[i] = (__bf16)fmaxf(q, q * a.slope); }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), rs_y, (chan_ok && ooff != MIL_OOB) ? ooff + nt * 32 : MIL_OOB, 0, 0);
+                }
+            }
+        }
+        img = nimg; s = ns;
+    }
+}
+
+// The row-walk forms take 64-pixel-wide maps when whole images fill the resident workgroups well: their unit of work is an image
+// (`steps` steps of `strip_cost` each), the tiled forms' a tile (`tile_cost` each; costs in k cycles, measured).
+// MIL_BLOCK_STRIP (a TEST knob, read per call: "0" never, "1" whenever the map is 64 wide) lets the tests compare the two forms
+// bit for bit on small inputs.
+static bool mil_block_strip_wanted(int W, int n_img, long tiles_per_img, int steps, int tile_cost, int strip_cost, int grid_cap) {
+    if (W != 64) return false;
+    const char* e = getenv("MIL_BLOCK_STRIP");
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    const long cost_tile = (n_img * tiles_per_img + grid_cap - 1) / grid_cap * tile_cost;
+    const long cost_strip = (long)((n_img + grid_cap - 1) / grid_cap) * steps * strip_cost;
+    return cost_strip < cost_tile;
+}
+
+static int launch_block_strip(BlockFwdArgs a, hipStream_t st) {
+    const ConvGeom& g = a.g;
+    constexpr int lds = MIL_STRIP_LDS;
+    auto kern = conv_block_strip_kernel;
+    static std::atomic<unsigned long long> attr_set{0};
+    if (mil_device_needs(attr_set)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MIL_ERR_LAUNCH;
+        mil_device_done(attr_set);
+    }
+    const int per_cu = mil_resident_per_cu(kern, lds, 2, 256);
+    const size_t img = (size_t)g.H * g.W * 48;
+    const int chunk = mil_imgs_under_2g(img);
+    for (int i0 = 0; i0 < g.n_img; i0 += chunk) {
+        const int n = (g.n_img - i0 < chunk) ? g.n_img - i0 : chunk;
+        BlockFwdArgs c = a;
+        c.x = a.x + (size_t)i0 * (img / 2); c.o1 = a.o1 + (size_t)i0 * (img / 2); c.y = a.y + (size_t)i0 * (img / 2);
+        int grid = mil_num_cus() * per_cu;
+        if (grid > n) grid = n;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, c, n, (unsigned)(img * n));
+        MIL_CHECK_LAUNCH();
+    }
+    return MIL_OK;
+}
+
 #include <type_traits>
 #include "conv_block_fwd_x3.cuh"
 
@@ -342,7 +554,10 @@ extern "C" int mil_conv_block_fwd(const void* x, const void* wpack1, const float
     a.o1 = (__bf16*)o1; a.y = (__bf16*)y; a.slope = slope;
     a.g.n_img = n_img; a.g.H = H; a.g.W = W; a.g.Ho = H; a.g.Wo = W; a.g.ks = 5; a.g.stride = 1; a.g.pad = 2; a.g.zins = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (cp == 24) return launch_block_fwd<24, 2>(a, st);
+    if (cp == 24) {
+        if (mil_block_strip_wanted(W, n_img, (long)((H + 15) >> 4) * 4, ((H + 3) >> 2) + 1, 11, 9, mil_num_cus() * 2)) return launch_block_strip(a, st);
+        return launch_block_fwd<24, 2>(a, st);
+    }
     if (cp == 40) return launch_block_fwd<40, 3>(a, st);
     return MIL_ERR_UNSUPPORTED;
 }

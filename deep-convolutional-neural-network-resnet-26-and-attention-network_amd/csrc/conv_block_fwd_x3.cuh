@@ -335,20 +335,6 @@ __global__ __launch_bounds__(256, 2) void conv_block_fwd_x3_kernel(BlockFwdX3Arg
 
 #include "conv_block_strip_x3.cuh"
 
-// The row-walk form (conv_block_strip_x3.cuh) takes 64-pixel-wide maps when whole images fill the resident workgroups well:
-// its unit of work is an image (S = H/2 + 1 steps of two rows, each measured at ~0.83 of the time of a 16 x 8 tile), the tiled
-// form's a tile.  MIL_BLOCK_STRIP (a TEST knob, read per call: "0" never, "1" whenever the map is 64 wide) lets the tests
-// compare the two forms bit for bit on small inputs.
-static bool mil_block_strip_wanted(const ConvGeom& g, int n_img, int grid_cap) {
-    if (g.W != 64) return false;
-    const char* e = getenv("MIL_BLOCK_STRIP");
-    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
-    const long tiles = (long)n_img * ((g.H + 7) >> 3) * 4;
-    const long cost_tile = (tiles + grid_cap - 1) / grid_cap * 6;           // measured: ~12 k cycles per tile, ~10 k per row-pair step
-    const long cost_strip = (long)((n_img + grid_cap - 1) / grid_cap) * (((g.H + 1) >> 1) + 1) * 5;
-    return cost_strip < cost_tile;
-}
-
 static int launch_block_strip_x3(BlockFwdX3Args a, hipStream_t st) {
     const ConvGeom& g = a.g;
     constexpr int lds = MIL_STRIP_X3_LDS;
@@ -383,7 +369,7 @@ static int launch_block_strip_x3(BlockFwdX3Args a, hipStream_t st) {
 
 static int launch_block_fwd_x3(BlockFwdX3Args a, hipStream_t st) {
     ConvGeom& g = a.g;
-    if (mil_block_strip_wanted(g, g.n_img, mil_num_cus() * 2)) return launch_block_strip_x3(a, st);
+    if (mil_block_strip_wanted(g.W, g.n_img, (long)((g.H + 7) >> 3) * 4, ((g.H + 1) >> 1) + 1, 6, 5, mil_num_cus() * 2)) return launch_block_strip_x3(a, st);
     g.tw_log2 = 4; g.th_log2 = 3; g.ti_log2 = 0;
     g.tiles_x = (g.W + 15) >> 4; g.tiles_y = (g.H + 7) >> 3; g.n_groups = g.n_img;
     g.hh = 12; g.hw = 20;

@@ -989,6 +989,40 @@ def test_identity_block_forward_one_pass_split_precision(ops, case, monkeypatch)
     assert ops.conv_block_fwd(xg, p1, bp1, p2, bp2) is None           # exact-fp32 mode: no such kernel
 
 
+@pytest.mark.parametrize("case", [(2, 64, 0), (5, 17, 0), (3, 16, 0), (9, 64, 3), (700, 16, 0), (1030, 18, 0)])
+def test_identity_block_forward_row_walk_equals_tiled_bf16(ops, case, monkeypatch):
+    """The row-walk form of the bf16 block forward (conv_block_strip_kernel: four rows of a 64-pixel-wide image per step, input
+    and mid activation in 8-row LDS rings, the residual from the input ring) against the 16 x 16-tile form: bit for bit; heights
+    that are not a multiple of four, several images per workgroup, the launch split by the buffer limit."""
+    monkeypatch.setenv("MIL_PF_MIN_TILES", "1")
+    L = _lib()
+    n, h, per_launch = case
+    c, w, dt = 20, 64, torch.bfloat16
+    g = torch.Generator().manual_seed(1409 + n + h)
+    x = round_to(torch.randn(n, c, h, w, generator=g), dt)
+    w1 = round_to(torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5, dt)
+    w2 = round_to(torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5, dt)
+    b1, b2 = torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1
+    xg = to_nhwc(x, dt)
+    if per_launch:
+        monkeypatch.setenv("MIL_BUFFER_LIMIT_BYTES", str(per_launch * h * w * 48 + 4096))
+    p1, bp1 = ops.pack_weights(w1.cuda(), b1.cuda(), L.PACK_FWD, dt)
+    p2, bp2 = ops.pack_weights(w2.cuda(), b2.cuda(), L.PACK_FWD, dt)
+    monkeypatch.setenv("MIL_BLOCK_STRIP", "0")
+    tiled = ops.conv_block_fwd(xg, p1, bp1, p2, bp2)
+    monkeypatch.setenv("MIL_BLOCK_STRIP", "1")
+    walk = ops.conv_block_fwd(xg, p1, bp1, p2, bp2)
+    torch.cuda.synchronize()
+    assert tiled is not None and walk is not None
+    for t, v in zip(tiled, walk):
+        assert float(v[..., c:].float().abs().max()) == 0.0
+        assert torch.equal(t.view(torch.int16), v.view(torch.int16)), float((t.float() - v.float()).abs().max())
+    if n <= 9:
+        ref1 = round_to(F.leaky_relu(F.conv2d(x, w1, b1, padding=1), LEAK), dt)
+        ref2 = F.leaky_relu(F.conv2d(ref1, w2, b2, padding=1) + x, LEAK)
+        assert rel_err(from_nhwc(walk[0], c), ref1) < TOL[dt] and rel_err(from_nhwc(walk[1], c), ref2) < 2 * TOL[dt]
+
+
 @pytest.mark.parametrize("case", [(2, 64, 0), (5, 17, 0), (3, 8, 0), (9, 64, 3), (700, 16, 0), (1030, 10, 0)])
 def test_identity_block_forward_row_walk_equals_tiled(ops, case, monkeypatch):
     """The row-walk form of the split-precision block forward (conv_block_strip_x3_kernel: a workgroup walks a 64-pixel-wide image

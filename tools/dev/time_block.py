@@ -1,5 +1,5 @@
-"""Times the split-precision identity-block forward alone (2048 images of 64x64x20 by default), tiled form against the row-walk
-form: `python tools/dev/time_block.py [n] [h]`.  With MIL_LIB_PATH=<stamp build> the kernels print their phase shares."""
+"""Times the identity-block forward alone (2048 images of 64x64x20 by default), tiled form against the row-walk form, in split
+precision and in bf16: `python tools/dev/time_block.py [n] [h]`.  With MIL_LIB_PATH=<stamp build> the kernels print their phase shares."""
 import os
 import sys
 
@@ -19,20 +19,22 @@ w1 = torch.randn((20, 20, 3, 3), generator=g, device="cuda") / 13.4
 w2 = torch.randn((20, 20, 3, 3), generator=g, device="cuda") / 13.4
 b = torch.randn((20,), generator=g, device="cuda") * 0.1
 reps = 3 if "stamp" in os.environ.get("MIL_LIB_PATH", "") else 20
-with L.f32_mma(L.MIL_DT_F32S):
-    p1, bp1 = ops.pack_weights(w1, b, L.PACK_FWD, torch.float32)
-    p2, bp2 = ops.pack_weights(w2, b, L.PACK_FWD, torch.float32)
-    outs = {}
-    for form in ("0", "1", "0", "1"):
-        os.environ["MIL_BLOCK_STRIP"] = form
-        for _ in range(3):
-            outs[form] = ops.conv_block_fwd(x, p1, bp1, p2, bp2)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            ops.conv_block_fwd(x, p1, bp1, p2, bp2)
-        e1.record()
-        torch.cuda.synchronize()
-        print(f"block_fwd x3 {'row walk' if form == '1' else 'tiled   '}: {e0.elapsed_time(e1) / reps * 1e3:.1f} us per launch ({n} images {h}x64)", flush=True)
-    print("bit-identical:", all(torch.equal(a, b_) for a, b_ in zip(outs["0"], outs["1"])))
+for mode, dt, code in (("x3", torch.float32, L.MIL_DT_F32S), ("bf16", torch.bfloat16, L.MIL_DT_F32)):
+    with L.f32_mma(code):
+        xx = x.to(dt)
+        p1, bp1 = ops.pack_weights(w1, b, L.PACK_FWD, dt)
+        p2, bp2 = ops.pack_weights(w2, b, L.PACK_FWD, dt)
+        outs = {}
+        for form in ("0", "1", "0", "1"):
+            os.environ["MIL_BLOCK_STRIP"] = form
+            for _ in range(3):
+                outs[form] = ops.conv_block_fwd(xx, p1, bp1, p2, bp2)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                ops.conv_block_fwd(xx, p1, bp1, p2, bp2)
+            e1.record()
+            torch.cuda.synchronize()
+            print(f"block_fwd {mode} {'row walk' if form == '1' else 'tiled   '}: {e0.elapsed_time(e1) / reps * 1e3:.1f} us per launch ({n} images {h}x64)", flush=True)
+        print(mode, "bit-identical:", all(torch.equal(a, b_) for a, b_ in zip(outs["0"], outs["1"])))
