@@ -328,43 +328,56 @@ static int launch_block_fwd(BlockFwdArgs a, hipStream_t st) {
 // Ring rows wrap: the row part of a fragment offset is ((base + m + ky) & 7) * ROW, rebuilt per step (28 mads).
 // 78.8 KB of LDS: two 4-wave workgroups per CU.  Whole images are the unit of work: launch_block_fwd takes this form when the
 // images fill the resident workgroups evenly enough (mil_block_strip_wanted; MIL_BLOCK_STRIP = 0 / 1 is a TEST knob).
-constexpr int MIL_STRIP_PLANE = (8 * 65 + 1) * 48;
-constexpr int MIL_STRIP_W_BYTES = 7 * 2 * 64 * 16;
-constexpr int MIL_STRIP_LDS = 2 * MIL_STRIP_PLANE + 2 * MIL_STRIP_W_BYTES + 64;
+//
+// SW x R = 64 x 4 (the 64 x 64 maps of 256 x 256 tiles) or 128 x 2 (the 128 x 128 maps of 512 x 512 tiles): 256 pixels per step
+// either way; rings of 2R rows.  Row tile m of a wave = (row m % R2, column block wave + 4 * (m / R2)) with R2 = rows per
+// column block = R (64 wide) or 2 (128 wide: two column blocks per wave), so that row tiles 2p, 2p+1 are always two rows of
+// the same columns (the epilogue's permlane pairs).
+template <int SW, int R> struct StripCfg {
+    static constexpr int RP = SW + 1, ROW = RP * 48, NR = 2 * R, PLANE = (NR * RP + 1) * 48;
+    static constexpr int W_BYTES = 7 * 2 * 64 * 16;
+    static constexpr int LDS = 2 * PLANE + 2 * W_BYTES + 64;
+};
 
+template <int SW, int R>
 __global__ __launch_bounds__(256, 2) void conv_block_strip_kernel(BlockFwdArgs a, int n_img, unsigned bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MIL_POISON(smem);
+    using Cfg = StripCfg<SW, R>;
     constexpr int NT = 2, NTHR = 256, KSTEPS = 7, CG = 3, MT = 4;
-    constexpr int PIXB = 48, SW = 64, RP = SW + 1, ROW = RP * PIXB;  // 3120 bytes per ring row
-    constexpr int PLANE = MIL_STRIP_PLANE, W_BYTES = MIL_STRIP_W_BYTES;
+    static_assert(SW * R == 256 && (SW == 64 || SW == 128), "256 pixels per step");
+    constexpr int PIXB = 48, RP = Cfg::RP, ROW = Cfg::ROW, NR = Cfg::NR, RMASK = NR - 1;
+    constexpr int PLANE = Cfg::PLANE, W_BYTES = Cfg::W_BYTES;
     constexpr int OFF_X = 0, OFF_O = PLANE, OFF_W1 = 2 * PLANE, OFF_W2 = OFF_W1 + W_BYTES, OFF_DUMP = OFF_W2 + W_BYTES;
+    constexpr int NCB = SW / 64;                                     // column blocks of 16 pixels per wave
+    auto m_row = [](int m) { return NCB == 1 ? m : (m & 1); };
+    auto m_cb = [](int m) { return NCB == 1 ? 0 : (m >> 1); };
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, gq = lane >> 4;
     char* ldsX = smem + OFF_X;
     char* ldsO = smem + OFF_O;
     const int H = a.g.H;
-    const int S = ((H + 3) >> 2) + 1;                                // steps per image: one per four rows + the last output rows
+    const int S = (H + R - 1) / R + 1;                               // steps per image: one per R rows + the last output rows
     mil_stage_filter(smem + OFF_W1, a.w1, W_BYTES, tid, NTHR);
     mil_stage_filter(smem + OFF_W2, a.w2, W_BYTES, tid, NTHR);
-    // the zero columns of both rings: records 0, 65, .., 520 (nothing ever writes them again)
-    if (tid < 2 * 9 * 3) {
-        const int pl = tid / 27, rem = tid - pl * 27, rec = rem / 3, pc = rem - rec * 3;
+    // the zero columns of both rings: records 0, RP, .., NR * RP (nothing ever writes them again)
+    if (tid < 2 * (NR + 1) * 3) {
+        const int pl = tid / ((NR + 1) * 3), rem = tid - pl * ((NR + 1) * 3), rec = rem / 3, pc = rem - rec * 3;
         *reinterpret_cast<u32x4_t*>(smem + pl * PLANE + rec * ROW + pc * 16) = u32x4_t{0u, 0u, 0u, 0u};
     }
     const __amdgpu_buffer_rsrc_t rs_x = mil_rsrc(a.x, bytes);
     const __amdgpu_buffer_rsrc_t rs_o = mil_rsrc(a.o1, bytes);
     const __amdgpu_buffer_rsrc_t rs_y = mil_rsrc(a.y, bytes);
 
-    // four rows = 256 pixels x 3 pieces (16 B = eight channels): flat id = tid + 256*i = byte offset / 16 inside the row group
+    // R rows = 256 pixels x 3 pieces (16 B = eight channels): flat id = tid + 256*i = byte offset / 16 inside the row group
     constexpr int NPX = 3;
     int p_lds[NPX], p_row[NPX];
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
         const int idx = tid + NTHR * i, px = idx / CG, j = idx - px * CG;
-        p_row[i] = px >> 6;
-        p_lds[i] = ((px & 63) + 1) * PIXB + j * 16;                  // inside its ring row
+        p_row[i] = px / SW;
+        p_lds[i] = ((px % SW) + 1) * PIXB + j * 16;                  // inside its ring row
     }
     // k-group q = 4*sl + gq = (tap, 8-channel group): column / channel part of the fragment offset, filter row in the low bits
     int kq[KSTEPS];
@@ -375,8 +388,8 @@ __global__ __launch_bounds__(256, 2) void conv_block_strip_kernel(BlockFwdArgs a
         if (tap >= 9) { tap = 0; cg = 0; }                           // zero weights: any finite operand
         kq[sl] = ((tap % 3) * PIXB + cg * 16) | (tap / 3);
     }
-    const int col = wave * 16 + r;                                   // this lane's pixel column in both convs
-    const int pb = col * PIXB;                                       // record under the top-left tap: column col - 1 = record col
+    const int col0 = wave * 16 + r;                                  // this lane's pixel column in column block 0 (+ 64 in block 1)
+    const int pb = col0 * PIXB;                                      // record under the top-left tap: column col - 1 = record col
     const bool last_ok = (gq >> 1) == 0;                             // column tile 1 holds channels 16-23 only
     f32x4_t b1r[NT], b2r[NT];
 #pragma unroll
@@ -388,9 +401,9 @@ __global__ __launch_bounds__(256, 2) void conv_block_strip_kernel(BlockFwdArgs a
         }
     int koff[MT][KSTEPS];
     u32x4_t rx[NPX];
-    // input rows 4s .. 4s+3 of image img (rows beyond the image: zeros = the bottom padding); no branch around the loads
+    // input rows R*s .. R*s+R-1 of image img (rows beyond the image: zeros = the bottom padding); no branch around the loads
     auto fetch = [&](int img, int s) {
-        const int y0 = 4 * s;
+        const int y0 = R * s;
         const int base = (img * H + y0) * (SW * PIXB);
 #pragma unroll
         for (int i = 0; i < NPX; ++i) {
@@ -402,28 +415,28 @@ __global__ __launch_bounds__(256, 2) void conv_block_strip_kernel(BlockFwdArgs a
     int img = blockIdx.x, s = 0;
     if (img < n_img) fetch(img, 0);
     while (img < n_img) {
-        const int nb = (s & 1) * 4;                                  // ring rows of the new input rows
+        const int nb = (s & 1) * R;                                  // ring rows of the new input rows
         __syncthreads();                       // previous step: every read of both rings is done
 #pragma unroll
         for (int i = 0; i < NPX; ++i) *reinterpret_cast<u32x4_t*>(ldsX + (nb + p_row[i]) * ROW + p_lds[i]) = rx[i];
         if (s == 0) {
-            // input rows -2, -1 (ring rows 6, 7) are the top padding: records 390 .. 520 (131 x 48 B = 393 pieces)
-            for (int id = tid; id < 393; id += NTHR) *reinterpret_cast<u32x4_t*>(ldsX + 6 * ROW + id * 16) = u32x4_t{0u, 0u, 0u, 0u};
+            // input rows -2, -1 (ring rows NR-2, NR-1) are the top padding: 2 * RP + 1 records
+            for (int id = tid; id < (2 * RP + 1) * 3; id += NTHR) *reinterpret_cast<u32x4_t*>(ldsX + (NR - 2) * ROW + id * 16) = u32x4_t{0u, 0u, 0u, 0u};
         }
         __syncthreads();                       // new input rows visible
         int ns = s + 1, nimg = img;
         if (ns == S) { ns = 0; nimg += G; }
         if (nimg < n_img) fetch(nimg, ns);
-        // conv row m, filter row ky: input rows 4s-2+m+ky (ring row = row & 7) for conv1, mid rows 4s-5+m+ky (ring row =
-        // (row + 3) & 7) for conv2 — the same ring rows
+        // conv row m_row, filter row ky: input rows R*s-2+m_row+ky (ring row = row & RMASK) for conv1, mid rows R*s-R-1+m_row+ky
+        // (ring row = (row + R - 1) & RMASK) for conv2 — the same ring rows
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int sl = 0; sl < KSTEPS; ++sl)
-                koff[m][sl] = ((nb + 6 + m + (kq[sl] & 3)) & 7) * ROW + (kq[sl] & ~3);
+                koff[m][sl] = ((nb + NR - 2 + m_row(m) + (kq[sl] & 3)) & RMASK) * ROW + (kq[sl] & ~3) + m_cb(m) * (64 * PIXB);
         const int ibase = img * H * (SW * PIXB);
 
-        // ---- conv1: mid rows 4s-1 .. 4s+2 -> the mid ring's rows (nb + 2 + m) & 7 -----------------------------------------
+        // ---- conv1: mid rows R*s-1 .. R*s+R-2 -> the mid ring's rows (nb + R - 2 + m_row) & RMASK -------------------------------
         {
             f32x4_t acc[MT][NT];
 #pragma unroll
@@ -433,8 +446,8 @@ __global__ __launch_bounds__(256, 2) void conv_block_strip_kernel(BlockFwdArgs a
             mil_conv_ring<NT, MT, KSTEPS, 2>(acc, smem + OFF_W1, lane, [&](int sl, int m) { return ldsX + pb + koff[m][sl]; });
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const bool inside = (unsigned)(4 * s - 1 + m) < (unsigned)H;     // wave-uniform: a mid row outside the image is conv2's zero padding
-                const int sdst = ((nb + 2 + m) & 7) * ROW + (col + 1) * PIXB + gq * 8;
+                const bool inside = (unsigned)(R * s - 1 + m_row(m)) < (unsigned)H;     // wave-uniform: a mid row outside the image is conv2's zero padding
+                const int sdst = ((nb + R - 2 + m_row(m)) & RMASK) * ROW + (col0 + m_cb(m) * 64 + 1) * PIXB + gq * 8;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     bf16x4_t ov;
@@ -452,12 +465,12 @@ __global__ __launch_bounds__(256, 2) void conv_block_strip_kernel(BlockFwdArgs a
         // ---- the new mid rows -> o1 tensor (kept for the backward): 12 KB, contiguous -----------------------------------------
 #pragma unroll
         for (int i = 0; i < NPX; ++i) {
-            const int jy = 4 * s - 1 + p_row[i];
-            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(ldsO + ((nb + 2 + p_row[i]) & 7) * ROW + p_lds[i]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, (unsigned)jy < (unsigned)H ? (unsigned)(ibase + (4 * s - 1) * (SW * PIXB) + (tid + NTHR * i) * 16) : MIL_OOB, 0, 0);
+            const int jy = R * s - 1 + p_row[i];
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(ldsO + ((nb + R - 2 + p_row[i]) & RMASK) * ROW + p_lds[i]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, (unsigned)jy < (unsigned)H ? (unsigned)(ibase + (R * s - 1) * (SW * PIXB) + (tid + NTHR * i) * 16) : MIL_OOB, 0, 0);
         }
         if (s > 0) {
-            // ---- conv2 + residual (input ring) + LeakyReLU -> y rows 4s-4 .. 4s-1 ---------------------------------------------
+            // ---- conv2 + residual (input ring) + LeakyReLU -> y rows R*s-R .. R*s-1 ---------------------------------------------
             f32x4_t acc[MT][NT];
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -466,9 +479,10 @@ __global__ __launch_bounds__(256, 2) void conv_block_strip_kernel(BlockFwdArgs a
             mil_conv_ring<NT, MT, KSTEPS, 2>(acc, smem + OFF_W2, lane, [&](int sl, int m) { return ldsO + pb + koff[m][sl]; });
 #pragma unroll
             for (int p = 0; p < MT / 2; ++p) {
-                const int rr = 2 * p + (gq & 1), ey = 4 * s - 4 + rr;    // after the swap a lane holds 8 channels of pixel (rr, col)
+                // after the swap a lane holds 8 channels of pixel (row rr, column col) of row tiles 2p, 2p+1
+                const int rr = m_row(2 * p) + (gq & 1), col = col0 + m_cb(2 * p) * 64, ey = R * s - R + rr;
                 const unsigned ooff = ey < H ? (unsigned)(ibase + (ey * SW + col) * PIXB + (gq >> 1) * 16) : MIL_OOB;
-                const int xres = ((nb + 4 + rr) & 7) * ROW + (col + 1) * PIXB + (gq >> 1) * 16;
+                const int xres = ((nb + R + rr) & RMASK) * ROW + (col + 1) * PIXB + (gq >> 1) * 16;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     float v[8];
@@ -492,12 +506,12 @@ __global__ __launch_bounds__(256, 2) void conv_block_strip_kernel(BlockFwdArgs a
     }
 }
 
-// The row-walk forms take 64-pixel-wide maps when whole images fill the resident workgroups well: their unit of work is an image
+// The row-walk forms take 64-pixel-wide (bf16: also 128-pixel-wide) maps when whole images fill the resident workgroups well: their unit of work is an image
 // (`steps` steps of `strip_cost` each), the tiled forms' a tile (`tile_cost` each; costs in k cycles, measured).
 // MIL_BLOCK_STRIP (a TEST knob, read per call: "0" never, "1" whenever the map is 64 wide) lets the tests compare the two forms
 // bit for bit on small inputs.
-static bool mil_block_strip_wanted(int W, int n_img, long tiles_per_img, int steps, int tile_cost, int strip_cost, int grid_cap) {
-    if (W != 64) return false;
+static bool mil_block_strip_wanted(bool width_ok, int n_img, long tiles_per_img, int steps, int tile_cost, int strip_cost, int grid_cap) {
+    if (!width_ok) return false;
     const char* e = getenv("MIL_BLOCK_STRIP");
     if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
     const long cost_tile = (n_img * tiles_per_img + grid_cap - 1) / grid_cap * tile_cost;
@@ -505,10 +519,11 @@ static bool mil_block_strip_wanted(int W, int n_img, long tiles_per_img, int ste
     return cost_strip < cost_tile;
 }
 
+template <int SW, int R>
 static int launch_block_strip(BlockFwdArgs a, hipStream_t st) {
     const ConvGeom& g = a.g;
-    constexpr int lds = MIL_STRIP_LDS;
-    auto kern = conv_block_strip_kernel;
+    constexpr int lds = StripCfg<SW, R>::LDS;
+    auto kern = conv_block_strip_kernel<SW, R>;
     static std::atomic<unsigned long long> attr_set{0};
     if (mil_device_needs(attr_set)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MIL_ERR_LAUNCH;
@@ -555,7 +570,9 @@ extern "C" int mil_conv_block_fwd(const void* x, const void* wpack1, const float
     a.g.n_img = n_img; a.g.H = H; a.g.W = W; a.g.Ho = H; a.g.Wo = W; a.g.ks = 5; a.g.stride = 1; a.g.pad = 2; a.g.zins = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (cp == 24) {
-        if (mil_block_strip_wanted(W, n_img, (long)((H + 15) >> 4) * 4, ((H + 3) >> 2) + 1, 11, 9, mil_num_cus() * 2)) return launch_block_strip(a, st);
+        const long tpi = (long)((H + 15) >> 4) * ((W + 15) >> 4);
+        if (W == 64 && mil_block_strip_wanted(true, n_img, tpi, ((H + 3) >> 2) + 1, 11, 9, mil_num_cus() * 2)) return launch_block_strip<64, 4>(a, st);
+        if (W == 128 && mil_block_strip_wanted(true, n_img, tpi, ((H + 1) >> 1) + 1, 11, 9, mil_num_cus() * 2)) return launch_block_strip<128, 2>(a, st);
         return launch_block_fwd<24, 2>(a, st);
     }
     if (cp == 40) return launch_block_fwd<40, 3>(a, st);

@@ -369,7 +369,7 @@ static int launch_block_strip_x3(BlockFwdX3Args a, hipStream_t st) {
 
 static int launch_block_fwd_x3(BlockFwdX3Args a, hipStream_t st) {
     ConvGeom& g = a.g;
-    if (mil_block_strip_wanted(g.W, g.n_img, (long)((g.H + 7) >> 3) * 4, ((g.H + 1) >> 1) + 1, 6, 5, mil_num_cus() * 2)) return launch_block_strip_x3(a, st);
+    if (mil_block_strip_wanted(g.W == 64, g.n_img, (long)((g.H + 7) >> 3) * 4, ((g.H + 1) >> 1) + 1, 6, 5, mil_num_cus() * 2)) return launch_block_strip_x3(a, st);
     g.tw_log2 = 4; g.th_log2 = 3; g.ti_log2 = 0;
     g.tiles_x = (g.W + 15) >> 4; g.tiles_y = (g.H + 7) >> 3; g.n_groups = g.n_img;
     g.hh = 12; g.hw = 20;

@@ -989,15 +989,17 @@ def test_identity_block_forward_one_pass_split_precision(ops, case, monkeypatch)
     assert ops.conv_block_fwd(xg, p1, bp1, p2, bp2) is None           # exact-fp32 mode: no such kernel
 
 
-@pytest.mark.parametrize("case", [(2, 64, 0), (5, 17, 0), (3, 16, 0), (9, 64, 3), (700, 16, 0), (1030, 18, 0)])
+@pytest.mark.parametrize("case", [(2, 64, 0, 64), (5, 17, 0, 64), (3, 16, 0, 64), (9, 64, 3, 64), (700, 16, 0, 64), (1030, 18, 0, 64),
+                                  (2, 128, 0, 128), (3, 19, 0, 128), (7, 32, 2, 128), (600, 16, 0, 128)])
 def test_identity_block_forward_row_walk_equals_tiled_bf16(ops, case, monkeypatch):
-    """The row-walk form of the bf16 block forward (conv_block_strip_kernel: four rows of a 64-pixel-wide image per step, input
-    and mid activation in 8-row LDS rings, the residual from the input ring) against the 16 x 16-tile form: bit for bit; heights
-    that are not a multiple of four, several images per workgroup, the launch split by the buffer limit."""
+    """The row-walk form of the bf16 block forward (conv_block_strip_kernel: four rows of a 64-pixel-wide image, or two of a
+    128-pixel-wide one, per step; input and mid activation in LDS rings, the residual from the input ring) against the
+    16 x 16-tile form: bit for bit; heights that are not a multiple of the step, several images per workgroup, the launch split
+    by the buffer limit."""
     monkeypatch.setenv("MIL_PF_MIN_TILES", "1")
     L = _lib()
-    n, h, per_launch = case
-    c, w, dt = 20, 64, torch.bfloat16
+    n, h, per_launch, w = case
+    c, dt = 20, torch.bfloat16
     g = torch.Generator().manual_seed(1409 + n + h)
     x = round_to(torch.randn(n, c, h, w, generator=g), dt)
     w1 = round_to(torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5, dt)
