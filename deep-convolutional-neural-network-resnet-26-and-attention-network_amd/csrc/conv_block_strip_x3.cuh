@@ -239,7 +239,11 @@ __global__ __launch_bounds__(256, 2) void conv_block_strip_x3_kernel(BlockFwdX3A
                 const int jy = 2 * s - 1 + m;
                 const bool inside = (unsigned)jy < (unsigned)H;      // wave-uniform: a mid row outside the image is conv2's zero padding
                 const int sdst = ((nb + m) * RP + col + 1) * PIXB;
+#ifdef MIL_EXP_STRIP_NO_O1
+                const unsigned ooff = MIL_OOB;
+#else
                 const unsigned ooff = inside ? (unsigned)(ibase + (jy * SW + col) * APX + gq * 16) : MIL_OOB;
+#endif
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {            // column tile 1: rows 4-7 (the lane group gq == 1) hold wl*xh of rows 0-3
                     float t0 = acc[m][1][e], t1 = t0;

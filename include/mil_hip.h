@@ -207,6 +207,15 @@ typedef struct MilChainConv {
 int mil_conv_chain(const void* x, const MilChainConv* convs, int nconv, int n_img, int H, int W, int cp, float slope,
                    int dtype, void* stream);
 
+/* Forward of a whole identity-shortcut block in one pass (nnBlocks.py:175-189):
+ *     o1 = lrelu(conv3x3(x) + bias1),   y = lrelu(conv3x3(o1) + bias2 + x)
+ * x is read once (operand and residual), o1 and y are written (what the backward needs), the mid activation goes from the
+ * accumulators to LDS.  bf16: cp in {24, 40}, H and W >= 16;  MIL_DT_F32S: cp = 24, H >= 8, W >= 16;  otherwise
+ * MIL_ERR_UNSUPPORTED (caller: two mil_conv_igemm calls — same results bit for bit in bf16, to fp32 rounding in split precision).
+ * Two kernels per precision, same arithmetic per output element (bit-identical, tested): tiles of one image (16x16 / 16x8
+ * pixels, input halo staged per tile), or — maps 64 pixels wide (bf16: also 128) and enough images to fill the resident
+ * workgroups evenly, about 512 — a row walk: one workgroup per image, input and mid activation in LDS rings, every input
+ * pixel fetched once.  The environment variable MIL_BLOCK_STRIP=0/1 (a test knob, read per call) forces either form. */
 int mil_conv_block_fwd(const void* x, const void* wpack1, const float* bias1, const void* wpack2, const float* bias2,
                        void* o1, void* y, int n_img, int H, int W, int cp, float slope, int dtype, void* stream);
 
