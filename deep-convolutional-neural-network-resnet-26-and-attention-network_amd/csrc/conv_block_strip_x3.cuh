@@ -1,7 +1,8 @@
 // Forward of a whole identity-shortcut residual block of the 20-channel stage, SPLIT PRECISION, on 64-pixel-wide maps (the layer-1
 // maps of 256 x 256 tiles), as a ROW WALK — nnBlocks.py:175-189:  o1 = lrelu(conv3x3(x) + b1),  y = lrelu(conv3x3(o1) + b2 + x).
 // Included by conv_block_fwd.hip behind conv_block_fwd_x3.cuh (same arguments, same K20 filter section, same arithmetic per
-// output element: bit-identical results).
+// output element: o1 bit-identical; y differs in how the residual is added — hi + lo from the input ring here, x to 2^-18
+// relative, against the exact fp32 re-read of the tiled kernel).
 //
 // Why a second form.  conv_block_fwd_x3_kernel cuts an image into 16 x 8 tiles: every tile stages a 20 x 12 input halo (1.875 x
 // its own pixels, re-fetched from HBM because fp32 halos of 512 resident workgroups do not fit the L2s: 1.41 GB fetched for a
@@ -274,12 +275,14 @@ __global__ __launch_bounds__(256, 2) void conv_block_strip_x3_kernel(BlockFwdX3A
             }
         }
         if (s > 0) {
-            // residual: output rows 2s-2, 2s-1 of x again, exact fp32 (fetched one step ago: an L2 hit), in the epilogue layout
+            // output rows 2s-2, 2s-1 of this lane's pixel.  Their residual = input rows that are still in the input ring (rows
+            // (nb ^ 2), + 1), as hi + lo: x to 2^-18 relative, the precision the products see.  (Re-read from the tensor as exact
+            // fp32 they had left the L2 two steps after their fetch: 1.54 GB fetched per launch for a 0.81 GB input.)
             const int ey = 2 * s - 2 + (gq & 1);
             const unsigned eoff = ey < H ? (unsigned)(ibase + (ey * SW + col) * APX + hsel * 32) : MIL_OOB;
-            const u32x4_t rr0 = __builtin_amdgcn_raw_buffer_load_b128(rs_x, eoff, 0, 0);
-            const u32x4_t rr1 = __builtin_amdgcn_raw_buffer_load_b128(rs_x, eoff == MIL_OOB ? MIL_OOB : eoff + 16, 0, 0);
-            const u32x4_t rr2 = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (eoff == MIL_OOB || !last_ok) ? MIL_OOB : eoff + 64, 0, 0);
+            const char* xrec = ldsX + ((nb ^ 2) + (gq & 1)) * ROW + (col + 1) * PIXB;
+            const bf16x8_t xh0 = *reinterpret_cast<const bf16x8_t*>(xrec + hsel * 16), xl0 = *reinterpret_cast<const bf16x8_t*>(xrec + PLANE + hsel * 16);
+            const bf16x4_t xh1 = *reinterpret_cast<const bf16x4_t*>(xrec + 32), xl1 = *reinterpret_cast<const bf16x4_t*>(xrec + PLANE + 32);
             MIL_STAMP_MARK(5)
             __syncthreads();                   // new mid rows visible
             MIL_STAMP_MARK(6)
@@ -305,12 +308,11 @@ __global__ __launch_bounds__(256, 2) void conv_block_strip_x3_kernel(BlockFwdX3A
                 if (i == 0) mil_swap16<true>(lo, hi); else mil_swap16<false>(lo, hi);
                 u[i] = lo + hi;                                    // rows 0-3 + rows 4-7 (wl x o1_hi) of the same pixel
             }
-            const f32x4_t t0 = __builtin_bit_cast(f32x4_t, rr0), t1 = __builtin_bit_cast(f32x4_t, rr1), t2 = __builtin_bit_cast(f32x4_t, rr2);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float q = v[i] + t0[i]; v[i] = fmaxf(q, q * a.slope);
-                q = v[4 + i] + t1[i]; v[4 + i] = fmaxf(q, q * a.slope);
-                q = u[i] + t2[i]; u[i] = fmaxf(q, q * a.slope);
+                float q = v[i] + ((float)xh0[i] + (float)xl0[i]); v[i] = fmaxf(q, q * a.slope);
+                q = v[4 + i] + ((float)xh0[4 + i] + (float)xl0[4 + i]); v[4 + i] = fmaxf(q, q * a.slope);
+                q = u[i] + ((float)xh1[i] + (float)xl1[i]); u[i] = fmaxf(q, q * a.slope);
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4_t{v[0], v[1], v[2], v[3]}), rs_y, eoff, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4_t{v[4], v[5], v[6], v[7]}), rs_y, eoff == MIL_OOB ? MIL_OOB : eoff + 16, 0, 0);
