@@ -956,6 +956,8 @@ static int launch_stem_fwd_pool(StemFwdArgs a, hipStream_t st) {
     return MIL_OK;
 }
 
+#include "stem_walk.cuh"
+
 template <int NT, bool X3 = false, bool FROM_XS = false>
 static int launch_stem_fwd(StemFwdArgs a, hipStream_t st) {
     constexpr int COUTP = mil_nt_to_cp(NT);
@@ -1027,8 +1029,11 @@ extern "C" int mil_stem_fwd_fused(const float* x_nchw, const void* wpack, const 
 #ifndef MIL_STEM_FWD_POOL
 #define MIL_STEM_FWD_POOL 1           // 0: the round-2..4 kernel (stem tile through LDS, bf16-rounded activations pooled)
 #endif
-    if (MIL_STEM_FWD_POOL && cout_p == 24)
+    if (MIL_STEM_FWD_POOL && cout_p == 24) {
+        if (mil_stem_walk_wanted(a, mil_num_cus() * 2))
+            return dtype == MIL_DT_F32S ? launch_stem_fwd_walk<true>(a, st) : launch_stem_fwd_walk<false>(a, st);
         return dtype == MIL_DT_F32S ? launch_stem_fwd_pool<true, false>(a, st) : launch_stem_fwd_pool<false, false>(a, st);
+    }
     if (dtype == MIL_DT_F32S) return launch_stem_fwd<2, true>(a, st);
     return cout_p == 24 ? launch_stem_fwd<2>(a, st) : launch_stem_fwd<4>(a, st);
 }

@@ -989,6 +989,40 @@ def test_identity_block_forward_one_pass_split_precision(ops, case, monkeypatch)
     assert ops.conv_block_fwd(xg, p1, bp1, p2, bp2) is None           # exact-fp32 mode: no such kernel
 
 
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("case", [(2, 256), (3, 64), (5, 34), (2, 6), (600, 16), (1100, 8)])
+def test_stem_forward_row_walk_equals_tiled(ops, case, mode, monkeypatch):
+    """The row-walk form of the fused 20-channel stem forward (stem_fwd_walk_kernel: a workgroup walks a 256-pixel-wide image two
+    pooled rows per step, s2d rows in an LDS ring, the window row above carried in registers) against the 8 x 16-pooled-pixel
+    tile form: same filter fragments, same k order, same in-register pooling and winner codes — pooled map and winner records
+    bit for bit; heights whose pooled map has an odd number of rows, a single step, one and several images per workgroup."""
+    L = _lib()
+    n, h = case
+    dt = torch.bfloat16 if mode == "bf16" else torch.float32
+    code = L.MIL_DT_F32S if mode == "bf16x3" else L.MIL_DT_F32
+    g = torch.Generator().manual_seed(1601 + n + h)
+    x = torch.randn(n, 3, h, 256, generator=g).clamp_(-1, 1).cuda()
+    wt = (torch.randn(20, 3, 7, 7, generator=g) * 0.08).cuda()
+    b = (torch.randn(20, generator=g) * 0.1).cuda()
+    with L.f32_mma(code):
+        wp, bp = ops.pack_weights(wt, b, L.PACK_STEM, dt)
+        monkeypatch.setenv("MIL_STEM_WALK", "0")
+        tiled = ops.stem_fwd_fused(x, wp, bp, 24, dtype=dt, keep_s2d=False)
+        monkeypatch.setenv("MIL_STEM_WALK", "1")
+        walk = ops.stem_fwd_fused(x, wp, bp, 24, dtype=dt, keep_s2d=False)
+        again = ops.stem_fwd_fused(x, wp, bp, 24, dtype=dt, keep_s2d=False)
+    torch.cuda.synchronize()
+    assert tiled is not None and walk is not None
+    (_, pool_t, widx_t), (_, pool_w, widx_w), (_, pool_a, widx_a) = tiled, walk, again
+    assert torch.equal(pool_w, pool_a) and torch.equal(widx_w, widx_a)
+    assert torch.equal(pool_t.view(torch.int16 if dt == torch.bfloat16 else torch.int32), pool_w.view(torch.int16 if dt == torch.bfloat16 else torch.int32)), \
+        float((pool_t.float() - pool_w.float()).abs().max())
+    assert torch.equal(widx_t, widx_w), int((widx_t != widx_w).sum())
+    if n <= 5:
+        ref = F.max_pool2d(F.leaky_relu(F.conv2d(x.cpu(), wt.cpu(), b.cpu(), stride=2, padding=3), LEAK), 3, 2, 1)
+        assert rel_err(from_nhwc(pool_w, 20), ref) < (TOL[dt] if mode == "bf16" else TOL[X3])
+
+
 @pytest.mark.parametrize("case", [(2, 64, 0, 64), (5, 17, 0, 64), (3, 16, 0, 64), (9, 64, 3, 64), (700, 16, 0, 64), (1030, 18, 0, 64),
                                   (2, 128, 0, 128), (3, 19, 0, 128), (7, 32, 2, 128), (600, 16, 0, 128)])
 def test_identity_block_forward_row_walk_equals_tiled_bf16(ops, case, monkeypatch):
