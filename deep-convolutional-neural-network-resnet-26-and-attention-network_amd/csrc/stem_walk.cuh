@@ -342,15 +342,15 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_walk_kernel(StemFwdArgs a) {
 }
 
 // Row walk when the tile is 256 pixels wide, no space-to-depth copy is kept, and whole images fill the resident workgroups
-// evenly enough (cost: rounds x steps x ~8 k cycles against rounds x tiles x ~9 k).  MIL_STEM_WALK = 0 / 1 (read per call) is a
+// evenly enough (cost: rounds x steps x time per step against rounds x tiles x time per tile).  MIL_STEM_WALK = 0 / 1 (read per call) is a
 // TEST knob that forces either form.
 static bool mil_stem_walk_wanted(const StemFwdArgs& a, int grid_cap) {
     if (a.W != 256 || a.xs || a.xs_in || (a.H & 1) || a.Wo != 64) return false;
     const char* e = getenv("MIL_STEM_WALK");
     if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
     const long tiles = (long)a.n_img * ((a.Ho + 7) / 8) * 4;
-    const long cost_tile = (tiles + grid_cap - 1) / grid_cap * 9;
-    const long cost_walk = (long)((a.n_img + grid_cap - 1) / grid_cap) * ((a.Ho + 1) / 2 + 1) * 8;
+    const long cost_tile = (tiles + grid_cap - 1) / grid_cap * 6;           // measured: 6.5 / 11.0 us per tile, 5.4 / 9.0 us per step (bf16 / split)
+    const long cost_walk = (long)((a.n_img + grid_cap - 1) / grid_cap) * ((a.Ho + 1) / 2 + 1) * 5;
     return cost_walk < cost_tile;
 }
 
