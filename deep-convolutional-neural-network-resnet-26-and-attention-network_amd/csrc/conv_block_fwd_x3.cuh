@@ -13,7 +13,7 @@
 //     row tiles (no idle waves), and one workgroup's commit / barrier phases run under the other's MFMA loops.
 //   * the mid activation goes from the accumulators to the LDS planes (split there) AND, for the tile's own pixels, straight to
 //     the o1 tensor as exact fp32 (a lane holds four consecutive channels of a pixel = one 16-byte store); the residual is
-//     re-read from the x tensor (an L2 hit: the halo fetch has just read it) so that y adds the exact fp32 value.
+//     the centre of the input halo, hi + lo (x to 2^-18 relative; round 5: the exact fp32 re-read it replaced missed L2).
 //   * x / o1 / y are addressed at a RUN-TIME pixel stride a.apx: 96 bytes (24 padded channels) or 80 (dense 20 channels).
 #pragma once
 #include "stamp.cuh"
@@ -282,12 +282,13 @@ __global__ __launch_bounds__(256, 2) void conv_block_fwd_x3_kernel(BlockFwdX3Arg
                 }
             }
         }
-        // residual: the tile's own x pixels again, exact fp32 (an L2 hit), in the epilogue layout
+        // residual: the tile's own x pixels = the centre of the input halo in LDS, as hi + lo (x to 2^-18 relative: the precision
+        // the products see) in the epilogue layout — the same expression as the row-walk kernel's, so the two forms agree bit for
+        // bit and a result does not depend on which of them a launch size selects.  (Until round 5 the pixels were re-read from the
+        // tensor as exact fp32; at this footprint that re-read missed L2.)
         const bool e_ok = e_ty < ylim && r < xlim;
         const unsigned eoff = e_ok ? (unsigned)(obase + (e_ty * W + r) * APX + hsel * 32) : MIL_OOB;
-        const u32x4_t rr0 = __builtin_amdgcn_raw_buffer_load_b128(rs_x, eoff, 0, 0);
-        const u32x4_t rr1 = __builtin_amdgcn_raw_buffer_load_b128(rs_x, eoff == MIL_OOB ? MIL_OOB : eoff + 16, 0, 0);
-        const u32x4_t rr2 = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (eoff == MIL_OOB || !last_ok) ? MIL_OOB : eoff + 64, 0, MIL_BFX3_STORE_AUX);
+        const char* xrec = ldsX + ((e_ty + 2) * XW + r + 2) * PIXB;
         MIL_STAMP_MARK(5)
         __syncthreads();                       // mid tile visible
         MIL_STAMP_MARK(6)
@@ -314,12 +315,13 @@ __global__ __launch_bounds__(256, 2) void conv_block_fwd_x3_kernel(BlockFwdX3Arg
                 if (i == 0) mil_swap16<true>(lo, hi); else mil_swap16<false>(lo, hi);
                 u[i] = lo + hi;                                    // rows 0-3 + rows 4-7 (wl x o1_hi) of the same pixel
             }
-            const f32x4_t t0 = __builtin_bit_cast(f32x4_t, rr0), t1 = __builtin_bit_cast(f32x4_t, rr1), t2 = __builtin_bit_cast(f32x4_t, rr2);
+            const bf16x8_t xh0 = *reinterpret_cast<const bf16x8_t*>(xrec + hsel * 16), xl0 = *reinterpret_cast<const bf16x8_t*>(xrec + X_PLANE + hsel * 16);
+            const bf16x4_t xh1 = *reinterpret_cast<const bf16x4_t*>(xrec + 32), xl1 = *reinterpret_cast<const bf16x4_t*>(xrec + X_PLANE + 32);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float s = v[i] + t0[i]; v[i] = fmaxf(s, s * a.slope);
-                s = v[4 + i] + t1[i]; v[4 + i] = fmaxf(s, s * a.slope);
-                s = u[i] + t2[i]; u[i] = fmaxf(s, s * a.slope);
+                float s = v[i] + ((float)xh0[i] + (float)xl0[i]); v[i] = fmaxf(s, s * a.slope);
+                s = v[4 + i] + ((float)xh0[4 + i] + (float)xl0[4 + i]); v[4 + i] = fmaxf(s, s * a.slope);
+                s = u[i] + ((float)xh1[i] + (float)xl1[i]); u[i] = fmaxf(s, s * a.slope);
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4_t{v[0], v[1], v[2], v[3]}), rs_y, eoff, 0, MIL_BFX3_STORE_AUX);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4_t{v[4], v[5], v[6], v[7]}), rs_y, eoff == MIL_OOB ? MIL_OOB : eoff + 16, 0, MIL_BFX3_STORE_AUX);

@@ -1,8 +1,7 @@
 // Forward of a whole identity-shortcut residual block of the 20-channel stage, SPLIT PRECISION, on 64-pixel-wide maps (the layer-1
 // maps of 256 x 256 tiles), as a ROW WALK — nnBlocks.py:175-189:  o1 = lrelu(conv3x3(x) + b1),  y = lrelu(conv3x3(o1) + b2 + x).
 // Included by conv_block_fwd.hip behind conv_block_fwd_x3.cuh (same arguments, same K20 filter section, same arithmetic per
-// output element: o1 bit-identical; y differs in how the residual is added — hi + lo from the input ring here, x to 2^-18
-// relative, against the exact fp32 re-read of the tiled kernel).
+// output element, the residual as hi + lo from LDS in both: bit-identical results).
 //
 // Why a second form.  conv_block_fwd_x3_kernel cuts an image into 16 x 8 tiles: every tile stages a 20 x 12 input halo (1.875 x
 // its own pixels, re-fetched from HBM because fp32 halos of 512 resident workgroups do not fit the L2s: 1.41 GB fetched for a

@@ -1063,7 +1063,7 @@ def test_identity_block_forward_row_walk_equals_tiled_bf16(ops, case, monkeypatc
 def test_identity_block_forward_row_walk_equals_tiled(ops, case, monkeypatch):
     """The row-walk form of the split-precision block forward (conv_block_strip_x3_kernel: a workgroup walks a 64-pixel-wide image
     two rows at a time, input and mid activation in 4-row LDS rings) against the 16 x 8-tile form on the same inputs: the same
-    arithmetic per output element (o1 bit for bit; y up to the residual's representation, see below); odd heights (a row pair half outside), one image per workgroup and several
+    arithmetic per output element, so bit for bit; odd heights (a row pair half outside), one image per workgroup and several
     (700 and 1030 images on 512 resident workgroups), the launch split by the buffer limit (9 images, 3 per launch)."""
     monkeypatch.setenv("MIL_PF_MIN_TILES", "1")
     L = _lib()
@@ -1090,10 +1090,10 @@ def test_identity_block_forward_row_walk_equals_tiled(ops, case, monkeypatch):
     for t, v, u in zip(tiled, walk, again):
         assert torch.equal(v, u)
         assert float(v[..., c:].abs().max()) == 0.0
-    # o1: the same arithmetic per element, bit for bit.  y: the row walk adds the residual as hi + lo from its input ring (x to
-    # 2^-18 relative: the precision the products see; the tiled form re-reads the exact fp32 value)
-    assert torch.equal(tiled[0].view(torch.int32), walk[0].view(torch.int32)), float((tiled[0] - walk[0]).abs().max())
-    assert float((tiled[1] - walk[1]).abs().max()) <= 8e-6 * float(x.abs().max()), float((tiled[1] - walk[1]).abs().max())
+    # the same arithmetic per element in both forms (the residual as hi + lo from LDS in both): bit for bit, so that a result does
+    # not depend on which form a launch size selects (tests/test_gpu_dist.py compares one process with two ranks)
+    for t, v in zip(tiled, walk):
+        assert torch.equal(t.view(torch.int32), v.view(torch.int32)), float((t - v).abs().max())
     if n <= 9:
         ref1 = F.leaky_relu(F.conv2d(x, w1, b1, padding=1), LEAK)
         ref2 = F.leaky_relu(F.conv2d(ref1, w2, b2, padding=1) + x, LEAK)
