@@ -228,10 +228,11 @@ __device__ __forceinline__ void mil_poison_lds(void* base) {
 #endif
 
 // A/B switches of the development builds.  The shipped library reads NO ambient environment for kernel selection: the
-// switches exist only in `make VARIANT=<name> EXTRA=-DMIL_AB_SWITCHES` builds (tools/README.md).  (Four TEST knobs stay in
+// switches exist only in `make VARIANT=<name> EXTRA=-DMIL_AB_SWITCHES` builds (tools/README.md).  (Five TEST knobs stay in
 // every build, because the -m gpu tests drive small inputs through the large-launch paths with them: MIL_PF_MIN_TILES,
-// MIL_BUFFER_LIMIT_BYTES, MIL_RES_GRID_CAP, MIL_BLOCK_STRIP (0 / 1: the tiled / the row-walk form of the identity-block forward
-// whatever the launch size); and MIL_LIB_PATH on the Python side selects which build is loaded.)
+// MIL_BUFFER_LIMIT_BYTES, MIL_RES_GRID_CAP, MIL_BLOCK_STRIP and MIL_STEM_WALK (0 / 1: the tiled / the row-walk form of the
+// identity-block forward / of the fused stem forward whatever the launch size); and MIL_LIB_PATH on the Python side selects
+// which build is loaded.)
 #include <cstdlib>
 __host__ inline const char* mil_ab_env(const char* name) {
 #ifdef MIL_AB_SWITCHES

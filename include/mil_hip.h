@@ -260,7 +260,10 @@ int mil_conv_dgrad_s2(const void* dz1, const void* dz2, const void* wpack, const
  * identical input patches, whose weight-gradient contributions are identical whichever of them the gradient is routed to).
  * The packed filter (MIL_PACK_STEM) of a 20-channel stem carries six K-packed k-steps behind the eight standard ones
  * (mil_packed_weight_elems says so); bias_pad needs 32 floats.  H even, W % 4 == 0, x 16-byte aligned, otherwise
- * MIL_ERR_UNSUPPORTED (the caller then uses the three calls). */
+ * MIL_ERR_UNSUPPORTED (the caller then uses the three calls).
+ * Two kernels for the 20-channel stem, bit-identical pool / widx: 8x16-pooled-pixel tiles, or — W == 256, xs == NULL and enough
+ * images to fill the resident workgroups evenly, about 512 — a row walk (one workgroup per image, the space-to-depth rows in an
+ * LDS ring, every input byte fetched once).  MIL_STEM_WALK=0/1 (a test knob, read per call) forces either form. */
 int mil_stem_fwd_fused(const float* x_nchw, const void* wpack, const float* bias_pad, void* xs, void* pool,
                        uint8_t* widx, int n_img, int H, int W, int cout_p, float slope, int dtype, void* stream);
 /* The same pass fed by the bf16 space-to-depth tensor xs [n,H2,W2,16] itself (mil_tile_preprocess_s2d's output): a
