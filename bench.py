@@ -345,8 +345,10 @@ def _family_kernel(fam, dtype_name):
     """(description, kernel-name keys into the rocprofv3 summaries) of a bracketed family, per compute mode."""
     x3 = dtype_name == "bf16x3"
     table = {
-        "block_fwd": (("conv_block_fwd_x3_kernel (whole identity block forward, split precision: conv-lrelu-conv-add-lrelu, 20 ch", ("conv_block_fwd_x3_kernel",)) if x3 else
-                      ("conv_block_fwd_kernel<24,..> (whole identity block forward: conv-lrelu-conv-add-lrelu, 20 ch", ("conv_block_fwd_kernel<24,",))),
+        "block_fwd": (("conv_block_strip_x3_kernel / conv_block_fwd_x3_kernel (whole identity block forward, split precision: conv-lrelu-conv-add-lrelu, 20 ch; "
+                       "row walk from about 512 images of 64-wide maps, else 16x8 tiles", ("conv_block_strip_x3_kernel", "conv_block_fwd_x3_kernel")) if x3 else
+                      ("conv_block_strip_kernel<SW,R> / conv_block_fwd_kernel<24,..> (whole identity block forward: conv-lrelu-conv-add-lrelu, 20 ch; "
+                       "row walk from about 512 images of 64- or 128-wide maps, else 16x16 tiles", ("conv_block_strip_kernel<", "conv_block_fwd_kernel<24,"))),
         "conv": (("conv_igemm_pf_kernel<F32S,24,2,3,4,..>" if x3 else "conv_igemm_pf_kernel<BF16,24,2,3,4,..>") +
                  " (3x3 s1 conv, forward or data gradient, 20->20 ch",
                  ("conv_igemm_pf_kernel<F32S, 24, 2, 3, 4",) if x3 else ("conv_igemm_pf_kernel<BF16, 24, 2, 3, 4", "conv_igemm_pf_kernel<24, 2, 3, 4")),
@@ -355,7 +357,8 @@ def _family_kernel(fam, dtype_name):
                       ("conv_bwd_fused16_kernel<ADD,MASK> (fused data+weight gradient of the 3x3 s1 conv, 16x16 tiles, 20->20 ch",
                        ("conv_bwd_fused16_kernel<", "conv_bwd_fused_kernel<BF16, 24, 2, 3", "conv_bwd_fused_kernel<24, 2, 3"))),
         "wgrad": ("wgrad_kernel<..3,24,2,..> (weight+bias gradient of the 3x3 s1 conv, 20->20 ch", ("wgrad_kernel<F32S, 3, 24, 2", "wgrad_kernel<BF16, 3, 24, 2")),
-        "stem_fwd": ("stem_fwd_pool_kernel (fp32 tiles -> s2d -> 7x7/s2 conv + bias + LeakyReLU -> 3x3/s2 max-pool in registers, one pass", ("stem_fwd_pool_kernel<", "stem_fwd_fused_kernel<")),
+        "stem_fwd": ("stem_fwd_walk_kernel / stem_fwd_pool_kernel (fp32 tiles -> s2d -> 7x7/s2 conv + bias + LeakyReLU -> 3x3/s2 max-pool in registers, one pass; "
+                     "row walk from about 512 tiles of 256x256, else 8x16-pooled-pixel tiles", ("stem_fwd_walk_kernel<", "stem_fwd_pool_kernel<", "stem_fwd_fused_kernel<")),
         "stem_bwd": ("stem_bwd_fused_kernel<FROM_X> (max-pool backward + LeakyReLU backward + 7x7 weight gradient, one pass", ("stem_bwd_fused_kernel<",)),
         "stem_fwd_xs": ("stem_fwd_pool_kernel<..FROM_XS> (bf16 s2d tiles -> 7x7/s2 conv + bias + LeakyReLU -> 3x3/s2 max-pool in registers, one pass", ("stem_fwd_pool_kernel<", "stem_fwd_fused_kernel<")),
         "stem_bwd_xs": ("stem_bwd_fused_kernel (bf16 s2d tiles: max-pool backward + LeakyReLU backward + 7x7 weight gradient, one pass", ("stem_bwd_fused_kernel<",)),

@@ -705,7 +705,11 @@ struct StemBwdArgs {
 #endif
 // X3 (MIL_DT_F32S, FROM_X only): fp32 pooled gradient; the s2d tile and the dz tile hold hi and lo bf16 planes ([hi | lo] per
 // pixel record), the weight-gradient GEMM takes x_lo*dz_hi + x_hi*dz_lo + x_hi*dz_hi, the bias sums are the un-rounded fp32 values.
-template <bool FROM_X, bool X3 = false>
+// NPW = pooled-window pieces per thread: 1 when the tile's windows x 3 pieces fit 256 threads (16 x 16 tiles of one image: 81
+// windows = 243 pieces — every map of at least 9 pixels), else 2.  An unused second slot is three more loads per thread and tile
+// with an out-of-range offset: no memory traffic, but a quarter of this kernel's load instructions, and issuing them is what
+// its "fetch issue" phase (23 % of a tile) pays for.
+template <bool FROM_X, bool X3 = false, int NPW = 2>
 __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel(StemBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MIL_POISON(smem);
@@ -719,7 +723,6 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
     constexpr int NPC = 3, MT = KS * KS * NPC / 4, MW = (MT + 3) / 4;
     constexpr int NPX = mil_halo_np(CINP, 2);
     constexpr int NL = 3;                                   // FROM_X load items per thread (<= 400 halo px: <= 210 pairs x 3 colours)
-    constexpr int NPW = 2;                                  // pooled-window pieces per thread (<= 144 windows x 3)
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1117,7 +1120,14 @@ static int stem_bwd_entry(const void* xs, const float* x, const void* gp, const 
     const int lds = xb + zb + gb + ib + 48;                 // + dump slot (FROM_X: second pixel of a pair behind an odd-width halo; hi + lo)
     const int groups = (chunk + (1 << g.ti_log2) - 1) >> g.ti_log2;
     const int ntiles_max = groups * g.tiles_y * g.tiles_x;
-    auto kern = x3 ? stem_bwd_fused_kernel<true, true> : from_x ? stem_bwd_fused_kernel<true> : stem_bwd_fused_kernel<false>;
+#ifdef MIL_EXP_STEM_BWD_NPW2                                // A/B build: always two window slots per thread (the form until round 5)
+    const bool one = false;
+#else
+    const bool one = nwin * 3 <= 256;                       // one window piece per thread
+#endif
+    auto kern = x3 ? (one ? stem_bwd_fused_kernel<true, true, 1> : stem_bwd_fused_kernel<true, true, 2>)
+              : from_x ? (one ? stem_bwd_fused_kernel<true, false, 1> : stem_bwd_fused_kernel<true, false, 2>)
+                       : (one ? stem_bwd_fused_kernel<false, false, 1> : stem_bwd_fused_kernel<false, false, 2>);
     int grid = mil_num_cus() * mil_resident_per_cu(kern, lds, 4) * 2;          // two rounds of the resident set
     if (grid > ntiles_max) grid = ntiles_max;
     const size_t slab_elems = (size_t)(MT + 1) * 16 * 32;
