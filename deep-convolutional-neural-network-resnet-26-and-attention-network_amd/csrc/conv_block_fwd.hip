@@ -333,6 +333,9 @@ static int launch_block_fwd(BlockFwdArgs a, hipStream_t st) {
 // either way; rings of 2R rows.  Row tile m of a wave = (row m % R2, column block wave + 4 * (m / R2)) with R2 = rows per
 // column block = R (64 wide) or 2 (128 wide: two column blocks per wave), so that row tiles 2p, 2p+1 are always two rows of
 // the same columns (the epilogue's permlane pairs).
+#ifndef MIL_STRIP_LA
+#define MIL_STRIP_LA 2                // pixel fragments read this many (k-step, row tile) steps ahead of their MFMAs
+#endif
 template <int SW, int R> struct StripCfg {
     static constexpr int RP = SW + 1, ROW = RP * 48, NR = 2 * R, PLANE = (NR * RP + 1) * 48;
     static constexpr int W_BYTES = 7 * 2 * 64 * 16;
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void conv_block_strip_kernel(BlockFwdArgs a
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[m][nt] = b1r[nt];
-            mil_conv_ring<NT, MT, KSTEPS, 2>(acc, smem + OFF_W1, lane, [&](int sl, int m) { return ldsX + pb + koff[m][sl]; });
+            mil_conv_ring<NT, MT, KSTEPS, MIL_STRIP_LA>(acc, smem + OFF_W1, lane, [&](int sl, int m) { return ldsX + pb + koff[m][sl]; });
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const bool inside = (unsigned)(R * s - 1 + m_row(m)) < (unsigned)H;     // wave-uniform: a mid row outside the image is conv2's zero padding
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void conv_block_strip_kernel(BlockFwdArgs a
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[m][nt] = b2r[nt];
-            mil_conv_ring<NT, MT, KSTEPS, 2>(acc, smem + OFF_W2, lane, [&](int sl, int m) { return ldsO + pb + koff[m][sl]; });
+            mil_conv_ring<NT, MT, KSTEPS, MIL_STRIP_LA>(acc, smem + OFF_W2, lane, [&](int sl, int m) { return ldsO + pb + koff[m][sl]; });
 #pragma unroll
             for (int p = 0; p < MT / 2; ++p) {
                 // after the swap a lane holds 8 channels of pixel (row rr, column col) of row tiles 2p, 2p+1

@@ -19,6 +19,9 @@
 // A step costs an image prologue (step 0 computes mid rows -1 and 0 only: +3 % of conv1) and whole images are the unit of
 // work, so the launcher takes this form only when the images fill the resident workgroups evenly enough (launch_block_fwd_x3).
 #pragma once
+#ifndef MIL_STRIP_X3_LA
+#define MIL_STRIP_X3_LA 2             // pixel fragments read this many (k-step, row tile) steps ahead of their MFMAs
+#endif
 
 __global__ __launch_bounds__(256, 2) void conv_block_strip_x3_kernel(BlockFwdX3Args a, int n_img, unsigned bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv_block_strip_x3_kernel(BlockFwdX3A
     };
     int koff[MT][KSTEPS];                                            // per step: fragment offsets of ring row m
     auto conv = [&](f32x4_t (&acc)[MT][NT], const char* ldsW, const char* plane0) {
-        constexpr int TOT = KSTEPS * MT, LA = 2, R = LA + 1;
+        constexpr int TOT = KSTEPS * MT, LA = MIL_STRIP_X3_LA, R = LA + 1;
         Frag8<F32S> ring[R], wq[2][NT];
         auto pfrag = [&](int j) {
             const char* p = plane0 + pb + koff[j % MT][j / MT];
