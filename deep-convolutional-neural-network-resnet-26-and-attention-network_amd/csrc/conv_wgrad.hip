@@ -1087,6 +1087,8 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
     }
 }
 
+#include "stem_bwd_walk.cuh"
+
 // xs != null: the bf16 space-to-depth copy [n,H2,W2,16] is the conv input; else x = the fp32 tiles [n,3,H,W] (H = 2*H2,
 // W = 2*W2, W % 4 == 0) and the kernel rebuilds its s2d tiles itself.  Inputs beyond the 2 GiB reach of a buffer
 // descriptor are walked in image chunks, later chunks accumulating into dW/db.
@@ -1137,6 +1139,19 @@ static int stem_bwd_entry(const void* xs, const float* x, const void* gp, const 
     a.slab = (float*)ws;
     a.lds_z_off = xb; a.lds_g_off = xb + zb; a.lds_i_off = xb + zb + gb; a.lds_dump_off = xb + zb + gb + ib; a.slope = slope;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // the row-walk form (stem_bwd_walk.cuh): one workgroup per image, no more slabs than the tiled form's workspace holds
+    const bool walk = mil_stem_walk_wanted_bwd(n, H2, W2, from_x, !x3, g.tiles_y * g.tiles_x, mil_num_cus() * 2);
+    int walk_grid = 0;
+    if (walk) {
+        auto wk = stem_bwd_walk_kernel;
+        static std::atomic<unsigned long long> attr_set{0};
+        if (mil_device_needs(attr_set)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, SBW_LDS) != hipSuccess) return MIL_ERR_LAUNCH;
+            mil_device_done(attr_set);
+        }
+        walk_grid = mil_num_cus() * mil_resident_per_cu(wk, SBW_LDS, 2);
+        if (walk_grid > grid) walk_grid = grid;
+    }
     for (int i0 = 0; i0 < n; i0 += chunk) {
         const int nc = n - i0 < chunk ? n - i0 : chunk;
         StemBwdArgs c = a;
@@ -1146,16 +1161,17 @@ static int stem_bwd_entry(const void* xs, const float* x, const void* gp, const 
         else { c.xs = (const __bf16*)xs + (size_t)i0 * H2 * W2 * 16; c.xs_bytes = (unsigned)((size_t)nc * H2 * W2 * 32); }
         c.gp = (const __bf16*)gp + (size_t)i0 * a.Hp * a.Wp * (gpx / 2); c.gp_bytes = (unsigned)((size_t)nc * gp_img);
         c.widx = widx + (size_t)i0 * a.Hp * a.Wp * 24; c.wi_bytes = (unsigned)((size_t)nc * a.Hp * a.Wp * 24);
-        const int gr = grid < c.ntiles ? grid : c.ntiles;
+        const int gr = walk ? (walk_grid < nc ? walk_grid : nc) : (grid < c.ntiles ? grid : c.ntiles);
 #ifdef MIL_STAMP
         static MilStampBuf sb;
         c.stamp = sb.get((size_t)gr * 4 * 9);
 #endif
-        hipLaunchKernelGGL(kern, dim3(gr), dim3(256), lds, st, c);
+        if (walk) hipLaunchKernelGGL(stem_bwd_walk_kernel, dim3(gr), dim3(256), SBW_LDS, st, c);
+        else hipLaunchKernelGGL(kern, dim3(gr), dim3(256), lds, st, c);
         MIL_CHECK_LAUNCH();
 #ifdef MIL_STAMP
         static const char* const ph[7] = {"barrier-top", "commit", "barrier-x", "fetch-issue", "gather", "barrier-z", "gemm"};
-        sb.report(x3 ? "stem_bwd_fused_kernel<x3>" : "stem_bwd_fused_kernel", gr, 4, 7, ph, st);
+        sb.report(walk ? "stem_bwd_walk_kernel" : x3 ? "stem_bwd_fused_kernel<x3>" : "stem_bwd_fused_kernel", gr, 4, 7, ph, st);
 #endif
         MilReduceJob j{};
         j.slab = (const float*)ws; j.nslab = gr; j.slab_elems = slab_elems; j.slab_cols = 32; j.n_rows = 16 * 12;

@@ -989,6 +989,38 @@ def test_identity_block_forward_one_pass_split_precision(ops, case, monkeypatch)
     assert ops.conv_block_fwd(xg, p1, bp1, p2, bp2) is None           # exact-fp32 mode: no such kernel
 
 
+@pytest.mark.parametrize("dense", [False, True])
+@pytest.mark.parametrize("case", [(2, 256), (3, 64), (5, 36), (2, 4), (600, 16), (1100, 8)])
+def test_stem_backward_row_walk_against_tiled(ops, case, dense, monkeypatch):
+    """The row-walk form of the fused bf16 stem backward (stem_bwd_walk_kernel: a workgroup walks a 256-pixel-wide image two stem
+    rows per step, s2d rows and pooling windows in LDS rings) against the 16 x 16-tile form on the same tiles, pooled gradient and
+    winner records: the same gather and the same GEMM per pixel, summed over other groups of pixels per workgroup — equal to fp32
+    summation order; against autograd for small inputs.  Padded and dense pooled-gradient layouts, one and several images per
+    workgroup, a single step."""
+    L = _lib()
+    n, h = case
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(1811 + n + h)
+    x = torch.randn(n, 3, h, 256, generator=g).clamp_(-1, 1).cuda()
+    wt = (torch.randn(20, 3, 7, 7, generator=g) * 0.08).cuda()
+    b = (torch.randn(20, generator=g) * 0.1).cuda()
+    wp, bp = ops.pack_weights(wt, b, L.PACK_STEM, dt)
+    _, pool, widx = ops.stem_fwd_fused(x, wp, bp, 24, dtype=dt, keep_s2d=False)
+    gp = torch.randn(pool.shape[:3] + (20 if dense else 24,), generator=torch.Generator(device="cuda").manual_seed(5), device="cuda").to(dt)
+    if not dense:
+        gp[..., 20:] = 0
+    monkeypatch.setenv("MIL_STEM_WALK", "0")
+    dw_t, db_t = ops.stem_bwd_fused_nchw(x, gp, widx)
+    monkeypatch.setenv("MIL_STEM_WALK", "1")
+    dw_w, db_w = ops.stem_bwd_fused_nchw(x, gp, widx)
+    dw_a, db_a = ops.stem_bwd_fused_nchw(x, gp, widx)
+    torch.cuda.synchronize()
+    assert torch.equal(dw_w, dw_a) and torch.equal(db_w, db_a)          # bit-reproducible
+    scale_w, scale_b = float(dw_t.abs().max()), float(db_t.abs().max())
+    assert float((dw_w - dw_t).abs().max()) <= 2e-5 * scale_w, (float((dw_w - dw_t).abs().max()), scale_w)
+    assert float((db_w - db_t).abs().max()) <= 2e-5 * scale_b, (float((db_w - db_t).abs().max()), scale_b)
+
+
 @pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
 @pytest.mark.parametrize("case", [(2, 256), (3, 64), (5, 34), (2, 6), (600, 16), (1100, 8)])
 def test_stem_forward_row_walk_equals_tiled(ops, case, mode, monkeypatch):
