@@ -359,7 +359,8 @@ def _family_kernel(fam, dtype_name):
         "wgrad": ("wgrad_kernel<..3,24,2,..> (weight+bias gradient of the 3x3 s1 conv, 20->20 ch", ("wgrad_kernel<F32S, 3, 24, 2", "wgrad_kernel<BF16, 3, 24, 2")),
         "stem_fwd": ("stem_fwd_walk_kernel / stem_fwd_pool_kernel (fp32 tiles -> s2d -> 7x7/s2 conv + bias + LeakyReLU -> 3x3/s2 max-pool in registers, one pass; "
                      "row walk from about 512 tiles of 256x256, else 8x16-pooled-pixel tiles", ("stem_fwd_walk_kernel<", "stem_fwd_pool_kernel<", "stem_fwd_fused_kernel<")),
-        "stem_bwd": ("stem_bwd_fused_kernel<FROM_X> (max-pool backward + LeakyReLU backward + 7x7 weight gradient, one pass", ("stem_bwd_fused_kernel<",)),
+        "stem_bwd": ("stem_bwd_walk_kernel / stem_bwd_fused_kernel<FROM_X> (max-pool backward + LeakyReLU backward + 7x7 weight gradient, one pass; "
+                     "bf16: row walk from about 512 tiles of 256x256, else 16x16 tiles", ("stem_bwd_walk_kernel", "stem_bwd_fused_kernel<")),
         "stem_fwd_xs": ("stem_fwd_pool_kernel<..FROM_XS> (bf16 s2d tiles -> 7x7/s2 conv + bias + LeakyReLU -> 3x3/s2 max-pool in registers, one pass", ("stem_fwd_pool_kernel<", "stem_fwd_fused_kernel<")),
         "stem_bwd_xs": ("stem_bwd_fused_kernel (bf16 s2d tiles: max-pool backward + LeakyReLU backward + 7x7 weight gradient, one pass", ("stem_bwd_fused_kernel<",)),
     }

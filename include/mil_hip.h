@@ -285,7 +285,10 @@ int mil_stem_bwd_fused(const void* xs, const void* g_pool, const uint8_t* widx, 
 /* Same backward when no space-to-depth copy was kept (mil_stem_fwd_fused with xs = NULL): reads the fp32 tiles
  * x [n,3,H,W] themselves and rebuilds the bf16 s2d tile in LDS (H even, W % 4 == 0, x 16-byte aligned, else
  * MIL_ERR_UNSUPPORTED).  The stem then moves 1.07 GB less in the forward and 0.5 GB more in the (compute-bound)
- * backward per 2048 tiles of 256x256. */
+ * backward per 2048 tiles of 256x256.
+ * bf16, W == 256 and enough images to fill the resident workgroups evenly (about 512): a row walk (one workgroup per image,
+ * s2d rows and pooling windows in LDS rings) instead of 16x16 tiles; dW / db agree between the two forms to fp32 summation
+ * order (a workgroup's partial sums cover other pixels).  MIL_STEM_WALK=0/1 (a test knob, read per call) forces either form. */
 int mil_stem_bwd_fused_nchw_workspace(size_t* bytes, int n, int H, int W, int dtype);
 int mil_stem_bwd_fused_nchw(const float* x_nchw, const void* g_pool, const uint8_t* widx, float* dw, float* db,
                             void* workspace, size_t workspace_bytes, int n, int H, int W, float slope, int accumulate,
