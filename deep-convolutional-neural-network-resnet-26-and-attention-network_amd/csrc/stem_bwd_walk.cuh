@@ -9,7 +9,8 @@
 // owns a whole IMAGE and walks down two stem rows (256 pixels, the GEMM's K per step as before) at a time:
 //   * s2d rows in a 6-row LDS ring: a step converts the two NEW rows (four image rows x three colours, each ONE contiguous 1 KB
 //     load instruction per wave) and re-uses three; every input byte fetched once;
-//   * pooling windows in a 3-row ring: one new pooled row (64 windows x 3 pieces: 3 KB contiguous) per step;
+//   * pooling windows in a 3-row ring: one new pooled row (64 windows x 3 pieces: 3 KB contiguous) per step, DECODED as it is
+//     committed (masked gradient as fp32): the gather's four blocks around a window read the decoded values;
 //   * columns -4 .. -1 / 128 .. 129 of an s2d row and window column 64 are padding: zeroed once, never written;
 //   * the row part of an A-operand address is ((2s + dy + ty) mod 6) * ROWB, rebuilt per step (6 values per lane).
 // Steps per image: H2/2 + 1 (step 0 only loads).  Whole images are the unit of work (mil_stem_walk_wanted_bwd); MIL_STEM_WALK
@@ -21,14 +22,14 @@ constexpr int SBW_XW = 134, SBW_NRING = 6, SBW_WW = 65;
 constexpr int SBW_ROWB = SBW_XW * 48;
 constexpr int SBW_XBYTES = SBW_NRING * SBW_ROWB;                       // 38592
 constexpr int SBW_ZBYTES = 256 * 48;                                    // 12288
-constexpr int SBW_GBYTES = 3 * SBW_WW * 48, SBW_IBYTES = 3 * SBW_WW * 24;      // 9360, 4680
+constexpr int SBW_GBYTES = 3 * SBW_WW * 96, SBW_IBYTES = 3 * SBW_WW * 24;      // 18720 (decoded fp32 gradients), 4680
 constexpr int SBW_LDS = SBW_XBYTES + SBW_ZBYTES + SBW_GBYTES + SBW_IBYTES + 64;
 
 __global__ __launch_bounds__(256, 2) void stem_bwd_walk_kernel(StemBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MIL_POISON(smem);
     constexpr int NT = 2, KS = 4, COUTP = 24;
-    constexpr int PIXB = 48, PIXZ = 48, PIXG = 48, ROWB = SBW_ROWB, NRING = SBW_NRING, WW = SBW_WW;
+    constexpr int PIXB = 48, PIXZ = 48, PIXG = 96, ROWB = SBW_ROWB, NRING = SBW_NRING, WW = SBW_WW;
     constexpr int NPC = 3, MT = KS * KS * NPC / 4, MW = (MT + 3) / 4;      // 12 row tiles of (tap, four s2d channels), three per wave
     static_assert(MT == 4 * MW, "every wave owns MW full row tiles");
     const int tid = threadIdx.x, lane = tid & 63;
@@ -135,8 +136,21 @@ __global__ __launch_bounds__(256, 2) void stem_bwd_walk_kernel(StemBwdArgs a) {
                 for (int id = tid; id < ROWB / 16; id += 256) *reinterpret_cast<uint4*>(ldsX + 2 * ROWB + id * 16) = make_uint4(0, 0, 0, 0);
             }
             if (w_used) {
+                // a window's record is decoded ONCE here — the masked gradient g * lrelu'(winner) as fp32 — instead of by each of the
+                // four 2x2 blocks around it in the gather (24 of a gather thread's decodes per step: a third of its instructions)
                 const int wr = s % 3;
-                *reinterpret_cast<u32x4_t*>(ldsG + (wr * WW + w_win) * PIXG + w_j * 16) = rgp;
+                f32x4_t g0, g1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned wb = (rwi[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                    const unsigned gw = rgp[j >> 1];
+                    const float gj = __uint_as_float((j & 1) ? (gw & 0xffff0000u) : (gw << 16));
+                    const float gm = (wb & 16u) ? gj * a.slope : gj;
+                    if (j < 4) g0[j] = gm; else g1[j - 4] = gm;
+                }
+                char* gd = ldsG + (wr * WW + w_win) * PIXG + w_j * 32;
+                *reinterpret_cast<f32x4_t*>(gd) = g0;
+                *reinterpret_cast<f32x4_t*>(gd + 16) = g1;
                 *reinterpret_cast<u32x2_t*>(ldsI + (wr * WW + w_win) * COUTP + w_j * 8) = rwi;
             }
         }
@@ -165,15 +179,13 @@ __global__ __launch_bounds__(256, 2) void stem_bwd_walk_kernel(StemBwdArgs a) {
                     for (int wx = 0; wx < 2; ++wx) {
                         const int win = wr * WW + b_x + wx;
                         const unsigned short* wi = reinterpret_cast<const unsigned short*>(ldsI + win * COUTP + bc6 * 6);
-                        const unsigned* gp = reinterpret_cast<const unsigned*>(ldsG + win * PIXG + bc6 * 12);
+                        const f32x2_t* gp = reinterpret_cast<const f32x2_t*>(ldsG + win * PIXG + bc6 * 24);
                         const unsigned wpk[3] = {wi[0], wi[1], wi[2]};
-                        const unsigned gpk[3] = {gp[0], gp[1], gp[2]};
+                        const f32x2_t gpk[3] = {gp[0], gp[1], gp[2]};
 #pragma unroll
                         for (int j = 0; j < 6; ++j) {
-                            const unsigned wb = (wpk[j >> 1] >> (8 * (j & 1))) & 0xffu;
-                            const float gj = __uint_as_float((j & 1) ? (gpk[j >> 1] & 0xffff0000u) : (gpk[j >> 1] << 16));
-                            const float gm = (wb & 16u) ? gj * a.slope : gj;
-                            const unsigned t = wb & 15u;
+                            const float gm = gpk[j >> 1][j & 1];
+                            const unsigned t = (wpk[j >> 1] >> (8 * (j & 1))) & 15u;
 #pragma unroll
                             for (int dy = 0; dy < 2; ++dy) {
                                 const int ky = dy + 1 - 2 * wy;          // tap row of pixel 2k+dy inside window k+wy
