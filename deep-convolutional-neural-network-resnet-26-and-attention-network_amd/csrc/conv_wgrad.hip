@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
     constexpr int CINP = 16, NT = 2, KS = 4, COUTP = 24;
     constexpr int PIXB = mil_pix_pitch(CINP, X3 ? 4 : 2);   // 48; X3: 80 = [hi 32 B][lo 32 B] + pad
     constexpr int PIXZ = mil_pix_pitch(COUTP, X3 ? 4 : 2);  // dz tile: 48; X3: 112 = [hi 48 B][lo 48 B] + pad
-    constexpr int PIXG = X3 ? 96 : PIXZ;                    // pooled-gradient tile: bf16 record, or 24 fp32
+    constexpr int PIXG = 96;                                // pooled-gradient tile: 24 fp32 per window — the DECODED gradient g * lrelu'(winner), see the commit
     // GEMM rows = (tap, s2d channel) in four-channel pieces (one ds_read_b64_tr_b16 each): 16 taps x 3 real pieces = 48 pieces
     // = 12 row tiles; the padding piece (channels 12-15) of a pixel record is never read
     constexpr int NPC = 3, MT = KS * KS * NPC / 4, MW = (MT + 3) / 4;
@@ -882,12 +882,20 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             if (w_pos[i] >= 0) {
-                if constexpr (X3) {
-                    *reinterpret_cast<u32x4_t*>(ldsG + w_lds[i] * 4) = rgp[i];
-                    *reinterpret_cast<u32x4_t*>(ldsG + w_lds[i] * 4 + 16) = rgp2[i];
-                } else {
-                    *reinterpret_cast<u32x4_t*>(ldsG + w_lds[i] * 2) = rgp[i];
+                // a window's record is decoded ONCE here (the masked gradient as fp32) instead of by each of the four 2x2 blocks
+                // around it in the gather (round 5: 24 decodes per gather thread and tile, a third of its instructions in bf16)
+                f32x4_t g0, g1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned wb = (rwi[i][j >> 2] >> (8 * (j & 3))) & 0xffu;
+                    float gj;
+                    if constexpr (X3) gj = __uint_as_float(j < 4 ? rgp[i][j] : rgp2[i][j - 4]);
+                    else { const unsigned gw = rgp[i][j >> 1]; gj = __uint_as_float((j & 1) ? (gw & 0xffff0000u) : (gw << 16)); }
+                    const float gm = (wb & 16u) ? gj * a.slope : gj;
+                    if (j < 4) g0[j] = gm; else g1[j - 4] = gm;
                 }
+                *reinterpret_cast<f32x4_t*>(ldsG + w_lds[i] * 4) = g0;
+                *reinterpret_cast<f32x4_t*>(ldsG + w_lds[i] * 4 + 16) = g1;
                 *reinterpret_cast<u32x2_t*>(ldsI + w_lds[i]) = rwi[i];
             }
         }
@@ -920,18 +928,13 @@ __global__ __launch_bounds__(256, MIL_STEM_BWD_WAVES) void stem_bwd_fused_kernel
                 for (int wx = 0; wx < 2; ++wx) {
                     const int win = (b_ti * WH + b_y + wy) * WW + b_x + wx;
                     const unsigned short* wi = reinterpret_cast<const unsigned short*>(ldsI + win * COUTP + bc6 * 6);
-                    const unsigned* gp = reinterpret_cast<const unsigned*>(ldsG + win * PIXG + bc6 * (X3 ? 24 : 12));
+                    const f32x2_t* gp = reinterpret_cast<const f32x2_t*>(ldsG + win * PIXG + bc6 * 24);
                     const unsigned wpk[3] = {wi[0], wi[1], wi[2]};
-                    unsigned gpk[X3 ? 6 : 3];
-#pragma unroll
-                    for (int k = 0; k < (X3 ? 6 : 3); ++k) gpk[k] = gp[k];
+                    const f32x2_t gpk[3] = {gp[0], gp[1], gp[2]};
 #pragma unroll
                     for (int j = 0; j < 6; ++j) {
-                        const unsigned wb = (wpk[j >> 1] >> (8 * (j & 1))) & 0xffu;
-                        const float gj = X3 ? __uint_as_float(gpk[X3 ? j : 0])
-                                            : __uint_as_float((j & 1) ? (gpk[j >> 1] & 0xffff0000u) : (gpk[j >> 1] << 16));
-                        const float gm = (wb & 16u) ? gj * a.slope : gj;
-                        const unsigned t = wb & 15u;
+                        const float gm = gpk[j >> 1][j & 1];
+                        const unsigned t = (wpk[j >> 1] >> (8 * (j & 1))) & 15u;
 #pragma unroll
                         for (int dy = 0; dy < 2; ++dy) {
                             const int ky = dy + 1 - 2 * wy;          // tap row of pixel 2*b_y+dy inside window b_y+wy
@@ -1100,7 +1103,7 @@ static int stem_bwd_entry(const void* xs, const float* x, const void* gp, const 
     const int gpx = x3 ? (dtype == MIL_DT_F32S_DGRAD ? 80 : 96) : dtype == MIL_DT_BF16_DGRAD ? 40 : 48;   // g_pool [n,Hp,Wp,20] dense or [n,Hp,Wp,24]
     if (n <= 0 || H2 <= 0 || W2 <= 0) return MIL_ERR_ARG;
     if (from_x && (W2 & 1)) return MIL_ERR_UNSUPPORTED;      // 16-byte input pieces: W % 4 == 0
-    const int PIXB = mil_pix_pitch(16, x3 ? 4 : 2), PIXZ = mil_pix_pitch(24, x3 ? 4 : 2), PIXG = x3 ? 96 : PIXZ;
+    const int PIXB = mil_pix_pitch(16, x3 ? 4 : 2), PIXZ = mil_pix_pitch(24, x3 ? 4 : 2), PIXG = 96;
     constexpr int MT = 12;                                  // 16 taps x 3 four-channel row pieces / 4 (see the kernel)
     StemBwdArgs a{};
     ConvGeom& g = a.g;
