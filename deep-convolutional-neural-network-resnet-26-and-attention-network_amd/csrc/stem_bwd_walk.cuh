@@ -5,7 +5,8 @@
 //
 // The tiled kernel stages a 19 x 19 s2d halo per 16 x 16 stem pixels (1.41 x) out of 152-byte row segments of three colour
 // planes: a wave's load instruction touches six or seven such segments, and ISSUING the nine loads per thread is 19 % of its
-// tile time (stamps: 147 cycles per load instruction); the 81 pooling windows of a tile are 1.27 x its own 64.  Here a workgroup
+// tile time (stamps: 147 cycles per load instruction); the 81 pooling windows of a tile are 1.27 x its own 64.  (With the
+// windows decoded once at the commit in both forms the row walk is 2-3 % ahead: 769 against 788 us per launch.)  Here a workgroup
 // owns a whole IMAGE and walks down two stem rows (256 pixels, the GEMM's K per step as before) at a time:
 //   * s2d rows in a 6-row LDS ring: a step converts the two NEW rows (four image rows x three colours, each ONE contiguous 1 KB
 //     load instruction per wave) and re-uses three; every input byte fetched once;
@@ -294,7 +295,8 @@ static bool mil_stem_walk_wanted_bwd(int n_img, int H2, int W2, bool from_x, boo
     if (!from_x || !bf16 || W2 != 128 || (H2 & 1)) return false;
     const char* e = getenv("MIL_STEM_WALK");
     if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
-    const long cost_tile = ((long)n_img * tiles_per_img + 2 * grid_cap - 1) / (2 * grid_cap) * 2 * 7;      // the tiled form runs two rounds of the resident set
-    const long cost_walk = (long)((n_img + grid_cap - 1) / grid_cap) * (H2 / 2 + 1) * 6;
+    // measured (windows decoded once in both forms): 6.3 k cycles per 16 x 16 tile, 6.0 k per two-row step
+    const long cost_tile = ((long)n_img * tiles_per_img + 2 * grid_cap - 1) / (2 * grid_cap) * 2 * 63;     // the tiled form runs two rounds of the resident set
+    const long cost_walk = (long)((n_img + grid_cap - 1) / grid_cap) * (H2 / 2 + 1) * 60;
     return cost_walk < cost_tile;
 }
