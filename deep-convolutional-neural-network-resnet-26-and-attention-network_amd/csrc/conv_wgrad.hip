@@ -1109,6 +1109,10 @@ static int stem_bwd_entry(const void* xs, const float* x, const void* gp, const 
     ConvGeom& g = a.g;
     g.n_img = n; g.H = H2; g.W = W2; g.Ho = H2; g.Wo = W2; g.ks = 4; g.stride = 1; g.pad = 2; g.zins = 0;
     mil_geom_tiles(g, 8);
+#ifndef MIL_STEM_BWD_WIDE
+#define MIL_STEM_BWD_WIDE 0           // 1: 32 x 8 tiles instead of 16 x 16 where the map allows (35 x 11 halo: 280-byte row segments instead of 152)
+#endif
+    if (MIL_STEM_BWD_WIDE && g.tw_log2 == 4 && g.th_log2 == 4 && g.ti_log2 == 0 && W2 >= 32) mil_geom_set(g, 5, 3, 0);
     a.Hp = (H2 - 1) / 2 + 1; a.Wp = (W2 - 1) / 2 + 1;
     a.H = 2 * H2; a.W = 2 * W2;
     const int halo_px = (g.hh * g.hw) << g.ti_log2;
