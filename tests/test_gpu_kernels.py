@@ -990,7 +990,7 @@ def test_identity_block_forward_one_pass_split_precision(ops, case, monkeypatch)
 
 
 @pytest.mark.parametrize("dense", [False, True])
-@pytest.mark.parametrize("case", [(2, 256), (3, 64), (5, 36), (2, 4), (600, 16), (1100, 8)])
+@pytest.mark.parametrize("case", [(2, 256), (3, 64), (5, 36), (2, 4), (600, 16), (1100, 8), (7, 32, 3)])
 def test_stem_backward_row_walk_against_tiled(ops, case, dense, monkeypatch):
     """The row-walk form of the fused bf16 stem backward (stem_bwd_walk_kernel: a workgroup walks a 256-pixel-wide image two stem
     rows per step, s2d rows and pooling windows in LDS rings) against the 16 x 16-tile form on the same tiles, pooled gradient and
@@ -998,7 +998,7 @@ def test_stem_backward_row_walk_against_tiled(ops, case, dense, monkeypatch):
     summation order; against autograd for small inputs.  Padded and dense pooled-gradient layouts, one and several images per
     workgroup, a single step."""
     L = _lib()
-    n, h = case
+    n, h = case[:2]
     dt = torch.bfloat16
     g = torch.Generator().manual_seed(1811 + n + h)
     x = torch.randn(n, 3, h, 256, generator=g).clamp_(-1, 1).cuda()
@@ -1009,6 +1009,8 @@ def test_stem_backward_row_walk_against_tiled(ops, case, dense, monkeypatch):
     gp = torch.randn(pool.shape[:3] + (20 if dense else 24,), generator=torch.Generator(device="cuda").manual_seed(5), device="cuda").to(dt)
     if not dense:
         gp[..., 20:] = 0
+    if len(case) > 2:                        # the launch split by the buffer limit (later chunks accumulate into dW / db)
+        monkeypatch.setenv("MIL_BUFFER_LIMIT_BYTES", str(case[2] * 3 * h * 256 * 4 + 4096))
     monkeypatch.setenv("MIL_STEM_WALK", "0")
     dw_t, db_t = ops.stem_bwd_fused_nchw(x, gp, widx)
     monkeypatch.setenv("MIL_STEM_WALK", "1")
@@ -1022,14 +1024,16 @@ def test_stem_backward_row_walk_against_tiled(ops, case, dense, monkeypatch):
 
 
 @pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
-@pytest.mark.parametrize("case", [(2, 256), (3, 64), (5, 34), (2, 6), (600, 16), (1100, 8)])
+@pytest.mark.parametrize("case", [(2, 256), (3, 64), (5, 34), (2, 6), (600, 16), (1100, 8), (7, 32, 3)])
 def test_stem_forward_row_walk_equals_tiled(ops, case, mode, monkeypatch):
     """The row-walk form of the fused 20-channel stem forward (stem_fwd_walk_kernel: a workgroup walks a 256-pixel-wide image two
     pooled rows per step, s2d rows in an LDS ring, the window row above carried in registers) against the 8 x 16-pooled-pixel
     tile form: same filter fragments, same k order, same in-register pooling and winner codes — pooled map and winner records
     bit for bit; heights whose pooled map has an odd number of rows, a single step, one and several images per workgroup."""
     L = _lib()
-    n, h = case
+    n, h = case[:2]
+    if len(case) > 2:                        # the launch split by the buffer limit: case[2] images per launch
+        monkeypatch.setenv("MIL_BUFFER_LIMIT_BYTES", str(case[2] * 3 * h * 256 * 4 + 4096))
     dt = torch.bfloat16 if mode == "bf16" else torch.float32
     code = L.MIL_DT_F32S if mode == "bf16x3" else L.MIL_DT_F32
     g = torch.Generator().manual_seed(1601 + n + h)
