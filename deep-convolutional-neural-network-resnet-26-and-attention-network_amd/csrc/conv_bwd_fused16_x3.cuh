@@ -152,6 +152,12 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused16x3_kernel(BwdFusedArgs
         }
     }
     const int xb = (8 * gq + q4) * PIXX + p4 * 8;
+    // column tile 1 of the weight gradient = x channels 16-23: four real channels, three padding, the ones channel (bias sums) —
+    // its columns 8-15 are idle.  The lanes that read the 4-channel piece of columns 8-11 (p4 == 2) read the LO plane's channels
+    // 16-19 instead: z_hi x [x_hi | x_lo] and z_lo x [x_hi | x_lo] are two MFMAs for what took three (z_lo*x_hi, z_hi*x_lo,
+    // z_hi*x_hi); columns 8-11 are added onto 0-3 when the slab is written.  (They also carry z_lo*x_lo, the 2^-18 term the
+    // three-product form drops.)
+    const int xb1 = p4 == 2 ? X_PLANE + (8 * gq + q4) * PIXX + 32 : xb + 32;
     f32x4_t wacc[MW][NTX];
 #pragma unroll
     for (int i = 0; i < MW; ++i)
@@ -327,9 +333,8 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused16x3_kernel(BwdFusedArgs
             auto loadw = [&](int kk, bf16x8_t (&xf)[2][NTX], bf16x8_t (&zf)[2][MW]) {
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll
-                    for (int nt = 0; nt < NTX; ++nt)
-                        xf[pl][nt] = mil_tr_pair(ldsX + pl * X_PLANE + xb + kk * 32 * PIXX + nt * 32, ldsX + pl * X_PLANE + xb + kk * 32 * PIXX + nt * 32 + 4 * PIXX);
+                    if (pl == 0) xf[0][1] = mil_tr_pair(ldsX + xb1 + kk * 32 * PIXX, ldsX + xb1 + kk * 32 * PIXX + 4 * PIXX);      // the folded fragment
+                    xf[pl][0] = mil_tr_pair(ldsX + pl * X_PLANE + xb + kk * 32 * PIXX, ldsX + pl * X_PLANE + xb + kk * 32 * PIXX + 4 * PIXX);
 #pragma unroll
                     for (int i = 0; i < MW; ++i)
                         zf[pl][i] = mil_tr_pair(ldsA + pl * A_PLANE + zw[i][0] + kk * 2 * ROWB, ldsA + pl * A_PLANE + zw[i][1] + kk * 2 * ROWB);
@@ -345,14 +350,14 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused16x3_kernel(BwdFusedArgs
 #pragma unroll
                     for (int nt = 0; nt < NTX; ++nt) {
                         wacc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zc[1][i], xc[0][nt], wacc[i][nt], 0, 0, 0);
-                        wacc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zc[0][i], xc[1][nt], wacc[i][nt], 0, 0, 0);
+                        if (nt == 0) wacc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zc[0][i], xc[1][nt], wacc[i][nt], 0, 0, 0);
                         wacc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zc[0][i], xc[0][nt], wacc[i][nt], 0, 0, 0);
                     }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
-                    for (int nt = 0; nt < NTX; ++nt) xc[pl][nt] = xn[pl][nt];
+                    for (int nt = 0; nt < NTX; ++nt) if (pl == 0 || nt == 0) xc[pl][nt] = xn[pl][nt];
 #pragma unroll
                     for (int i = 0; i < MW; ++i) zc[pl][i] = zn[pl][i];
                 }
@@ -371,7 +376,13 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused16x3_kernel(BwdFusedArgs
 #pragma unroll
         for (int nt = 0; nt < NTX; ++nt)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                slab[(size_t)(mt * 16 + gq * 4 + e) * SLAB_COLS + nt * 16 + r] = wacc[i][nt][e];
+            for (int e = 0; e < 4; ++e) {
+                float v = wacc[i][nt][e];
+                if (nt == 1) {                                   // folded column tile: columns 8-11 (the x_lo products) onto columns 0-3
+                    const float up = __shfl_down(v, 8, 16);
+                    v = r < 4 ? v + up : (r < 8 ? v : 0.f);
+                }
+                slab[(size_t)(mt * 16 + gq * 4 + e) * SLAB_COLS + nt * 16 + r] = v;
+            }
     }
 }
