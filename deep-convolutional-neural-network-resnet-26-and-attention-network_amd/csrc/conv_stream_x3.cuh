@@ -127,9 +127,19 @@ __global__ __launch_bounds__(256, 2) void conv_stream_x3_kernel(StreamX3Args a, 
 #endif
             constexpr int WD = MIL_STREAM_WD, WR = WD + 1;             // filter fragments: k-steps ahead / ring slots
             Frag8<F32S> wq[WR][NT], ring[R];
+            // The last column tile of a 40-channel filter holds channels 32-39: rows 8-15 idle (zero weights).  Lanes of rows 8-15 read
+            // the LO half of row r-8 instead, so ONE fragment F = [w_hi ; w_lo] serves both planes — F x x_hi and F x x_lo, two MFMAs
+            // for what took three (rows 8-15 also collect w_lo*x_lo, the 2^-18 term the three-product form drops) — and the epilogue
+            // adds rows 8-15 (lanes 32-63) onto rows 0-7.  One filter load less per k-step, too.
+            constexpr bool FOLD = (C % 16) == 8;
+            const unsigned wfold = (unsigned)((r >= 8 ? lane - 8 : lane) * 32 + (r >= 8 ? 16 : 0));
             auto fetch_w = [&](int sl) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
+                    if (FOLD && nt == NT - 1) {
+                        wq[sl % WR][nt].h = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wfold, (sl * NT + nt) * 2048, 0));
+                        continue;
+                    }
                     wq[sl % WR][nt].h = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(lane * 32), (sl * NT + nt) * 2048, 0));
                     wq[sl % WR][nt].l = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(lane * 32 + 16), (sl * NT + nt) * 2048, 0));
                 }
@@ -152,8 +162,20 @@ __global__ __launch_bounds__(256, 2) void conv_stream_x3_kernel(StreamX3Args a, 
                 if (m == 0 && sl + WD < KSTEPS) fetch_w(sl + WD);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mma8(wq[sl % WR][nt], ring[j % R], acc[m][nt]);
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (FOLD && nt == NT - 1) {
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[sl % WR][nt].h, ring[j % R].l, acc[m][nt], 0, 0, 0);
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[sl % WR][nt].h, ring[j % R].h, acc[m][nt], 0, 0, 0);
+                    } else
+                    acc[m][nt] = mma8(wq[sl % WR][nt], ring[j % R], acc[m][nt]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (FOLD) {                  // rows 8-15 of the folded tile (lanes 32-63) onto rows 0-7
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[m][NT - 1][i] += __shfl_down(acc[m][NT - 1][i], 32, 64);
             }
         }
         MIL_STAMP_MARK(3)
