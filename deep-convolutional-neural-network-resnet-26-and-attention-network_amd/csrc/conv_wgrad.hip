@@ -93,6 +93,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((T::SPLIT && CINP <= 24 && NT <
     constexpr int MW = (MT_S + NW - 1) / NW;    // tiles per wave
     constexpr int PM0 = 2 * CG, PM1 = (5 * CG - 1) / 2, PMN = PROJ ? PM1 - PM0 + 1 : 0;    // row tiles holding centre-tap rows
     constexpr bool WPIPE = MIL_WGRAD_PIPE(T::DT == MIL_DT_BF16, PF, CINP, NW, PROJ);
+    // Split precision, 24 or 40 output channels: the last column tile holds eight real columns, columns 8-15 idle.  The lanes that
+    // read the pieces of columns 8-15 (p >= 2) read the LO plane's pieces of the tile's eight channels instead, so x_lo * [dz_hi |
+    // dz_lo] and x_hi * [dz_hi | dz_lo] are two MFMAs for what took three (columns 8-15 also collect x_lo*dz_lo, the 2^-18 term the
+    // three-product form drops); they are added onto columns 0-7 when the slab is written.
+#ifndef MIL_WGRAD_ZFOLD
+#define MIL_WGRAD_ZFOLD 1
+#endif
+    constexpr bool ZFOLD = MIL_WGRAD_ZFOLD && T::SPLIT && (COUTP % 16) == 8;
+    constexpr int ZFOLD_D = COUTP * 2 - 16;
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     // wave id through readfirstlane: provably wave-uniform, so branches on it are scalar branches (an MFMA or a
@@ -256,15 +265,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((T::SPLIT && CINP <= 24 && NT <
                 for (int nt = 0; nt < NT; ++nt) bf[nt] = tr_pair(z0 + nt * 32, z1 + nt * 32);
                 if constexpr (T::SPLIT) {        // MIL_DT_F32S: dW += x_lo*dz_hi + x_hi*dz_lo + x_hi*dz_hi from the hi/lo planes of both tiles
                     bf16x8_t bl[NT], bl2[PROJ ? NT : 1];
+                    const int zf = (ZFOLD && p >= 2) ? ZFOLD_D : 0;      // the folded fragment of the last column tile (see ZFOLD)
+                    if constexpr (ZFOLD) bf[NT - 1] = tr_pair(z0 + (NT - 1) * 32 + zf, z1 + (NT - 1) * 32 + zf);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bl[nt] = tr_pair(z0 + COUTP * 2 + nt * 32, z1 + COUTP * 2 + nt * 32);
+                    for (int nt = 0; nt < NT; ++nt)
+                        if (!(ZFOLD && nt == NT - 1)) bl[nt] = tr_pair(z0 + COUTP * 2 + nt * 32, z1 + COUTP * 2 + nt * 32);
                     if constexpr (PROJ) {
                         if (proj_i >= 0) {       // wave-uniform: hi and lo planes of the projection's dz tile
                             const char* y0 = ldsZ2 + (k32 + 8 * gq + q4) * PIXZ + p * 8;
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt) {
-                                bf2[nt] = tr_pair(y0 + nt * 32, y0 + 4 * PIXZ + nt * 32);
-                                bl2[nt] = tr_pair(y0 + COUTP * 2 + nt * 32, y0 + 4 * PIXZ + COUTP * 2 + nt * 32);
+                                const int yf = (ZFOLD && nt == NT - 1) ? zf : 0;
+                                bf2[nt] = tr_pair(y0 + nt * 32 + yf, y0 + 4 * PIXZ + nt * 32 + yf);
+                                if (!(ZFOLD && nt == NT - 1)) bl2[nt] = tr_pair(y0 + COUTP * 2 + nt * 32, y0 + 4 * PIXZ + COUTP * 2 + nt * 32);
                             }
                         }
                     }
@@ -276,7 +289,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((T::SPLIT && CINP <= 24 && NT <
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt) {
                                 acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bf[nt], acc[i][nt], 0, 0, 0);
-                                acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bl[nt], acc[i][nt], 0, 0, 0);
+                                if (!(ZFOLD && nt == NT - 1)) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bl[nt], acc[i][nt], 0, 0, 0);
                                 acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[nt], acc[i][nt], 0, 0, 0);
                             }
                             if constexpr (PROJ) {
@@ -284,7 +297,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((T::SPLIT && CINP <= 24 && NT <
 #pragma unroll
                                     for (int nt = 0; nt < NT; ++nt) {
                                         accp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bf2[nt], accp[nt], 0, 0, 0);
-                                        accp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bl2[nt], accp[nt], 0, 0, 0);
+                                        if (!(ZFOLD && nt == NT - 1)) accp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bl2[nt], accp[nt], 0, 0, 0);
                                         accp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf2[nt], accp[nt], 0, 0, 0);
                                     }
                                 }
@@ -294,7 +307,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((T::SPLIT && CINP <= 24 && NT <
                     if (bias_wave) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            accb[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bl[nt], accb[nt], 0, 0, 0);
+                            if (!(ZFOLD && nt == NT - 1)) accb[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bl[nt], accb[nt], 0, 0, 0);
                             accb[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bf[nt], accb[nt], 0, 0, 0);
                         }
                     }
@@ -364,13 +377,21 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((T::SPLIT && CINP <= 24 && NT <
     constexpr size_t SLAB_ELEMS = (size_t)(MT + 1 + PMN) * 16 * SLAB_COLS;
     float* slab = a.slab + (size_t)blockIdx.x * SLAB_ELEMS;
     const int gq = lane >> 4, col = lane & 15;
+    // ZFOLD: columns 8-15 of the last column tile (the dz_lo products) onto columns 0-7
+    auto unfold = [&](float v, int nt) {
+        if (ZFOLD && nt == NT - 1) {
+            const float up = __shfl_down(v, 8, 16);
+            return col < 8 ? v + up : 0.f;
+        }
+        return v;
+    };
     if constexpr (PROJ) {
         if (proj_i >= 0) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    slab[(size_t)((MT + 1 + proj_mt - PM0) * 16 + gq * 4 + e) * SLAB_COLS + nt * 16 + col] = accp[nt][e];
+                    slab[(size_t)((MT + 1 + proj_mt - PM0) * 16 + gq * 4 + e) * SLAB_COLS + nt * 16 + col] = unfold(accp[nt][e], nt);
         }
     }
 #pragma unroll
@@ -381,14 +402,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((T::SPLIT && CINP <= 24 && NT <
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                slab[(size_t)(mt * 16 + gq * 4 + e) * SLAB_COLS + nt * 16 + col] = acc[i][nt][e];
+                slab[(size_t)(mt * 16 + gq * 4 + e) * SLAB_COLS + nt * 16 + col] = unfold(acc[i][nt][e], nt);
     }
     if (bias_wave) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                slab[(size_t)(MT * 16 + gq * 4 + e) * SLAB_COLS + nt * 16 + col] = accb[nt][e];
+                slab[(size_t)(MT * 16 + gq * 4 + e) * SLAB_COLS + nt * 16 + col] = unfold(accb[nt][e], nt);
     }
 }
 
