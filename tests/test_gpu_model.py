@@ -346,6 +346,40 @@ def test_benchmark_sized_launch_properties(golden_dir, monkeypatch):
         assert torch.equal(outs[1]["Aterm"], outs2[1]["Aterm"])
 
 
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+def test_row_walk_kernels_inside_the_model(golden_dir, mode, monkeypatch):
+    """The row-walk kernels (block forward, stem forward, bf16 stem backward) forced on against forced off through the whole model
+    at 2 bags x 256 tiles @256x256: every forward output bit for bit — the forward row walks are bit-identical to their tiled forms,
+    so a result does not depend on which form a launch size selects —, every gradient bit for bit in split precision (its stem
+    backward has one form), and in bf16 to the fp32 summation order of the stem's weight gradient (the stem has no input gradient,
+    so nothing else can differ)."""
+    import mil_amd
+    monkeypatch.delenv("MIL_PF_MIN_TILES", raising=False)
+    dtype = torch.bfloat16 if mode == "bf16" else mil_amd.BF16X3
+    gen = torch.Generator(device="cuda").manual_seed(321)
+    x = torch.randn((512, 3, 256, 256), generator=gen, device="cuda").clamp_(-1, 1)
+    labels = torch.tensor([1, 2])
+    res = {}
+    for forced in ("0", "1"):
+        monkeypatch.setenv("MIL_BLOCK_STRIP", forced)
+        monkeypatch.setenv("MIL_STEM_WALK", forced)
+        net = _model(golden_dir, dtype).eval()
+        outs = net.forward_bags((x, [256, 256]), labels)
+        torch.stack([o["loss"] for o in outs]).sum().backward()
+        torch.cuda.synchronize()
+        res[forced] = ([{k: o[k].detach().clone() for k in ("Aterm", "Mterm", "Fterm", "loss", "y_pred")} for o in outs],
+                       {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    for o0, o1 in zip(res["0"][0], res["1"][0]):
+        for k in o0:
+            assert torch.equal(o0[k], o1[k]), k
+    for k, g0 in res["0"][1].items():
+        g1 = res["1"][1][k]
+        if mode == "bf16x3" or not k.startswith("cnn.module.conv1."):
+            assert torch.equal(g0, g1), k
+        else:
+            assert float((g0 - g1).abs().max()) <= 2e-5 * float(g0.abs().max()), k
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, "bf16x3"], ids=["fp32", "bf16x3"])
 def test_live_driver_tile_size_and_ragged_bags(golden_dir, dtype):
     """The reference's live driver feeds 300x300 tiles (gbm/classify_combined.py:412; maps 150->75->38->19->10, no
